@@ -1,0 +1,428 @@
+"""CPU oracle for the speaker-aware LSTHM hot path -- TEST INFRASTRUCTURE ONLY.
+
+This file is a CPU restatement (plain PyTorch, fp32 or fp64, autograd for the
+backward) of the reference algorithm on the path BASELINE.json names.  It is
+the *checker*: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.  The product package never
+does; the product fails loudly when its HIP library is missing.
+
+Pinning: every function here is checked against golden vectors produced by
+importing the reference itself in the build container
+(``tests/golden/make_golden.py`` -> ``tests/golden/*.npz``,
+``tests/test_oracle_golden.py``).  Parity is therefore *pinned* for the
+reference-native dims (D=100, H=128, d_r in {768,1024}); for widths the
+reference cannot run (H != 128, multi-head cross-modal attention) this oracle is
+the definition.
+
+All parameters are passed as a flat ``dict[str, Tensor]`` whose keys are the
+reference's ``state_dict`` names (``/root/reference/model/lsthm_sps.py:298-346``),
+so golden weights load without translation.
+
+Reference citations are ``path:line`` relative to the reference checkout.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+Params = Dict[str, Tensor]
+
+
+# --------------------------------------------------------------------------------------
+# L2 ops
+# --------------------------------------------------------------------------------------
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
+    y = x.matmul(w.t())
+    return y if b is None else y + b
+
+
+def lsthm1(P: Params, pre: str, x: Tensor, ctm: Tensor, htm: Tensor, ztm: Tensor, s: Tensor):
+    """LSTHM1.forward -- model/lsthm_sps.py:28-44.  Gate order f, i, o, c~."""
+    g = (linear(x, P[pre + "W.weight"], P[pre + "W.bias"])
+         + linear(htm, P[pre + "U.weight"], P[pre + "U.bias"])
+         + linear(ztm, P[pre + "V.weight"], P[pre + "V.bias"])
+         + linear(s, P[pre + "S.weight"], P[pre + "S.bias"]))
+    H = ctm.shape[1]
+    f = torch.sigmoid(g[:, :H])
+    i = torch.sigmoid(g[:, H:2 * H])
+    o = torch.sigmoid(g[:, 2 * H:3 * H])
+    ch = torch.tanh(g[:, 3 * H:])
+    c = f * ctm + i * ch
+    h = torch.tanh(c) * o
+    return c, h
+
+
+def lstm_cell(P: Params, pre: str, x: Tensor, h: Tensor, c: Tensor):
+    """torch.nn.LSTMCell semantics (gate order i, f, g, o) -- used at model/lsthm_sps.py:182,187."""
+    g = (linear(x, P[pre + "weight_ih"], P[pre + "bias_ih"])
+         + linear(h, P[pre + "weight_hh"], P[pre + "bias_hh"]))
+    H = h.shape[1]
+    i = torch.sigmoid(g[:, :H])
+    f = torch.sigmoid(g[:, H:2 * H])
+    gg = torch.tanh(g[:, 2 * H:3 * H])
+    o = torch.sigmoid(g[:, 3 * H:])
+    c2 = f * c + i * gg
+    h2 = o * torch.tanh(c2)
+    return h2, c2
+
+
+def cross_attention(P: Params, pre: str, x1: Tensor, x2: Tensor) -> Tensor:
+    """CrossAttention.forward (per-step, over the FEATURE axis) -- model/lsthm_sps.py:59-72.
+
+    As written: Q = x1 (x) Wq, K = x2 (x) Wk are [B,H,H]; softmax(Q/sqrt(dh) K, -1) x2.
+    ``dh`` is the hard-coded 128 of :50 when H == 128; for other widths this oracle
+    uses the feature width (the reference cannot run those).
+    """
+    H = x1.shape[1]
+    Q = x1.unsqueeze(-1).matmul(P[pre + "Wq"])          # [B,H,H]
+    K = x2.unsqueeze(-1).matmul(P[pre + "Wk"])          # [B,H,H]
+    attn = F.softmax((Q / (H ** 0.5)).matmul(K), dim=-1)
+    return attn.matmul(x2.unsqueeze(-1)).squeeze(-1)
+
+
+def cross_attention_seq(P: Params, pre: str, x1: Tensor, x2: Tensor, heads: int = 1) -> Tensor:
+    """CrossAttention2 / CrossAttention3 (over the UTTERANCE axis) -- model/lsthm_sps.py:88-101, :116-129.
+
+    x1 [L1,B,D1], x2 [L2,B,D2] time-major -> [L1,B,Dv].  ``heads`` > 1 is the build's
+    extension for BASELINE config 5 (split Dk/Dv into heads, scale 1/sqrt(Dk/heads));
+    heads == 1 is the reference.
+    """
+    Wq, Wk, Wv = P[pre + "Wq"], P[pre + "Wk"], P[pre + "Wv"]
+    a = x1.permute(1, 0, 2)
+    b = x2.permute(1, 0, 2)
+    Q, K, V = a.matmul(Wq), b.matmul(Wk), b.matmul(Wv)
+    dk = Wq.shape[1]
+    if heads == 1:
+        attn = F.softmax((Q / (dk ** 0.5)).matmul(K.transpose(1, 2)), dim=-1)
+        return attn.matmul(V).permute(1, 0, 2)
+    Bn, L1, _ = Q.shape
+    L2 = K.shape[1]
+    hd = dk // heads
+    Qh = Q.view(Bn, L1, heads, hd).transpose(1, 2)
+    Kh = K.view(Bn, L2, heads, hd).transpose(1, 2)
+    Vh = V.view(Bn, L2, heads, -1).transpose(1, 2)
+    attn = F.softmax((Qh / (hd ** 0.5)).matmul(Kh.transpose(2, 3)), dim=-1)
+    return attn.matmul(Vh).transpose(1, 2).reshape(Bn, L1, -1).permute(1, 0, 2)
+
+
+# --------------------------------------------------------------------------------------
+# encoder (model/encoder.py)
+# --------------------------------------------------------------------------------------
+def sdpa(q: Tensor, k: Tensor, v: Tensor, temperature: float, mask: Optional[Tensor] = None):
+    """ScaledDotProductAttention.forward -- model/encoder.py:71-86."""
+    attn = (q / temperature).matmul(k.transpose(2, 3))
+    if mask is not None:
+        attn = attn.masked_fill(mask == 0, -1e9)
+    attn = F.softmax(attn, dim=-1)
+    return attn.matmul(v), attn
+
+
+def mha(P: Params, pre: str, q: Tensor, k: Tensor, v: Tensor, n_head: int, d_k: int, d_v: int,
+        mask: Optional[Tensor] = None):
+    """MultiHeadAttention.forward -- model/encoder.py:27-60 (bias-free projections, post-LN eps 1e-6)."""
+    B, Lq, Lk = q.shape[0], q.shape[1], k.shape[1]
+    residual = q
+    qh = linear(q, P[pre + "w_qs.weight"]).view(B, Lq, n_head, d_k).transpose(1, 2)
+    kh = linear(k, P[pre + "w_ks.weight"]).view(B, Lk, n_head, d_k).transpose(1, 2)
+    vh = linear(v, P[pre + "w_vs.weight"]).view(B, Lk, n_head, d_v).transpose(1, 2)
+    if mask is not None:
+        mask = mask.unsqueeze(1)
+    o, attn = sdpa(qh, kh, vh, d_k ** 0.5, mask)
+    o = o.transpose(1, 2).contiguous().view(B, Lq, -1)
+    o = linear(o, P[pre + "fc.weight"]) + residual
+    o = F.layer_norm(o, (o.shape[-1],), P[pre + "layer_norm.weight"], P[pre + "layer_norm.bias"], 1e-6)
+    return o, attn
+
+
+def ffn(P: Params, pre: str, x: Tensor) -> Tensor:
+    """PositionwiseFeedForward.forward -- model/encoder.py:101-113 (``fc`` is dead)."""
+    y = linear(F.relu(linear(x, P[pre + "w_1.weight"], P[pre + "w_1.bias"])),
+               P[pre + "w_2.weight"], P[pre + "w_2.bias"]) + x
+    return F.layer_norm(y, (y.shape[-1],), P[pre + "layer_norm.weight"], P[pre + "layer_norm.bias"], 1e-6)
+
+
+def encoder_layer(P: Params, pre: str, x: Tensor, n_head: int = 8, d_k: int = 40, d_v: int = 40,
+                  mask: Optional[Tensor] = None):
+    """EncoderLayer.forward -- model/encoder.py:130-133."""
+    o, attn = mha(P, pre + "slf_attn.", x, x, x, n_head, d_k, d_v, mask)
+    return ffn(P, pre + "pos_ffn.", o), attn
+
+
+def self_attention_lib(P: Params, pre: str, queries: Tensor, keys: Tensor, values: Tensor, h: int,
+                       d_k: int, d_v: int, attention_mask: Optional[Tensor] = None,
+                       attention_weights: Optional[Tensor] = None) -> Tensor:
+    """attention:/SelfAttention.py::ScaledDotProductAttention.forward -- :49-76 (biased projections)."""
+    b, nq, nk = queries.shape[0], queries.shape[1], keys.shape[1]
+    q = linear(queries, P[pre + "fc_q.weight"], P[pre + "fc_q.bias"]).view(b, nq, h, d_k).permute(0, 2, 1, 3)
+    k = linear(keys, P[pre + "fc_k.weight"], P[pre + "fc_k.bias"]).view(b, nk, h, d_k).permute(0, 2, 3, 1)
+    v = linear(values, P[pre + "fc_v.weight"], P[pre + "fc_v.bias"]).view(b, nk, h, d_v).permute(0, 2, 1, 3)
+    att = q.matmul(k) / math.sqrt(d_k)
+    if attention_weights is not None:
+        att = att * attention_weights
+    if attention_mask is not None:
+        att = att.masked_fill(attention_mask, float("-inf"))
+    att = torch.softmax(att, -1)
+    out = att.matmul(v).permute(0, 2, 1, 3).contiguous().view(b, nq, h * d_v)
+    return linear(out, P[pre + "fc_o.weight"], P[pre + "fc_o.bias"])
+
+
+# --------------------------------------------------------------------------------------
+# MARN_cell: slot-table restatement of model/lsthm_sps.py:156-221 + :238-259
+# --------------------------------------------------------------------------------------
+def slot_tables(qmask: Tensor):
+    """Per-step speaker slot tables from qmask [T,B,2] alone.
+
+    party[t,b]  = argmax(qmask[t,b]) (ties / all-zero -> 0)            (:177)
+    perm[t,r]   = dialogue whose state lands in row r of the (P0 || P1) ordering  (:242-257, :191-193)
+    n0[t]       = number of party-0 dialogues at step t.
+    """
+    party = torch.argmax(qmask, dim=2)                       # [T,B]
+    perm = torch.argsort(party, dim=1, stable=True)          # P0 rows (dialogue order), then P1 rows
+    n0 = (party == 0).sum(dim=1)
+    return party, perm, n0
+
+
+def speaker_recurrence(P: Params, pre: str, qmask: Tensor, Hs: int):
+    """The qmask-only recurrence inside MARN_cell.forward (:172-207): returns h_q[t] for every step.
+
+    Rows of the two LSTMCell states are indexed by compaction slot, not dialogue; padded slots
+    are fed zeros and still advance (:249-257, :182, :187).  The blended ``q`` is applied row-wise
+    in the permuted order (:204-207).
+    """
+    T, B, _ = qmask.shape
+    dt, dev = qmask.dtype, qmask.device
+    party, perm, n0 = slot_tables(qmask)
+    q = torch.zeros(B, 2, Hs, dtype=dt, device=dev)
+    hq0 = torch.zeros(B, Hs, dtype=dt, device=dev)
+    cq0 = torch.zeros_like(hq0)
+    hq1 = torch.zeros_like(hq0)
+    cq1 = torch.zeros_like(hq0)
+    out = []
+    for t in range(T):
+        N0 = int(n0[t])
+        N1 = B - N0
+        src = perm[t]
+        h0 = q[src, party[t][src]]                                   # cat[q0_sel[:N0], q1_sel[:N1]]
+        zeros = torch.zeros(B, Hs, dtype=dt, device=dev)
+        if N0:
+            q0_sel = torch.cat([h0[:N0], zeros[:B - N0]], 0)
+            hq0, cq0 = lstm_cell(P, pre + "lstm_q0.", q0_sel, hq0, cq0)
+        if N1:
+            q1_sel = torch.cat([h0[N0:], zeros[:B - N1]], 0)
+            hq1, cq1 = lstm_cell(P, pre + "lstm_q1.", q1_sel, hq1, cq1)
+        hq = torch.cat([hq0[:N0], hq1[:N1]], 0)
+        m = qmask[t].unsqueeze(2)
+        q = h0.unsqueeze(1) * (1 - m) + hq.unsqueeze(1) * m
+        out.append(hq)
+    return torch.stack(out, 0)                                          # [T,B,Hs]
+
+
+def marn_cell(P: Params, pre: str, x_l: Tensor, x_a: Tensor, qmask: Tensor, H: int = 128, Hs: int = 128) -> Tensor:
+    """MARN_cell.forward -- model/lsthm_sps.py:156-221.  Returns h [T,B,3H+Hs] = cat(h_l,h_a,z_l,h_q)."""
+    T, B, _ = x_l.shape
+    dt, dev = x_l.dtype, x_l.device
+    hq_all = speaker_recurrence(P, pre, qmask.to(dt), Hs)
+    h_l = torch.zeros(B, H, dtype=dt, device=dev)
+    h_a, c_l, c_a, z = (torch.zeros_like(h_l) for _ in range(4))
+    outs = []
+    for t in range(T):
+        hq = hq_all[t]
+        c_l, h_l = lsthm1(P, pre + "lsthm_l.", x_l[t], c_l, h_l, z, hq)     # :210
+        c_a, h_a = lsthm1(P, pre + "lsthm_a.", x_a[t], c_a, h_a, z, hq)     # :212 (also z_l)
+        z = cross_attention(P, pre + "crossatt_l2a.", c_l, c_a)             # :215
+        outs.append(torch.cat([h_l, h_a, z, hq], 1))
+    return torch.stack(outs, 0)
+
+
+def reverse_seq(X: Tensor, umask: Tensor) -> Tensor:
+    """MARN1_sps._reverse_seq -- model/lsthm_sps.py:396-409 (flip the first len_b steps, zero-pad)."""
+    L, B = X.shape[0], X.shape[1]
+    lens = umask.sum(1).to(torch.int64)
+    Lmax = int(lens.max())
+    t = torch.arange(Lmax, device=X.device).unsqueeze(1)                   # [Lmax,1]
+    src = lens.unsqueeze(0) - 1 - t                                        # [Lmax,B]
+    valid = src >= 0
+    src = src.clamp(min=0)
+    g = X[src, torch.arange(B, device=X.device).unsqueeze(0)]              # [Lmax,B,...]
+    return g * valid.view(Lmax, B, *([1] * (X.dim() - 2))).to(X.dtype)
+
+
+def marn1_sps_forward(P: Params, x: Tensor, qmask: Tensor, umask: Tensor, d_r: int = 1024, d_a: int = 100,
+                      H: int = 128, n_head: int = 8, d_k: int = 40, d_v: int = 40, xattn_heads: int = 1,
+                      return_intermediates: bool = False):
+    """MARN1_sps.forward -- model/lsthm_sps.py:349-394 (eval mode: every Dropout is the identity)."""
+    x_l = x[:, :, :d_r].permute(1, 0, 2)
+    x_a = x[:, :, d_r:d_r + d_a].permute(1, 0, 2)
+    x_l = linear(x_l, P["linear_in.weight"], P["linear_in.bias"])
+    x_l_1, _ = encoder_layer(P, "encoder_l.", x_l, n_head, d_k, d_v)
+    x_a_1, _ = encoder_layer(P, "encoder_a.", x_a, n_head, d_k, d_v)
+    x_l, _ = encoder_layer(P, "encoder_l.", x_l + x_l_1, n_head, d_k, d_v)
+    x_a, _ = encoder_layer(P, "encoder_a.", x_a + x_a_1, n_head, d_k, d_v)
+    x_l = x_l.permute(1, 0, 2)
+    x_a = x_a.permute(1, 0, 2)
+
+    h_f = marn_cell(P, "marn_cell_f.", x_l, x_a, qmask, H, H)
+    rev_x_l = reverse_seq(x_l, umask)
+    rev_x_a = reverse_seq(x_a, umask)
+    rev_qmask = reverse_seq(qmask, umask)
+    h_b_raw = marn_cell(P, "marn_cell_b.", rev_x_l, rev_x_a, rev_qmask, H, H)
+    h_b = reverse_seq(h_b_raw, umask)
+    h = torch.cat([h_f, h_b], -1)
+
+    w, v, v1, v2 = P["w"], P["v"], P["v1"], P["v2"]
+    attn1 = cross_attention_seq(P, "crossatt_l2a.", w * x_l, v * x_a, xattn_heads)
+    attn2 = cross_attention_seq(P, "crossatt_a2l.", v * x_a, w * x_l, xattn_heads)
+    attn1 = cross_attention_seq(P, "crossatt_l2a_1.", v * x_a, v1 * attn1, xattn_heads)
+    attn2 = cross_attention_seq(P, "crossatt_a2l_1.", w * x_l, v2 * attn2, xattn_heads)
+
+    out = F.relu(linear(torch.cat([h, attn1, attn2], -1), P["fc.0.weight"], P["fc.0.bias"]))
+    out = out + x_l + x_a
+    out = F.relu(linear(out, P["nn_out.0.weight"], P["nn_out.0.bias"]))
+    out = linear(out, P["nn_out.3.weight"], P["nn_out.3.bias"])
+    lp = F.log_softmax(out, 2).permute(1, 0, 2)
+    lp = lp.reshape(-1, lp.shape[-1])
+    if return_intermediates:
+        return lp, x_l, x_a, dict(h_f=h_f, h_b=h_b, attn1=attn1, attn2=attn2)
+    return lp, x_l, x_a
+
+
+def masked_nll(pred: Tensor, target: Tensor, mask: Tensor) -> Tensor:
+    """MaskedLoss.forward with NLLLoss(sum), weight=None -- loss.py:13-21."""
+    m = mask.reshape(-1, 1)
+    return F.nll_loss(pred * m, target, reduction="sum") / mask.sum()
+
+
+# --------------------------------------------------------------------------------------
+# optimiser (model_trainer.py:82-83, :92)
+# --------------------------------------------------------------------------------------
+def step_lr(lr0: float, gamma: float, step_size: int, epoch: int) -> float:
+    """Closed form of scheduler.step(epoch-1) -- model_trainer.py:92."""
+    return lr0 * gamma ** ((epoch - 1) // step_size)
+
+
+def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, wd: float = 2e-5,
+              b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8) -> None:
+    """torch.optim.Adam single-tensor update with L2-coupled weight decay (model_trainer.py:82)."""
+    g = g + wd * p
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+# --------------------------------------------------------------------------------------
+# deterministic parameter / input generators shared by tests, golden maker, bench
+# --------------------------------------------------------------------------------------
+def param_shapes(n_classes: int = 6, d_r: int = 1024, D: int = 100, H: int = 128, n_head: int = 8,
+                 d_k: int = 40, d_v: int = 40, d_inner: int = 40, h_out: int = 32) -> Dict[str, Tuple[int, ...]]:
+    """state_dict key -> shape, in the reference's registration order."""
+    S: Dict[str, Tuple[int, ...]] = {}
+    for k in ("w", "v", "v1", "v2"):
+        S[k] = (1,)
+    S["linear_in.weight"] = (D, d_r)
+    S["linear_in.bias"] = (D,)
+    for cell in ("marn_cell_f.", "marn_cell_b."):
+        for ca in ("crossatt_l2a.", "crossatt_a2l."):
+            for wn in ("Wq", "Wk", "Wv"):
+                S[cell + ca + wn] = (1, H)
+        for st in ("lsthm_l.", "lsthm_a."):
+            for nm, k in (("W", D), ("U", H), ("V", H), ("S", H)):
+                S[cell + st + nm + ".weight"] = (4 * H, k)
+                S[cell + st + nm + ".bias"] = (4 * H,)
+        for lc in ("lstm_q0.", "lstm_q1.", "lstm_s."):
+            S[cell + lc + "weight_ih"] = (4 * H, H)
+            S[cell + lc + "weight_hh"] = (4 * H, H)
+            S[cell + lc + "bias_ih"] = (4 * H,)
+            S[cell + lc + "bias_hh"] = (4 * H,)
+    S["fc.0.weight"] = (D, 8 * H + 2 * H)
+    S["fc.0.bias"] = (D,)
+    S["nn_out.0.weight"] = (h_out, D)
+    S["nn_out.0.bias"] = (h_out,)
+    S["nn_out.3.weight"] = (n_classes, h_out)
+    S["nn_out.3.bias"] = (n_classes,)
+    for enc in ("encoder_l.", "encoder_a."):
+        S[enc + "slf_attn.w_qs.weight"] = (n_head * d_k, D)
+        S[enc + "slf_attn.w_ks.weight"] = (n_head * d_k, D)
+        S[enc + "slf_attn.w_vs.weight"] = (n_head * d_v, D)
+        S[enc + "slf_attn.fc.weight"] = (D, n_head * d_v)
+        S[enc + "slf_attn.layer_norm.weight"] = (D,)
+        S[enc + "slf_attn.layer_norm.bias"] = (D,)
+        S[enc + "pos_ffn.w_1.weight"] = (d_inner, D)
+        S[enc + "pos_ffn.w_1.bias"] = (d_inner,)
+        S[enc + "pos_ffn.w_2.weight"] = (D, d_inner)
+        S[enc + "pos_ffn.w_2.bias"] = (D,)
+        S[enc + "pos_ffn.layer_norm.weight"] = (D,)
+        S[enc + "pos_ffn.layer_norm.bias"] = (D,)
+        S[enc + "pos_ffn.fc.weight"] = (100, D)
+        S[enc + "pos_ffn.fc.bias"] = (100,)
+    for ca in ("crossatt_l2a.", "crossatt_a2l."):
+        for wn in ("Wq", "Wk", "Wv"):
+            S[ca + wn] = (D, H)
+    for ca in ("crossatt_l2a_1.", "crossatt_a2l_1."):
+        S[ca + "Wq"] = (D, H)
+        S[ca + "Wk"] = (H, H)
+        S[ca + "Wv"] = (H, H)
+    return S
+
+
+def seeded_params(seed: int = 0, dtype=torch.float32, **dims) -> Params:
+    """Deterministic, platform-independent parameters keyed by name (numpy RandomState stream).
+
+    Scales follow the reference's initialisers in spirit (U(-1/sqrt(fan_in), +) for Linear/LSTMCell)
+    but the attention matrices, which the reference initialises to ones (model/lsthm_sps.py:53-55,
+    82-84, 110-112), are drawn N(0, s^2) so that every softmax is non-uniform and the tests bite.
+    """
+    import zlib
+
+    import numpy as np
+
+    P: Params = {}
+    for name, shp in param_shapes(**dims).items():
+        rs = np.random.RandomState((zlib.crc32(name.encode()) + 7919 * seed) % (2 ** 31))
+        if name in ("w", "v", "v1", "v2"):
+            a = 1.0 + 0.1 * rs.standard_normal(shp)
+        elif name.endswith("layer_norm.weight"):
+            a = 1.0 + 0.1 * rs.standard_normal(shp)
+        elif name.endswith("layer_norm.bias"):
+            a = 0.1 * rs.standard_normal(shp)
+        elif ".crossatt_" in name:                       # per-step rank-1 attention vectors [1,H]
+            a = 0.5 * rs.standard_normal(shp)
+        elif name.startswith("crossatt_"):               # sequence-level attention matrices
+            a = rs.standard_normal(shp) * (0.6 / math.sqrt(shp[0]))
+        else:
+            fan_in = shp[1] if len(shp) == 2 else None
+            if fan_in is None:                           # bias: use the matching weight's fan-in scale
+                a = rs.uniform(-0.08, 0.08, shp)
+            else:
+                k = 1.0 / math.sqrt(fan_in)
+                a = rs.uniform(-k, k, shp)
+        P[name] = torch.tensor(a, dtype=dtype)
+    return P
+
+
+def seeded_batch(B: int, L: int, d_r: int = 1024, d_a: int = 100, seed: int = 1, ragged: bool = False,
+                 n_classes: int = 6, dtype=torch.float32):
+    """Synthetic batch in the reference's layout: x [L,B,d_r+d_a], qmask [L,B,2], umask [B,L], label [B,L]."""
+    import numpy as np
+
+    rs = np.random.RandomState(seed)
+    x = rs.standard_normal((L, B, d_r + d_a)).astype(np.float32)
+    spk = rs.randint(0, 2, (L, B))
+    qmask = np.eye(2, dtype=np.float32)[spk]
+    lens = np.full(B, L)
+    if ragged and B > 1:
+        lens = rs.randint(max(1, L // 2), L + 1, B)
+        lens[0] = L                                       # the reference needs max(len) == L (:373-375)
+    umask = (np.arange(L)[None, :] < lens[:, None]).astype(np.float32)
+    tm = umask.T[:, :, None]
+    x = x * tm
+    qmask = qmask * tm
+    label = (rs.randint(0, n_classes, (B, L)) * umask).astype(np.int64)
+    return (torch.tensor(x, dtype=dtype), torch.tensor(qmask, dtype=dtype),
+            torch.tensor(umask, dtype=dtype), torch.tensor(label))

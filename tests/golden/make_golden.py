@@ -1,0 +1,238 @@
+"""Generate golden vectors by running the REFERENCE ITSELF (CPU, torch fp32, eval mode).
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+Writes small ``.npz`` fixtures next to this file.  The reference's Python never travels:
+only arrays (inputs are regenerated from seeds by ``oracle.ref_cpu.seeded_*``; the fixtures hold
+expected OUTPUTS plus a few sampled gradient entries).  The import shim is the one SURVEY.md 8(c)
+describes: the checkout's ``model/`` dir is imported as ``models`` and ``attention:/`` as
+``attention``; ``librosa`` / ``soundfile`` (imported, never used, model_trainer.py:4-5) are stubbed.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from oracle import ref_cpu as O  # noqa: E402  (seeded generators only)
+
+
+def _shim():
+    m = types.ModuleType("models")
+    m.__path__ = [os.path.join(REF, "model")]
+    sys.modules["models"] = m
+    a = types.ModuleType("attention")
+    a.__path__ = [os.path.join(REF, "attention:")]
+    sys.modules["attention"] = a
+    for stub in ("librosa", "soundfile"):
+        sys.modules[stub] = types.ModuleType(stub)
+    sys.path.insert(0, REF)
+
+
+def _load(net, P, strict=True):
+    sd = net.state_dict()
+    for k in sd:
+        if k in P:
+            assert tuple(sd[k].shape) == tuple(P[k].shape), k
+            sd[k].copy_(P[k])
+        elif strict:
+            raise KeyError(k)
+
+
+def _grad_samples(named_params, n=6):
+    """L2 norm + n sampled entries of each parameter gradient (fixed pseudo-random positions)."""
+    out = {}
+    for name, p in named_params:
+        if p.grad is None:
+            out["gnorm/" + name] = np.float64(-1.0)         # marks a dead parameter
+            continue
+        g = p.grad.detach().double().reshape(-1)
+        rs = np.random.RandomState(len(name) * 131 + g.numel() % 9973)
+        idx = rs.randint(0, g.numel(), n)
+        out["gnorm/" + name] = g.norm().numpy()
+        out["gidx/" + name] = idx.astype(np.int64)
+        out["gval/" + name] = g[idx].numpy()
+    return out
+
+
+def model_case(tag, B, L, d_r, ragged, seed, full_logits):
+    from models.lsthm_sps import MARN1_sps
+    import torch.nn as nn
+
+    torch.manual_seed(0)
+    net = MARN1_sps(6)
+    if d_r != 1024:                                          # SURVEY 8(c) "Patching for BASELINE dims"
+        net.d_r = d_r
+        net.linear_in = nn.Linear(d_r, 100)
+    net.eval()
+    P = O.seeded_params(seed=seed, d_r=d_r)
+    _load(net, P)
+    x, qmask, umask, label = O.seeded_batch(B, L, d_r=d_r, seed=seed + 1, ragged=ragged)
+    lp, x_l, x_a = net(x, qmask, umask)
+    m = umask.reshape(-1, 1)
+    loss = torch.nn.functional.nll_loss(lp * m, label.view(-1), reduction="sum") / umask.sum()
+    loss.backward()
+    lpn = lp.detach().numpy()
+    srt = np.sort(lpn, 1)
+    rec = dict(
+        torch_version=np.array(torch.__version__), B=B, L=L, d_r=d_r, ragged=int(ragged), seed=seed,
+        loss=loss.detach().double().numpy(), argmax=lpn.argmax(1).astype(np.int8),
+        margin=(srt[:, -1] - srt[:, -2]).astype(np.float32),
+        x_l_sum=x_l.detach().double().sum().numpy(), x_a_sum=x_a.detach().double().sum().numpy(),
+        x_l_abs=x_l.detach().double().abs().sum().numpy(), x_a_abs=x_a.detach().double().abs().sum().numpy(),
+    )
+    if full_logits:
+        rec["logits"] = lpn
+        rec["x_l"] = x_l.detach().numpy()
+        rec["x_a"] = x_a.detach().numpy()
+    else:
+        rs = np.random.RandomState(5)
+        rows = np.sort(rs.choice(lpn.shape[0], 96, replace=False))
+        rec["rows"] = rows.astype(np.int64)
+        rec["logits"] = lpn[rows]
+    rec.update(_grad_samples(net.named_parameters()))
+    np.savez_compressed(os.path.join(HERE, f"model_{tag}.npz"), **rec)
+    print(tag, "loss", float(loss), "min margin", float(rec["margin"].min()))
+
+
+def cell_case():
+    """MARN_cell alone: T=24, N=6, a padded tail (all-zero qmask rows) and an all-party-0 step."""
+    from models.lsthm_sps import MARN_cell
+
+    torch.manual_seed(0)
+    cell = MARN_cell(128, 128, 100, 100).eval()
+    P = O.seeded_params(seed=3)
+    _load(cell, {k[len("marn_cell_f."):]: v for k, v in P.items() if k.startswith("marn_cell_f.")})
+    T, N = 24, 6
+    rs = np.random.RandomState(11)
+    x_l = torch.tensor(rs.standard_normal((T, N, 100)).astype(np.float32), requires_grad=True)
+    x_a = torch.tensor(rs.standard_normal((T, N, 100)).astype(np.float32), requires_grad=True)
+    spk = rs.randint(0, 2, (T, N))
+    spk[5, :] = 0                                            # all party 0
+    spk[9, :] = 1                                            # all party 1
+    qmask = np.eye(2, dtype=np.float32)[spk]
+    qmask[20:, 2] = 0                                        # padded tail for dialogue 2
+    qmask[17:, 4] = 0
+    qmask = torch.tensor(qmask)
+    h = cell(torch.zeros(T, N, 1), x_l, x_a, qmask)
+    wsum = torch.tensor(rs.standard_normal(tuple(h.shape)).astype(np.float32))
+    (h * wsum).sum().backward()
+    rec = dict(h=h.detach().numpy(), qmask=qmask.numpy(), x_l=x_l.detach().numpy(), x_a=x_a.detach().numpy(),
+               wsum=wsum.numpy(), dx_l=x_l.grad.numpy(), dx_a=x_a.grad.numpy(), seed=3)
+    rec.update(_grad_samples(cell.named_parameters()))
+    np.savez_compressed(os.path.join(HERE, "cell_T24_N6.npz"), **rec)
+    print("cell", float(h.abs().mean()))
+
+
+def module_cases():
+    from models.lsthm_sps import LSTHM1, CrossAttention, CrossAttention2, CrossAttention3
+    from models.encoder import EncoderLayer
+    from attention.SelfAttention import ScaledDotProductAttention as LibSA
+
+    rs = np.random.RandomState(21)
+    P = O.seeded_params(seed=4)
+    rec = {}
+
+    def rn(*s):
+        return torch.tensor(rs.standard_normal(s).astype(np.float32))
+
+    # LSTHM1
+    m = LSTHM1(128, 100, 128, 128).eval()
+    _load(m, {k[len("marn_cell_f.lsthm_l."):]: v for k, v in P.items() if k.startswith("marn_cell_f.lsthm_l.")})
+    x, c, h, z, s = rn(5, 100), rn(5, 128), rn(5, 128), rn(5, 128), rn(5, 128)
+    c2, h2 = m(x, c, h, z, s)
+    rec.update(lsthm_x=x.numpy(), lsthm_c=c.numpy(), lsthm_h=h.numpy(), lsthm_z=z.numpy(), lsthm_s=s.numpy(),
+               lsthm_c2=c2.detach().numpy(), lsthm_h2=h2.detach().numpy())
+    # CrossAttention (per step)
+    m = CrossAttention().eval()
+    _load(m, {k[len("marn_cell_f.crossatt_l2a."):]: v for k, v in P.items() if k.startswith("marn_cell_f.crossatt_l2a.")})
+    a, b = rn(7, 128), rn(7, 128)
+    rec.update(ca_x1=a.numpy(), ca_x2=b.numpy(), ca_out=m(a, b).detach().numpy())
+    # CrossAttention2 / 3
+    m = CrossAttention2(100, 128, 128).eval()
+    _load(m, {k[len("crossatt_l2a."):]: v for k, v in P.items() if k.startswith("crossatt_l2a.")})
+    a, b = rn(12, 3, 100), rn(12, 3, 100)
+    o2 = m(a, b)
+    rec.update(ca2_x1=a.numpy(), ca2_x2=b.numpy(), ca2_out=o2.detach().numpy())
+    m = CrossAttention3(128, 100, 100).eval()
+    _load(m, {k[len("crossatt_l2a_1."):]: v for k, v in P.items() if k.startswith("crossatt_l2a_1.")})
+    b3 = rn(12, 3, 128)
+    rec.update(ca3_x2=b3.numpy(), ca3_out=m(a, b3).detach().numpy())
+    # EncoderLayer
+    m = EncoderLayer(100, 40, 8, 40, 40).eval()
+    _load(m, {k[len("encoder_l."):]: v for k, v in P.items() if k.startswith("encoder_l.")})
+    e = rn(3, 12, 100)
+    eo, ea = m(e.clone())
+    rec.update(enc_x=e.numpy(), enc_out=eo.detach().numpy(), enc_attn=ea.detach().numpy())
+    # library self-attention (attention:/SelfAttention.py), weights N(0, 0.05) to make it non-trivial
+    torch.manual_seed(0)
+    m = LibSA(64, 16, 16, 4).eval()
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            r2 = np.random.RandomState(len(n_) + 77)
+            p_.copy_(torch.tensor((0.2 * r2.standard_normal(tuple(p_.shape))).astype(np.float32)))
+    qi, ki = rn(2, 9, 64), rn(2, 11, 64)
+    amask = torch.tensor(rs.rand(2, 4, 9, 11) < 0.2)
+    amask[..., 0] = False
+    aw = torch.tensor(rs.rand(2, 4, 9, 11).astype(np.float32))
+    for n_, p_ in m.named_parameters():
+        rec["sa_p/" + n_] = p_.detach().numpy()
+    rec.update(sa_q=qi.numpy(), sa_k=ki.numpy(), sa_mask=amask.numpy(), sa_w=aw.numpy(),
+               sa_out=m(qi, ki, ki).detach().numpy(),
+               sa_out_mw=m(qi, ki, ki, attention_mask=amask, attention_weights=aw).detach().numpy())
+    np.savez_compressed(os.path.join(HERE, "modules.npz"), **rec)
+    print("modules ok")
+
+
+def trainer_case():
+    """3 ``train_network`` steps with every Dropout p set to 0: pins MaskedLoss + Adam(wd) + StepLR."""
+    import torch.nn as nn
+    from model_trainer import ModelTrainer
+
+    torch.manual_seed(0)
+    tr = ModelTrainer(torch.device("cpu"), lr=1e-3, test_step=1, lr_decay=0.98, model="MARN1_sps", loss="NLL",
+                      n_classes=6, dataset="IEMOCAP")
+    for mod in tr.modules():
+        if isinstance(mod, nn.Dropout):
+            mod.p = 0.0
+    P = O.seeded_params(seed=5, d_r=1024)
+    _load(tr.model, P)
+    B, L = 3, 10
+    batches = []
+    for s in range(3):
+        x, qmask, umask, label = O.seeded_batch(B, L, d_r=1024, seed=40 + s, ragged=True)
+        r = x[:, :, :1024]
+        # r1..r4 with mean == r ; visuf unused
+        d = torch.tensor(np.random.RandomState(s).standard_normal(tuple(r.shape)).astype(np.float32)) * 0.1
+        batches.append([r + d, r - d, r + 2 * d, r - 2 * d, torch.zeros(L, B, 4), x[:, :, 1024:], qmask, umask, label,
+                        ["v"] * B])
+    rec = {}
+    for ep in (1, 2):
+        lr, avg = tr.train_network(ep, batches)
+        rec[f"lr{ep}"] = np.float64(lr)
+        rec[f"avg_loss{ep}"] = np.float64(avg)
+    sd = tr.model.state_dict()
+    for k in ("w", "v", "fc.0.bias", "nn_out.3.weight", "marn_cell_f.lsthm_l.U.bias", "encoder_l.slf_attn.layer_norm.weight",
+              "marn_cell_b.lstm_q1.bias_hh", "crossatt_l2a_1.Wk", "linear_in.bias", "marn_cell_f.crossatt_l2a.Wk"):
+        rec["p/" + k] = sd[k].detach().numpy().reshape(-1)[:16].copy()
+    np.savez_compressed(os.path.join(HERE, "trainer.npz"), **rec)
+    print("trainer", rec["lr1"], rec["lr2"], rec["avg_loss1"], rec["avg_loss2"])
+
+
+if __name__ == "__main__":
+    _shim()
+    torch.set_num_threads(8)
+    module_cases()
+    cell_case()
+    model_case("c1_B2_L16_dr1024", 2, 16, 1024, False, 0, True)
+    model_case("c1r_B3_L12_dr768_ragged", 3, 12, 768, True, 1, True)
+    model_case("c2_B32_L128_dr768", 32, 128, 768, False, 2, False)
+    trainer_case()

@@ -1,0 +1,101 @@
+"""Pin the CPU oracle (oracle/ref_cpu.py) against golden vectors produced by the reference itself
+(tests/golden/make_golden.py, run in the build container with /root/reference importable).
+
+CPU only.  Tolerances: the oracle is a re-ordering of the same fp32 torch ops, so agreement is ~1e-6;
+the stated gate is 2e-5 on log-probs (the reference's own fp32-vs-fp64 noise is up to 4.7e-5).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+
+torch.set_num_threads(min(8, os.cpu_count() or 1))
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _t(a):
+    return torch.tensor(np.asarray(a))
+
+
+def test_modules(golden_dir):
+    g = _g(golden_dir, "modules.npz")
+    P = O.seeded_params(seed=4)
+    c2, h2 = O.lsthm1(P, "marn_cell_f.lsthm_l.", _t(g["lsthm_x"]), _t(g["lsthm_c"]), _t(g["lsthm_h"]),
+                      _t(g["lsthm_z"]), _t(g["lsthm_s"]))
+    np.testing.assert_allclose(c2.numpy(), g["lsthm_c2"], atol=2e-6)
+    np.testing.assert_allclose(h2.numpy(), g["lsthm_h2"], atol=2e-6)
+    o = O.cross_attention(P, "marn_cell_f.crossatt_l2a.", _t(g["ca_x1"]), _t(g["ca_x2"]))
+    np.testing.assert_allclose(o.numpy(), g["ca_out"], atol=2e-6)
+    o = O.cross_attention_seq(P, "crossatt_l2a.", _t(g["ca2_x1"]), _t(g["ca2_x2"]))
+    np.testing.assert_allclose(o.numpy(), g["ca2_out"], atol=5e-6)
+    o = O.cross_attention_seq(P, "crossatt_l2a_1.", _t(g["ca2_x1"]), _t(g["ca3_x2"]))
+    np.testing.assert_allclose(o.numpy(), g["ca3_out"], atol=5e-6)
+    eo, ea = O.encoder_layer(P, "encoder_l.", _t(g["enc_x"]))
+    np.testing.assert_allclose(eo.numpy(), g["enc_out"], atol=5e-6)
+    np.testing.assert_allclose(ea.numpy(), g["enc_attn"], atol=2e-6)
+    PS = {k[len("sa_p/"):]: _t(g[k]) for k in g.files if k.startswith("sa_p/")}
+    o = O.self_attention_lib(PS, "", _t(g["sa_q"]), _t(g["sa_k"]), _t(g["sa_k"]), 4, 16, 16)
+    np.testing.assert_allclose(o.numpy(), g["sa_out"], atol=2e-6)
+    o = O.self_attention_lib(PS, "", _t(g["sa_q"]), _t(g["sa_k"]), _t(g["sa_k"]), 4, 16, 16,
+                             attention_mask=_t(g["sa_mask"]), attention_weights=_t(g["sa_w"]))
+    np.testing.assert_allclose(o.numpy(), g["sa_out_mw"], atol=2e-6)
+
+
+def _check_grads(g, named, atol_rel=2e-4):
+    for name, p in named:
+        gn = float(g["gnorm/" + name])
+        if gn < 0:
+            assert p.grad is None or float(p.grad.abs().sum()) == 0.0, f"{name} should be dead"
+            continue
+        assert p.grad is not None, name
+        got = p.grad.double().reshape(-1)
+        assert abs(float(got.norm()) - gn) <= atol_rel * max(gn, 1e-3), (name, float(got.norm()), gn)
+        idx = g["gidx/" + name]
+        np.testing.assert_allclose(got[idx].numpy(), g["gval/" + name], atol=atol_rel * max(gn, 1e-3), err_msg=name)
+
+
+def test_marn_cell(golden_dir):
+    g = _g(golden_dir, "cell_T24_N6.npz")
+    P = {k: v.clone().requires_grad_(True) for k, v in O.seeded_params(seed=3).items() if k.startswith("marn_cell_f.")}
+    x_l = _t(g["x_l"]).requires_grad_(True)
+    x_a = _t(g["x_a"]).requires_grad_(True)
+    h = O.marn_cell(P, "marn_cell_f.", x_l, x_a, _t(g["qmask"]))
+    np.testing.assert_allclose(h.detach().numpy(), g["h"], atol=3e-6)
+    (h * _t(g["wsum"])).sum().backward()
+    np.testing.assert_allclose(x_l.grad.numpy(), g["dx_l"], atol=2e-5)
+    np.testing.assert_allclose(x_a.grad.numpy(), g["dx_a"], atol=2e-5)
+    _check_grads(g, [(k[len("marn_cell_f."):], v) for k, v in P.items()])
+
+
+@pytest.mark.parametrize("name", ["model_c1_B2_L16_dr1024.npz", "model_c1r_B3_L12_dr768_ragged.npz",
+                                  "model_c2_B32_L128_dr768.npz"])
+def test_model(golden_dir, name):
+    g = _g(golden_dir, name)
+    B, L, d_r, seed, ragged = int(g["B"]), int(g["L"]), int(g["d_r"]), int(g["seed"]), bool(g["ragged"])
+    P = {k: v.clone().requires_grad_(True) for k, v in O.seeded_params(seed=seed, d_r=d_r).items()}
+    x, qmask, umask, label = O.seeded_batch(B, L, d_r=d_r, seed=seed + 1, ragged=ragged)
+    lp, x_l, x_a = O.marn1_sps_forward(P, x, qmask, umask, d_r=d_r)
+    loss = O.masked_nll(lp, label.view(-1), umask)
+    loss.backward()
+    lpn = lp.detach().numpy()
+    rows = g["rows"] if "rows" in g.files else np.arange(lpn.shape[0])
+    err = np.abs(lpn[rows] - g["logits"]).max()
+    assert err < 2e-5, err
+    assert abs(float(loss) - float(g["loss"])) < 2e-6
+    # bit-exact argmax wherever the reference's own top-1/top-2 margin exceeds 2x the tolerance
+    safe = g["margin"] > 4e-5
+    assert (lpn.argmax(1)[safe] == g["argmax"][safe]).all()
+    assert abs(float(x_l.double().sum()) - float(g["x_l_sum"])) < 1e-3 * max(1.0, float(g["x_l_abs"]) * 1e-3)
+    _check_grads(g, list(P.items()))
+
+
+def test_trainer_lr_schedule(golden_dir):
+    g = _g(golden_dir, "trainer.npz")
+    assert O.step_lr(1e-3, 0.98, 1, 1) == pytest.approx(float(g["lr1"]), rel=1e-12)
+    assert O.step_lr(1e-3, 0.98, 1, 2) == pytest.approx(float(g["lr2"]), rel=1e-12)
