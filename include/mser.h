@@ -1,0 +1,183 @@
+/* libmser -- C-ABI of the MI355X-native speaker-aware LSTHM hot path.
+ *
+ * The reference (MallVilliers/Multimodal-Framework-for-speaker-emotion-recognition) is pure Python/PyTorch and has NO
+ * FFI of its own; the drop-in boundary is its nn.Module surface.  This header is the boundary the
+ * replacement puts *under* that surface: every entry point takes raw device pointers owned by the caller (PyTorch
+ * tensors on the Python side), explicit sizes/strides and a hipStream_t; it never allocates, frees or synchronises,
+ * returns 0 on success and a non-zero code otherwise (message via mser_last_error()).  No torch types cross it.
+ *
+ * Each entry names the reference code it replaces (path:line relative to the reference checkout).
+ * Layout conventions: activations are TIME-MAJOR row matrices, row r = t*B + b (the reference's [L,B,D]),
+ * fp32, innermost dimension contiguous unless a leading dimension ("ld", in elements) is given.
+ */
+#ifndef MSER_H_
+#define MSER_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mser_stream_t; /* hipStream_t */
+
+#define MSER_VERSION 100
+
+int mser_version(void);
+const char* mser_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Generic strided batched fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chains).
+ *   C[z1,z2][m,n] (+)= epilogue( alpha * (*alpha_dev) * sum_k A[z1,z2][m,k] * B[z1,z2][k,n] )
+ *   epilogue(v) = relu?( v + bias[n] ) + R1[m,n] + R2[m,n]
+ * Replaces every nn.Linear / torch.matmul on the path (model/lsthm_sps.py:29-32,64-70,93-99,121-127,
+ * 316,321,324,353; model/encoder.py:37-39,53,74,84,105).
+ * ------------------------------------------------------------------------------------------------ */
+enum { MSER_GEMM_RELU = 1, MSER_GEMM_ACCUM = 2 };
+
+typedef struct mser_gemm_desc {
+  const float* A;
+  const float* B;
+  float* C;
+  int32_t M, N, K;
+  int64_t sAm, sAk;       /* element strides of A[m,k] */
+  int64_t sBk, sBn;       /* element strides of B[k,n] */
+  int64_t ldc;            /* row stride of C (n contiguous) */
+  int32_t batch1, batch2; /* >= 1 */
+  int64_t sA1, sA2, sB1, sB2, sC1, sC2;
+  const float* bias;      /* [N] or NULL */
+  const float* alpha_dev; /* device scalar or NULL */
+  float alpha;
+  int32_t flags;          /* MSER_GEMM_* */
+  int32_t splitk;         /* >= 1; > 1 accumulates with float atomics (C must be pre-initialised) */
+  const float* R1;        /* residuals, same indexing as C with row stride ldr1/ldr2; or NULL */
+  const float* R2;
+  int64_t ldr1, ldr2;
+  int64_t sR1_1, sR1_2;   /* batch strides of R1 (R2 shares them) */
+} mser_gemm_desc;
+
+int mser_gemm(const mser_gemm_desc* d, mser_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row kernels.
+ * ------------------------------------------------------------------------------------------------ */
+/* in-place softmax over the last dim of S[rows,n] (row stride ld); optional multiplicative weights `mul`
+ * and byte mask `mask` (same indexing as S): where mask[i]==mask_on the logit is replaced by `fill`
+ * BEFORE the softmax (model/encoder.py:75-80 uses mask==0 -> -1e9; attention:/SelfAttention.py:67-71
+ * uses weights then mask==1 -> -inf). */
+int mser_softmax_rows(float* S, int64_t rows, int32_t n, int64_t ld, const float* mul, const uint8_t* mask,
+                      int32_t mask_on, float fill, mser_stream_t stream);
+/* dS = P * (dP - sum_j P*dP) (* mul), written over dP. */
+int mser_softmax_bwd_rows(const float* P, float* dP, int64_t rows, int32_t n, int64_t ld, const float* mul,
+                          mser_stream_t stream);
+/* y = LayerNorm(x + res) * gamma + beta over D (model/encoder.py:56-58, 109-111); saves mean/rstd [rows].
+ * `sum_out` (optional) receives x + res (needed by the backward). res may be NULL. */
+int mser_add_layernorm_fwd(const float* x, int64_t ldx, const float* res, int64_t ldres, const float* gamma,
+                           const float* beta, float* y, float* sum_out, float* mean, float* rstd, int64_t rows,
+                           int32_t D, float eps, mser_stream_t stream);
+/* dx = LN backward wrt the summed input; dgamma/dbeta are ACCUMULATED (float atomics). */
+int mser_layernorm_bwd(const float* dy, const float* xsum, const float* mean, const float* rstd,
+                       const float* gamma, float* dx, float* dgamma, float* dbeta, int64_t rows, int32_t D,
+                       mser_stream_t stream);
+/* out[n] += sum_m X[m,n] */
+int mser_colsum_acc(const float* X, int64_t rows, int32_t n, int64_t ld, float* out, mser_stream_t stream);
+/* dY *= (Y > 0) */
+int mser_relu_bwd(float* dY, const float* Y, int64_t count, mser_stream_t stream);
+/* out[r, :D] = a[r, :D] (+ b[r, :D]); b may be NULL */
+int mser_add_rows(float* out, int64_t ldo, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows,
+                  int32_t D, mser_stream_t stream);
+/* acc[r,:D] += (*s_dev) * t[r,:D];  *ds += <t, x>   (gradient of y = s * x w.r.t. x and the scalar s;
+ * replaces autograd through `self.w * x_l` etc., model/lsthm_sps.py:377-383). s_dev/ds may be NULL (s = 1). */
+int mser_scale_acc_dot(float* acc, int64_t ldacc, const float* t, int64_t ldt, const float* x, int64_t ldx,
+                       const float* s_dev, float* ds, int64_t rows, int32_t D, mser_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sequence bookkeeping (model/lsthm_sps.py:396-409 _reverse_seq; :177 argmax; :238-259 _select_parties).
+ * ------------------------------------------------------------------------------------------------ */
+/* lens[b] = sum_t umask[b,t];  rev[t,b] = lens[b]-1-t if t < lens[b] else -1   (rev is int32 [L,B]) */
+int mser_build_reverse_index(const float* umask, int32_t B, int32_t L, int32_t* lens, int32_t* rev,
+                             mser_stream_t stream);
+/* out[t,b,:D] = rev[t,b] >= 0 ? X[rev[t,b], b, :D] : 0 */
+int mser_reverse_by_length(const float* X, int64_t ldx, const int32_t* rev, float* out, int64_t ldo, int32_t L,
+                           int32_t B, int32_t D, mser_stream_t stream);
+/* Slot tables for the speaker recurrence from qmask[T,B,2] (optionally read through `rev`, i.e. the reversed
+ * dialogue): party[t,b] (argmax, ties -> 0), perm[t,r] = dialogue landing in row r of the (party-0 || party-1)
+ * ordering, n0[t].  qm_out[t,b,2] receives the (possibly reversed) mask values used by the blend (:204-207). */
+int mser_build_slot_tables(const float* qmask, const int32_t* rev, int32_t T, int32_t B, int32_t* party,
+                           int32_t* perm, int32_t* n0, float* qm_out, mser_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * MARN_cell (model/lsthm_sps.py:132-221): speaker recurrence + LSTHM recurrence + per-step rank-1 attention.
+ * One call runs `ndir` independent cells (forward / backward direction) in the same launches.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct mser_cell_params {      /* one direction; pointers into the parameter (or gradient) storage */
+  float* lsthm_W[2];  float* lsthm_Wb[2];   /* [4H,D], [4H]   index 0 = lsthm_l, 1 = lsthm_a  (:16) */
+  float* lsthm_U[2];  float* lsthm_Ub[2];   /* [4H,H]                                          (:17) */
+  float* lsthm_V[2];  float* lsthm_Vb[2];   /* [4H,H]                                          (:18) */
+  float* lsthm_S[2];  float* lsthm_Sb[2];   /* [4H,Hs]                                         (:19) */
+  float* q_Wih[2];    float* q_Whh[2];      /* [4Hs,Hs] nn.LSTMCell lstm_q0 / lstm_q1          (:147-148) */
+  float* q_bih[2];    float* q_bhh[2];      /* [4Hs] */
+  float* att_Wq;      float* att_Wk;        /* [H] crossatt_l2a.Wq / .Wk                       (:53-54) */
+} mser_cell_params;
+
+typedef struct mser_cell_dir {
+  mser_cell_params p;          /* parameters */
+  mser_cell_params g;          /* gradients (accumulated); used by the backward only */
+  const float* qmask;          /* [T,B,2] natural time order */
+  const int32_t* rev;          /* NULL for the forward direction; rev[t,b] (mser_build_reverse_index) for the backward */
+  float* out;                  /* h rows written at natural time position: out[(tau*B+b)*ldo + 0..3H+Hs) = h_l|h_a|z|h_q */
+  float* dout;                 /* gradient of `out`, same indexing (backward only) */
+} mser_cell_dir;
+
+typedef struct mser_cell_desc {
+  int32_t T, B, D, H;          /* Hs == H (the reference feeds zeros(N,dh_q=dh_l) to LSTMCell(dh_s,dh_s), :147,:162) */
+  int32_t ndir;                /* 1 or 2 */
+  const float* x_l; int64_t ldxl;   /* [T*B, D] natural order, shared by the directions */
+  const float* x_a; int64_t ldxa;
+  float* dx_l; float* dx_a;    /* [T*B, D] contiguous, ACCUMULATED (backward only) */
+  int64_t ldo;                 /* row stride of out / dout */
+  mser_cell_dir dir[2];
+  void* workspace;             /* mser_marn_cell_workspace_bytes(); holds everything saved for the backward */
+  size_t workspace_bytes;
+} mser_cell_desc;
+
+size_t mser_marn_cell_workspace_bytes(int32_t T, int32_t B, int32_t D, int32_t H, int32_t ndir);
+int mser_marn_cell_fwd(const mser_cell_desc* d, mser_stream_t stream);
+int mser_marn_cell_bwd(const mser_cell_desc* d, mser_stream_t stream);
+
+/* Single LSTHM1 step (model/lsthm_sps.py:28-44) and single rank-1 CrossAttention (:59-72) for the module-level API. */
+int mser_lsthm_step_fwd(const float* x, const float* c, const float* h, const float* z, const float* s,
+                        const float* W, const float* Wb, const float* U, const float* Ub, const float* V,
+                        const float* Vb, const float* S, const float* Sb, float* c_out, float* h_out, float* gates,
+                        int32_t B, int32_t D, int32_t H, int32_t Hz, int32_t Hs, mser_stream_t stream);
+int mser_rank1_attention_fwd(const float* x1, const float* x2, const float* Wq, const float* Wk, float* out,
+                             int32_t B, int32_t H, mser_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Head: log_softmax + permute to batch-major (model/lsthm_sps.py:391-393) and MaskedLoss (loss.py:13-21).
+ * ------------------------------------------------------------------------------------------------ */
+/* lp[b*L+t, :C] = log_softmax(y[t*B+b, :C]) */
+int mser_logsoftmax_tb_fwd(const float* y, float* lp, int32_t L, int32_t B, int32_t C, mser_stream_t stream);
+/* dy[t*B+b,:] = dlp[b*L+t,:] - exp(lp[b*L+t,:]) * sum_c dlp[b*L+t,c] */
+int mser_logsoftmax_tb_bwd(const float* dlp, const float* lp, float* dy, int32_t L, int32_t B, int32_t C,
+                           mser_stream_t stream);
+/* loss = -sum_r mask[r]*pred[r,target[r]] / sum(mask);  loss_out[0] = loss, loss_out[1] = sum(mask) */
+int mser_masked_nll_fwd(const float* pred, const int64_t* target, const float* mask, int64_t rows, int32_t C,
+                        float* loss_out, mser_stream_t stream);
+/* dpred[r,c] = -(*gscale_dev) * mask[r] / sum(mask) * (c == target[r]) */
+int mser_masked_nll_bwd(const int64_t* target, const float* mask, const float* loss_out, const float* gscale_dev,
+                        float* dpred, int64_t rows, int32_t C, mser_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser over the flat parameter buffer: torch.optim.Adam(lr, weight_decay=wd) (model_trainer.py:82).
+ * `live` (optional, uint8 per element) marks elements that own a gradient; dead parameters are skipped like
+ * torch skips tensors whose .grad is None.  gscale multiplies the gradient first (data-parallel mean).
+ * ------------------------------------------------------------------------------------------------ */
+int mser_adam_flat(float* p, const float* g, float* m, float* v, const uint8_t* live, int64_t n, int32_t step,
+                   float lr, float beta1, float beta2, float eps, float wd, float gscale, mser_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSER_H_ */

@@ -1,0 +1,998 @@
+// MARN_cell on gfx950: speaker-state recurrence + LSTHM recurrence + per-step rank-1 cross-modal attention,
+// forward and backward (BPTT).  Replaces model/lsthm_sps.py:132-221, :28-44, :59-72, :238-259 of the reference.
+//
+// Structure (DESIGN.md "recurrent path"):
+//  * The speaker recurrence (two per-party nn.LSTMCell states indexed by compaction slot) depends on qmask only, so
+//    it runs as its own chain first and its outputs h_q[t] are folded, together with W x[t], into one big
+//    pre-activation GEMM outside the time loop.  Only  U h + V z  remains inside the loop.
+//  * Every time step is an all-to-all seam between workgroups (each workgroup owns a slice of hidden units but needs
+//    every unit of h/z for the next step).  On MI355X a dependent kernel boundary (~1.5 us) is cheaper than an
+//    in-launch grid barrier (~4-7 us) or an all-gather hand-off (~2.4-4 us) -- MI355X_MICROARCH.md price list, rows
+//    "boundary", "barrier-xcd", "allgather" -- so the chain is cut into per-step launches (captured into one hipGraph
+//    by the host) and both directions share each launch.
+//  * A step's matvec is a 32(rows) x 32(cols) x K tile per workgroup: 16 waves split K, each wave runs a short chain of
+//    v_mfma_f32_32x32x2_f32 with operands loaded straight from L2 (weights stay L2-resident per XCD because the
+//    blockIdx -> weight-slice mapping is static), partials are reduced through LDS in a fixed order (deterministic),
+//    and the gate non-linearities run as the epilogue of the same workgroup.
+//  * The rank-1 attention never materialises the reference's [B,H,H] tensors: logits[i,j] = c_l[i] * s * Wk[j] with
+//    s = <Wq, c_a>/sqrt(H); the row maximum is analytic (u * max(Wk) or u * min(Wk)), so one pass suffices.
+#include "common.h"
+#include "../../include/mser.h"
+#include <cstring>
+
+namespace mser {
+
+int gemm(const mser_gemm_desc& d, hipStream_t s);   // gemm.hip
+
+struct DirP {
+  // parameters
+  const float *W[2], *Wb[2], *U[2], *Ub[2], *V[2], *Vb[2], *S[2], *Sb[2];
+  const float *Wih[2], *Whh[2], *bih[2], *bhh[2];
+  const float *attWq, *attWk;
+  // tables (direction time order)
+  int *party, *perm, *rowof, *n0;
+  const int* rev;
+  float* qm;
+  // saved by the forward
+  float *qsel, *hq_state, *cq_state, *sgates, *HQ;
+  float *pre, *gates, *cstate, *hz;
+  float* out;
+  const float* dout;
+  // backward scratch
+  float *dgates, *dc_carry, *dA, *attacc, *dHQ;
+  float *dsg, *raw_ih, *dhprev, *dcprev, *dh0;
+};
+
+struct CellK {
+  int T, B, D, H, ndir, nmb;
+  long ldo;
+  DirP d[2];
+};
+
+constexpr int RED_FLOATS = 16 * 1024;
+
+// 32 x 32 x K product by one 1024-thread workgroup; result (row-major [32][32]) left in tile[], all threads synced.
+// aload(r, k, a[8]) must return A[row r][k..k+7]; bload(n, k, b[8]) must return B[k..k+7][col n].
+template <class ALoad, class BLoad>
+__device__ __forceinline__ void wg_mm32(int K, ALoad aload, BLoad bload, float* red, float* tile) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int KC = ((K + 255) / 256) * 16;   // per-wave K chunk (multiple of 16)
+  f32x16 acc = {0};
+  const int kend = min(K, (wave + 1) * KC);
+  for (int kb = wave * KC; kb < kend; kb += 16) {
+    float a[8], b[8];
+    aload(r, kb + half * 8, a);
+    bload(r, kb + half * 8, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
+    red[wave * 1024 + row * 32 + r] = acc[i];
+  }
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) s += red[w * 1024 + tid];
+  tile[tid] = s;
+  __syncthreads();
+}
+
+__device__ __forceinline__ void load8(const float* p, float* a) {
+  const float4 v0 = *reinterpret_cast<const float4*>(p);
+  const float4 v1 = *reinterpret_cast<const float4*>(p + 4);
+  a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w;
+  a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+}
+__device__ __forceinline__ void zero8(float* a) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = 0.f;
+}
+
+// ================================================================================================ speaker forward
+// grid (H/8, 2 cells, ndir*nmb), block 1024.  One nn.LSTMCell (gate order i,f,g,o) step for 8 hidden units of one party
+// cell over a block of 32 compaction slots.  q_sel is rebuilt on the fly from the previous step's saved rows:
+//   q_{t-1}[b,c] = (1-m_{t-1}[b,c]) * h0_{t-1}[b] + m_{t-1}[b,c] * hq_{t-1}[b]           (model/lsthm_sps.py:204-207)
+__global__ __launch_bounds__(1024) void spk_fwd_step(CellK P, int t) {
+  extern __shared__ float smem[];
+  float* red = smem;
+  float* tile = smem + RED_FLOATS;
+  const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
+  const DirP& D = P.d[dir];
+  const int c = blockIdx.y, u0 = blockIdx.x * 8;
+  const int H = P.H, B = P.B, T = P.T;
+  const int N0 = D.n0[t];
+  const int Nc = c ? B - N0 : N0, off = c ? N0 : 0;
+  const long SB = (long)B * H;
+  float* hq_new = D.hq_state + ((long)c * (T + 1) + t + 1) * SB;
+  float* cq_new = D.cq_state + ((long)c * (T + 1) + t + 1) * SB;
+  const float* hq_old = hq_new - SB;
+  const float* cq_old = cq_new - SB;
+  float* sg = D.sgates + ((long)c * T + t) * B * 4 * H;
+  float* qs = D.qsel + ((long)c * T + t) * SB;
+  const int tid = threadIdx.x;
+
+  if (Nc == 0) {   // `if N0:` / `if N1:` false -> the cell is not stepped (:180,:185); carry its state
+    if (tid < 256) {
+      const int slot = mb * 32 + (tid >> 3), u = u0 + (tid & 7);
+      if (slot < B) {
+        hq_new[(long)slot * H + u] = hq_old[(long)slot * H + u];
+        cq_new[(long)slot * H + u] = cq_old[(long)slot * H + u];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) sg[(long)slot * 4 * H + g * H + u] = 0.f;
+      }
+    }
+    if (blockIdx.x == 0)
+      for (int e = tid; e < 32 * H; e += 1024) {
+        const int slot = mb * 32 + e / H;
+        if (slot < B) qs[(long)slot * H + e % H] = 0.f;
+      }
+    return;
+  }
+
+  const int N0p = t > 0 ? D.n0[t - 1] : 0;
+  const bool writer = blockIdx.x == 0;
+  auto aload = [&](int r, int k, float* a) {
+    const int slot = mb * 32 + r;
+    if (slot >= B) { zero8(a); return; }
+    if (k < H) {
+      if (slot < Nc && t > 0) {
+        const int b = D.perm[(long)t * B + off + slot];
+        const float m = D.qm[((long)(t - 1) * B + b) * 2 + c];
+        const float* h0 = (b < N0p) ? D.qsel + ((long)(0 * T + t - 1) * B + b) * H
+                                    : D.qsel + ((long)(1 * T + t - 1) * B + (b - N0p)) * H;
+        const float* hq = D.HQ + ((long)(t - 1) * B + b) * H;
+        float x0[8], x1[8];
+        load8(h0 + k, x0);
+        load8(hq + k, x1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = x0[j] * (1.f - m) + x1[j] * m;
+      } else {
+        zero8(a);
+      }
+      if (writer) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qs[(long)slot * H + k + j] = a[j];
+      }
+    } else {
+      load8(hq_old + (long)slot * H + (k - H), a);
+    }
+  };
+  auto bload = [&](int n, int k, float* b) {
+    const long wrow = (long)(n >> 3) * H + u0 + (n & 7);
+    if (k < H) load8(D.Wih[c] + wrow * H + k, b);
+    else load8(D.Whh[c] + wrow * H + (k - H), b);
+  };
+  wg_mm32(2 * H, aload, bload, red, tile);
+
+  {
+    const int n = tid & 31;
+    const long wrow = (long)(n >> 3) * H + u0 + (n & 7);
+    tile[tid] += D.bih[c][wrow] + D.bhh[c][wrow];
+  }
+  __syncthreads();
+  if (tid < 256) {
+    const int rr = tid >> 3, uu = tid & 7;
+    const int slot = mb * 32 + rr, u = u0 + uu;
+    if (slot < B) {
+      const float gi = sigmoidf_(tile[rr * 32 + 0 + uu]);
+      const float gf = sigmoidf_(tile[rr * 32 + 8 + uu]);
+      const float gg = tanhf(tile[rr * 32 + 16 + uu]);
+      const float go = sigmoidf_(tile[rr * 32 + 24 + uu]);
+      const float cn = gf * cq_old[(long)slot * H + u] + gi * gg;
+      const float hn = go * tanhf(cn);
+      cq_new[(long)slot * H + u] = cn;
+      hq_new[(long)slot * H + u] = hn;
+      float* g = sg + (long)slot * 4 * H + u;
+      g[0] = gi; g[H] = gf; g[2 * H] = gg; g[3 * H] = go;
+      if (slot < Nc) D.HQ[((long)t * B + off + slot) * H + u] = hn;   // h_q = cat[h_q0[:N0], h_q1[:N1]] (:192)
+    }
+  }
+}
+
+// ================================================================================================ LSTHM forward
+// grid (H/8, 2 streams, ndir*nmb), block 1024.  gates = pre[t] + U h_{t-1} + V z_{t-1} (+ U.bias + V.bias), order f,i,o,c~.
+__global__ __launch_bounds__(1024) void lsthm_fwd_gates(CellK P, int t) {
+  extern __shared__ float smem[];
+  float* red = smem;
+  float* tile = smem + RED_FLOATS;
+  const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
+  const DirP& D = P.d[dir];
+  const int m = blockIdx.y, u0 = blockIdx.x * 8;
+  const int H = P.H, B = P.B, T = P.T;
+  const float* hz_old = D.hz + (long)t * B * 3 * H;
+  float* hz_new = D.hz + (long)(t + 1) * B * 3 * H;
+  const float* c_old = D.cstate + ((long)m * (T + 1) + t) * B * H;
+  float* c_new = D.cstate + ((long)m * (T + 1) + t + 1) * B * H;
+  const int tid = threadIdx.x;
+
+  auto aload = [&](int r, int k, float* a) {
+    const int b = mb * 32 + r;
+    if (b >= B) { zero8(a); return; }
+    const float* row = hz_old + (long)b * 3 * H;
+    if (k < H) load8(row + m * H + k, a);
+    else load8(row + 2 * H + (k - H), a);
+  };
+  auto bload = [&](int n, int k, float* bb) {
+    const long wrow = (long)(n >> 3) * H + u0 + (n & 7);
+    if (k < H) load8(D.U[m] + wrow * H + k, bb);
+    else load8(D.V[m] + wrow * H + (k - H), bb);
+  };
+  wg_mm32(2 * H, aload, bload, red, tile);
+
+  {
+    const int rr = tid >> 5, n = tid & 31;
+    const int b = mb * 32 + rr;
+    const long wrow = (long)(n >> 3) * H + u0 + (n & 7);
+    if (b < B) tile[tid] += D.pre[((long)m * T * B + (long)t * B + b) * 4 * H + wrow] + D.Ub[m][wrow] + D.Vb[m][wrow];
+  }
+  __syncthreads();
+  if (tid < 256) {
+    const int rr = tid >> 3, uu = tid & 7;
+    const int b = mb * 32 + rr, u = u0 + uu;
+    if (b < B) {
+      const float gf = sigmoidf_(tile[rr * 32 + 0 + uu]);
+      const float gi = sigmoidf_(tile[rr * 32 + 8 + uu]);
+      const float go = sigmoidf_(tile[rr * 32 + 16 + uu]);
+      const float gc = tanhf(tile[rr * 32 + 24 + uu]);
+      const float cn = gf * c_old[(long)b * H + u] + gi * gc;
+      const float hn = tanhf(cn) * go;
+      c_new[(long)b * H + u] = cn;
+      hz_new[(long)b * 3 * H + m * H + u] = hn;
+      float* g = D.gates + ((long)m * T * B + (long)t * B + b) * 4 * H + u;
+      g[0] = gf; g[H] = gi; g[2 * H] = go; g[3 * H] = gc;
+      const int tau = D.rev ? D.rev[(long)t * B + b] : t;
+      if (tau >= 0) D.out[((long)tau * B + b) * P.ldo + m * H + u] = hn;
+    }
+  }
+}
+
+// block-wide helpers for the row kernels (blockDim = NT threads, NT/64 waves)
+__device__ __forceinline__ float block_sum(float v, float* sh, int nw) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int w = 0; w < nw; ++w) s += sh[w];
+  return s;
+}
+__device__ __forceinline__ float block_max(float v, float* sh, int nw) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = -INFINITY;
+  for (int w = 0; w < nw; ++w) s = fmaxf(s, sh[w]);
+  return s;
+}
+
+// grid (B, ndir), block NT = max(512,H) threads.  z[b,i] = sum_j softmax_j(c_l[i] * s_b * Wk[j]) c_a[j]   (:59-72, rank-1 form)
+// LDS: ca[H] wk[H] part[2][NT] sh[16]
+__global__ __launch_bounds__(1024) void lsthm_fwd_z(CellK P, int t) {
+  extern __shared__ float smem[];
+  const int H = P.H, B = P.B, T = P.T;
+  const int NT = blockDim.x, Q = NT / H, JC = H / Q;
+  float* ca = smem;
+  float* wk = ca + H;
+  float* pZ = wk + H;
+  float* pN = pZ + NT;
+  float* sh = pN + NT;
+  const int b = blockIdx.x, dir = blockIdx.y;
+  const DirP& D = P.d[dir];
+  const int tid = threadIdx.x, nw = NT >> 6;
+  const float* c_l = D.cstate + ((long)0 * (T + 1) + t + 1) * B * H + (long)b * H;
+  const float* c_a = D.cstate + ((long)1 * (T + 1) + t + 1) * B * H + (long)b * H;
+  float sp = 0.f, wmx = -INFINITY, wmn = INFINITY;
+  for (int k = tid; k < H; k += NT) {
+    const float cv = c_a[k], w = D.attWk[k];
+    ca[k] = cv;
+    wk[k] = w;
+    sp += D.attWq[k] * cv;
+    wmx = fmaxf(wmx, w);
+    wmn = fminf(wmn, w);
+  }
+  const float s = block_sum(sp, sh, nw) / sqrtf((float)H);
+  wmx = block_max(wmx, sh, nw);
+  wmn = -block_max(-wmn, sh, nw);
+  const int i = tid % H, q = tid / H;
+  const float u = c_l[i] * s;
+  const float mx = (u >= 0.f) ? u * wmx : u * wmn;
+  float Z = 0.f, N = 0.f;
+  for (int j = q * JC; j < (q + 1) * JC; ++j) {
+    const float e = expf(u * wk[j] - mx);
+    Z += e;
+    N += e * ca[j];
+  }
+  pZ[tid] = Z;
+  pN[tid] = N;
+  __syncthreads();
+  if (q == 0) {
+    for (int qq = 1; qq < Q; ++qq) { Z += pZ[qq * H + i]; N += pN[qq * H + i]; }
+    const float z = N / Z;
+    D.hz[((long)(t + 1) * B + b) * 3 * H + 2 * H + i] = z;
+    const int tau = D.rev ? D.rev[(long)t * B + b] : t;
+    if (tau >= 0) {
+      float* o = D.out + ((long)tau * B + b) * P.ldo;
+      o[2 * H + i] = z;
+      o[3 * H + i] = D.HQ[((long)t * B + b) * H + i];      // all_hs = cat[h_l, h_a, z_l, h_q] (:218)
+    }
+  }
+}
+
+// ================================================================================================ LSTHM backward
+// Row kernel: grid (B, ndir), block NT.  Attention backward (recomputing the softmax), then the gate backward for both
+// streams.  Writes dgates[t], the dc carry, dHQ[t] (the h_q part of dout) and accumulates the attention-vector grads of
+// its own row (reduced over rows once after the chain).
+// LDS floats: ca cl wk wq ua ma aa wa za (9H) + part[3][NT] + sh[16]
+__global__ __launch_bounds__(1024) void lsthm_bwd_row(CellK P, int t) {
+  extern __shared__ float smem[];
+  const int H = P.H, B = P.B, T = P.T;
+  const int NT = blockDim.x, Q = NT / H, JC = H / Q;
+  float* ca = smem;          float* cl = ca + H;   float* wk = cl + H;   float* wq = wk + H;
+  float* ua = wq + H;        float* ma = ua + H;   float* aa = ma + H;   float* wa = aa + H;   float* za = wa + H;
+  float* p0 = za + H;        float* p1 = p0 + NT;  float* p2 = p1 + NT;  float* sh = p2 + NT;
+  const int b = blockIdx.x, dir = blockIdx.y;
+  const DirP& D = P.d[dir];
+  const int tid = threadIdx.x, nw = NT >> 6;
+  const long rowt = (long)t * B + b;
+  const float* c_l = D.cstate + ((long)0 * (T + 1) + t + 1) * B * H + (long)b * H;
+  const float* c_a = D.cstate + ((long)1 * (T + 1) + t + 1) * B * H + (long)b * H;
+  const float* zrow = D.hz + ((long)(t + 1) * B + b) * 3 * H + 2 * H;
+  const int tau = D.rev ? D.rev[rowt] : t;
+  const float* dorow = (tau >= 0) ? D.dout + ((long)tau * B + b) * P.ldo : nullptr;
+  const bool last = (t == T - 1);
+  const float* dA = D.dA + (long)b * H;          // [4][B][H]: U_l, V_l, U_a, V_a products of step t+1
+  const long SA = (long)B * H;
+  const float rsH = 1.0f / sqrtf((float)H);
+
+  float sp = 0.f, wmx = -INFINITY, wmn = INFINITY;
+  for (int k = tid; k < H; k += NT) {
+    const float cv = c_a[k], w = D.attWk[k], wqv = D.attWq[k];
+    ca[k] = cv; wk[k] = w; wq[k] = wqv; cl[k] = c_l[k];
+    sp += wqv * cv;
+    wmx = fmaxf(wmx, w);
+    wmn = fminf(wmn, w);
+  }
+  const float s = block_sum(sp, sh, nw) * rsH;
+  wmx = block_max(wmx, sh, nw);
+  wmn = -block_max(-wmn, sh, nw);
+
+  const int i = tid % H, q = tid / H;
+  // ---- pass 1: per output unit i, sums over j
+  const float u = cl[i] * s;
+  const float mx = (u >= 0.f) ? u * wmx : u * wmn;
+  float Z = 0.f, N2 = 0.f, N3 = 0.f;
+  for (int j = q * JC; j < (q + 1) * JC; ++j) {
+    const float e = expf(u * wk[j] - mx);
+    Z += e;
+    N2 += e * ca[j] * wk[j];
+    N3 += e * wk[j];
+  }
+  p0[tid] = Z; p1[tid] = N2; p2[tid] = N3;
+  __syncthreads();
+  float du_cl = 0.f;   // du_i * c_l[i], for ds
+  float dcl_att = 0.f;
+  if (q == 0) {
+    for (int qq = 1; qq < Q; ++qq) { Z += p0[qq * H + i]; N2 += p1[qq * H + i]; N3 += p2[qq * H + i]; }
+    float dz = (dorow ? dorow[2 * H + i] : 0.f);
+    if (!last) dz += dA[1 * SA + i] + dA[3 * SA + i];
+    const float zi = zrow[i];
+    const float du = dz * (N2 - zi * N3) / Z;
+    const float a = dz / Z;
+    ua[i] = u; ma[i] = mx; aa[i] = a; wa[i] = a * u; za[i] = a * u * zi;
+    du_cl = du * cl[i];
+    dcl_att = du * s;
+  }
+  const float ds = block_sum(du_cl, sh, nw);      // includes the barrier that publishes ua..za, p0
+  // ---- pass 2: per key index j, sums over i
+  const int j = i;
+  float S1 = 0.f, S2 = 0.f, S3 = 0.f;
+  {
+    const float wkj = wk[j];
+    for (int ii = q * JC; ii < (q + 1) * JC; ++ii) {
+      const float e = expf(ua[ii] * wkj - ma[ii]);
+      S1 += aa[ii] * e;
+      S2 += wa[ii] * e;
+      S3 += za[ii] * e;
+    }
+  }
+  __syncthreads();
+  p1[tid] = S1; p2[tid] = S2;
+  __syncthreads();
+  float S1t = 0.f, S2t = 0.f;
+  if (q == 0)
+    for (int qq = 0; qq < Q; ++qq) { S1t += p1[qq * H + j]; S2t += p2[qq * H + j]; }
+  __syncthreads();
+  p1[tid] = S3;
+  __syncthreads();
+  if (q == 0) {
+    float S3t = 0.f;
+    for (int qq = 0; qq < Q; ++qq) S3t += p1[qq * H + j];
+    const float dca_att = S1t + ds * wq[j] * rsH;
+    float* acc = D.attacc + (long)b * 2 * H;
+    acc[j] += ds * ca[j] * rsH;                  // dWq[j]
+    acc[H + j] += ca[j] * S2t - S3t;             // dWk[j]
+    // ---- gate backward, both streams (unit i == j)
+    const float* cprev_l = D.cstate + ((long)0 * (T + 1) + t) * B * H + (long)b * H;
+    const float* cprev_a = D.cstate + ((long)1 * (T + 1) + t) * B * H + (long)b * H;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const float* g = D.gates + ((long)m * T * B + rowt) * 4 * H + i;
+      const float gf = g[0], gi = g[H], go = g[2 * H], gc = g[3 * H];
+      float dh = dorow ? dorow[m * H + i] : 0.f;
+      if (!last) dh += dA[(2 * m) * SA + i];
+      const float cc = m ? ca[i] : cl[i];
+      const float tc = tanhf(cc);
+      float* carry = D.dc_carry + (long)m * SA + (long)b * H + i;
+      const float dc = *carry + dh * go * (1.f - tc * tc) + (m ? dca_att : dcl_att);
+      const float cp = m ? cprev_a[i] : cprev_l[i];
+      float* dg = D.dgates + ((long)m * T * B + rowt) * 4 * H + i;
+      dg[0] = dc * cp * gf * (1.f - gf);
+      dg[H] = dc * gc * gi * (1.f - gi);
+      dg[2 * H] = dh * tc * go * (1.f - go);
+      dg[3 * H] = dc * gi * (1.f - gc * gc);
+      *carry = dc * gf;
+    }
+    D.dHQ[rowt * H + i] = dorow ? dorow[3 * H + i] : 0.f;
+  }
+}
+
+// Matvec kernel: grid (H/32, 4 products, ndir*nmb), block 1024.  dA[p][b][n] = sum_col dgates_m[t][b][col] * Wp[col][n]
+// with p = 0: U_l, 1: V_l, 2: U_a, 3: V_a (m = p>>1).  Consumed by lsthm_bwd_row at step t-1.
+__global__ __launch_bounds__(1024) void lsthm_bwd_mat(CellK P, int t) {
+  extern __shared__ float smem[];
+  float* red = smem;
+  float* tile = smem + RED_FLOATS;
+  const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
+  const DirP& D = P.d[dir];
+  const int p = blockIdx.y, m = p >> 1, n0 = blockIdx.x * 32;
+  const int H = P.H, B = P.B, T = P.T;
+  const float* Wp = (p & 1) ? D.V[m] : D.U[m];
+  const float* dg = D.dgates + ((long)m * T * B + (long)t * B) * 4 * H;
+  auto aload = [&](int r, int k, float* a) {
+    const int b = mb * 32 + r;
+    if (b >= B) { zero8(a); return; }
+    load8(dg + (long)b * 4 * H + k, a);
+  };
+  auto bload = [&](int n, int k, float* bb) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bb[j] = Wp[(long)(k + j) * H + n0 + n];
+  };
+  wg_mm32(4 * H, aload, bload, red, tile);
+  const int rr = threadIdx.x >> 5, n = threadIdx.x & 31;
+  const int b = mb * 32 + rr;
+  if (b < B) D.dA[((long)p * B + b) * H + n0 + n] = tile[threadIdx.x];
+}
+
+// ================================================================================================ speaker backward
+// grid (H/32, 4 products, ndir*nmb), block 1024, one launch per step (descending t).
+// product p: cell c = p>>1, (p&1) ? W_hh : W_ih.  Prologue: every workgroup rebuilds the LSTMCell gate gradients of its
+// cell for its 32 slots (element-wise, cheap, keeps the step at ONE launch); then raw = dsg @ W.
+// Ping-pong buffers by step parity: raw_ih/dhprev/dcprev [2][2][B][H], dh0 [2][B][H].
+__global__ __launch_bounds__(1024) void spk_bwd_step(CellK P, int t) {
+  extern __shared__ float smem[];
+  float* red = smem;
+  float* tile = smem + RED_FLOATS;
+  float* dsg_s = tile + 1024;                 // [32][4H + 4]
+  const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
+  const DirP& D = P.d[dir];
+  const int p = blockIdx.y, c = p >> 1, n0 = blockIdx.x * 32;
+  const int H = P.H, B = P.B, T = P.T;
+  const int LDS_LD = 4 * H + 4;
+  const long SB = (long)B * H;
+  const int N0 = D.n0[t];
+  const int Nc = c ? B - N0 : N0, off = c ? N0 : 0;
+  const bool last = (t == T - 1);
+  const int cur = t & 1, nxt = cur ^ 1;       // buffers written at step t / step t+1
+  const float* raw_ih_n = D.raw_ih + (long)nxt * 2 * SB;
+  const float* dhprev_n = D.dhprev + (long)nxt * 2 * SB + (long)c * SB;
+  const float* dcprev_n = D.dcprev + (long)nxt * 2 * SB + (long)c * SB;
+  const float* dh0_n = D.dh0 + (long)nxt * SB;
+  float* raw_ih_c = D.raw_ih + (long)cur * 2 * SB + (long)c * SB;
+  float* dhprev_c = D.dhprev + (long)cur * 2 * SB + (long)c * SB;
+  float* dcprev_c = D.dcprev + (long)cur * 2 * SB + (long)c * SB;
+  float* dh0_c = D.dh0 + (long)cur * SB;
+  const bool w_elem = (blockIdx.x == 0) && ((p & 1) == 0);    // writes dsg / dcprev of its cell
+  const bool w_dh0 = w_elem && (c == 0);                      // writes dh0 rows of this slot block
+  const int N0n = last ? 0 : D.n0[t + 1];
+  const int tid = threadIdx.x;
+  const float* sg = D.sgates + ((long)c * T + t) * B * 4 * H;
+  const float* cq_old = D.cq_state + ((long)c * (T + 1) + t) * SB;
+  const float* cq_new = cq_old + SB;
+  float* dsg_g = D.dsg + ((long)c * T + t) * B * 4 * H;
+
+  // X_{t+1}[r] = grad wrt q_t[r, party_{t+1}[r]]  = raw_ih_{t+1}[P][slot] + dh0_{t+1}[row]
+  auto Xnext = [&](int r, int u, float& mP) -> float {
+    if (last) { mP = 0.f; return 0.f; }
+    const int Pn = D.party[(long)(t + 1) * B + r];
+    const int rown = D.rowof[(long)(t + 1) * B + r];
+    const int slotn = rown - (Pn ? N0n : 0);
+    mP = D.qm[((long)t * B + r) * 2 + Pn];
+    return raw_ih_n[(long)Pn * SB + (long)slotn * H + u] + dh0_n[(long)rown * H + u];
+  };
+
+  for (int e = tid; e < 32 * H; e += 1024) {
+    const int rr = e / H, u = e % H;
+    const int slot = mb * 32 + rr;
+    float d_i = 0.f, d_f = 0.f, d_g = 0.f, d_o = 0.f;
+    if (slot < B) {
+      // dh0 of row `slot` (cell-independent), written once per slot block
+      if (w_dh0) {
+        float mP;
+        const float X = Xnext(slot, u, mP);
+        dh0_c[(long)slot * H + u] = (1.f - mP) * X;
+      }
+      float dh = last ? 0.f : dhprev_n[(long)slot * H + u];
+      const float dc_in = last ? 0.f : dcprev_n[(long)slot * H + u];
+      if (slot < Nc) {
+        const int r = off + slot;
+        float mP;
+        const float X = Xnext(r, u, mP);
+        dh += D.dHQ[((long)t * B + r) * H + u] + mP * X;
+      }
+      if (Nc == 0) {
+        // skipped cell: identity on (h, c)
+        if (w_elem) {
+          dcprev_c[(long)slot * H + u] = dc_in;
+          dhprev_c[(long)slot * H + u] = dh;
+          raw_ih_c[(long)slot * H + u] = 0.f;
+        }
+      } else {
+        const float* g = sg + (long)slot * 4 * H + u;
+        const float gi = g[0], gf = g[H], gg = g[2 * H], go = g[3 * H];
+        const float tc = tanhf(cq_new[(long)slot * H + u]);
+        const float dcn = dc_in + dh * go * (1.f - tc * tc);
+        d_i = dcn * gg * gi * (1.f - gi);
+        d_f = dcn * cq_old[(long)slot * H + u] * gf * (1.f - gf);
+        d_g = dcn * gi * (1.f - gg * gg);
+        d_o = dh * tc * go * (1.f - go);
+        if (w_elem) dcprev_c[(long)slot * H + u] = dcn * gf;
+      }
+      if (w_elem) {
+        float* o = dsg_g + (long)slot * 4 * H + u;
+        o[0] = d_i; o[H] = d_f; o[2 * H] = d_g; o[3 * H] = d_o;
+      }
+    }
+    float* l = dsg_s + rr * LDS_LD + u;
+    l[0] = d_i; l[H] = d_f; l[2 * H] = d_g; l[3 * H] = d_o;
+  }
+  if (Nc == 0) return;     // uniform per workgroup
+  __syncthreads();
+
+  const float* Wp = (p & 1) ? D.Whh[c] : D.Wih[c];
+  auto aload = [&](int r, int k, float* a) { load8(dsg_s + r * LDS_LD + k, a); };
+  auto bload = [&](int n, int k, float* bb) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bb[j] = Wp[(long)(k + j) * H + n0 + n];
+  };
+  wg_mm32(4 * H, aload, bload, red, tile);
+  const int rr = tid >> 5, n = tid & 31;
+  const int slot = mb * 32 + rr;
+  if (slot < B) {
+    float* dst = (p & 1) ? dhprev_c : raw_ih_c;
+    dst[(long)slot * H + n0 + n] = tile[tid];
+  }
+}
+
+// ================================================================================================ small helpers
+__global__ void rowof_kernel(const int* perm, int* rowof, long TB, int B) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= TB) return;
+  const long t = i / B;
+  rowof[t * B + perm[i]] = (int)(i - t * B);
+}
+
+// out[tau,b,:D] += X[t,b,:D] with tau = rev[t,b] >= 0   (adjoint of reverse_by_length)
+__global__ void reverse_acc_kernel(const float* X, const int* rev, float* out, long ldo, int L, int B, int D) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)L * B * D) return;
+  const long r = i / D;
+  const int j = (int)(i - r * D);
+  const int b = (int)(r % B);
+  const int tau = rev[r];
+  if (tau >= 0) out[((long)tau * B + b) * ldo + j] += X[i];
+}
+
+// out_k[n] += sum_m X[m,n] for up to 4 destinations (the four LSTHM biases share one gradient)
+__global__ __launch_bounds__(256) void colsum4_kernel(const float* X, long rows, int n, long ld, float* o0, float* o1, float* o2,
+                                                      float* o3) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.y * 512;
+  float s = 0.f;
+  if (c < n)
+    for (long r = r0 + rl; r < min(rows, r0 + 512); r += 4) s += X[r * ld + c];
+  part[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < n) {
+    const float v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    if (o0) atomicAdd(&o0[c], v);
+    if (o1) atomicAdd(&o1[c], v);
+    if (o2) atomicAdd(&o2[c], v);
+    if (o3) atomicAdd(&o3[c], v);
+  }
+}
+
+static int colsum4(const float* X, long rows, int n, long ld, float* o0, float* o1, float* o2, float* o3, hipStream_t s) {
+  hipLaunchKernelGGL(colsum4_kernel, dim3(cdiv(n, 64), cdiv(rows, 512)), dim3(256), 0, s, X, rows, n, ld, o0, o1, o2, o3);
+  return check_launch("colsum4");
+}
+
+// ================================================================================================ host side
+struct Carver {
+  char* base; size_t off;
+  template <class T> T* take(size_t n) {
+    off = (off + 255) & ~size_t(255);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+static void carve_dir(Carver& cv, DirP& d, int T, int B, int D, int H) {
+  const size_t TB = (size_t)T * B, SB = (size_t)B * H;
+  d.party = cv.take<int>(TB); d.perm = cv.take<int>(TB); d.rowof = cv.take<int>(TB); d.n0 = cv.take<int>(T);
+  d.qm = cv.take<float>(TB * 2);
+  d.qsel = cv.take<float>(2 * TB * H);
+  d.hq_state = cv.take<float>(2 * (T + 1) * SB);
+  d.cq_state = cv.take<float>(2 * (T + 1) * SB);
+  d.sgates = cv.take<float>(2 * TB * 4 * H);
+  d.HQ = cv.take<float>(TB * H);
+  d.pre = cv.take<float>(2 * TB * 4 * H);
+  d.gates = cv.take<float>(2 * TB * 4 * H);
+  d.cstate = cv.take<float>(2 * (T + 1) * SB);
+  d.hz = cv.take<float>((T + 1) * (size_t)B * 3 * H);
+  d.dgates = cv.take<float>(2 * TB * 4 * H);
+  d.dc_carry = cv.take<float>(2 * SB);
+  d.dA = cv.take<float>(4 * SB);
+  d.attacc = cv.take<float>((size_t)B * 2 * H);
+  d.dHQ = cv.take<float>(TB * H);
+  d.dsg = cv.take<float>(2 * TB * 4 * H);
+  d.raw_ih = cv.take<float>(2 * 2 * SB);
+  d.dhprev = cv.take<float>(2 * 2 * SB);
+  d.dcprev = cv.take<float>(2 * 2 * SB);
+  d.dh0 = cv.take<float>(2 * SB);
+}
+
+struct CellHost {
+  CellK k;
+  float* xrev[2];     // reversed x_l / x_a for the backward direction [T*B, D]
+  float* dxtmp;       // [T*B, D]
+};
+
+static size_t carve_all(char* base, const mser_cell_desc& d, CellHost* out) {
+  Carver cv{base, 0};
+  CellHost h;
+  h.k.T = d.T; h.k.B = d.B; h.k.D = d.D; h.k.H = d.H; h.k.ndir = d.ndir; h.k.nmb = cdiv(d.B, 32); h.k.ldo = d.ldo;
+  for (int i = 0; i < d.ndir; ++i) carve_dir(cv, h.k.d[i], d.T, d.B, d.D, d.H);
+  const size_t TBD = (size_t)d.T * d.B * d.D;
+  h.xrev[0] = cv.take<float>(TBD);
+  h.xrev[1] = cv.take<float>(TBD);
+  h.dxtmp = cv.take<float>(TBD);
+  if (out) *out = h;
+  return (cv.off + 255) & ~size_t(255);
+}
+
+static int validate(const mser_cell_desc& d, bool bwd) {
+  MSER_REQUIRE(d.T > 0 && d.B > 0 && d.D > 0, "marn_cell: bad sizes T=%d B=%d D=%d", d.T, d.B, d.D);
+  MSER_REQUIRE(d.H >= 32 && d.H <= 1024 && (d.H & (d.H - 1)) == 0, "marn_cell: H=%d must be a power of two in [32,1024]", d.H);
+  MSER_REQUIRE(d.ndir == 1 || d.ndir == 2, "marn_cell: ndir=%d", d.ndir);
+  MSER_REQUIRE(d.x_l && d.x_a && d.workspace, "marn_cell: null input/workspace");
+  MSER_REQUIRE(((uintptr_t)d.workspace & 255) == 0, "marn_cell: workspace must be 256-byte aligned");
+  MSER_REQUIRE(d.workspace_bytes >= mser_marn_cell_workspace_bytes(d.T, d.B, d.D, d.H, d.ndir),
+               "marn_cell: workspace too small (%zu < %zu)", d.workspace_bytes,
+               mser_marn_cell_workspace_bytes(d.T, d.B, d.D, d.H, d.ndir));
+  MSER_REQUIRE(d.ldo >= 4L * d.H, "marn_cell: ldo=%ld < 4H", (long)d.ldo);
+  if (bwd) MSER_REQUIRE(d.H <= 256, "marn_cell_bwd: H=%d > 256 not supported yet (LDS gate-gradient tile)", d.H);
+  for (int i = 0; i < d.ndir; ++i) {
+    const mser_cell_dir& r = d.dir[i];
+    MSER_REQUIRE(r.qmask && r.out, "marn_cell: dir %d null qmask/out", i);
+    const mser_cell_params& p = r.p;
+    for (int m = 0; m < 2; ++m)
+      MSER_REQUIRE(p.lsthm_W[m] && p.lsthm_Wb[m] && p.lsthm_U[m] && p.lsthm_Ub[m] && p.lsthm_V[m] && p.lsthm_Vb[m] &&
+                       p.lsthm_S[m] && p.lsthm_Sb[m] && p.q_Wih[m] && p.q_Whh[m] && p.q_bih[m] && p.q_bhh[m],
+                   "marn_cell: dir %d null parameter", i);
+    MSER_REQUIRE(p.att_Wq && p.att_Wk, "marn_cell: dir %d null attention vector", i);
+    if (bwd) MSER_REQUIRE(r.dout, "marn_cell_bwd: dir %d null dout", i);
+  }
+  if (bwd) MSER_REQUIRE(d.dx_l && d.dx_a, "marn_cell_bwd: null dx");
+  return 0;
+}
+
+static void fill_params(DirP& k, const mser_cell_dir& r) {
+  for (int m = 0; m < 2; ++m) {
+    k.W[m] = r.p.lsthm_W[m]; k.Wb[m] = r.p.lsthm_Wb[m]; k.U[m] = r.p.lsthm_U[m]; k.Ub[m] = r.p.lsthm_Ub[m];
+    k.V[m] = r.p.lsthm_V[m]; k.Vb[m] = r.p.lsthm_Vb[m]; k.S[m] = r.p.lsthm_S[m]; k.Sb[m] = r.p.lsthm_Sb[m];
+    k.Wih[m] = r.p.q_Wih[m]; k.Whh[m] = r.p.q_Whh[m]; k.bih[m] = r.p.q_bih[m]; k.bhh[m] = r.p.q_bhh[m];
+  }
+  k.attWq = r.p.att_Wq; k.attWk = r.p.att_Wk;
+  k.rev = r.rev; k.out = r.out; k.dout = r.dout;
+}
+
+static mser_gemm_desc gd(const float* A, long sAm, long sAk, const float* Bm, long sBk, long sBn, float* C, long ldc, int M,
+                         int N, int K) {
+  mser_gemm_desc g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.B = Bm; g.C = C; g.M = M; g.N = N; g.K = K;
+  g.sAm = sAm; g.sAk = sAk; g.sBk = sBk; g.sBn = sBn; g.ldc = ldc;
+  g.batch1 = g.batch2 = 1; g.alpha = 1.f; g.splitk = 1;
+  return g;
+}
+
+template <class K>
+static int allow_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024) MSER_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return 0;
+}
+
+static size_t row_lds_bytes(int H, int NT, int narr) { return ((size_t)narr * H + 3 * (size_t)NT + 16) * sizeof(float); }
+
+int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s) {
+  MSER_TRY(validate(d, false));
+  CellHost h;
+  carve_all((char*)d.workspace, d, &h);
+  CellK& K = h.k;
+  const int T = d.T, B = d.B, D = d.D, H = d.H;
+  const long TB = (long)T * B, SB = (long)B * H;
+  for (int i = 0; i < d.ndir; ++i) {
+    DirP& k = K.d[i];
+    fill_params(k, d.dir[i]);
+    MSER_TRY(mser_build_slot_tables(d.dir[i].qmask, k.rev, T, B, k.party, k.perm, k.n0, k.qm, s));
+    hipLaunchKernelGGL(rowof_kernel, dim3(cdiv(TB, 256)), dim3(256), 0, s, k.perm, k.rowof, TB, B);
+    MSER_TRY(check_launch("rowof"));
+    // zero initial states (index 0 of the (T+1)-long state arrays, both cells / streams)
+    for (int c = 0; c < 2; ++c) {
+      MSER_CHECK_HIP(hipMemsetAsync(k.hq_state + (long)c * (T + 1) * SB, 0, SB * sizeof(float), s));
+      MSER_CHECK_HIP(hipMemsetAsync(k.cq_state + (long)c * (T + 1) * SB, 0, SB * sizeof(float), s));
+      MSER_CHECK_HIP(hipMemsetAsync(k.cstate + (long)c * (T + 1) * SB, 0, SB * sizeof(float), s));
+    }
+    MSER_CHECK_HIP(hipMemsetAsync(k.hz, 0, (size_t)B * 3 * H * sizeof(float), s));
+    if (k.rev)   // rows at and beyond len_b stay zero in the reversed output (pad_sequence, :410)
+      MSER_CHECK_HIP(hipMemset2DAsync(k.out, d.ldo * sizeof(float), 0, 4 * (size_t)H * sizeof(float), TB, s));
+  }
+  const size_t mm_lds = (RED_FLOATS + 1024) * sizeof(float);
+  MSER_TRY(allow_lds(spk_fwd_step, mm_lds));
+  MSER_TRY(allow_lds(lsthm_fwd_gates, mm_lds));
+  // ---- speaker chain
+  for (int t = 0; t < T; ++t) {
+    hipLaunchKernelGGL(spk_fwd_step, dim3(H / 8, 2, d.ndir * K.nmb), dim3(1024), mm_lds, s, K, t);
+  }
+  MSER_TRY(check_launch("spk_fwd_step"));
+  // ---- hoisted pre-activations: pre_m = xdir W_m^T + W.bias + HQ S_m^T + S.bias
+  for (int i = 0; i < d.ndir; ++i) {
+    DirP& k = K.d[i];
+    const float* xs[2] = {d.x_l, d.x_a};
+    long lds[2] = {d.ldxl, d.ldxa};
+    if (k.rev) {
+      MSER_TRY(mser_reverse_by_length(d.x_l, d.ldxl, k.rev, h.xrev[0], D, T, B, D, s));
+      MSER_TRY(mser_reverse_by_length(d.x_a, d.ldxa, k.rev, h.xrev[1], D, T, B, D, s));
+      xs[0] = h.xrev[0]; xs[1] = h.xrev[1]; lds[0] = lds[1] = D;
+    }
+    for (int m = 0; m < 2; ++m) {
+      float* pre = k.pre + (long)m * TB * 4 * H;
+      mser_gemm_desc g = gd(xs[m], lds[m], 1, k.W[m], 1, D, pre, 4 * H, (int)TB, 4 * H, D);
+      g.bias = k.Wb[m];
+      MSER_TRY(gemm(g, s));
+      g = gd(k.HQ, H, 1, k.S[m], 1, H, pre, 4 * H, (int)TB, 4 * H, H);
+      g.bias = k.Sb[m];
+      g.flags = MSER_GEMM_ACCUM;
+      MSER_TRY(gemm(g, s));
+    }
+  }
+  // ---- LSTHM chain
+  const int NT = H > 512 ? H : 512;
+  const size_t z_lds = row_lds_bytes(H, NT, 2);
+  for (int t = 0; t < T; ++t) {
+    hipLaunchKernelGGL(lsthm_fwd_gates, dim3(H / 8, 2, d.ndir * K.nmb), dim3(1024), mm_lds, s, K, t);
+    hipLaunchKernelGGL(lsthm_fwd_z, dim3(B, d.ndir), dim3(NT), z_lds, s, K, t);
+  }
+  return check_launch("lsthm_fwd");
+}
+
+int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s) {
+  MSER_TRY(validate(d, true));
+  CellHost h;
+  carve_all((char*)d.workspace, d, &h);
+  CellK& K = h.k;
+  const int T = d.T, B = d.B, D = d.D, H = d.H;
+  const long TB = (long)T * B, SB = (long)B * H;
+  for (int i = 0; i < d.ndir; ++i) {
+    DirP& k = K.d[i];
+    fill_params(k, d.dir[i]);
+    MSER_CHECK_HIP(hipMemsetAsync(k.dc_carry, 0, 2 * SB * sizeof(float), s));
+    MSER_CHECK_HIP(hipMemsetAsync(k.attacc, 0, (size_t)B * 2 * H * sizeof(float), s));
+  }
+  const size_t mm_lds = (RED_FLOATS + 1024) * sizeof(float);
+  const int NT = H > 512 ? H : 512;
+  const size_t row_lds = row_lds_bytes(H, NT, 9);
+  MSER_TRY(allow_lds(lsthm_bwd_mat, mm_lds));
+  // ---- LSTHM chain, reverse time
+  for (int t = T - 1; t >= 0; --t) {
+    hipLaunchKernelGGL(lsthm_bwd_row, dim3(B, d.ndir), dim3(NT), row_lds, s, K, t);
+    if (t > 0) hipLaunchKernelGGL(lsthm_bwd_mat, dim3(H / 32, 4, d.ndir * K.nmb), dim3(1024), mm_lds, s, K, t);
+  }
+  MSER_TRY(check_launch("lsthm_bwd"));
+  // ---- deferred (non-recurrent) gradient GEMMs of the LSTHM streams
+  const int SPLITK = 16;
+  for (int i = 0; i < d.ndir; ++i) {
+    DirP& k = K.d[i];
+    const mser_cell_params& G = d.dir[i].g;
+    const float* xs[2] = {d.x_l, d.x_a};
+    long lds[2] = {d.ldxl, d.ldxa};
+    float* dxs[2] = {d.dx_l, d.dx_a};
+    if (k.rev) { xs[0] = h.xrev[0]; xs[1] = h.xrev[1]; lds[0] = lds[1] = D; }
+    for (int m = 0; m < 2; ++m) {
+      const float* dg = k.dgates + (long)m * TB * 4 * H;
+      mser_gemm_desc g;
+      // dHQ += dg S_m
+      g = gd(dg, 4 * H, 1, k.S[m], H, 1, k.dHQ, H, (int)TB, H, 4 * H);
+      g.flags = MSER_GEMM_ACCUM;
+      MSER_TRY(gemm(g, s));
+      // dx (direction order) = dg W_m
+      if (!k.rev) {
+        g = gd(dg, 4 * H, 1, k.W[m], D, 1, dxs[m], D, (int)TB, D, 4 * H);
+        g.flags = MSER_GEMM_ACCUM;
+        MSER_TRY(gemm(g, s));
+      } else {
+        g = gd(dg, 4 * H, 1, k.W[m], D, 1, h.dxtmp, D, (int)TB, D, 4 * H);
+        MSER_TRY(gemm(g, s));
+        hipLaunchKernelGGL(reverse_acc_kernel, dim3(cdiv(TB * D, 256)), dim3(256), 0, s, h.dxtmp, k.rev, dxs[m], (long)D, T, B, D);
+        MSER_TRY(check_launch("reverse_acc"));
+      }
+      if (G.lsthm_W[m]) {
+        // dW_m += dg^T xdir ; dS_m += dg^T HQ ; dU_m += dg^T h_prev ; dV_m += dg^T z_prev
+        g = gd(dg, 1, 4 * H, xs[m], lds[m], 1, G.lsthm_W[m], D, 4 * H, D, (int)TB);
+        g.splitk = SPLITK;
+        MSER_TRY(gemm(g, s));
+        g = gd(dg, 1, 4 * H, k.HQ, H, 1, G.lsthm_S[m], H, 4 * H, H, (int)TB);
+        g.splitk = SPLITK;
+        MSER_TRY(gemm(g, s));
+        g = gd(dg, 1, 4 * H, k.hz + m * H, 3 * H, 1, G.lsthm_U[m], H, 4 * H, H, (int)TB);
+        g.splitk = SPLITK;
+        MSER_TRY(gemm(g, s));
+        g = gd(dg, 1, 4 * H, k.hz + 2 * H, 3 * H, 1, G.lsthm_V[m], H, 4 * H, H, (int)TB);
+        g.splitk = SPLITK;
+        MSER_TRY(gemm(g, s));
+        MSER_TRY(colsum4(dg, TB, 4 * H, 4 * H, G.lsthm_Wb[m], G.lsthm_Ub[m], G.lsthm_Vb[m], G.lsthm_Sb[m], s));
+      }
+    }
+    if (G.att_Wq) {
+      MSER_TRY(colsum4(k.attacc, B, H, 2 * H, G.att_Wq, nullptr, nullptr, nullptr, s));
+      MSER_TRY(colsum4(k.attacc + H, B, H, 2 * H, G.att_Wk, nullptr, nullptr, nullptr, s));
+    }
+  }
+  // ---- speaker chain, reverse time
+  const size_t spk_lds = mm_lds + 32 * (4 * (size_t)H + 4) * sizeof(float);
+  MSER_TRY(allow_lds(spk_bwd_step, spk_lds));
+  for (int t = T - 1; t >= 0; --t) {
+    hipLaunchKernelGGL(spk_bwd_step, dim3(H / 32, 4, d.ndir * K.nmb), dim3(1024), spk_lds, s, K, t);
+  }
+  MSER_TRY(check_launch("spk_bwd_step"));
+  for (int i = 0; i < d.ndir; ++i) {
+    DirP& k = K.d[i];
+    const mser_cell_params& G = d.dir[i].g;
+    if (!G.q_Wih[0]) continue;
+    for (int c = 0; c < 2; ++c) {
+      const float* dsg = k.dsg + (long)c * TB * 4 * H;
+      mser_gemm_desc g = gd(dsg, 1, 4 * H, k.qsel + (long)c * TB * H, H, 1, G.q_Wih[c], H, 4 * H, H, (int)TB);
+      g.splitk = SPLITK;
+      MSER_TRY(gemm(g, s));
+      g = gd(dsg, 1, 4 * H, k.hq_state + (long)c * (T + 1) * SB, H, 1, G.q_Whh[c], H, 4 * H, H, (int)TB);
+      g.splitk = SPLITK;
+      MSER_TRY(gemm(g, s));
+      MSER_TRY(colsum4(dsg, TB, 4 * H, 4 * H, G.q_bih[c], G.q_bhh[c], nullptr, nullptr, s));
+    }
+  }
+  return 0;
+}
+
+// ================================================================================================ module-level single steps
+__global__ void lsthm_step_kernel(const float* x, const float* c, const float* h, const float* z, const float* sp, const float* W,
+                                  const float* Wb, const float* U, const float* Ub, const float* V, const float* Vb, const float* S,
+                                  const float* Sb, float* c_out, float* h_out, float* gates, int B, int D, int H, int Hz, int Hs) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * H) return;
+  const int b = (int)(i / H), u = (int)(i % H);
+  float g[4];
+  for (int gt = 0; gt < 4; ++gt) {
+    const long r = (long)gt * H + u;
+    float a = Wb[r] + Ub[r] + Vb[r] + Sb[r];
+    for (int k = 0; k < D; ++k) a = fmaf(x[(long)b * D + k], W[r * D + k], a);
+    for (int k = 0; k < H; ++k) a = fmaf(h[(long)b * H + k], U[r * H + k], a);
+    for (int k = 0; k < Hz; ++k) a = fmaf(z[(long)b * Hz + k], V[r * Hz + k], a);
+    for (int k = 0; k < Hs; ++k) a = fmaf(sp[(long)b * Hs + k], S[r * Hs + k], a);
+    g[gt] = a;
+  }
+  const float gf = sigmoidf_(g[0]), gi = sigmoidf_(g[1]), go = sigmoidf_(g[2]), gc = tanhf(g[3]);
+  const float cn = gf * c[i] + gi * gc;
+  c_out[i] = cn;
+  h_out[i] = tanhf(cn) * go;
+  if (gates) {
+    float* o = gates + (long)b * 4 * H + u;
+    o[0] = gf; o[H] = gi; o[2 * H] = go; o[3 * H] = gc;
+  }
+}
+
+__global__ __launch_bounds__(1024) void rank1_attention_kernel(const float* x1, const float* x2, const float* Wq, const float* Wk,
+                                                               float* out, int B, int H) {
+  extern __shared__ float smem[];
+  const int NT = blockDim.x, Q = NT / H, JC = H / Q;
+  float* ca = smem; float* wk = ca + H; float* pZ = wk + H; float* pN = pZ + NT; float* sh = pN + NT;
+  const int b = blockIdx.x, tid = threadIdx.x, nw = NT >> 6;
+  float sp = 0.f, wmx = -INFINITY, wmn = INFINITY;
+  for (int k = tid; k < H; k += NT) {
+    const float cv = x2[(long)b * H + k], w = Wk[k];
+    ca[k] = cv; wk[k] = w;
+    sp += Wq[k] * cv;
+    wmx = fmaxf(wmx, w);
+    wmn = fminf(wmn, w);
+  }
+  const float s = block_sum(sp, sh, nw) / sqrtf((float)H);
+  wmx = block_max(wmx, sh, nw);
+  wmn = -block_max(-wmn, sh, nw);
+  const int i = tid % H, q = tid / H;
+  const float u = x1[(long)b * H + i] * s;
+  const float mx = (u >= 0.f) ? u * wmx : u * wmn;
+  float Z = 0.f, N = 0.f;
+  for (int j = q * JC; j < (q + 1) * JC; ++j) {
+    const float e = expf(u * wk[j] - mx);
+    Z += e;
+    N += e * ca[j];
+  }
+  pZ[tid] = Z; pN[tid] = N;
+  __syncthreads();
+  if (q == 0) {
+    for (int qq = 1; qq < Q; ++qq) { Z += pZ[qq * H + i]; N += pN[qq * H + i]; }
+    out[(long)b * H + i] = N / Z;
+  }
+}
+
+}  // namespace mser
+
+using namespace mser;
+
+extern "C" {
+
+size_t mser_marn_cell_workspace_bytes(int32_t T, int32_t B, int32_t D, int32_t H, int32_t ndir) {
+  mser_cell_desc d;
+  memset(&d, 0, sizeof(d));
+  d.T = T; d.B = B; d.D = D; d.H = H; d.ndir = ndir;
+  return carve_all(nullptr, d, nullptr);
+}
+
+int mser_marn_cell_fwd(const mser_cell_desc* d, mser_stream_t stream) {
+  if (!d) { set_error("mser_marn_cell_fwd: null descriptor"); return -1; }
+  return marn_cell_fwd(*d, (hipStream_t)stream);
+}
+
+int mser_marn_cell_bwd(const mser_cell_desc* d, mser_stream_t stream) {
+  if (!d) { set_error("mser_marn_cell_bwd: null descriptor"); return -1; }
+  return marn_cell_bwd(*d, (hipStream_t)stream);
+}
+
+int mser_lsthm_step_fwd(const float* x, const float* c, const float* h, const float* z, const float* s, const float* W,
+                        const float* Wb, const float* U, const float* Ub, const float* V, const float* Vb, const float* S,
+                        const float* Sb, float* c_out, float* h_out, float* gates, int32_t B, int32_t D, int32_t H, int32_t Hz,
+                        int32_t Hs, mser_stream_t stream) {
+  MSER_REQUIRE(x && c && h && z && s && W && Wb && U && Ub && V && Vb && S && Sb && c_out && h_out, "mser_lsthm_step_fwd: null pointer");
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(lsthm_step_kernel, dim3(cdiv((long)B * H, 128)), dim3(128), 0, (hipStream_t)stream, x, c, h, z, s, W, Wb, U,
+                     Ub, V, Vb, S, Sb, c_out, h_out, gates, B, D, H, Hz, Hs);
+  return check_launch("mser_lsthm_step_fwd");
+}
+
+int mser_rank1_attention_fwd(const float* x1, const float* x2, const float* Wq, const float* Wk, float* out, int32_t B, int32_t H,
+                             mser_stream_t stream) {
+  MSER_REQUIRE(x1 && x2 && Wq && Wk && out, "mser_rank1_attention_fwd: null pointer");
+  MSER_REQUIRE(H >= 32 && H <= 1024 && (H & (H - 1)) == 0, "mser_rank1_attention_fwd: H=%d must be a power of two in [32,1024]", H);
+  if (B <= 0) return 0;
+  const int NT = H > 512 ? H : 512;
+  hipLaunchKernelGGL(rank1_attention_kernel, dim3(B), dim3(NT), row_lds_bytes(H, NT, 2), (hipStream_t)stream, x1, x2, Wq, Wk, out, B, H);
+  return check_launch("mser_rank1_attention_fwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,511 @@
+// Row-wise / element-wise kernels of the hot path (softmax, add+LayerNorm, reductions, bookkeeping, loss, Adam).
+// All of these are HBM/L2-bandwidth kernels: one 64-lane wave per row with butterfly (DPP shuffle) reductions,
+// rows short enough (<= 1280 floats) to live in registers between the passes.
+#include "common.h"
+#include "../../include/mser.h"
+
+namespace mser {
+
+constexpr int WPB = 4;  // waves per block for the one-wave-per-row kernels
+
+// ---------------------------------------------------------------------------------------------- softmax
+template <int NV>  // NV = ceil(n / 64) values per lane
+__global__ __launch_bounds__(64 * WPB) void softmax_rows_kernel(float* S, long rows, int n, long ld, const float* mul,
+                                                                const uint8_t* mask, int mask_on, float fill) {
+  const long row = (long)blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float* p = S + row * ld;
+  float v[NV];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = lane + i * 64;
+    float x = -INFINITY;
+    if (j < n) {
+      x = p[j];
+      if (mul) x *= mul[row * ld + j];
+      if (mask && mask[row * ld + j] == mask_on) x = fill;
+    }
+    v[i] = x;
+    mx = fmaxf(mx, x);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = lane + i * 64;
+    v[i] = (j < n) ? expf(v[i] - mx) : 0.f;
+    sum += v[i];
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = lane + i * 64;
+    if (j < n) p[j] = v[i] * inv;
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(64 * WPB) void softmax_bwd_rows_kernel(const float* P, float* dP, long rows, int n, long ld,
+                                                                    const float* mul) {
+  const long row = (long)blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* p = P + row * ld;
+  float* d = dP + row * ld;
+  float pv[NV], dv[NV];
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = lane + i * 64;
+    pv[i] = (j < n) ? p[j] : 0.f;
+    dv[i] = (j < n) ? d[j] : 0.f;
+    dot += pv[i] * dv[i];
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = lane + i * 64;
+    if (j < n) {
+      float g = pv[i] * (dv[i] - dot);
+      if (mul) g *= mul[row * ld + j];
+      d[j] = g;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- LayerNorm
+// D <= 256 (the path uses D = 100); one wave per row, two-pass mean/variance in registers (matches
+// torch's layer_norm to ~1e-7: biased variance, rstd = 1/sqrt(var + eps)).
+__global__ __launch_bounds__(64 * WPB) void add_layernorm_fwd_kernel(const float* x, long ldx, const float* res, long ldres,
+                                                                     const float* gamma, const float* beta, float* y,
+                                                                     float* sum_out, float* mean, float* rstd, long rows,
+                                                                     int D, float eps) {
+  const long row = (long)blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = lane + i * 64;
+    float t = 0.f;
+    if (j < D) {
+      t = x[row * ldx + j];
+      if (res) t += res[row * ldres + j];
+      if (sum_out) sum_out[row * D + j] = t;
+    }
+    v[i] = t;
+    s += t;
+  }
+  const float mu = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = lane + i * 64;
+    const float dlt = (j < D) ? v[i] - mu : 0.f;
+    q += dlt * dlt;
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = lane + i * 64;
+    if (j < D) y[row * D + j] = (v[i] - mu) * rs * gamma[j] + beta[j];
+  }
+  if (lane == 0) {
+    mean[row] = mu;
+    rstd[row] = rs;
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.  dgamma / dbeta: per-block partial sums in
+// LDS, then one float atomic per column per block.
+constexpr int LN_ROWS_PER_BLOCK = 32;
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dy, const float* xsum, const float* mean,
+                                                            const float* rstd, const float* gamma, float* dx,
+                                                            float* dgamma, float* dbeta, long rows, int D) {
+  __shared__ float sg[256], sb[256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < 256) { sg[threadIdx.x] = 0.f; sb[threadIdx.x] = 0.f; }
+  __syncthreads();
+  float ag[4] = {0, 0, 0, 0}, ab[4] = {0, 0, 0, 0};
+  const long r0 = (long)blockIdx.x * LN_ROWS_PER_BLOCK;
+  for (int rr = wave; rr < LN_ROWS_PER_BLOCK; rr += 4) {
+    const long row = r0 + rr;
+    if (row >= rows) break;
+    const float mu = mean[row], rs = rstd[row];
+    float g[4], xh[4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = lane + i * 64;
+      g[i] = 0.f; xh[i] = 0.f;
+      if (j < D) {
+        const float d = dy[row * D + j];
+        xh[i] = (xsum[row * D + j] - mu) * rs;
+        g[i] = d * gamma[j];
+        ag[i] += d * xh[i];
+        ab[i] += d;
+      }
+      s1 += g[i];
+      s2 += g[i] * xh[i];
+    }
+    s1 = wave_sum(s1) / D;
+    s2 = wave_sum(s2) / D;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = lane + i * 64;
+      if (j < D) dx[row * D + j] = rs * (g[i] - s1 - xh[i] * s2);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = lane + i * 64;
+    if (j < D) { atomicAdd(&sg[j], ag[i]); atomicAdd(&sb[j], ab[i]); }
+  }
+  __syncthreads();
+  if (threadIdx.x < D) {
+    atomicAdd(&dgamma[threadIdx.x], sg[threadIdx.x]);
+    atomicAdd(&dbeta[threadIdx.x], sb[threadIdx.x]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- reductions
+// out[n] += sum_m X[m,n]; block = 256 threads covering 64 columns x 4 row-lanes, 64 rows per block.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* X, long rows, int n, long ld, float* out) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.y * 256;
+  float s = 0.f;
+  if (c < n)
+    for (long r = r0 + rl; r < min(rows, r0 + 256); r += 4) s += X[r * ld + c];
+  part[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < n) atomicAdd(&out[c], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+__global__ void relu_bwd_kernel(float* dY, const float* Y, long count) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count && !(Y[i] > 0.f)) dY[i] = 0.f;
+}
+
+__global__ void add_rows_kernel(float* out, long ldo, const float* a, long lda, const float* b, long ldb, long rows, int D) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * D) return;
+  const long r = i / D;
+  const int j = (int)(i - r * D);
+  float v = a[r * lda + j];
+  if (b) v += b[r * ldb + j];
+  out[r * ldo + j] = v;
+}
+
+__global__ __launch_bounds__(256) void scale_acc_dot_kernel(float* acc, long ldacc, const float* t, long ldt, const float* x,
+                                                            long ldx, const float* s_dev, float* ds, long rows, int D) {
+  __shared__ float red[4];
+  const float s = s_dev ? *s_dev : 1.f;
+  float dot = 0.f;
+  const long total = rows * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / D;
+    const int j = (int)(i - r * D);
+    const float tv = t[r * ldt + j];
+    acc[r * ldacc + j] += s * tv;
+    if (ds) dot += tv * x[r * ldx + j];
+  }
+  if (ds) {
+    dot = wave_sum(dot);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(ds, red[0] + red[1] + red[2] + red[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- bookkeeping
+__global__ void reverse_index_kernel(const float* umask, int B, int L, int* lens, int* rev) {
+  const int b = blockIdx.x;
+  __shared__ int len_s;
+  float s = 0.f;
+  for (int t = threadIdx.x; t < L; t += 64) s += umask[(long)b * L + t];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) { len_s = (int)s; lens[b] = (int)s; }   // torch: sum(mask,1).int() truncates
+  __syncthreads();
+  const int len = len_s;
+  for (int t = threadIdx.x; t < L; t += 64) rev[(long)t * B + b] = (t < len) ? (len - 1 - t) : -1;
+}
+
+__global__ void reverse_rows_kernel(const float* X, long ldx, const int* rev, float* out, long ldo, int L, int B, int D) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)L * B * D) return;
+  const long r = i / D;
+  const int j = (int)(i - r * D);
+  const int b = (int)(r % B);
+  const int src = rev[r];
+  out[r * ldo + j] = (src >= 0) ? X[((long)src * B + b) * ldx + j] : 0.f;
+}
+
+// One block per time step: party = argmax over the 2 mask values (ties -> 0, like torch.argmax returning the first
+// maximum), then a stable partition of the dialogues by party (ballot-based prefix counts, B <= 1024).
+__global__ __launch_bounds__(1024) void slot_tables_kernel(const float* qmask, const int* rev, int T, int B, int* party,
+                                                           int* perm, int* n0, float* qm_out) {
+  __shared__ int cnt0[17];   // per-wave counts of party-0 rows
+  const int t = blockIdx.x, b = threadIdx.x;
+  const int lane = b & 63, wave = b >> 6;
+  int p = 1;   // inactive lanes count as party 1 so they never enter the party-0 ballot
+  float m0 = 0.f, m1 = 0.f;
+  if (b < B) {
+    int src_t = t;
+    if (rev) src_t = rev[(long)t * B + b];
+    if (src_t >= 0) {
+      m0 = qmask[((long)src_t * B + b) * 2 + 0];
+      m1 = qmask[((long)src_t * B + b) * 2 + 1];
+    }
+    p = (m1 > m0) ? 1 : 0;
+    party[(long)t * B + b] = p;
+    qm_out[((long)t * B + b) * 2 + 0] = m0;
+    qm_out[((long)t * B + b) * 2 + 1] = m1;
+  }
+  const unsigned long long bal = __ballot(p == 0);
+  const int before0 = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) cnt0[wave] = __popcll(bal);
+  __syncthreads();
+  int base0 = 0, total0 = 0;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int w = 0; w < nw; ++w) {
+    if (w < wave) base0 += cnt0[w];
+    total0 += cnt0[w];
+  }
+  if (b < B) {
+    const int idx0 = base0 + before0;             // rank among party-0 rows
+    const int idx1 = b - idx0;                    // rank among party-1 rows (rows before b that are not party 0)
+    const int row = (p == 0) ? idx0 : total0 + idx1;
+    perm[(long)t * B + row] = b;
+  }
+  if (b == 0) n0[t] = total0;
+}
+
+// ---------------------------------------------------------------------------------------------- head / loss
+__global__ void logsoftmax_tb_fwd_kernel(const float* y, float* lp, int L, int B, int C) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;   // r = b*L + t (output row)
+  if (r >= (long)L * B) return;
+  const int b = (int)(r / L), t = (int)(r % L);
+  const float* src = y + ((long)t * B + b) * C;
+  float mx = -INFINITY;
+  for (int c = 0; c < C; ++c) mx = fmaxf(mx, src[c]);
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += expf(src[c] - mx);
+  const float lse = mx + logf(s);
+  for (int c = 0; c < C; ++c) lp[r * C + c] = src[c] - lse;
+}
+
+__global__ void logsoftmax_tb_bwd_kernel(const float* dlp, const float* lp, float* dy, int L, int B, int C) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= (long)L * B) return;
+  const int b = (int)(r / L), t = (int)(r % L);
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += dlp[r * C + c];
+  float* dst = dy + ((long)t * B + b) * C;
+  for (int c = 0; c < C; ++c) dst[c] = dlp[r * C + c] - expf(lp[r * C + c]) * s;
+}
+
+// single block: deterministic two-level reduction (the loss is a scalar; rows <= ~1e6)
+__global__ __launch_bounds__(1024) void masked_nll_fwd_kernel(const float* pred, const long* target, const float* mask,
+                                                              long rows, int C, float* loss_out) {
+  __shared__ float s_num[16], s_den[16];
+  float num = 0.f, den = 0.f;
+  for (long r = threadIdx.x; r < rows; r += 1024) {
+    const float m = mask[r];
+    num -= pred[r * C + target[r]] * m;
+    den += m;
+  }
+  num = wave_sum(num);
+  den = wave_sum(den);
+  if ((threadIdx.x & 63) == 0) { s_num[threadIdx.x >> 6] = num; s_den[threadIdx.x >> 6] = den; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < 16; ++i) { a += s_num[i]; b += s_den[i]; }
+    loss_out[0] = a / b;
+    loss_out[1] = b;
+  }
+}
+
+__global__ void masked_nll_bwd_kernel(const long* target, const float* mask, const float* loss_out, const float* gscale_dev,
+                                      float* dpred, long rows, int C) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C) return;
+  const long r = i / C;
+  const int c = (int)(i - r * C);
+  const float gs = gscale_dev ? *gscale_dev : 1.f;
+  dpred[i] = (c == (int)target[r]) ? -gs * mask[r] / loss_out[1] : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------- Adam
+__global__ void adam_flat_kernel(float* p, const float* g, float* m, float* v, const uint8_t* live, long n, float lr_bc1,
+                                 float inv_sqrt_bc2, float b1, float b2, float eps, float wd, float gscale) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (live && !live[i]) return;
+  const float pi = p[i];
+  const float gi = g[i] * gscale + wd * pi;
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+  p[i] = pi - lr_bc1 * mi / denom;
+}
+
+}  // namespace mser
+
+using namespace mser;
+
+extern "C" {
+
+int mser_softmax_rows(float* S, int64_t rows, int32_t n, int64_t ld, const float* mul, const uint8_t* mask, int32_t mask_on,
+                      float fill, mser_stream_t stream) {
+  MSER_REQUIRE(S && n > 0 && n <= 1024, "mser_softmax_rows: need 0 < n <= 1024 (got %d)", n);
+  if (rows <= 0) return 0;
+  dim3 grid(cdiv(rows, WPB)), block(64 * WPB);
+  hipStream_t s = (hipStream_t)stream;
+  const int nv = cdiv(n, 64);
+#define SM(NV) hipLaunchKernelGGL((softmax_rows_kernel<NV>), grid, block, 0, s, S, (long)rows, n, (long)ld, mul, mask, mask_on, fill)
+  if (nv <= 1) SM(1); else if (nv <= 2) SM(2); else if (nv <= 4) SM(4); else if (nv <= 8) SM(8); else SM(16);
+#undef SM
+  return check_launch("mser_softmax_rows");
+}
+
+int mser_softmax_bwd_rows(const float* P, float* dP, int64_t rows, int32_t n, int64_t ld, const float* mul,
+                          mser_stream_t stream) {
+  MSER_REQUIRE(P && dP && n > 0 && n <= 1024, "mser_softmax_bwd_rows: need 0 < n <= 1024 (got %d)", n);
+  if (rows <= 0) return 0;
+  dim3 grid(cdiv(rows, WPB)), block(64 * WPB);
+  hipStream_t s = (hipStream_t)stream;
+  const int nv = cdiv(n, 64);
+#define SM(NV) hipLaunchKernelGGL((softmax_bwd_rows_kernel<NV>), grid, block, 0, s, P, dP, (long)rows, n, (long)ld, mul)
+  if (nv <= 1) SM(1); else if (nv <= 2) SM(2); else if (nv <= 4) SM(4); else if (nv <= 8) SM(8); else SM(16);
+#undef SM
+  return check_launch("mser_softmax_bwd_rows");
+}
+
+int mser_add_layernorm_fwd(const float* x, int64_t ldx, const float* res, int64_t ldres, const float* gamma, const float* beta,
+                           float* y, float* sum_out, float* mean, float* rstd, int64_t rows, int32_t D, float eps,
+                           mser_stream_t stream) {
+  MSER_REQUIRE(x && gamma && beta && y && mean && rstd, "mser_add_layernorm_fwd: null pointer");
+  MSER_REQUIRE(D > 0 && D <= 256, "mser_add_layernorm_fwd: D=%d unsupported (<=256)", D);
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3(cdiv(rows, WPB)), dim3(64 * WPB), 0, (hipStream_t)stream, x, (long)ldx, res,
+                     (long)ldres, gamma, beta, y, sum_out, mean, rstd, (long)rows, D, eps);
+  return check_launch("mser_add_layernorm_fwd");
+}
+
+int mser_layernorm_bwd(const float* dy, const float* xsum, const float* mean, const float* rstd, const float* gamma, float* dx,
+                       float* dgamma, float* dbeta, int64_t rows, int32_t D, mser_stream_t stream) {
+  MSER_REQUIRE(dy && xsum && mean && rstd && gamma && dx && dgamma && dbeta, "mser_layernorm_bwd: null pointer");
+  MSER_REQUIRE(D > 0 && D <= 256, "mser_layernorm_bwd: D=%d unsupported (<=256)", D);
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(rows, LN_ROWS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, dy, xsum, mean,
+                     rstd, gamma, dx, dgamma, dbeta, (long)rows, D);
+  return check_launch("mser_layernorm_bwd");
+}
+
+int mser_colsum_acc(const float* X, int64_t rows, int32_t n, int64_t ld, float* out, mser_stream_t stream) {
+  MSER_REQUIRE(X && out, "mser_colsum_acc: null pointer");
+  if (rows <= 0 || n <= 0) return 0;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(n, 64), cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, X, (long)rows, n,
+                     (long)ld, out);
+  return check_launch("mser_colsum_acc");
+}
+
+int mser_relu_bwd(float* dY, const float* Y, int64_t count, mser_stream_t stream) {
+  MSER_REQUIRE(dY && Y, "mser_relu_bwd: null pointer");
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(cdiv(count, 256)), dim3(256), 0, (hipStream_t)stream, dY, Y, (long)count);
+  return check_launch("mser_relu_bwd");
+}
+
+int mser_add_rows(float* out, int64_t ldo, const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int32_t D,
+                  mser_stream_t stream) {
+  MSER_REQUIRE(out && a, "mser_add_rows: null pointer");
+  if (rows <= 0 || D <= 0) return 0;
+  hipLaunchKernelGGL(add_rows_kernel, dim3(cdiv(rows * D, 256)), dim3(256), 0, (hipStream_t)stream, out, (long)ldo, a, (long)lda,
+                     b, (long)ldb, (long)rows, D);
+  return check_launch("mser_add_rows");
+}
+
+int mser_scale_acc_dot(float* acc, int64_t ldacc, const float* t, int64_t ldt, const float* x, int64_t ldx, const float* s_dev,
+                       float* ds, int64_t rows, int32_t D, mser_stream_t stream) {
+  MSER_REQUIRE(acc && t && (!ds || x), "mser_scale_acc_dot: null pointer");
+  if (rows <= 0 || D <= 0) return 0;
+  const int blocks = (int)fmin((double)cdiv(rows * D, 256), 1024.0);
+  hipLaunchKernelGGL(scale_acc_dot_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, acc, (long)ldacc, t, (long)ldt, x,
+                     (long)ldx, s_dev, ds, (long)rows, D);
+  return check_launch("mser_scale_acc_dot");
+}
+
+int mser_build_reverse_index(const float* umask, int32_t B, int32_t L, int32_t* lens, int32_t* rev, mser_stream_t stream) {
+  MSER_REQUIRE(umask && lens && rev && B > 0 && L > 0, "mser_build_reverse_index: bad arguments");
+  hipLaunchKernelGGL(reverse_index_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, umask, B, L, lens, rev);
+  return check_launch("mser_build_reverse_index");
+}
+
+int mser_reverse_by_length(const float* X, int64_t ldx, const int32_t* rev, float* out, int64_t ldo, int32_t L, int32_t B,
+                           int32_t D, mser_stream_t stream) {
+  MSER_REQUIRE(X && rev && out, "mser_reverse_by_length: null pointer");
+  const long total = (long)L * B * D;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(reverse_rows_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, X, (long)ldx, rev, out,
+                     (long)ldo, L, B, D);
+  return check_launch("mser_reverse_by_length");
+}
+
+int mser_build_slot_tables(const float* qmask, const int32_t* rev, int32_t T, int32_t B, int32_t* party, int32_t* perm,
+                           int32_t* n0, float* qm_out, mser_stream_t stream) {
+  MSER_REQUIRE(qmask && party && perm && n0 && qm_out, "mser_build_slot_tables: null pointer");
+  MSER_REQUIRE(B > 0 && B <= 1024 && T > 0, "mser_build_slot_tables: need 0 < B <= 1024 (got %d)", B);
+  const int threads = cdiv(B, 64) * 64;
+  hipLaunchKernelGGL(slot_tables_kernel, dim3(T), dim3(threads), 0, (hipStream_t)stream, qmask, rev, T, B, party, perm, n0, qm_out);
+  return check_launch("mser_build_slot_tables");
+}
+
+int mser_logsoftmax_tb_fwd(const float* y, float* lp, int32_t L, int32_t B, int32_t C, mser_stream_t stream) {
+  MSER_REQUIRE(y && lp && C > 0, "mser_logsoftmax_tb_fwd: bad arguments");
+  hipLaunchKernelGGL(logsoftmax_tb_fwd_kernel, dim3(cdiv((long)L * B, 256)), dim3(256), 0, (hipStream_t)stream, y, lp, L, B, C);
+  return check_launch("mser_logsoftmax_tb_fwd");
+}
+
+int mser_logsoftmax_tb_bwd(const float* dlp, const float* lp, float* dy, int32_t L, int32_t B, int32_t C, mser_stream_t stream) {
+  MSER_REQUIRE(dlp && lp && dy && C > 0, "mser_logsoftmax_tb_bwd: bad arguments");
+  hipLaunchKernelGGL(logsoftmax_tb_bwd_kernel, dim3(cdiv((long)L * B, 256)), dim3(256), 0, (hipStream_t)stream, dlp, lp, dy, L, B, C);
+  return check_launch("mser_logsoftmax_tb_bwd");
+}
+
+int mser_masked_nll_fwd(const float* pred, const int64_t* target, const float* mask, int64_t rows, int32_t C, float* loss_out,
+                        mser_stream_t stream) {
+  MSER_REQUIRE(pred && target && mask && loss_out && rows > 0, "mser_masked_nll_fwd: bad arguments");
+  hipLaunchKernelGGL(masked_nll_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, (const long*)target, mask, (long)rows,
+                     C, loss_out);
+  return check_launch("mser_masked_nll_fwd");
+}
+
+int mser_masked_nll_bwd(const int64_t* target, const float* mask, const float* loss_out, const float* gscale_dev, float* dpred,
+                        int64_t rows, int32_t C, mser_stream_t stream) {
+  MSER_REQUIRE(target && mask && loss_out && dpred && rows > 0, "mser_masked_nll_bwd: bad arguments");
+  hipLaunchKernelGGL(masked_nll_bwd_kernel, dim3(cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, (const long*)target, mask,
+                     loss_out, gscale_dev, dpred, (long)rows, C);
+  return check_launch("mser_masked_nll_bwd");
+}
+
+int mser_adam_flat(float* p, const float* g, float* m, float* v, const uint8_t* live, int64_t n, int32_t step, float lr, float beta1,
+                   float beta2, float eps, float wd, float gscale, mser_stream_t stream) {
+  MSER_REQUIRE(p && g && m && v && step >= 1, "mser_adam_flat: bad arguments");
+  if (n <= 0) return 0;
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adam_flat_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, live, (long)n,
+                     (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, wd, gscale);
+  return check_launch("mser_adam_flat");
+}
+
+}  // extern "C"

@@ -1,0 +1,125 @@
+"""MI355X-native mirror of the reference's ``model_trainer.ModelTrainer`` (reference model_trainer.py:28-187) for the
+``MARN1_sps`` path: same constructor, ``train_network(epoch, loader) -> (lr, avg_loss)``, ``eval_network(loader) ->
+(acc, f1, {})``, ``save_parameters`` / ``load_parameters`` (state_dict keys prefixed ``model.`` exactly like the reference's
+files, so checkpoints interchange in both directions).
+
+Inner loop per batch (reference :96-120): zero_grad -> textf = (r1+r2+r3+r4)/4 -> model(cat(textf, acouf), qmask, umask)
+-> MaskedLoss -> backward -> Adam step.  Here the model forward/backward is the HIP path, the optimiser is ONE fused
+Adam launch over the flat parameter buffer, and -- when torch.distributed is initialised -- the gradients of all ranks are
+combined by ONE RCCL all-reduce (mser.dist).  The running loss is accumulated on the device and read back once per epoch
+instead of ``loss.item()`` per batch (:117-118).
+"""
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from loss import MaskedLoss
+from models.lsthm_sps import MARN1_sps
+from mser.dist import FlatAllReduce
+from mser.optim import FlatAdam, StepLR
+
+_OUT_OF_SCOPE = ("DialogueRNN", "MARN", "BiLSTM", "MARN1_newz", "MARN1_azs", "MARN1_mf", "MARN1_la", "MARN1_cf", "MARN1_sp",
+                 "MARN1_nsps", "MARN1_onlysp", "MARN1_no_en")
+
+
+class ModelTrainer(nn.Module):
+
+    def __init__(self, device, lr, test_step, lr_decay, model, loss, n_classes, dataset, **kwargs):
+        super(ModelTrainer, self).__init__()
+        self.device = torch.device(device)
+        self.dataset = dataset
+        if model == 'MARN1_sps':
+            self.model = MARN1_sps(n_classes, d_r=kwargs.get("d_r", 1024)).to(self.device)
+        elif model in _OUT_OF_SCOPE:
+            raise NotImplementedError(f"model '{model}' is outside the accelerated hot path (SURVEY.md 8(f)); only 'MARN1_sps' is built")
+        else:
+            raise ValueError(f"unknown model '{model}'")
+        if loss == 'CrossEntropy':
+            losser = nn.CrossEntropyLoss
+        elif loss == 'NLL':
+            losser = nn.NLLLoss
+        else:
+            raise ValueError(f"unknown loss '{loss}'")
+        self.loss = MaskedLoss(losser).to(self.device)
+        self.optim = FlatAdam(self.model.flat_store, lr=lr, weight_decay=2e-5)
+        self.scheduler = StepLR(self.optim, step_size=test_step, gamma=lr_decay)
+        self._allreduce = None
+        if not kwargs.get("quiet", False):
+            print(time.strftime("%m-%d %H:%M:%S") + " Model para number = %.2f" % (
+                sum(param.numel() for param in self.model.parameters()) / 1024 / 1024))
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _unpack(self, data):
+        r1, r2, r3, r4, _, acouf, qmask, umask, label = [d.to(self.device) for d in data[:-1]]
+        return r1, r2, r3, r4, acouf, qmask, umask, label
+
+    def _features(self, r1, r2, r3, r4, acouf):
+        # batch prep stays in torch (SURVEY.md 8(f3) "next" row): textf = (r1+r2+r3+r4)/4 ; x = cat(textf, acouf)
+        textf = (r1 + r2 + r3 + r4) / 4
+        return torch.cat((textf, acouf), dim=-1)
+
+    def train_step(self, x, qmask, umask, label):
+        """One optimisation step on a prepared batch; returns (loss tensor, mask-count tensor), both on the device."""
+        self.optim.zero_grad()
+        lp_, x_a, x_l = self.model(x, qmask, umask)
+        loss = self.loss(lp_, label.view(-1), umask)
+        loss.backward()
+        n = umask.sum()
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            store = self.model.flat_store
+            if self._allreduce is None:
+                self._allreduce = FlatAllReduce(store.total, store.grad.device)
+            self._allreduce.combine(store.grad, n)
+        self.optim.step()
+        return loss.detach(), n
+
+    def train_network(self, epoch, loader):
+        self.train()
+        self.scheduler.step(epoch - 1)
+        lr = self.optim.param_groups[0]['lr']
+        num = torch.zeros((), device=self.device, dtype=torch.float64)
+        den = torch.zeros((), device=self.device, dtype=torch.float64)
+        for _, data in enumerate(loader):
+            r1, r2, r3, r4, acouf, qmask, umask, label = self._unpack(data)
+            loss, n = self.train_step(self._features(r1, r2, r3, r4, acouf), qmask, umask, label)
+            num += loss.double() * n.double()
+            den += n.double()
+        avg_loss = round(float(num / den), 4)
+        return lr, avg_loss
+
+    def eval_network(self, loader):
+        from sklearn.metrics import accuracy_score, f1_score
+        self.eval()
+        preds, labels, masks = [], [], []
+        with torch.no_grad():
+            for _, data in enumerate(loader):
+                r1, r2, r3, r4, acouf, qmask, umask, label = self._unpack(data)
+                lp_, x_a, x_l = self.model(self._features(r1, r2, r3, r4, acouf), qmask, umask)
+                preds.append(torch.argmax(lp_, 1).cpu().numpy())
+                labels.append(label.view(-1).cpu().numpy())
+                masks.append(umask.view(-1).cpu().numpy())
+        preds, labels, masks = np.concatenate(preds), np.concatenate(labels), np.concatenate(masks)
+        avg_accuracy = round(accuracy_score(labels, preds, sample_weight=masks) * 100, 2)
+        avg_fscore = round(f1_score(labels, preds, sample_weight=masks, average='weighted') * 100, 2)
+        return avg_accuracy, avg_fscore, {}
+
+    def save_parameters(self, path):
+        torch.save(self.state_dict(), path)
+
+    def load_parameters(self, path):
+        self_state = self.state_dict()
+        loaded_state = torch.load(path, map_location=self.device, weights_only=True)
+        for name, param in loaded_state.items():
+            origname = name
+            if name not in self_state:
+                name = name.replace("module.", "")
+                if name not in self_state:
+                    print("%s is not in the model." % origname)
+                    continue
+            if self_state[name].size() != loaded_state[origname].size():
+                print("Wrong parameter length: %s, model: %s, loaded: %s" % (
+                    origname, self_state[name].size(), loaded_state[origname].size()))
+                continue
+            self_state[name].copy_(param)

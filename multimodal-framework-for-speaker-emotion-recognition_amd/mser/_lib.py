@@ -1,0 +1,115 @@
+"""ctypes binding of libmser.so (the C-ABI declared in include/mser.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a symbol is absent this module raises, and
+every op raises ``RuntimeError`` with ``mser_last_error()`` when a call returns non-zero.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmser.so")
+
+c_float_p = C.c_void_p   # raw device pointers travel as integers
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("sAm", C.c_int64), ("sAk", C.c_int64), ("sBk", C.c_int64), ("sBn", C.c_int64), ("ldc", C.c_int64),
+        ("batch1", C.c_int32), ("batch2", C.c_int32),
+        ("sA1", C.c_int64), ("sA2", C.c_int64), ("sB1", C.c_int64), ("sB2", C.c_int64), ("sC1", C.c_int64), ("sC2", C.c_int64),
+        ("bias", C.c_void_p), ("alpha_dev", C.c_void_p), ("alpha", C.c_float), ("flags", C.c_int32), ("splitk", C.c_int32),
+        ("R1", C.c_void_p), ("R2", C.c_void_p), ("ldr1", C.c_int64), ("ldr2", C.c_int64),
+        ("sR1_1", C.c_int64), ("sR1_2", C.c_int64),
+    ]
+
+
+_P2 = C.c_void_p * 2
+
+
+class CellParams(C.Structure):
+    _fields_ = [
+        ("lsthm_W", _P2), ("lsthm_Wb", _P2), ("lsthm_U", _P2), ("lsthm_Ub", _P2),
+        ("lsthm_V", _P2), ("lsthm_Vb", _P2), ("lsthm_S", _P2), ("lsthm_Sb", _P2),
+        ("q_Wih", _P2), ("q_Whh", _P2), ("q_bih", _P2), ("q_bhh", _P2),
+        ("att_Wq", C.c_void_p), ("att_Wk", C.c_void_p),
+    ]
+
+
+class CellDir(C.Structure):
+    _fields_ = [("p", CellParams), ("g", CellParams), ("qmask", C.c_void_p), ("rev", C.c_void_p),
+                ("out", C.c_void_p), ("dout", C.c_void_p)]
+
+
+class CellDesc(C.Structure):
+    _fields_ = [
+        ("T", C.c_int32), ("B", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("ndir", C.c_int32),
+        ("x_l", C.c_void_p), ("ldxl", C.c_int64), ("x_a", C.c_void_p), ("ldxa", C.c_int64),
+        ("dx_l", C.c_void_p), ("dx_a", C.c_void_p), ("ldo", C.c_int64),
+        ("dir", CellDir * 2), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+MSER_GEMM_RELU = 1
+MSER_GEMM_ACCUM = 2
+
+_i32, _i64, _f32, _vp, _sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/mser.h one to one (tests/test_abi.py checks the header against this table)
+SIGNATURES = {
+    "mser_version": (C.c_int, []),
+    "mser_last_error": (C.c_char_p, []),
+    "mser_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "mser_softmax_rows": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _i32, _f32, _vp]),
+    "mser_softmax_bwd_rows": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp]),
+    "mser_add_layernorm_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "mser_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "mser_colsum_acc": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _vp]),
+    "mser_relu_bwd": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "mser_add_rows": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
+    "mser_scale_acc_dot": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _vp]),
+    "mser_build_reverse_index": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "mser_reverse_by_length": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "mser_build_slot_tables": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "mser_marn_cell_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    "mser_marn_cell_fwd": (C.c_int, [C.POINTER(CellDesc), _vp]),
+    "mser_marn_cell_bwd": (C.c_int, [C.POINTER(CellDesc), _vp]),
+    "mser_lsthm_step_fwd": (C.c_int, [_vp] * 16 + [_i32] * 5 + [_vp]),
+    "mser_rank1_attention_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "mser_logsoftmax_tb_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "mser_logsoftmax_tb_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "mser_masked_nll_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "mser_masked_nll_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "mser_adam_flat": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libmser.so and bind every symbol of include/mser.h; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libmser.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback on the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mser_version() < 100:
+        raise RuntimeError("libmser.so is older than this binding")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().mser_last_error().decode(errors="replace")
+        raise RuntimeError(f"libmser {what} failed (code {rc}): {msg}")

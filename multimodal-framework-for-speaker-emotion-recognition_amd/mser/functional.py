@@ -1,0 +1,271 @@
+"""Host-side composition of the hot path out of libmser kernels: forward AND hand-written backward of every block
+(encoder layer, sequence-level cross-modal attention, MARN cell, fusion head).  No torch arithmetic on the path:
+torch only allocates buffers and provides streams.
+
+Row layout: an activation is a 2-D [rows, D] matrix; ``Layout(nb, nl, sb, sl)`` says where sequence position l of
+dialogue b lives: row = b*sb + l*sl (time-major [L,B,D]: sb=1, sl=B; batch-major [B,L,D]: sb=L, sl=1).
+
+``P(name)`` returns a parameter tensor, ``G(name)`` the tensor its gradient is ACCUMULATED into (or None to skip).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Dict, Optional
+
+import torch
+
+from . import ops
+
+Tensor = torch.Tensor
+Getter = Callable[[str], Optional[Tensor]]
+
+
+@dataclass
+class Layout:
+    nb: int
+    nl: int
+    sb: int
+    sl: int
+
+    @property
+    def rows(self) -> int:
+        return self.nb * self.nl
+
+    @staticmethod
+    def time_major(L: int, B: int) -> "Layout":
+        return Layout(B, L, 1, B)
+
+    @staticmethod
+    def batch_major(B: int, L: int) -> "Layout":
+        return Layout(B, L, L, 1)
+
+
+def _empty(*shape, like: Tensor, dtype=torch.float32) -> Tensor:
+    return torch.empty(*shape, device=like.device, dtype=dtype)
+
+
+def _zeros(*shape, like: Tensor, dtype=torch.float32) -> Tensor:
+    return torch.zeros(*shape, device=like.device, dtype=dtype)
+
+
+# ====================================================================================================== attention core
+def attn_core_fwd(q: Tensor, k: Tensor, v: Tensor, out: Tensor, lq: Layout, lk: Layout, nh: int, dk: int, dv: int,
+                  scale: float, mul: Optional[Tensor] = None, mask: Optional[Tensor] = None, mask_on: int = 1,
+                  fill: float = float("-inf")) -> Tensor:
+    """P = softmax(scale * Q K^T [* mul, masked]) ; out = P V.  q/k/v/out are 2-D row views [rows, nh*d]. Returns P."""
+    nb, Lq, Lk = lq.nb, lq.nl, lk.nl
+    ldq, ldk, ldv, ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    P = _empty(nb, nh, Lq, Lk, like=q)
+    ops.gemm_raw(q, k, P, Lq, Lk, dk, lq.sl * ldq, 1, 1, lk.sl * ldk, Lk, batch=(nb, nh), sA=(lq.sb * ldq, dk),
+                 sB=(lk.sb * ldk, dk), sC=(nh * Lq * Lk, Lq * Lk), alpha=scale)
+    ops.softmax_rows_(P, nb * nh * Lq, Lk, Lk, mul=mul, mask=mask, mask_on=mask_on, fill=fill)
+    ops.gemm_raw(P, v, out, Lq, dv, Lk, Lk, 1, lk.sl * ldv, 1, lq.sl * ldo, batch=(nb, nh), sA=(nh * Lq * Lk, Lq * Lk),
+                 sB=(lk.sb * ldv, dv), sC=(lq.sb * ldo, dv))
+    return P
+
+
+def attn_core_bwd(dO: Tensor, q: Tensor, k: Tensor, v: Tensor, P: Tensor, dq: Tensor, dk_: Tensor, dv_: Tensor, lq: Layout,
+                  lk: Layout, nh: int, dk: int, dv: int, scale: float, mul: Optional[Tensor] = None) -> None:
+    """Writes dq, dk_, dv_ (2-D row views shaped like q, k, v)."""
+    nb, Lq, Lk = lq.nb, lq.nl, lk.nl
+    ldq, ldk, ldv, lddo = q.stride(0), k.stride(0), v.stride(0), dO.stride(0)
+    PP = (nh * Lq * Lk, Lq * Lk)
+    dP = torch.empty_like(P)
+    ops.gemm_raw(dO, v, dP, Lq, Lk, dv, lq.sl * lddo, 1, 1, lk.sl * ldv, Lk, batch=(nb, nh), sA=(lq.sb * lddo, dv),
+                 sB=(lk.sb * ldv, dv), sC=PP)
+    ops.gemm_raw(P, dO, dv_, Lk, dv, Lq, 1, Lk, lq.sl * lddo, 1, lk.sl * dv_.stride(0), batch=(nb, nh), sA=PP,
+                 sB=(lq.sb * lddo, dv), sC=(lk.sb * dv_.stride(0), dv))
+    ops.softmax_bwd_rows_(P, dP, nb * nh * Lq, Lk, Lk, mul=mul)
+    ops.gemm_raw(dP, k, dq, Lq, dk, Lk, Lk, 1, lk.sl * ldk, 1, lq.sl * dq.stride(0), batch=(nb, nh), sA=PP,
+                 sB=(lk.sb * ldk, dk), sC=(lq.sb * dq.stride(0), dk), alpha=scale)
+    ops.gemm_raw(dP, q, dk_, Lk, dk, Lq, 1, Lk, lq.sl * ldq, 1, lk.sl * dk_.stride(0), batch=(nb, nh), sA=PP,
+                 sB=(lq.sb * ldq, dk), sC=(lk.sb * dk_.stride(0), dk), alpha=scale)
+
+
+# ====================================================================================================== encoder layer
+@dataclass
+class MhaCtx:
+    lq: Layout = None
+    lk: Layout = None
+    xq: Tensor = None
+    xk: Tensor = None
+    xv: Tensor = None
+    q: Tensor = None
+    k: Tensor = None
+    v: Tensor = None
+    P: Tensor = None
+    O: Tensor = None
+    y1: Tensor = None
+    mean: Tensor = None
+    rstd: Tensor = None
+    nh: int = 0
+    dk: int = 0
+    dv: int = 0
+
+
+def mha_fwd(xq: Tensor, xk: Tensor, xv: Tensor, P: Getter, lq: Layout, lk: Layout, nh: int, dk: int, dv: int,
+            mask: Optional[Tensor] = None, out: Optional[Tensor] = None):
+    """MultiHeadAttention.forward -- reference model/encoder.py:27-60: bias-free projections, softmax(q/sqrt(dk) k^T) v,
+    fc, + residual(q input), LayerNorm(eps 1e-6).  Inputs are contiguous 2-D row matrices.  ``mask`` (uint8 [nb,nh,Lq,Lk],
+    0 = masked) reproduces masked_fill(mask == 0, -1e9) (:75-77).  Returns (out, ctx); ctx.P is the attention [nb,nh,Lq,Lk]."""
+    rows, D = xq.shape
+    c = MhaCtx(lq=lq, lk=lk, xq=xq, xk=xk, xv=xv, nh=nh, dk=dk, dv=dv)
+    nq, nv = nh * dk, nh * dv
+    if xq is xk and xk is xv:                       # self-attention: one [rows, 2nq+nv] buffer
+        qkv = _empty(rows, 2 * nq + nv, like=xq)
+        c.q, c.k, c.v = qkv[:, :nq], qkv[:, nq:2 * nq], qkv[:, 2 * nq:]
+    else:
+        c.q, c.k, c.v = _empty(rows, nq, like=xq), _empty(xk.shape[0], nq, like=xq), _empty(xv.shape[0], nv, like=xq)
+    ops.linear(xq, P("w_qs.weight"), c.q)
+    ops.linear(xk, P("w_ks.weight"), c.k)
+    ops.linear(xv, P("w_vs.weight"), c.v)
+    c.O = _empty(rows, nv, like=xq)
+    c.P = attn_core_fwd(c.q, c.k, c.v, c.O, lq, lk, nh, dk, dv, 1.0 / (dk ** 0.5), mask=mask, mask_on=0, fill=-1e9)
+    t = _empty(rows, D, like=xq)
+    ops.linear(c.O, P("fc.weight"), t)
+    c.y1 = _empty(rows, D, like=xq)
+    if out is None:
+        out = _empty(rows, D, like=xq)
+    c.mean, c.rstd = _empty(rows, like=xq), _empty(rows, like=xq)
+    ops.add_layernorm_fwd(t, xq, P("layer_norm.weight"), P("layer_norm.bias"), out, c.y1, c.mean, c.rstd, 1e-6)
+    return out, c
+
+
+def mha_bwd(c: MhaCtx, dout: Tensor, P: Getter, G: Getter, dxq: Tensor, dxk: Tensor, dxv: Tensor, init_q: bool) -> None:
+    """Accumulates into dxq/dxk/dxv (which may alias).  If ``init_q`` the residual gradient INITIALISES dxq (no prior read)."""
+    rows, D = dout.shape
+    nh, dk, dv = c.nh, c.dk, c.dv
+    dy1 = dxq if init_q else _empty(rows, D, like=dout)
+    ops.layernorm_bwd(dout, c.y1, c.mean, c.rstd, P("layer_norm.weight"), dy1, G("layer_norm.weight"), G("layer_norm.bias"))
+    dO = _empty(rows, nh * dv, like=dout)
+    ops.matmul(dy1, P("fc.weight"), dO)
+    ops.grad_weight(dy1, c.O, G("fc.weight"))
+    if not init_q:
+        ops.add_rows(dxq, dxq, dy1)
+    dq, dk_, dv_ = torch.empty_like(c.q), torch.empty_like(c.k), torch.empty_like(c.v)
+    attn_core_bwd(dO, c.q, c.k, c.v, c.P, dq, dk_, dv_, c.lq, c.lk, nh, dk, dv, 1.0 / (dk ** 0.5))
+    for nm, dg, xin, dx in (("w_qs.weight", dq, c.xq, dxq), ("w_ks.weight", dk_, c.xk, dxk), ("w_vs.weight", dv_, c.xv, dxv)):
+        if dx is not None:
+            ops.matmul(dg, P(nm), dx, accum=True)
+        ops.grad_weight(dg, xin, G(nm))
+
+
+@dataclass
+class FfnCtx:
+    x: Tensor = None
+    hdn: Tensor = None
+    y2: Tensor = None
+    mean: Tensor = None
+    rstd: Tensor = None
+
+
+def ffn_fwd(x: Tensor, P: Getter, out: Optional[Tensor] = None):
+    """PositionwiseFeedForward.forward -- reference model/encoder.py:101-113 (w_2(relu(w_1 x)) + x, LayerNorm; ``fc`` unused)."""
+    rows, D = x.shape
+    c = FfnCtx(x=x)
+    c.hdn = _empty(rows, P("w_1.weight").shape[0], like=x)
+    ops.linear(x, P("w_1.weight"), c.hdn, bias=P("w_1.bias"), relu=True)
+    t = _empty(rows, D, like=x)
+    ops.linear(c.hdn, P("w_2.weight"), t, bias=P("w_2.bias"))
+    c.y2 = _empty(rows, D, like=x)
+    if out is None:
+        out = _empty(rows, D, like=x)
+    c.mean, c.rstd = _empty(rows, like=x), _empty(rows, like=x)
+    ops.add_layernorm_fwd(t, x, P("layer_norm.weight"), P("layer_norm.bias"), out, c.y2, c.mean, c.rstd, 1e-6)
+    return out, c
+
+
+def ffn_bwd(c: FfnCtx, dout: Tensor, P: Getter, G: Getter) -> Tensor:
+    rows, D = dout.shape
+    dy2 = _empty(rows, D, like=dout)
+    ops.layernorm_bwd(dout, c.y2, c.mean, c.rstd, P("layer_norm.weight"), dy2, G("layer_norm.weight"), G("layer_norm.bias"))
+    dh = _empty(rows, c.hdn.shape[1], like=dout)
+    ops.matmul(dy2, P("w_2.weight"), dh)
+    ops.grad_weight(dy2, c.hdn, G("w_2.weight"))
+    ops.colsum_acc(dy2, G("w_2.bias"))
+    ops.relu_bwd_(dh, c.hdn)
+    ops.matmul(dh, P("w_1.weight"), dy2, accum=True)                  # dy2 doubles as d(x): residual + FFN input path
+    ops.grad_weight(dh, c.x, G("w_1.weight"))
+    ops.colsum_acc(dh, G("w_1.bias"))
+    return dy2
+
+
+def _sub(P: Getter, prefix: str) -> Getter:
+    return lambda n: P(prefix + n)
+
+
+def encoder_layer_fwd(x: Tensor, x2: Optional[Tensor], P: Getter, lay: Layout, nh: int, dk: int, dv: int,
+                      mask: Optional[Tensor] = None, out: Optional[Tensor] = None):
+    """EncoderLayer.forward on input (x + x2) -- reference model/encoder.py:130-133; x2 carries the residual of the model's
+    second pass (model/lsthm_sps.py:357-358).  Returns (out [rows,D], (mha_ctx, ffn_ctx))."""
+    rows, D = x.shape
+    if x2 is None and x.stride(0) == D:
+        e0 = x
+    else:
+        e0 = _empty(rows, D, like=x)
+        ops.add_rows(e0, x, x2)
+    e1, cm = mha_fwd(e0, e0, e0, _sub(P, "slf_attn."), lay, lay, nh, dk, dv, mask=mask)
+    out, cf = ffn_fwd(e1, _sub(P, "pos_ffn."), out=out)
+    return out, (cm, cf)
+
+
+def encoder_layer_bwd(c, dout: Tensor, P: Getter, G: Getter) -> Tensor:
+    """Returns d(x + x2) [rows, D]; parameter gradients are accumulated into G(name)."""
+    cm, cf = c
+    de1 = ffn_bwd(cf, dout, _sub(P, "pos_ffn."), _sub(G, "pos_ffn."))
+    de0 = torch.empty_like(de1)
+    mha_bwd(cm, de1, _sub(P, "slf_attn."), _sub(G, "slf_attn."), de0, de0, de0, init_q=True)
+    return de0
+
+
+# ====================================================================================================== CrossAttention2/3
+@dataclass
+class XAttnCtx:
+    x1: Tensor = None
+    x2: Tensor = None
+    a1: Optional[Tensor] = None
+    a2: Optional[Tensor] = None
+    Q: Tensor = None
+    KV: Tensor = None
+    P: Tensor = None
+    l1: Layout = None
+    l2: Layout = None
+    heads: int = 1
+    dk: int = 0
+    dv: int = 0
+
+
+def xattn_fwd(x1: Tensor, a1: Optional[Tensor], x2: Tensor, a2: Optional[Tensor], Wq: Tensor, Wk: Tensor, Wv: Tensor,
+              l1: Layout, l2: Layout, out: Tensor, heads: int = 1):
+    """CrossAttention2/3.forward(a1*x1, a2*x2) -- reference model/lsthm_sps.py:88-101 / :116-129 with the learnable scalars of
+    :377-383 folded into the projection GEMMs.  x1 [rows1,D1], x2 [rows2,D2]; out [rows1,Dv] (any leading dimension)."""
+    c = XAttnCtx(x1=x1, x2=x2, a1=a1, a2=a2, l1=l1, l2=l2, heads=heads)
+    Dk, Dv = Wq.shape[1], Wv.shape[1]
+    c.dk, c.dv = Dk // heads, Dv // heads
+    c.Q = _empty(x1.shape[0], Dk, like=x1)
+    c.KV = _empty(x2.shape[0], Dk + Dv, like=x1)
+    ops.matmul(x1, Wq, c.Q, alpha_dev=a1)
+    ops.matmul(x2, Wk, c.KV[:, :Dk], alpha_dev=a2)
+    ops.matmul(x2, Wv, c.KV[:, Dk:], alpha_dev=a2)
+    c.P = attn_core_fwd(c.Q, c.KV[:, :Dk], c.KV[:, Dk:], out, l1, l2, heads, c.dk, c.dv, 1.0 / (c.dk ** 0.5))
+    return c
+
+
+def xattn_bwd(c: XAttnCtx, dout: Tensor, Wq: Tensor, Wk: Tensor, Wv: Tensor, gWq: Tensor, gWk: Tensor, gWv: Tensor,
+              dx1: Tensor, dx2: Tensor, ga1: Optional[Tensor], ga2: Optional[Tensor]) -> None:
+    """Accumulates into dx1, dx2 (grads of the UNSCALED inputs), the weight grads and the scalar grads."""
+    Dk = Wq.shape[1]
+    dQ = torch.empty_like(c.Q)
+    dKV = torch.empty_like(c.KV)
+    attn_core_bwd(dout, c.Q, c.KV[:, :Dk], c.KV[:, Dk:], c.P, dQ, dKV[:, :Dk], dKV[:, Dk:], c.l1, c.l2, c.heads, c.dk, c.dv,
+                  1.0 / (c.dk ** 0.5))
+    ops.grad_weight(dQ, c.x1, gWq, transposed=True, alpha_dev=c.a1)
+    ops.grad_weight(dKV[:, :Dk], c.x2, gWk, transposed=True, alpha_dev=c.a2)
+    ops.grad_weight(dKV[:, Dk:], c.x2, gWv, transposed=True, alpha_dev=c.a2)
+    t1 = _empty(c.x1.shape[0], c.x1.shape[1], like=dout)
+    ops.matmul_nt(dQ, Wq, t1)                                         # grad wrt (a1 * x1)
+    ops.scale_acc_dot(dx1, t1, c.x1, c.a1, ga1)
+    t2 = _empty(c.x2.shape[0], c.x2.shape[1], like=dout)
+    ops.matmul_nt(dKV[:, :Dk], Wk, t2)
+    ops.matmul_nt(dKV[:, Dk:], Wv, t2, accum=True)
+    ops.scale_acc_dot(dx2, t2, c.x2, c.a2, ga2)

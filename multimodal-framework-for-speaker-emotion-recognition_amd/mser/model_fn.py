@@ -1,0 +1,239 @@
+"""Forward / backward of the whole MARN1_sps path (reference model/lsthm_sps.py:349-394) as explicit kernel sequences.
+
+``marn1_forward`` returns the outputs and a context object; ``marn1_backward`` consumes it.  Dropout sites of the
+reference are identities here (parity is defined in eval mode / p = 0, SURVEY.md 7 "Dropout").
+The two encoder branches (text / audio) and the speaker chain are independent until the LSTHM chain, so they are
+enqueued on side streams (fork/join with events; capturable into one hipGraph).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional
+
+import torch
+
+from . import functional as F_
+from . import ops
+from .functional import Layout
+
+Tensor = torch.Tensor
+Getter = Callable[[str], Optional[Tensor]]
+
+
+@dataclass
+class ModelDims:
+    d_r: int = 1024
+    d_a: int = 100
+    D: int = 100
+    H: int = 128
+    n_head: int = 8
+    d_k: int = 40
+    d_v: int = 40
+    n_classes: int = 6
+    xattn_heads: int = 1
+
+
+@dataclass
+class ModelCtx:
+    dims: ModelDims = None
+    L: int = 0
+    B: int = 0
+    x2d: Tensor = None
+    xl0: Tensor = None
+    enc: list = None
+    x_l: Tensor = None
+    x_a: Tensor = None
+    rev: Tensor = None
+    lens: Tensor = None
+    Hcat: Tensor = None
+    cell_ws: Tensor = None
+    cell_dirs: list = None
+    A1: Tensor = None
+    A2: Tensor = None
+    xa: list = None
+    y1: Tensor = None
+    y1r: Tensor = None
+    y2: Tensor = None
+    lp: Tensor = None
+    qmask: Tensor = None
+
+
+def _sub(P: Getter, prefix: str) -> Getter:
+    return lambda n: P(prefix + n)
+
+
+class _Streams:
+    """Lazily created side streams for the independent branches."""
+    _s = None
+
+    @classmethod
+    def get(cls, dev):
+        if cls._s is None or cls._s[0].device != dev:
+            cls._s = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        return cls._s
+
+
+def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: ModelDims, use_streams: bool = True):
+    """x [L,B,d_r+d_a] f32, qmask [L,B,2] f32, umask [B,L] f32 -> (log_probs [B*L,C], x_l [L,B,D], x_a [L,B,D], ctx)."""
+    Ln, B, Fin = x.shape
+    d = dims
+    if Fin < d.d_r + d.d_a:
+        raise RuntimeError(f"x has {Fin} features, model expects d_r+d_a = {d.d_r + d.d_a}")
+    for t, nm in ((x, "x"), (qmask, "qmask"), (umask, "umask")):
+        if t.dtype != torch.float32 or not t.is_cuda:
+            raise RuntimeError(f"{nm} must be a float32 GPU tensor (got {t.dtype} on {t.device})")
+    x = x.contiguous()
+    qmask = qmask.contiguous()
+    umask = umask.contiguous()
+    N, D, H = Ln * B, d.D, d.H
+    lay = Layout.time_major(Ln, B)
+    c = ModelCtx(dims=d, L=Ln, B=B, qmask=qmask)
+    c.x2d = x.view(N, Fin)
+    cur = torch.cuda.current_stream()
+    side = _Streams.get(x.device) if use_streams else None
+
+    # ---- text branch (current stream) and audio branch (side stream 0): linear_in + 2 x EncoderLayer each
+    c.xl0 = torch.empty(N, D, device=x.device)
+    xa0 = c.x2d[:, d.d_r:d.d_r + d.d_a]
+    c.x_l = torch.empty(N, D, device=x.device)
+    c.x_a = torch.empty(N, D, device=x.device)
+    c.enc = [None] * 4
+    Pl, Pa = _sub(P, "encoder_l."), _sub(P, "encoder_a.")
+
+    def text_branch():
+        ops.linear(c.x2d[:, :d.d_r], P("linear_in.weight"), c.xl0, bias=P("linear_in.bias"))
+        e1, c.enc[0] = F_.encoder_layer_fwd(c.xl0, None, Pl, lay, d.n_head, d.d_k, d.d_v)
+        _, c.enc[1] = F_.encoder_layer_fwd(c.xl0, e1, Pl, lay, d.n_head, d.d_k, d.d_v, out=c.x_l)
+
+    def audio_branch():
+        e1, c.enc[2] = F_.encoder_layer_fwd(xa0, None, Pa, lay, d.n_head, d.d_k, d.d_v)
+        _, c.enc[3] = F_.encoder_layer_fwd(xa0, e1, Pa, lay, d.n_head, d.d_k, d.d_v, out=c.x_a)
+
+    c.lens = torch.empty(B, device=x.device, dtype=torch.int32)
+    c.rev = torch.empty(Ln, B, device=x.device, dtype=torch.int32)
+    ops.build_reverse_index(umask, c.lens, c.rev)
+    if side is not None:
+        side[0].wait_stream(cur)
+        with torch.cuda.stream(side[0]):
+            audio_branch()
+        text_branch()
+        cur.wait_stream(side[0])
+    else:
+        text_branch()
+        audio_branch()
+
+    # ---- bidirectional MARN cell (both directions share every launch)
+    c.Hcat = torch.empty(N, 10 * H, device=x.device)
+    nbytes = ops.cell_workspace_bytes(Ln, B, D, H, 2)
+    c.cell_ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    c.cell_dirs = [
+        dict(p=ops.cell_param_struct(_sub(P, "marn_cell_f.")), qmask=qmask, rev=None, out=c.Hcat[:, 0:4 * H]),
+        dict(p=ops.cell_param_struct(_sub(P, "marn_cell_b.")), qmask=qmask, rev=c.rev, out=c.Hcat[:, 4 * H:8 * H]),
+    ]
+    desc = ops.make_cell_desc(Ln, B, D, H, c.x_l, c.x_a, c.cell_dirs, 10 * H, c.cell_ws)
+    ops.marn_cell_fwd(desc)
+
+    # ---- sequence-level cross-modal attention (:377-383)
+    w, v, v1, v2 = P("w"), P("v"), P("v1"), P("v2")
+    c.A1 = torch.empty(N, H, device=x.device)
+    c.A2 = torch.empty(N, H, device=x.device)
+    hh = d.xattn_heads
+    c.xa = [None] * 4
+    c.xa[0] = F_.xattn_fwd(c.x_l, w, c.x_a, v, P("crossatt_l2a.Wq"), P("crossatt_l2a.Wk"), P("crossatt_l2a.Wv"), lay, lay, c.A1, hh)
+    c.xa[1] = F_.xattn_fwd(c.x_a, v, c.x_l, w, P("crossatt_a2l.Wq"), P("crossatt_a2l.Wk"), P("crossatt_a2l.Wv"), lay, lay, c.A2, hh)
+    c.xa[2] = F_.xattn_fwd(c.x_a, v, c.A1, v1, P("crossatt_l2a_1.Wq"), P("crossatt_l2a_1.Wk"), P("crossatt_l2a_1.Wv"), lay, lay,
+                           c.Hcat[:, 8 * H:9 * H], hh)
+    c.xa[3] = F_.xattn_fwd(c.x_l, w, c.A2, v2, P("crossatt_a2l_1.Wq"), P("crossatt_a2l_1.Wk"), P("crossatt_a2l_1.Wv"), lay, lay,
+                           c.Hcat[:, 9 * H:10 * H], hh)
+
+    # ---- fusion head (:390-393)
+    c.y1 = torch.empty(N, D, device=x.device)
+    ops.linear(c.Hcat, P("fc.0.weight"), c.y1, bias=P("fc.0.bias"), relu=True)
+    c.y1r = torch.empty(N, D, device=x.device)
+    ops.add_rows(c.y1r, c.y1, c.x_l)
+    ops.add_rows(c.y1r, c.y1r, c.x_a)
+    h_out = P("nn_out.0.weight").shape[0]
+    c.y2 = torch.empty(N, h_out, device=x.device)
+    ops.linear(c.y1r, P("nn_out.0.weight"), c.y2, bias=P("nn_out.0.bias"), relu=True)
+    y3 = torch.empty(N, d.n_classes, device=x.device)
+    ops.linear(c.y2, P("nn_out.3.weight"), y3, bias=P("nn_out.3.bias"))
+    c.lp = torch.empty(B * Ln, d.n_classes, device=x.device)
+    ops.logsoftmax_tb_fwd(y3, c.lp, Ln, B)
+    return c.lp, c.x_l.view(Ln, B, D), c.x_a.view(Ln, B, D), c
+
+
+def marn1_backward(c: ModelCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: Optional[Tensor] = None,
+                   dx_a_out: Optional[Tensor] = None, use_streams: bool = True) -> None:
+    """Accumulates every parameter gradient into G(name).  dlp [B*L,C]; optional grads of the returned x_l / x_a."""
+    d = c.dims
+    Ln, B, N, D, H = c.L, c.B, c.L * c.B, c.dims.D, c.dims.H
+    dev = dlp.device
+    lay = Layout.time_major(Ln, B)
+    dlp = dlp.contiguous()
+    # ---- head
+    dy3 = torch.empty(N, d.n_classes, device=dev)
+    ops.logsoftmax_tb_bwd(dlp, c.lp, dy3, Ln, B)
+    dy2 = torch.empty_like(c.y2)
+    ops.matmul(dy3, P("nn_out.3.weight"), dy2)
+    ops.grad_weight(dy3, c.y2, G("nn_out.3.weight"))
+    ops.colsum_acc(dy3, G("nn_out.3.bias"))
+    ops.relu_bwd_(dy2, c.y2)
+    dx_l = torch.empty(N, D, device=dev)                      # = d(y1r), then accumulates every x_l gradient
+    ops.matmul(dy2, P("nn_out.0.weight"), dx_l)
+    ops.grad_weight(dy2, c.y1r, G("nn_out.0.weight"))
+    ops.colsum_acc(dy2, G("nn_out.0.bias"))
+    dy1 = torch.empty(N, D, device=dev)
+    ops.add_rows(dy1, dx_l, None)
+    ops.relu_bwd_(dy1, c.y1)
+    dx_a = torch.empty(N, D, device=dev)
+    ops.add_rows(dx_a, dx_l, dx_a_out.reshape(N, D) if dx_a_out is not None else None)
+    if dx_l_out is not None:
+        ops.add_rows(dx_l, dx_l, dx_l_out.reshape(N, D))
+    dH = torch.empty(N, 10 * H, device=dev)
+    ops.matmul(dy1, P("fc.0.weight"), dH)
+    ops.grad_weight(dy1, c.Hcat, G("fc.0.weight"))
+    ops.colsum_acc(dy1, G("fc.0.bias"))
+    # ---- sequence-level attention, reverse order
+    w, v, v1, v2 = P("w"), P("v"), P("v1"), P("v2")
+    dA1 = torch.zeros(N, H, device=dev)
+    dA2 = torch.zeros(N, H, device=dev)
+
+    def xb(i, name, dout, dx1, dx2, ga1, ga2):
+        F_.xattn_bwd(c.xa[i], dout, P(name + ".Wq"), P(name + ".Wk"), P(name + ".Wv"), G(name + ".Wq"), G(name + ".Wk"),
+                     G(name + ".Wv"), dx1, dx2, ga1, ga2)
+
+    xb(3, "crossatt_a2l_1", dH[:, 9 * H:10 * H], dx_l, dA2, G("w"), G("v2"))
+    xb(2, "crossatt_l2a_1", dH[:, 8 * H:9 * H], dx_a, dA1, G("v"), G("v1"))
+    xb(1, "crossatt_a2l", dA2, dx_a, dx_l, G("v"), G("w"))
+    xb(0, "crossatt_l2a", dA1, dx_l, dx_a, G("w"), G("v"))
+    # ---- MARN cell
+    for r, pre, sl in ((c.cell_dirs[0], "marn_cell_f.", slice(0, 4 * H)), (c.cell_dirs[1], "marn_cell_b.", slice(4 * H, 8 * H))):
+        r["g"] = ops.cell_param_struct(_sub(G, pre))
+        r["dout"] = dH[:, sl]
+    desc = ops.make_cell_desc(Ln, B, D, H, c.x_l, c.x_a, c.cell_dirs, 10 * H, c.cell_ws, dx_l=dx_l, dx_a=dx_a)
+    ops.marn_cell_bwd(desc)
+    # ---- encoders (two passes with shared weights) + linear_in
+    Pl, Pa, Gl, Ga = _sub(P, "encoder_l."), _sub(P, "encoder_a."), _sub(G, "encoder_l."), _sub(G, "encoder_a.")
+    cur = torch.cuda.current_stream()
+    side = _Streams.get(dev) if use_streams else None
+
+    def text_branch():
+        d2 = F_.encoder_layer_bwd(c.enc[1], dx_l, Pl, Gl)          # grad of (xl0 + e1): flows to both
+        d1 = F_.encoder_layer_bwd(c.enc[0], d2, Pl, Gl)
+        ops.add_rows(d1, d1, d2)                                   # d(xl0)
+        ops.grad_weight(d1, c.x2d[:, :d.d_r], G("linear_in.weight"))
+        ops.colsum_acc(d1, G("linear_in.bias"))
+
+    def audio_branch():
+        d2 = F_.encoder_layer_bwd(c.enc[3], dx_a, Pa, Ga)
+        F_.encoder_layer_bwd(c.enc[2], d2, Pa, Ga)                 # input features need no gradient
+
+    if side is not None:
+        side[0].wait_stream(cur)
+        with torch.cuda.stream(side[0]):
+            audio_branch()
+        text_branch()
+        cur.wait_stream(side[0])
+    else:
+        text_branch()
+        audio_branch()

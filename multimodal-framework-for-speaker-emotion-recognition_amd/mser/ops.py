@@ -1,0 +1,254 @@
+"""Tensor-level wrappers over the C-ABI: every function takes torch tensors that already live on the GPU, passes raw
+pointers / strides and enqueues on PyTorch's current HIP stream.  PyTorch is plumbing here (device memory, streams);
+all arithmetic happens in libmser.so.
+
+2-D operands are torch views whose last stride is 1 (``stride(0)`` is the leading dimension), so slices such as
+``x.view(L*B, d_r+100)[:, d_r:]`` are passed without a copy.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+Tensor = torch.Tensor
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("mser ops need GPU tensors (the product path has no CPU fallback)")
+    return t.data_ptr()
+
+
+def _f32(t: Tensor, what: str) -> None:
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{what}: expected float32, got {t.dtype}")
+
+
+def _ld(t: Tensor) -> int:
+    """leading dimension of a 2-D row view"""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise RuntimeError(f"expected a 2-D view with unit inner stride, got shape {tuple(t.shape)} stride {t.stride()}")
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+
+
+def gemm_raw(A: Tensor, B: Tensor, Cm: Tensor, M: int, N: int, K: int, sAm: int, sAk: int, sBk: int, sBn: int, ldc: int,
+             batch: Tuple[int, int] = (1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), bias: Optional[Tensor] = None,
+             alpha: float = 1.0, alpha_dev: Optional[Tensor] = None, relu: bool = False, accum: bool = False,
+             splitk: int = 1, R1: Optional[Tensor] = None, ldr1: int = 0, R2: Optional[Tensor] = None, ldr2: int = 0,
+             sR=(0, 0)) -> None:
+    d = L.GemmDesc()
+    d.A, d.B, d.C = _p(A), _p(B), _p(Cm)
+    d.M, d.N, d.K = M, N, K
+    d.sAm, d.sAk, d.sBk, d.sBn, d.ldc = sAm, sAk, sBk, sBn, ldc
+    d.batch1, d.batch2 = batch
+    d.sA1, d.sA2 = sA
+    d.sB1, d.sB2 = sB
+    d.sC1, d.sC2 = sC
+    d.bias, d.alpha_dev, d.alpha = _p(bias), _p(alpha_dev), alpha
+    d.flags = (L.MSER_GEMM_RELU if relu else 0) | (L.MSER_GEMM_ACCUM if accum else 0)
+    d.splitk = splitk
+    d.R1, d.R2, d.ldr1, d.ldr2 = _p(R1), _p(R2), ldr1, ldr2
+    d.sR1_1, d.sR1_2 = sR
+    L.check(L.load().mser_gemm(C.byref(d), _stream()), "mser_gemm")
+
+
+def linear(x: Tensor, W: Tensor, out: Tensor, bias: Optional[Tensor] = None, relu: bool = False, accum: bool = False,
+           alpha_dev: Optional[Tensor] = None, R1: Optional[Tensor] = None, R2: Optional[Tensor] = None) -> None:
+    """out[rows,N] (+)= x[rows,K] @ W[N,K]^T (+bias, relu, +R1 +R2)   -- nn.Linear layout"""
+    rows, K = x.shape
+    N = W.shape[0]
+    gemm_raw(x, W, out, rows, N, K, _ld(x), 1, 1, W.stride(0), _ld(out), bias=bias, relu=relu, accum=accum,
+             alpha_dev=alpha_dev, R1=R1, ldr1=_ld(R1) if R1 is not None else 0, R2=R2,
+             ldr2=_ld(R2) if R2 is not None else 0)
+
+
+def matmul(x: Tensor, Wkn: Tensor, out: Tensor, accum: bool = False, alpha_dev: Optional[Tensor] = None) -> None:
+    """out[rows,N] (+)= alpha * x[rows,K] @ Wkn[K,N]   -- torch.matmul(x, W) layout (CrossAttention2/3)"""
+    rows, K = x.shape
+    N = Wkn.shape[1]
+    gemm_raw(x, Wkn, out, rows, N, K, _ld(x), 1, Wkn.stride(0), 1, _ld(out), accum=accum, alpha_dev=alpha_dev)
+
+
+def matmul_nt(dy: Tensor, Wkn: Tensor, out: Tensor, accum: bool = False, alpha_dev: Optional[Tensor] = None) -> None:
+    """out[rows,K] (+)= alpha * dy[rows,N] @ Wkn[K,N]^T"""
+    rows, N = dy.shape
+    K = Wkn.shape[0]
+    gemm_raw(dy, Wkn, out, rows, K, N, _ld(dy), 1, 1, Wkn.stride(0), _ld(out), accum=accum, alpha_dev=alpha_dev)
+
+
+def grad_weight(dy: Tensor, x: Tensor, dW: Tensor, transposed: bool = False, alpha_dev: Optional[Tensor] = None,
+                splitk: int = 16) -> None:
+    """dW += dy^T x (nn.Linear weight [N,K]) or, transposed, dW += x^T dy (matmul weight [K,N]); split-K float atomics."""
+    rows = dy.shape[0]
+    if not transposed:
+        N, K = dy.shape[1], x.shape[1]
+        gemm_raw(dy, x, dW, N, K, rows, 1, _ld(dy), _ld(x), 1, dW.stride(0), splitk=splitk, alpha_dev=alpha_dev)
+    else:
+        K, N = x.shape[1], dy.shape[1]
+        gemm_raw(x, dy, dW, K, N, rows, 1, _ld(x), _ld(dy), 1, dW.stride(0), splitk=splitk, alpha_dev=alpha_dev)
+
+
+def softmax_rows_(S: Tensor, rows: int, n: int, ld: int, mul: Optional[Tensor] = None, mask: Optional[Tensor] = None,
+                  mask_on: int = 1, fill: float = float("-inf")) -> None:
+    L.check(L.load().mser_softmax_rows(_p(S), rows, n, ld, _p(mul), _p(mask), mask_on, fill, _stream()), "softmax_rows")
+
+
+def softmax_bwd_rows_(P: Tensor, dP: Tensor, rows: int, n: int, ld: int, mul: Optional[Tensor] = None) -> None:
+    L.check(L.load().mser_softmax_bwd_rows(_p(P), _p(dP), rows, n, ld, _p(mul), _stream()), "softmax_bwd_rows")
+
+
+def add_layernorm_fwd(x: Tensor, res: Optional[Tensor], gamma: Tensor, beta: Tensor, y: Tensor, sum_out: Optional[Tensor],
+                      mean: Tensor, rstd: Tensor, eps: float) -> None:
+    rows, D = x.shape
+    L.check(L.load().mser_add_layernorm_fwd(_p(x), _ld(x), _p(res), _ld(res) if res is not None else 0, _p(gamma), _p(beta),
+                                            _p(y), _p(sum_out), _p(mean), _p(rstd), rows, D, eps, _stream()), "add_layernorm_fwd")
+
+
+def layernorm_bwd(dy: Tensor, xsum: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, dx: Tensor, dgamma: Tensor,
+                  dbeta: Tensor) -> None:
+    rows, D = dy.shape
+    L.check(L.load().mser_layernorm_bwd(_p(dy), _p(xsum), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), rows, D,
+                                        _stream()), "layernorm_bwd")
+
+
+def colsum_acc(X: Tensor, out: Tensor) -> None:
+    rows, n = X.shape
+    L.check(L.load().mser_colsum_acc(_p(X), rows, n, _ld(X), _p(out), _stream()), "colsum_acc")
+
+
+def relu_bwd_(dY: Tensor, Y: Tensor) -> None:
+    L.check(L.load().mser_relu_bwd(_p(dY), _p(Y), dY.numel(), _stream()), "relu_bwd")
+
+
+def add_rows(out: Tensor, a: Tensor, b: Optional[Tensor] = None) -> None:
+    rows, D = a.shape
+    L.check(L.load().mser_add_rows(_p(out), _ld(out), _p(a), _ld(a), _p(b), _ld(b) if b is not None else 0, rows, D, _stream()),
+            "add_rows")
+
+
+def scale_acc_dot(acc: Tensor, t: Tensor, x: Optional[Tensor], s_dev: Optional[Tensor], ds: Optional[Tensor]) -> None:
+    rows, D = t.shape
+    L.check(L.load().mser_scale_acc_dot(_p(acc), _ld(acc), _p(t), _ld(t), _p(x), _ld(x) if x is not None else 0, _p(s_dev), _p(ds),
+                                        rows, D, _stream()), "scale_acc_dot")
+
+
+def build_reverse_index(umask: Tensor, lens: Tensor, rev: Tensor) -> None:
+    B, Ln = umask.shape
+    L.check(L.load().mser_build_reverse_index(_p(umask), B, Ln, _p(lens), _p(rev), _stream()), "build_reverse_index")
+
+
+def reverse_by_length(X: Tensor, rev: Tensor, out: Tensor, Ln: int, B: int) -> None:
+    D = X.shape[1]
+    L.check(L.load().mser_reverse_by_length(_p(X), _ld(X), _p(rev), _p(out), _ld(out), Ln, B, D, _stream()), "reverse_by_length")
+
+
+def build_slot_tables(qmask: Tensor, rev: Optional[Tensor], party: Tensor, perm: Tensor, n0: Tensor, qm_out: Tensor) -> None:
+    T, B = qmask.shape[0], qmask.shape[1]
+    L.check(L.load().mser_build_slot_tables(_p(qmask), _p(rev), T, B, _p(party), _p(perm), _p(n0), _p(qm_out), _stream()),
+            "build_slot_tables")
+
+
+def logsoftmax_tb_fwd(y: Tensor, lp: Tensor, Ln: int, B: int) -> None:
+    L.check(L.load().mser_logsoftmax_tb_fwd(_p(y), _p(lp), Ln, B, y.shape[-1], _stream()), "logsoftmax_tb_fwd")
+
+
+def logsoftmax_tb_bwd(dlp: Tensor, lp: Tensor, dy: Tensor, Ln: int, B: int) -> None:
+    L.check(L.load().mser_logsoftmax_tb_bwd(_p(dlp), _p(lp), _p(dy), Ln, B, lp.shape[-1], _stream()), "logsoftmax_tb_bwd")
+
+
+def masked_nll_fwd(pred: Tensor, target: Tensor, mask: Tensor, loss_out: Tensor) -> None:
+    rows, Cn = pred.shape
+    L.check(L.load().mser_masked_nll_fwd(_p(pred), _p(target), _p(mask), rows, Cn, _p(loss_out), _stream()), "masked_nll_fwd")
+
+
+def masked_nll_bwd(target: Tensor, mask: Tensor, loss_out: Tensor, gscale: Optional[Tensor], dpred: Tensor) -> None:
+    rows, Cn = dpred.shape
+    L.check(L.load().mser_masked_nll_bwd(_p(target), _p(mask), _p(loss_out), _p(gscale), _p(dpred), rows, Cn, _stream()),
+            "masked_nll_bwd")
+
+
+def adam_flat(p: Tensor, g: Tensor, m: Tensor, v: Tensor, live: Optional[Tensor], step: int, lr: float, beta1: float = 0.9,
+              beta2: float = 0.999, eps: float = 1e-8, wd: float = 0.0, gscale: float = 1.0) -> None:
+    L.check(L.load().mser_adam_flat(_p(p), _p(g), _p(m), _p(v), _p(live), p.numel(), step, lr, beta1, beta2, eps, wd, gscale,
+                                    _stream()), "adam_flat")
+
+
+def lsthm_step_fwd(x, c, h, z, s, W, Wb, U, Ub, V, Vb, S, Sb, c_out, h_out, gates=None) -> None:
+    B, D = x.shape
+    H, Hz, Hs = c.shape[1], z.shape[1], s.shape[1]
+    L.check(L.load().mser_lsthm_step_fwd(_p(x), _p(c), _p(h), _p(z), _p(s), _p(W), _p(Wb), _p(U), _p(Ub), _p(V), _p(Vb), _p(S),
+                                         _p(Sb), _p(c_out), _p(h_out), _p(gates), B, D, H, Hz, Hs, _stream()), "lsthm_step_fwd")
+
+
+def rank1_attention_fwd(x1: Tensor, x2: Tensor, Wq: Tensor, Wk: Tensor, out: Tensor) -> None:
+    B, H = x1.shape
+    L.check(L.load().mser_rank1_attention_fwd(_p(x1), _p(x2), _p(Wq), _p(Wk), _p(out), B, H, _stream()), "rank1_attention_fwd")
+
+
+# ---------------------------------------------------------------------------------------------- MARN cell
+CELL_KEYS = ("lsthm_W", "lsthm_Wb", "lsthm_U", "lsthm_Ub", "lsthm_V", "lsthm_Vb", "lsthm_S", "lsthm_Sb",
+             "q_Wih", "q_Whh", "q_bih", "q_bhh")
+
+
+def cell_param_struct(get) -> L.CellParams:
+    """``get(name)`` returns the tensor for a reference parameter name relative to the MARN_cell (or None)."""
+    cp = L.CellParams()
+    names = {
+        "lsthm_W": ("lsthm_l.W.weight", "lsthm_a.W.weight"), "lsthm_Wb": ("lsthm_l.W.bias", "lsthm_a.W.bias"),
+        "lsthm_U": ("lsthm_l.U.weight", "lsthm_a.U.weight"), "lsthm_Ub": ("lsthm_l.U.bias", "lsthm_a.U.bias"),
+        "lsthm_V": ("lsthm_l.V.weight", "lsthm_a.V.weight"), "lsthm_Vb": ("lsthm_l.V.bias", "lsthm_a.V.bias"),
+        "lsthm_S": ("lsthm_l.S.weight", "lsthm_a.S.weight"), "lsthm_Sb": ("lsthm_l.S.bias", "lsthm_a.S.bias"),
+        "q_Wih": ("lstm_q0.weight_ih", "lstm_q1.weight_ih"), "q_Whh": ("lstm_q0.weight_hh", "lstm_q1.weight_hh"),
+        "q_bih": ("lstm_q0.bias_ih", "lstm_q1.bias_ih"), "q_bhh": ("lstm_q0.bias_hh", "lstm_q1.bias_hh"),
+    }
+    for field, (n0, n1) in names.items():
+        arr = getattr(cp, field)
+        arr[0] = _p(get(n0))
+        arr[1] = _p(get(n1))
+    cp.att_Wq = _p(get("crossatt_l2a.Wq"))
+    cp.att_Wk = _p(get("crossatt_l2a.Wk"))
+    return cp
+
+
+def cell_workspace_bytes(T: int, B: int, D: int, H: int, ndir: int) -> int:
+    return int(L.load().mser_marn_cell_workspace_bytes(T, B, D, H, ndir))
+
+
+def make_cell_desc(T: int, B: int, D: int, H: int, x_l: Tensor, x_a: Tensor, dirs: Sequence[dict], ldo: int,
+                   workspace: Tensor, dx_l: Optional[Tensor] = None, dx_a: Optional[Tensor] = None) -> L.CellDesc:
+    """dirs: list of dicts with keys p (CellParams), g (CellParams or None), qmask, rev (or None), out, dout (or None)."""
+    d = L.CellDesc()
+    d.T, d.B, d.D, d.H, d.ndir = T, B, D, H, len(dirs)
+    d.x_l, d.ldxl = _p(x_l), _ld(x_l)
+    d.x_a, d.ldxa = _p(x_a), _ld(x_a)
+    d.dx_l, d.dx_a = _p(dx_l), _p(dx_a)
+    d.ldo = ldo
+    for i, r in enumerate(dirs):
+        d.dir[i].p = r["p"]
+        if r.get("g") is not None:
+            d.dir[i].g = r["g"]
+        d.dir[i].qmask = _p(r["qmask"])
+        d.dir[i].rev = _p(r.get("rev"))
+        d.dir[i].out = _p(r["out"])
+        d.dir[i].dout = _p(r.get("dout"))
+    d.workspace = _p(workspace)
+    d.workspace_bytes = workspace.numel() * workspace.element_size()
+    return d
+
+
+def marn_cell_fwd(desc: L.CellDesc) -> None:
+    L.check(L.load().mser_marn_cell_fwd(C.byref(desc), _stream()), "marn_cell_fwd")
+
+
+def marn_cell_bwd(desc: L.CellDesc) -> None:
+    L.check(L.load().mser_marn_cell_bwd(C.byref(desc), _stream()), "marn_cell_bwd")

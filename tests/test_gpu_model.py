@@ -1,0 +1,155 @@
+"""GPU parity of the module-level and whole-model HIP paths against (a) golden vectors produced by the reference itself and
+(b) the CPU oracle on the same seeded inputs (run with -m gpu).  Gate from BASELINE.json: log-probs within 1e-4 (fp32),
+argmax bit-exact wherever the reference's own top-1/top-2 margin exceeds 2x that tolerance."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import load_params, maxabs
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def O():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import ref_cpu
+    return ref_cpu
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _check_grads(g, named, rel=3e-4):
+    bad = []
+    for name, p in named:
+        gn = float(g["gnorm/" + name])
+        if gn < 0:
+            assert p.grad is None or float(p.grad.abs().sum()) == 0.0, f"{name} must stay dead"
+            continue
+        assert p.grad is not None, name
+        got = p.grad.detach().cpu().double().reshape(-1)
+        tol = rel * max(gn, 1e-3)
+        e1 = abs(float(got.norm()) - gn)
+        e2 = float(np.abs(got[g["gidx/" + name]].numpy() - g["gval/" + name]).max())
+        if e1 > tol or e2 > tol:
+            bad.append((name, gn, e1, e2))
+    assert not bad, bad
+
+
+def test_encoder_layer_module(O, golden_dir):
+    from models.encoder import EncoderLayer
+    g = _g(golden_dir, "modules.npz")
+    m = EncoderLayer(100, 40, 8, 40, 40).cuda()
+    P = O.seeded_params(seed=4)
+    load_params(m, {k[len("encoder_l."):]: v for k, v in P.items() if k.startswith("encoder_l.")})
+    x = torch.tensor(g["enc_x"]).cuda().requires_grad_(True)
+    out, attn = m(x)
+    assert maxabs(out, g["enc_out"]) < 2e-5
+    assert maxabs(attn, g["enc_attn"]) < 5e-6
+    # backward vs oracle autograd
+    wsum = torch.tensor(np.random.RandomState(0).standard_normal(out.shape).astype(np.float32))
+    (out * wsum.cuda()).sum().backward()
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items() if k.startswith("encoder_l.")}
+    xr = torch.tensor(g["enc_x"]).requires_grad_(True)
+    o2, _ = O.encoder_layer(Pr, "encoder_l.", xr)
+    (o2 * wsum).sum().backward()
+    assert maxabs(x.grad, xr.grad) < 5e-5
+    for n, p in m.named_parameters():
+        r = Pr["encoder_l." + n].grad
+        if r is None:
+            continue
+        assert maxabs(p.grad, r) < 2e-4 * max(1.0, float(r.abs().max())), n
+
+
+def test_seq_cross_attention_modules(O, golden_dir):
+    from models.lsthm_sps import CrossAttention2, CrossAttention3
+    g = _g(golden_dir, "modules.npz")
+    P = O.seeded_params(seed=4)
+    for cls, pre, x2k, outk in ((CrossAttention2, "crossatt_l2a.", "ca2_x2", "ca2_out"), (CrossAttention3, "crossatt_l2a_1.", "ca3_x2", "ca3_out")):
+        m = cls(100, 128, 128).cuda()
+        load_params(m, {k[len(pre):]: v for k, v in P.items() if k.startswith(pre)})
+        a = torch.tensor(g["ca2_x1"]).cuda().requires_grad_(True)
+        b = torch.tensor(g[x2k]).cuda().requires_grad_(True)
+        out = m(a, b)
+        assert maxabs(out, g[outk]) < 2e-5
+        wsum = torch.tensor(np.random.RandomState(1).standard_normal(out.shape).astype(np.float32))
+        (out * wsum.cuda()).sum().backward()
+        Pr = {k: v.clone().requires_grad_(True) for k, v in P.items() if k.startswith(pre)}
+        ar, br = torch.tensor(g["ca2_x1"]).requires_grad_(True), torch.tensor(g[x2k]).requires_grad_(True)
+        (O.cross_attention_seq(Pr, pre, ar, br) * wsum).sum().backward()
+        assert maxabs(a.grad, ar.grad) < 5e-5 and maxabs(b.grad, br.grad) < 5e-5
+        for n in ("Wq", "Wk", "Wv"):
+            r = Pr[pre + n].grad
+            assert maxabs(getattr(m, n).grad, r) < 2e-4 * max(1.0, float(r.abs().max())), n
+
+
+def test_library_self_attention(O, golden_dir):
+    from attention.SelfAttention import ScaledDotProductAttention
+    g = _g(golden_dir, "modules.npz")
+    m = ScaledDotProductAttention(64, 16, 16, 4).cuda()
+    load_params(m, {k[len("sa_p/"):]: torch.tensor(g[k]) for k in g.files if k.startswith("sa_p/")})
+    q, k = torch.tensor(g["sa_q"]).cuda(), torch.tensor(g["sa_k"]).cuda()
+    assert maxabs(m(q, k, k), g["sa_out"]) < 2e-5
+    out = m(q, k, k, attention_mask=torch.tensor(g["sa_mask"]).cuda(), attention_weights=torch.tensor(g["sa_w"]).cuda())
+    assert maxabs(out, g["sa_out_mw"]) < 2e-5
+
+
+def test_marn_cell_module(O, golden_dir):
+    """MARN_cell alone against the reference's own outputs: padded tail, all-party-0 and all-party-1 steps."""
+    from models.lsthm_sps import MARN_cell
+    g = _g(golden_dir, "cell_T24_N6.npz")
+    m = MARN_cell(128, 128, 100, 100).cuda()
+    P = O.seeded_params(seed=3)
+    load_params(m, {k[len("marn_cell_f."):]: v for k, v in P.items() if k.startswith("marn_cell_f.")})
+    x_l = torch.tensor(g["x_l"]).cuda().requires_grad_(True)
+    x_a = torch.tensor(g["x_a"]).cuda().requires_grad_(True)
+    h = m(torch.zeros(24, 6, 1, device="cuda"), x_l, x_a, torch.tensor(g["qmask"]).cuda())
+    assert maxabs(h, g["h"]) < 3e-5
+    (h * torch.tensor(g["wsum"]).cuda()).sum().backward()
+    assert maxabs(x_l.grad, g["dx_l"]) < 1e-4
+    assert maxabs(x_a.grad, g["dx_a"]) < 1e-4
+    _check_grads(g, list(m.named_parameters()))
+
+
+@pytest.mark.parametrize("name", ["model_c1_B2_L16_dr1024.npz", "model_c1r_B3_L12_dr768_ragged.npz", "model_c2_B32_L128_dr768.npz"])
+def test_model_vs_reference_golden(O, golden_dir, name):
+    from models.lsthm_sps import MARN1_sps
+    from loss import MaskedLoss
+    g = _g(golden_dir, name)
+    B, L, d_r, seed, ragged = int(g["B"]), int(g["L"]), int(g["d_r"]), int(g["seed"]), bool(g["ragged"])
+    net = MARN1_sps(6, d_r=d_r).cuda().eval()
+    load_params(net, O.seeded_params(seed=seed, d_r=d_r))
+    x, qmask, umask, label = (t.cuda() for t in O.seeded_batch(B, L, d_r=d_r, seed=seed + 1, ragged=ragged))
+    lp, x_l, x_a = net(x, qmask, umask)
+    loss = MaskedLoss(torch.nn.NLLLoss)(lp, label.view(-1), umask)
+    loss.backward()
+    lpn = lp.detach().cpu().numpy()
+    rows = g["rows"] if "rows" in g.files else np.arange(lpn.shape[0])
+    err = float(np.abs(lpn[rows] - g["logits"]).max())
+    assert err < LOGIT_TOL, err
+    assert abs(float(loss) - float(g["loss"])) < 2e-5
+    safe = g["margin"] > 2 * LOGIT_TOL
+    assert (lpn.argmax(1)[safe] == g["argmax"][safe]).all()
+    if "x_l" in g.files:
+        assert maxabs(x_l, g["x_l"]) < 3e-5 and maxabs(x_a, g["x_a"]) < 3e-5
+    _check_grads(g, list(net.named_parameters()))
+    print(f"{name}: max|dlogit| {err:.2e}")
+
+
+def test_model_determinism_and_no_grad(O):
+    from models.lsthm_sps import MARN1_sps
+    net = MARN1_sps(6, d_r=768).cuda().eval()
+    load_params(net, O.seeded_params(seed=9, d_r=768))
+    x, qmask, umask, _ = (t.cuda() for t in O.seeded_batch(4, 20, d_r=768, seed=5, ragged=True))
+    with torch.no_grad():
+        a = net(x, qmask, umask)[0].clone()
+        b = net(x, qmask, umask)[0].clone()
+    assert torch.equal(a, b)                       # forward is bit-reproducible (fixed-order reductions)
+    assert torch.isfinite(a).all()
