@@ -177,6 +177,27 @@ int mser_masked_nll_bwd(const int64_t* target, const float* mask, const float* l
 int mser_adam_flat(float* p, const float* g, float* m, float* v, const uint8_t* live, int64_t n, int32_t step,
                    float lr, float beta1, float beta2, float eps, float wd, float gscale, mser_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Measurement hook (bench.py): bracket every launch of ONE recurrent kernel with HIP events on its launch stream.
+ * mser_prof_enable(id, max) arms it (id 0 disarms); mser_prof_collect returns the summed elapsed time and the number of
+ * launches seen since the last collect.  Not for use inside hipGraph capture.
+ * ------------------------------------------------------------------------------------------------ */
+enum { MSER_PROF_SPK_FWD = 1, MSER_PROF_LSTHM_FWD_GATES = 2, MSER_PROF_LSTHM_FWD_Z = 3, MSER_PROF_LSTHM_BWD_ROW = 4,
+       MSER_PROF_LSTHM_BWD_MAT = 5, MSER_PROF_SPK_BWD = 6 };
+int mser_prof_enable(int32_t kernel_id, int32_t max_launches);
+int mser_prof_collect(float* total_ms, int32_t* launches);
+
+/* Same update with the step counter, {lr, beta1, beta2} and the bias-correction scratch (2 floats) on the device, so the two
+ * launches can be captured into a hipGraph and replayed.  The gradient is multiplied by gscale / (*gscale_div_dev)
+ * (gscale_div_dev may be NULL): after the data-parallel all-reduce *gscale_div_dev is the global mask count. */
+int mser_adam_flat_dev(float* p, const float* g, float* m, float* v, const uint8_t* live, int64_t n, int32_t* step_dev,
+                       const float* hp_dev, float* sched_dev, float eps, float wd, const float* gscale_div_dev, float gscale,
+                       mser_stream_t stream);
+/* Pack for the single data-parallel all-reduce (new: the reference has no distributed code):
+ * buf[0..n) = g * (*cnt_dev), buf[n] = *cnt_dev, so that after a SUM all-reduce buf[0..n)/buf[n] is the gradient of the
+ * globally mask-weighted loss (loss.py:21 divides by the local mask count). */
+int mser_dp_pack(float* buf, const float* g, const float* cnt_dev, int64_t n, mser_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,24 @@ struct CellK {
 
 constexpr int RED_FLOATS = 16 * 1024;
 
+// ---- optional per-kernel timing with HIP events (bench.py's live roofline measurement; off by default) ----------------------
+struct Prof {
+  int kernel_id = 0;            // MSER_PROF_* of include/mser.h, 0 = off
+  int cap = 0, used = 0;
+  hipEvent_t* ev = nullptr;     // 2*cap events: (start, stop) pairs
+};
+static Prof g_prof;
+struct ProfScope {
+  bool on;
+  hipStream_t s;
+  ProfScope(int id, hipStream_t st) : on(g_prof.kernel_id == id && g_prof.used < g_prof.cap), s(st) {
+    if (on) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
+  }
+  ~ProfScope() {
+    if (on) { (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s); ++g_prof.used; }
+  }
+};
+
 // 32 x 32 x K product by one 1024-thread workgroup; result (row-major [32][32]) left in tile[], all threads synced.
 // aload(r, k, a[8]) must return A[row r][k..k+7]; bload(n, k, b[8]) must return B[k..k+7][col n].
 template <class ALoad, class BLoad>
@@ -723,9 +741,20 @@ static mser_gemm_desc gd(const float* A, long sAm, long sAk, const float* Bm, lo
   return g;
 }
 
-template <class K>
-static int allow_lds(K kernel, size_t bytes) {
-  if (bytes > 64 * 1024) MSER_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+// Raise the dynamic-LDS limit of a kernel (> 64 KiB needs the attribute); remembered per kernel address so that
+// steady-state calls (and hipGraph captures) issue no runtime call.
+static int allow_lds(const void* kernel, size_t bytes) {
+  static const void* seen[16];
+  static size_t granted[16];
+  static int nseen = 0;
+  if (bytes <= 64 * 1024) return 0;
+  int i = 0;
+  for (; i < nseen; ++i)
+    if (seen[i] == kernel) break;
+  if (i < nseen && granted[i] >= bytes) return 0;
+  MSER_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  if (i == nseen && nseen < 16) { seen[nseen] = kernel; ++nseen; }
+  if (i < 16) granted[i] = bytes;
   return 0;
 }
 
@@ -755,10 +784,11 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s) {
       MSER_CHECK_HIP(hipMemset2DAsync(k.out, d.ldo * sizeof(float), 0, 4 * (size_t)H * sizeof(float), TB, s));
   }
   const size_t mm_lds = (RED_FLOATS + 1024) * sizeof(float);
-  MSER_TRY(allow_lds(spk_fwd_step, mm_lds));
-  MSER_TRY(allow_lds(lsthm_fwd_gates, mm_lds));
+  MSER_TRY(allow_lds((const void*)spk_fwd_step, mm_lds));
+  MSER_TRY(allow_lds((const void*)lsthm_fwd_gates, mm_lds));
   // ---- speaker chain
   for (int t = 0; t < T; ++t) {
+    ProfScope ps(MSER_PROF_SPK_FWD, s);
     hipLaunchKernelGGL(spk_fwd_step, dim3(H / 8, 2, d.ndir * K.nmb), dim3(1024), mm_lds, s, K, t);
   }
   MSER_TRY(check_launch("spk_fwd_step"));
@@ -787,8 +817,14 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s) {
   const int NT = H > 512 ? H : 512;
   const size_t z_lds = row_lds_bytes(H, NT, 2);
   for (int t = 0; t < T; ++t) {
-    hipLaunchKernelGGL(lsthm_fwd_gates, dim3(H / 8, 2, d.ndir * K.nmb), dim3(1024), mm_lds, s, K, t);
-    hipLaunchKernelGGL(lsthm_fwd_z, dim3(B, d.ndir), dim3(NT), z_lds, s, K, t);
+    {
+      ProfScope ps(MSER_PROF_LSTHM_FWD_GATES, s);
+      hipLaunchKernelGGL(lsthm_fwd_gates, dim3(H / 8, 2, d.ndir * K.nmb), dim3(1024), mm_lds, s, K, t);
+    }
+    {
+      ProfScope ps(MSER_PROF_LSTHM_FWD_Z, s);
+      hipLaunchKernelGGL(lsthm_fwd_z, dim3(B, d.ndir), dim3(NT), z_lds, s, K, t);
+    }
   }
   return check_launch("lsthm_fwd");
 }
@@ -809,11 +845,17 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s) {
   const size_t mm_lds = (RED_FLOATS + 1024) * sizeof(float);
   const int NT = H > 512 ? H : 512;
   const size_t row_lds = row_lds_bytes(H, NT, 9);
-  MSER_TRY(allow_lds(lsthm_bwd_mat, mm_lds));
+  MSER_TRY(allow_lds((const void*)lsthm_bwd_mat, mm_lds));
   // ---- LSTHM chain, reverse time
   for (int t = T - 1; t >= 0; --t) {
-    hipLaunchKernelGGL(lsthm_bwd_row, dim3(B, d.ndir), dim3(NT), row_lds, s, K, t);
-    if (t > 0) hipLaunchKernelGGL(lsthm_bwd_mat, dim3(H / 32, 4, d.ndir * K.nmb), dim3(1024), mm_lds, s, K, t);
+    {
+      ProfScope ps(MSER_PROF_LSTHM_BWD_ROW, s);
+      hipLaunchKernelGGL(lsthm_bwd_row, dim3(B, d.ndir), dim3(NT), row_lds, s, K, t);
+    }
+    if (t > 0) {
+      ProfScope ps(MSER_PROF_LSTHM_BWD_MAT, s);
+      hipLaunchKernelGGL(lsthm_bwd_mat, dim3(H / 32, 4, d.ndir * K.nmb), dim3(1024), mm_lds, s, K, t);
+    }
   }
   MSER_TRY(check_launch("lsthm_bwd"));
   // ---- deferred (non-recurrent) gradient GEMMs of the LSTHM streams
@@ -867,8 +909,9 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s) {
   }
   // ---- speaker chain, reverse time
   const size_t spk_lds = mm_lds + 32 * (4 * (size_t)H + 4) * sizeof(float);
-  MSER_TRY(allow_lds(spk_bwd_step, spk_lds));
+  MSER_TRY(allow_lds((const void*)spk_bwd_step, spk_lds));
   for (int t = T - 1; t >= 0; --t) {
+    ProfScope ps(MSER_PROF_SPK_BWD, s);
     hipLaunchKernelGGL(spk_bwd_step, dim3(H / 32, 4, d.ndir * K.nmb), dim3(1024), spk_lds, s, K, t);
   }
   MSER_TRY(check_launch("spk_bwd_step"));
@@ -956,6 +999,33 @@ __global__ __launch_bounds__(1024) void rank1_attention_kernel(const float* x1, 
 using namespace mser;
 
 extern "C" {
+
+int mser_prof_enable(int32_t kernel_id, int32_t max_launches) {
+  for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
+  delete[] g_prof.ev;
+  g_prof = Prof();
+  if (kernel_id <= 0 || max_launches <= 0) return 0;
+  g_prof.ev = new hipEvent_t[2 * (size_t)max_launches];
+  for (int i = 0; i < 2 * max_launches; ++i) MSER_CHECK_HIP(hipEventCreate(&g_prof.ev[i]));
+  g_prof.cap = max_launches;
+  g_prof.kernel_id = kernel_id;
+  return 0;
+}
+
+int mser_prof_collect(float* total_ms, int32_t* launches) {
+  MSER_REQUIRE(total_ms && launches, "mser_prof_collect: null pointer");
+  float tot = 0.f;
+  for (int i = 0; i < g_prof.used; ++i) {
+    MSER_CHECK_HIP(hipEventSynchronize(g_prof.ev[2 * i + 1]));
+    float ms = 0.f;
+    MSER_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = g_prof.used;
+  g_prof.used = 0;
+  return 0;
+}
 
 size_t mser_marn_cell_workspace_bytes(int32_t T, int32_t B, int32_t D, int32_t H, int32_t ndir) {
   mser_cell_desc d;

@@ -358,6 +358,40 @@ __global__ void adam_flat_kernel(float* p, const float* g, float* m, float* v, c
   p[i] = pi - lr_bc1 * mi / denom;
 }
 
+// Graph-capturable Adam: the step counter and learning rate live on the device, so a captured launch stays valid for every
+// replay.  hp = {lr, beta1, beta2}; sched (2 floats of scratch) receives lr/(1-beta1^t) and 1/sqrt(1-beta2^t).
+__global__ void adam_sched_kernel(int* step, const float* hp, float* sched) {
+  const int t = *step + 1;
+  *step = t;
+  const double bc1 = 1.0 - pow((double)hp[1], (double)t), bc2 = 1.0 - pow((double)hp[2], (double)t);
+  sched[0] = (float)((double)hp[0] / bc1);
+  sched[1] = (float)(1.0 / sqrt(bc2));
+}
+
+__global__ void adam_flat_dev_kernel(float* p, const float* g, float* m, float* v, const uint8_t* live, long n, const float* sched,
+                                     const float* hp, float eps, float wd, const float* gscale_dev, float gscale) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (live && !live[i]) return;
+  const float b1 = hp[1], b2 = hp[2];
+  const float gs = gscale_dev ? gscale / *gscale_dev : gscale;
+  const float pi = p[i];
+  const float gi = g[i] * gs + wd * pi;
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  p[i] = pi - sched[0] * mi / (sqrtf(vi) * sched[1] + eps);
+}
+
+// buf[0..n) = g[0..n) * (*cnt) ; buf[n] = *cnt       (pack for the single data-parallel all-reduce)
+__global__ void dp_pack_kernel(float* buf, const float* g, const float* cnt, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const float c = *cnt;
+  if (i < n) buf[i] = g[i] * c;
+  if (i == 0) buf[n] = c;
+}
+
 }  // namespace mser
 
 using namespace mser;
@@ -506,6 +540,23 @@ int mser_adam_flat(float* p, const float* g, float* m, float* v, const uint8_t* 
   hipLaunchKernelGGL(adam_flat_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, live, (long)n,
                      (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, wd, gscale);
   return check_launch("mser_adam_flat");
+}
+
+int mser_adam_flat_dev(float* p, const float* g, float* m, float* v, const uint8_t* live, int64_t n, int32_t* step_dev,
+                       const float* hp_dev, float* sched_dev, float eps, float wd, const float* gscale_div_dev, float gscale,
+                       mser_stream_t stream) {
+  MSER_REQUIRE(p && g && m && v && step_dev && hp_dev && sched_dev, "mser_adam_flat_dev: bad arguments");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(adam_sched_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, hp_dev, sched_dev);
+  hipLaunchKernelGGL(adam_flat_dev_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, live, (long)n, sched_dev,
+                     hp_dev, eps, wd, gscale_div_dev, gscale);
+  return check_launch("mser_adam_flat_dev");
+}
+
+int mser_dp_pack(float* buf, const float* g, const float* cnt_dev, int64_t n, mser_stream_t stream) {
+  MSER_REQUIRE(buf && g && cnt_dev && n > 0, "mser_dp_pack: bad arguments");
+  hipLaunchKernelGGL(dp_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, buf, g, cnt_dev, (long)n);
+  return check_launch("mser_dp_pack");
 }
 
 }  // extern "C"

@@ -60,20 +60,34 @@ class ModelTrainer(nn.Module):
         textf = (r1 + r2 + r3 + r4) / 4
         return torch.cat((textf, acouf), dim=-1)
 
-    def train_step(self, x, qmask, umask, label):
-        """One optimisation step on a prepared batch; returns (loss tensor, mask-count tensor), both on the device."""
+    def forward_backward(self, x, qmask, umask, label):
+        """zero_grad + forward + MaskedLoss + backward (graph-capturable: no host sync, no host-dependent scalars)."""
         self.optim.zero_grad()
         lp_, x_a, x_l = self.model(x, qmask, umask)
         loss = self.loss(lp_, label.view(-1), umask)
         loss.backward()
-        n = umask.sum()
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        return loss.detach()
+
+    def _world(self):
+        d = torch.distributed
+        return d.get_world_size() if d.is_available() and d.is_initialized() else 1
+
+    def optimizer_step(self, umask, sync_hp=True):
+        """(N > 1: ONE all-reduce of the flat gradient buffer, weighted by the local mask counts) + fused Adam."""
+        if self._world() > 1:
             store = self.model.flat_store
             if self._allreduce is None:
                 self._allreduce = FlatAllReduce(store.total, store.grad.device)
-            self._allreduce.combine(store.grad, n)
-        self.optim.step()
-        return loss.detach(), n
+            self._allreduce.reduce(store.grad, umask.sum())
+            self.optim.step(sync_hp=sync_hp, grad=self._allreduce.grad, grad_div=self._allreduce.count)
+        else:
+            self.optim.step(sync_hp=sync_hp)
+
+    def train_step(self, x, qmask, umask, label):
+        """One optimisation step on a prepared batch; returns (loss tensor, mask-count tensor), both on the device."""
+        loss = self.forward_backward(x, qmask, umask, label)
+        self.optimizer_step(umask)
+        return loss, umask.sum()
 
     def train_network(self, epoch, loader):
         self.train()

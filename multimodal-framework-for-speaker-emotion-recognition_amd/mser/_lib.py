@@ -84,6 +84,10 @@ SIGNATURES = {
     "mser_masked_nll_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "mser_masked_nll_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "mser_adam_flat": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
+    "mser_adam_flat_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _f32, _vp, _f32, _vp]),
+    "mser_dp_pack": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "mser_prof_enable": (C.c_int, [_i32, _i32]),
+    "mser_prof_collect": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
 }
 
 _lib = None

@@ -183,6 +183,17 @@ def adam_flat(p: Tensor, g: Tensor, m: Tensor, v: Tensor, live: Optional[Tensor]
                                     _stream()), "adam_flat")
 
 
+def adam_flat_dev(p: Tensor, g: Tensor, m: Tensor, v: Tensor, live: Optional[Tensor], step_dev: Tensor, hp_dev: Tensor,
+                  sched_dev: Tensor, eps: float = 1e-8, wd: float = 0.0, gscale_div_dev: Optional[Tensor] = None,
+                  gscale: float = 1.0) -> None:
+    L.check(L.load().mser_adam_flat_dev(_p(p), _p(g), _p(m), _p(v), _p(live), p.numel(), _p(step_dev), _p(hp_dev), _p(sched_dev),
+                                        eps, wd, _p(gscale_div_dev), gscale, _stream()), "adam_flat_dev")
+
+
+def dp_pack(buf: Tensor, g: Tensor, cnt_dev: Tensor) -> None:
+    L.check(L.load().mser_dp_pack(_p(buf), _p(g), _p(cnt_dev), g.numel(), _stream()), "dp_pack")
+
+
 def lsthm_step_fwd(x, c, h, z, s, W, Wb, U, Ub, V, Vb, S, Sb, c_out, h_out, gates=None) -> None:
     B, D = x.shape
     H, Hz, Hs = c.shape[1], z.shape[1], s.shape[1]
