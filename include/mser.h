@@ -146,6 +146,15 @@ size_t mser_marn_cell_workspace_bytes(int32_t T, int32_t B, int32_t D, int32_t H
 int mser_marn_cell_fwd(const mser_cell_desc* d, mser_stream_t stream);
 int mser_marn_cell_bwd(const mser_cell_desc* d, mser_stream_t stream);
 
+/* Launch mode of the recurrent chains.  MSER_OPT_PERSISTENT = 1 (default): each chain is ONE persistent launch with the time
+ * loop inside (weights in registers, per-direction counter barriers, write-through hand-offs) whenever every workgroup can be
+ * co-resident (H in {128,256}, workgroups <= CUs); 0: one launch per time step (always valid; used as the cross-check). */
+enum { MSER_OPT_PERSISTENT = 1 };
+int mser_set_option(int32_t key, int32_t value);
+/* Synchronises `stream` and reports whether a persistent kernel of the last fwd/bwd call on this workspace gave up at a
+ * barrier (bounded spins; returns -2 and a message in that case).  Diagnostic; not needed on the hot path. */
+int mser_marn_cell_status(const mser_cell_desc* d, mser_stream_t stream);
+
 /* Single LSTHM1 step (model/lsthm_sps.py:28-44) and single rank-1 CrossAttention (:59-72) for the module-level API. */
 int mser_lsthm_step_fwd(const float* x, const float* c, const float* h, const float* z, const float* s,
                         const float* W, const float* Wb, const float* U, const float* Ub, const float* V,

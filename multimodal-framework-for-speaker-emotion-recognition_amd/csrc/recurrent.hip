@@ -46,8 +46,10 @@ struct DirP {
 struct CellK {
   int T, B, D, H, ndir, nmb;
   long ldo;
+  unsigned* sync;      // persistent-kernel counters: [SYNC_*] words, zeroed by a memset node before every launch
   DirP d[2];
 };
+enum { SYNC_SPK_FWD = 0, SYNC_LSTHM_FWD = 2, SYNC_LSTHM_BWD = 4, SYNC_SPK_BWD = 6, SYNC_ABORT = 8, SYNC_WORDS = 16 };
 
 constexpr int RED_FLOATS = 16 * 1024;
 
@@ -69,19 +71,98 @@ struct ProfScope {
   }
 };
 
+// ---- cross-workgroup accessors ---------------------------------------------------------------------------------------
+// PS = true inside the persistent kernels: every array that another workgroup wrote (or will read) during the same launch is
+// stored write-through and loaded L1-bypassing (`sc1`: relaxed agent-scope atomics on address-space-1 pointers), which is the
+// hand-off form of cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "Valid forms" row 1 (sc1 payload, one counter
+// add per workgroup behind s_waitcnt vmcnt(0) + barrier, sc1-load poll, workgroup barrier, sc1 loads).  PS = false in the
+// per-step launches, where the kernel boundary orders everything and plain accesses are correct.
+typedef __attribute__((address_space(1))) unsigned int gu32;
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+template <bool PS>
+__device__ __forceinline__ float ldx(const float* p) {
+  if constexpr (PS) return __uint_as_float(__hip_atomic_load((const gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  else return *p;
+}
+template <bool PS>
+__device__ __forceinline__ void stx(float* p, float v) {
+  if constexpr (PS) __hip_atomic_store((gu32*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+__device__ __forceinline__ void load8(const float* p, float* a) {
+  const float4 v0 = *reinterpret_cast<const float4*>(p);
+  const float4 v1 = *reinterpret_cast<const float4*>(p + 4);
+  a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w;
+  a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+}
+template <bool PS>
+__device__ __forceinline__ void load8x(const float* p, float* a) {
+  if constexpr (PS) {
+    const gu64* q = (const gu64*)p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned long long v = __hip_atomic_load(q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a[2 * i] = __uint_as_float((unsigned)v);
+      a[2 * i + 1] = __uint_as_float((unsigned)(v >> 32));
+    }
+  } else {
+    load8(p, a);
+  }
+}
+__device__ __forceinline__ void zero8(float* a) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = 0.f;
+}
+
+// Barrier among the `nwg` workgroups of one direction inside a persistent launch.  One monotonic counter per direction
+// (zeroed by a memset node before the launch); `target` = nwg * (index of this barrier + 1).  Every spin is bounded: on
+// time-out (or when another workgroup has already given up) the abort word is set and every workgroup leaves the kernel.
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+__device__ __forceinline__ bool dir_barrier(unsigned* cnt, unsigned* abortw, unsigned target, int* lds_ok) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its write-through stores
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add((gu32*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 1;
+    unsigned spins = 0;
+    while (__hip_atomic_load((const gu32*)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 255u) == 0u) {
+        if (spins > SPIN_LIMIT || __hip_atomic_load((const gu32*)abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          ok = 0;
+          break;
+        }
+      }
+    }
+    if (!ok) __hip_atomic_store((gu32*)abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *lds_ok = ok;
+  }
+  __syncthreads();
+  return *lds_ok != 0;
+}
+
 // 32 x 32 x K product by one 1024-thread workgroup; result (row-major [32][32]) left in tile[], all threads synced.
 // aload(r, k, a[8]) must return A[row r][k..k+7]; bload(n, k, b[8]) must return B[k..k+7][col n].
-template <class ALoad, class BLoad>
-__device__ __forceinline__ void wg_mm32(int K, ALoad aload, BLoad bload, float* red, float* tile) {
+// NP > 0: the B fragments of this wave's NP k-passes were loaded once into bpre[][] (persistent kernels keep the weights
+// in registers across the whole time loop).
+template <int NP, class ALoad, class BLoad>
+__device__ __forceinline__ void wg_mm32(int K, ALoad aload, BLoad bload, const float (*bpre)[8], float* red, float* tile) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
   const int KC = ((K + 255) / 256) * 16;   // per-wave K chunk (multiple of 16)
   f32x16 acc = {0};
   const int kend = min(K, (wave + 1) * KC);
-  for (int kb = wave * KC; kb < kend; kb += 16) {
+  int pass = 0;
+  for (int kb = wave * KC; kb < kend; kb += 16, ++pass) {
     float a[8], b[8];
     aload(r, kb + half * 8, a);
-    bload(r, kb + half * 8, b);
+    if constexpr (NP > 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b[j] = bpre[pass < NP ? pass : NP - 1][j];
+    } else {
+      bload(r, kb + half * 8, b);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
   }
@@ -97,29 +178,36 @@ __device__ __forceinline__ void wg_mm32(int K, ALoad aload, BLoad bload, float* 
   tile[tid] = s;
   __syncthreads();
 }
-
-__device__ __forceinline__ void load8(const float* p, float* a) {
-  const float4 v0 = *reinterpret_cast<const float4*>(p);
-  const float4 v1 = *reinterpret_cast<const float4*>(p + 4);
-  a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w;
-  a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
-}
-__device__ __forceinline__ void zero8(float* a) {
+template <int NP, class BLoad>
+__device__ __forceinline__ void preload_b(int K, BLoad bload, float (*bpre)[8]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int KC = ((K + 255) / 256) * 16;
+  const int kend = min(K, (wave + 1) * KC);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) a[j] = 0.f;
+  for (int pass = 0; pass < NP; ++pass) {
+    const int kb = wave * KC + pass * 16;
+    if (kb < kend) bload(r, kb + half * 8, bpre[pass]);
+    else zero8(bpre[pass]);
+  }
 }
 
 // ================================================================================================ speaker forward
-// grid (H/8, 2 cells, ndir*nmb), block 1024.  One nn.LSTMCell (gate order i,f,g,o) step for 8 hidden units of one party
-// cell over a block of 32 compaction slots.  q_sel is rebuilt on the fly from the previous step's saved rows:
+// Role: (cell c, units u0..u0+7, slot block mb) of direction D.  One nn.LSTMCell (gate order i,f,g,o) step for 8 hidden
+// units of one party cell over a block of 32 compaction slots.  q_sel is rebuilt on the fly from the previous step's rows:
 //   q_{t-1}[b,c] = (1-m_{t-1}[b,c]) * h0_{t-1}[b] + m_{t-1}[b,c] * hq_{t-1}[b]           (model/lsthm_sps.py:204-207)
-__global__ __launch_bounds__(1024) void spk_fwd_step(CellK P, int t) {
-  extern __shared__ float smem[];
-  float* red = smem;
-  float* tile = smem + RED_FLOATS;
-  const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
-  const DirP& D = P.d[dir];
-  const int c = blockIdx.y, u0 = blockIdx.x * 8;
+struct SpkFwdB {
+  const DirP& D; int c, u0, H;
+  __device__ __forceinline__ void operator()(int n, int k, float* b) const {
+    const long wrow = (long)(n >> 3) * H + u0 + (n & 7);
+    if (k < H) load8(D.Wih[c] + wrow * H + k, b);
+    else load8(D.Whh[c] + wrow * H + (k - H), b);
+  }
+};
+
+template <bool PS, int NP>
+__device__ __forceinline__ void spk_fwd_body(const CellK& P, const DirP& D, int t, int c, int u0, int mb, bool writer,
+                                             const float (*bpre)[8], float* red, float* tile) {
   const int H = P.H, B = P.B, T = P.T;
   const int N0 = D.n0[t];
   const int Nc = c ? B - N0 : N0, off = c ? N0 : 0;
@@ -136,22 +224,21 @@ __global__ __launch_bounds__(1024) void spk_fwd_step(CellK P, int t) {
     if (tid < 256) {
       const int slot = mb * 32 + (tid >> 3), u = u0 + (tid & 7);
       if (slot < B) {
-        hq_new[(long)slot * H + u] = hq_old[(long)slot * H + u];
-        cq_new[(long)slot * H + u] = cq_old[(long)slot * H + u];
+        stx<PS>(hq_new + (long)slot * H + u, ldx<PS>(hq_old + (long)slot * H + u));
+        stx<PS>(cq_new + (long)slot * H + u, ldx<PS>(cq_old + (long)slot * H + u));
 #pragma unroll
         for (int g = 0; g < 4; ++g) sg[(long)slot * 4 * H + g * H + u] = 0.f;
       }
     }
-    if (blockIdx.x == 0)
+    if (writer)
       for (int e = tid; e < 32 * H; e += 1024) {
         const int slot = mb * 32 + e / H;
-        if (slot < B) qs[(long)slot * H + e % H] = 0.f;
+        if (slot < B) stx<PS>(qs + (long)slot * H + e % H, 0.f);
       }
     return;
   }
 
   const int N0p = t > 0 ? D.n0[t - 1] : 0;
-  const bool writer = blockIdx.x == 0;
   auto aload = [&](int r, int k, float* a) {
     const int slot = mb * 32 + r;
     if (slot >= B) { zero8(a); return; }
@@ -163,8 +250,8 @@ __global__ __launch_bounds__(1024) void spk_fwd_step(CellK P, int t) {
                                     : D.qsel + ((long)(1 * T + t - 1) * B + (b - N0p)) * H;
         const float* hq = D.HQ + ((long)(t - 1) * B + b) * H;
         float x0[8], x1[8];
-        load8(h0 + k, x0);
-        load8(hq + k, x1);
+        load8x<PS>(h0 + k, x0);
+        load8x<PS>(hq + k, x1);
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] = x0[j] * (1.f - m) + x1[j] * m;
       } else {
@@ -172,18 +259,13 @@ __global__ __launch_bounds__(1024) void spk_fwd_step(CellK P, int t) {
       }
       if (writer) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qs[(long)slot * H + k + j] = a[j];
+        for (int j = 0; j < 8; ++j) stx<PS>(qs + (long)slot * H + k + j, a[j]);
       }
     } else {
-      load8(hq_old + (long)slot * H + (k - H), a);
+      load8x<PS>(hq_old + (long)slot * H + (k - H), a);
     }
   };
-  auto bload = [&](int n, int k, float* b) {
-    const long wrow = (long)(n >> 3) * H + u0 + (n & 7);
-    if (k < H) load8(D.Wih[c] + wrow * H + k, b);
-    else load8(D.Whh[c] + wrow * H + (k - H), b);
-  };
-  wg_mm32(2 * H, aload, bload, red, tile);
+  wg_mm32<NP>(2 * H, aload, SpkFwdB{D, c, u0, H}, bpre, red, tile);
 
   {
     const int n = tid & 31;
@@ -199,26 +281,57 @@ __global__ __launch_bounds__(1024) void spk_fwd_step(CellK P, int t) {
       const float gf = sigmoidf_(tile[rr * 32 + 8 + uu]);
       const float gg = tanhf(tile[rr * 32 + 16 + uu]);
       const float go = sigmoidf_(tile[rr * 32 + 24 + uu]);
-      const float cn = gf * cq_old[(long)slot * H + u] + gi * gg;
+      const float cn = gf * ldx<PS>(cq_old + (long)slot * H + u) + gi * gg;
       const float hn = go * tanhf(cn);
-      cq_new[(long)slot * H + u] = cn;
-      hq_new[(long)slot * H + u] = hn;
+      stx<PS>(cq_new + (long)slot * H + u, cn);
+      stx<PS>(hq_new + (long)slot * H + u, hn);
       float* g = sg + (long)slot * 4 * H + u;
       g[0] = gi; g[H] = gf; g[2 * H] = gg; g[3 * H] = go;
-      if (slot < Nc) D.HQ[((long)t * B + off + slot) * H + u] = hn;   // h_q = cat[h_q0[:N0], h_q1[:N1]] (:192)
+      if (slot < Nc) stx<PS>(D.HQ + ((long)t * B + off + slot) * H + u, hn);   // h_q = cat[h_q0[:N0], h_q1[:N1]] (:192)
     }
   }
 }
 
-// ================================================================================================ LSTHM forward
-// grid (H/8, 2 streams, ndir*nmb), block 1024.  gates = pre[t] + U h_{t-1} + V z_{t-1} (+ U.bias + V.bias), order f,i,o,c~.
-__global__ __launch_bounds__(1024) void lsthm_fwd_gates(CellK P, int t) {
+// per-step launch: grid (H/8, 2 cells, ndir*nmb), block 1024
+__global__ __launch_bounds__(1024) void spk_fwd_step(CellK P, int t) {
+  extern __shared__ float smem[];
+  const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
+  spk_fwd_body<false, 0>(P, P.d[dir], t, blockIdx.y, blockIdx.x * 8, mb, blockIdx.x == 0, nullptr, smem, smem + RED_FLOATS);
+}
+
+// persistent launch: same grid, the whole time loop inside; weights of this workgroup's slice stay in registers.
+template <int NP>
+__global__ __launch_bounds__(1024) void spk_fwd_persist(CellK P) {
   extern __shared__ float smem[];
   float* red = smem;
   float* tile = smem + RED_FLOATS;
+  int* lds_ok = (int*)(tile + 1024);
   const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
   const DirP& D = P.d[dir];
-  const int m = blockIdx.y, u0 = blockIdx.x * 8;
+  const int c = blockIdx.y, u0 = blockIdx.x * 8;
+  const unsigned nwg = gridDim.x * gridDim.y * P.nmb;
+  float bpre[NP][8];
+  preload_b<NP>(2 * P.H, SpkFwdB{D, c, u0, P.H}, bpre);
+  for (int t = 0; t < P.T; ++t) {
+    spk_fwd_body<true, NP>(P, D, t, c, u0, mb, blockIdx.x == 0, bpre, red, tile);
+    if (!dir_barrier(P.sync + SYNC_SPK_FWD + dir, P.sync + SYNC_ABORT, nwg * (unsigned)(t + 1), lds_ok)) return;
+  }
+}
+
+// ================================================================================================ LSTHM forward
+// Role: (stream m, units u0..u0+7, row block mb).  gates = pre[t] + U h_{t-1} + V z_{t-1} (+ U.bias + V.bias), order f,i,o,c~.
+struct LsthmFwdB {
+  const DirP& D; int m, u0, H;
+  __device__ __forceinline__ void operator()(int n, int k, float* b) const {
+    const long wrow = (long)(n >> 3) * H + u0 + (n & 7);
+    if (k < H) load8(D.U[m] + wrow * H + k, b);
+    else load8(D.V[m] + wrow * H + (k - H), b);
+  }
+};
+
+template <bool PS, int NP>
+__device__ __forceinline__ void lsthm_gates_body(const CellK& P, const DirP& D, int t, int m, int u0, int mb,
+                                                 const float (*bpre)[8], float* red, float* tile) {
   const int H = P.H, B = P.B, T = P.T;
   const float* hz_old = D.hz + (long)t * B * 3 * H;
   float* hz_new = D.hz + (long)(t + 1) * B * 3 * H;
@@ -226,26 +339,23 @@ __global__ __launch_bounds__(1024) void lsthm_fwd_gates(CellK P, int t) {
   float* c_new = D.cstate + ((long)m * (T + 1) + t + 1) * B * H;
   const int tid = threadIdx.x;
 
-  auto aload = [&](int r, int k, float* a) {
-    const int b = mb * 32 + r;
-    if (b >= B) { zero8(a); return; }
-    const float* row = hz_old + (long)b * 3 * H;
-    if (k < H) load8(row + m * H + k, a);
-    else load8(row + 2 * H + (k - H), a);
-  };
-  auto bload = [&](int n, int k, float* bb) {
-    const long wrow = (long)(n >> 3) * H + u0 + (n & 7);
-    if (k < H) load8(D.U[m] + wrow * H + k, bb);
-    else load8(D.V[m] + wrow * H + (k - H), bb);
-  };
-  wg_mm32(2 * H, aload, bload, red, tile);
-
+  // epilogue operands that do not depend on the matvec: issue their loads first so their latency hides behind it
+  float pre_v = 0.f;
   {
     const int rr = tid >> 5, n = tid & 31;
     const int b = mb * 32 + rr;
     const long wrow = (long)(n >> 3) * H + u0 + (n & 7);
-    if (b < B) tile[tid] += D.pre[((long)m * T * B + (long)t * B + b) * 4 * H + wrow] + D.Ub[m][wrow] + D.Vb[m][wrow];
+    if (b < B) pre_v = D.pre[((long)m * T * B + (long)t * B + b) * 4 * H + wrow] + D.Ub[m][wrow] + D.Vb[m][wrow];
   }
+  auto aload = [&](int r, int k, float* a) {
+    const int b = mb * 32 + r;
+    if (b >= B) { zero8(a); return; }
+    const float* row = hz_old + (long)b * 3 * H;
+    if (k < H) load8x<PS>(row + m * H + k, a);
+    else load8x<PS>(row + 2 * H + (k - H), a);
+  };
+  wg_mm32<NP>(2 * H, aload, LsthmFwdB{D, m, u0, H}, bpre, red, tile);
+  tile[tid] += pre_v;
   __syncthreads();
   if (tid < 256) {
     const int rr = tid >> 3, uu = tid & 7;
@@ -255,10 +365,10 @@ __global__ __launch_bounds__(1024) void lsthm_fwd_gates(CellK P, int t) {
       const float gi = sigmoidf_(tile[rr * 32 + 8 + uu]);
       const float go = sigmoidf_(tile[rr * 32 + 16 + uu]);
       const float gc = tanhf(tile[rr * 32 + 24 + uu]);
-      const float cn = gf * c_old[(long)b * H + u] + gi * gc;
+      const float cn = gf * ldx<PS>(c_old + (long)b * H + u) + gi * gc;
       const float hn = tanhf(cn) * go;
-      c_new[(long)b * H + u] = cn;
-      hz_new[(long)b * 3 * H + m * H + u] = hn;
+      stx<PS>(c_new + (long)b * H + u, cn);
+      stx<PS>(hz_new + (long)b * 3 * H + m * H + u, hn);
       float* g = D.gates + ((long)m * T * B + (long)t * B + b) * 4 * H + u;
       g[0] = gf; g[H] = gi; g[2 * H] = go; g[3 * H] = gc;
       const int tau = D.rev ? D.rev[(long)t * B + b] : t;
@@ -267,7 +377,7 @@ __global__ __launch_bounds__(1024) void lsthm_fwd_gates(CellK P, int t) {
   }
 }
 
-// block-wide helpers for the row kernels (blockDim = NT threads, NT/64 waves)
+// block-wide helpers for the row phases (NT threads, NT/64 waves)
 __device__ __forceinline__ float block_sum(float v, float* sh, int nw) {
   v = wave_sum(v);
   __syncthreads();
@@ -287,10 +397,10 @@ __device__ __forceinline__ float block_max(float v, float* sh, int nw) {
   return s;
 }
 
-// grid (B, ndir), block NT = max(512,H) threads.  z[b,i] = sum_j softmax_j(c_l[i] * s_b * Wk[j]) c_a[j]   (:59-72, rank-1 form)
-// LDS: ca[H] wk[H] part[2][NT] sh[16]
-__global__ __launch_bounds__(1024) void lsthm_fwd_z(CellK P, int t) {
-  extern __shared__ float smem[];
+// Row phase, one dialogue row b per call, NT = blockDim.x threads.
+// z[b,i] = sum_j softmax_j(c_l[i] * s_b * Wk[j]) c_a[j]   (:59-72, rank-1 form).  LDS floats: ca[H] wk[H] part[2][NT] sh[16]
+template <bool PS>
+__device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, int t, int b, float* smem) {
   const int H = P.H, B = P.B, T = P.T;
   const int NT = blockDim.x, Q = NT / H, JC = H / Q;
   float* ca = smem;
@@ -298,25 +408,24 @@ __global__ __launch_bounds__(1024) void lsthm_fwd_z(CellK P, int t) {
   float* pZ = wk + H;
   float* pN = pZ + NT;
   float* sh = pN + NT;
-  const int b = blockIdx.x, dir = blockIdx.y;
-  const DirP& D = P.d[dir];
   const int tid = threadIdx.x, nw = NT >> 6;
   const float* c_l = D.cstate + ((long)0 * (T + 1) + t + 1) * B * H + (long)b * H;
   const float* c_a = D.cstate + ((long)1 * (T + 1) + t + 1) * B * H + (long)b * H;
   float sp = 0.f, wmx = -INFINITY, wmn = INFINITY;
   for (int k = tid; k < H; k += NT) {
-    const float cv = c_a[k], w = D.attWk[k];
+    const float cv = ldx<PS>(c_a + k), w = D.attWk[k];
     ca[k] = cv;
     wk[k] = w;
     sp += D.attWq[k] * cv;
     wmx = fmaxf(wmx, w);
     wmn = fminf(wmn, w);
   }
+  const int i = tid % H, q = tid / H;
+  const float cli = ldx<PS>(c_l + i);
   const float s = block_sum(sp, sh, nw) / sqrtf((float)H);
   wmx = block_max(wmx, sh, nw);
   wmn = -block_max(-wmn, sh, nw);
-  const int i = tid % H, q = tid / H;
-  const float u = c_l[i] * s;
+  const float u = cli * s;
   const float mx = (u >= 0.f) ? u * wmx : u * wmn;
   float Z = 0.f, N = 0.f;
   for (int j = q * JC; j < (q + 1) * JC; ++j) {
@@ -330,7 +439,7 @@ __global__ __launch_bounds__(1024) void lsthm_fwd_z(CellK P, int t) {
   if (q == 0) {
     for (int qq = 1; qq < Q; ++qq) { Z += pZ[qq * H + i]; N += pN[qq * H + i]; }
     const float z = N / Z;
-    D.hz[((long)(t + 1) * B + b) * 3 * H + 2 * H + i] = z;
+    stx<PS>(D.hz + ((long)(t + 1) * B + b) * 3 * H + 2 * H + i, z);
     const int tau = D.rev ? D.rev[(long)t * B + b] : t;
     if (tau >= 0) {
       float* o = D.out + ((long)tau * B + b) * P.ldo;
@@ -338,22 +447,74 @@ __global__ __launch_bounds__(1024) void lsthm_fwd_z(CellK P, int t) {
       o[3 * H + i] = D.HQ[((long)t * B + b) * H + i];      // all_hs = cat[h_l, h_a, z_l, h_q] (:218)
     }
   }
+  __syncthreads();     // LDS is reused by the next row / phase
+}
+
+// per-step launches
+__global__ __launch_bounds__(1024) void lsthm_fwd_gates(CellK P, int t) {
+  extern __shared__ float smem[];
+  const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
+  lsthm_gates_body<false, 0>(P, P.d[dir], t, blockIdx.y, blockIdx.x * 8, mb, nullptr, smem, smem + RED_FLOATS);
+}
+__global__ __launch_bounds__(1024) void lsthm_fwd_z(CellK P, int t) {
+  extern __shared__ float smem[];
+  lsthm_z_body<false>(P, P.d[blockIdx.y], t, blockIdx.x, smem);
+}
+
+// persistent launch: grid (H/8, 2 streams, ndir*nmb); two barriers per step (gates -> z -> next gates)
+template <int NP>
+__global__ __launch_bounds__(1024) void lsthm_fwd_persist(CellK P) {
+  extern __shared__ float smem[];
+  float* red = smem;
+  float* tile = smem + RED_FLOATS;
+  int* lds_ok = (int*)(tile + 1024);
+  const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
+  const DirP& D = P.d[dir];
+  const int m = blockIdx.y, u0 = blockIdx.x * 8;
+  const unsigned nwg = gridDim.x * gridDim.y * P.nmb;
+  const int w = (mb * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;    // linear workgroup index inside the direction
+  float bpre[NP][8];
+  preload_b<NP>(2 * P.H, LsthmFwdB{D, m, u0, P.H}, bpre);
+  unsigned nbar = 0;
+#ifdef MSER_STAMPS
+  unsigned long long acc4[4] = {0, 0, 0, 0};
+#define STAMP(v) unsigned long long v = __builtin_amdgcn_s_memrealtime()
+#else
+#define STAMP(v)
+#endif
+  for (int t = 0; t < P.T; ++t) {
+    STAMP(s0);
+    lsthm_gates_body<true, NP>(P, D, t, m, u0, mb, bpre, red, tile);
+    STAMP(s1);
+    if (!dir_barrier(P.sync + SYNC_LSTHM_FWD + dir, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
+    STAMP(s2);
+    for (int b = w; b < P.B; b += (int)nwg) lsthm_z_body<true>(P, D, t, b, smem);
+    STAMP(s3);
+    if (!dir_barrier(P.sync + SYNC_LSTHM_FWD + dir, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
+#ifdef MSER_STAMPS
+    STAMP(s4);
+    acc4[0] += s1 - s0; acc4[1] += s2 - s1; acc4[2] += s3 - s2; acc4[3] += s4 - s3;
+#endif
+  }
+#ifdef MSER_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x == 3 && blockIdx.y == 1 && blockIdx.z == 0)
+    for (int i = 0; i < 4; ++i) P.sync[10 + i] = (unsigned)(acc4[i] / P.T);     // 10 ns ticks per step
+#endif
+#undef STAMP
 }
 
 // ================================================================================================ LSTHM backward
-// Row kernel: grid (B, ndir), block NT.  Attention backward (recomputing the softmax), then the gate backward for both
+// Row phase (one dialogue row per call): attention backward (recomputing the softmax), then the gate backward for both
 // streams.  Writes dgates[t], the dc carry, dHQ[t] (the h_q part of dout) and accumulates the attention-vector grads of
 // its own row (reduced over rows once after the chain).
 // LDS floats: ca cl wk wq ua ma aa wa za (9H) + part[3][NT] + sh[16]
-__global__ __launch_bounds__(1024) void lsthm_bwd_row(CellK P, int t) {
-  extern __shared__ float smem[];
+template <bool PS>
+__device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D, int t, int b, float* smem) {
   const int H = P.H, B = P.B, T = P.T;
   const int NT = blockDim.x, Q = NT / H, JC = H / Q;
   float* ca = smem;          float* cl = ca + H;   float* wk = cl + H;   float* wq = wk + H;
   float* ua = wq + H;        float* ma = ua + H;   float* aa = ma + H;   float* wa = aa + H;   float* za = wa + H;
   float* p0 = za + H;        float* p1 = p0 + NT;  float* p2 = p1 + NT;  float* sh = p2 + NT;
-  const int b = blockIdx.x, dir = blockIdx.y;
-  const DirP& D = P.d[dir];
   const int tid = threadIdx.x, nw = NT >> 6;
   const long rowt = (long)t * B + b;
   const float* c_l = D.cstate + ((long)0 * (T + 1) + t + 1) * B * H + (long)b * H;
@@ -374,11 +535,18 @@ __global__ __launch_bounds__(1024) void lsthm_bwd_row(CellK P, int t) {
     wmx = fmaxf(wmx, w);
     wmn = fminf(wmn, w);
   }
+  const int i = tid % H, q = tid / H;
+  // operands of the per-unit epilogue: issue the loads early (they do not depend on the reductions)
+  float dz_in = 0.f, zi = 0.f;
+  if (q == 0) {
+    dz_in = dorow ? dorow[2 * H + i] : 0.f;
+    if (!last) dz_in += ldx<PS>(dA + 1 * SA + i) + ldx<PS>(dA + 3 * SA + i);
+    zi = zrow[i];
+  }
   const float s = block_sum(sp, sh, nw) * rsH;
   wmx = block_max(wmx, sh, nw);
   wmn = -block_max(-wmn, sh, nw);
 
-  const int i = tid % H, q = tid / H;
   // ---- pass 1: per output unit i, sums over j
   const float u = cl[i] * s;
   const float mx = (u >= 0.f) ? u * wmx : u * wmn;
@@ -395,16 +563,13 @@ __global__ __launch_bounds__(1024) void lsthm_bwd_row(CellK P, int t) {
   float dcl_att = 0.f;
   if (q == 0) {
     for (int qq = 1; qq < Q; ++qq) { Z += p0[qq * H + i]; N2 += p1[qq * H + i]; N3 += p2[qq * H + i]; }
-    float dz = (dorow ? dorow[2 * H + i] : 0.f);
-    if (!last) dz += dA[1 * SA + i] + dA[3 * SA + i];
-    const float zi = zrow[i];
-    const float du = dz * (N2 - zi * N3) / Z;
-    const float a = dz / Z;
+    const float du = dz_in * (N2 - zi * N3) / Z;
+    const float a = dz_in / Z;
     ua[i] = u; ma[i] = mx; aa[i] = a; wa[i] = a * u; za[i] = a * u * zi;
     du_cl = du * cl[i];
     dcl_att = du * s;
   }
-  const float ds = block_sum(du_cl, sh, nw);      // includes the barrier that publishes ua..za, p0
+  const float ds = block_sum(du_cl, sh, nw);      // includes the barrier that publishes ua..za
   // ---- pass 2: per key index j, sums over i
   const int j = i;
   float S1 = 0.f, S2 = 0.f, S3 = 0.f;
@@ -417,18 +582,11 @@ __global__ __launch_bounds__(1024) void lsthm_bwd_row(CellK P, int t) {
       S3 += za[ii] * e;
     }
   }
-  __syncthreads();
-  p1[tid] = S1; p2[tid] = S2;
-  __syncthreads();
-  float S1t = 0.f, S2t = 0.f;
-  if (q == 0)
-    for (int qq = 0; qq < Q; ++qq) { S1t += p1[qq * H + j]; S2t += p2[qq * H + j]; }
-  __syncthreads();
-  p1[tid] = S3;
+  p0[tid] = S1; p1[tid] = S2; p2[tid] = S3;
   __syncthreads();
   if (q == 0) {
-    float S3t = 0.f;
-    for (int qq = 0; qq < Q; ++qq) S3t += p1[qq * H + j];
+    float S1t = 0.f, S2t = 0.f, S3t = 0.f;
+    for (int qq = 0; qq < Q; ++qq) { S1t += p0[qq * H + j]; S2t += p1[qq * H + j]; S3t += p2[qq * H + j]; }
     const float dca_att = S1t + ds * wq[j] * rsH;
     float* acc = D.attacc + (long)b * 2 * H;
     acc[j] += ds * ca[j] * rsH;                  // dWq[j]
@@ -441,63 +599,100 @@ __global__ __launch_bounds__(1024) void lsthm_bwd_row(CellK P, int t) {
       const float* g = D.gates + ((long)m * T * B + rowt) * 4 * H + i;
       const float gf = g[0], gi = g[H], go = g[2 * H], gc = g[3 * H];
       float dh = dorow ? dorow[m * H + i] : 0.f;
-      if (!last) dh += dA[(2 * m) * SA + i];
+      if (!last) dh += ldx<PS>(dA + (2 * m) * SA + i);
       const float cc = m ? ca[i] : cl[i];
       const float tc = tanhf(cc);
       float* carry = D.dc_carry + (long)m * SA + (long)b * H + i;
       const float dc = *carry + dh * go * (1.f - tc * tc) + (m ? dca_att : dcl_att);
       const float cp = m ? cprev_a[i] : cprev_l[i];
       float* dg = D.dgates + ((long)m * T * B + rowt) * 4 * H + i;
-      dg[0] = dc * cp * gf * (1.f - gf);
-      dg[H] = dc * gc * gi * (1.f - gi);
-      dg[2 * H] = dh * tc * go * (1.f - go);
-      dg[3 * H] = dc * gi * (1.f - gc * gc);
+      stx<PS>(dg, dc * cp * gf * (1.f - gf));
+      stx<PS>(dg + H, dc * gc * gi * (1.f - gi));
+      stx<PS>(dg + 2 * H, dh * tc * go * (1.f - go));
+      stx<PS>(dg + 3 * H, dc * gi * (1.f - gc * gc));
       *carry = dc * gf;
     }
     D.dHQ[rowt * H + i] = dorow ? dorow[3 * H + i] : 0.f;
   }
+  __syncthreads();     // LDS is reused by the next row / phase
 }
 
-// Matvec kernel: grid (H/32, 4 products, ndir*nmb), block 1024.  dA[p][b][n] = sum_col dgates_m[t][b][col] * Wp[col][n]
-// with p = 0: U_l, 1: V_l, 2: U_a, 3: V_a (m = p>>1).  Consumed by lsthm_bwd_row at step t-1.
-__global__ __launch_bounds__(1024) void lsthm_bwd_mat(CellK P, int t) {
-  extern __shared__ float smem[];
-  float* red = smem;
-  float* tile = smem + RED_FLOATS;
-  const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
-  const DirP& D = P.d[dir];
-  const int p = blockIdx.y, m = p >> 1, n0 = blockIdx.x * 32;
+// Matvec phase, role (product p, output slice n0..n0+31, row block mb):
+// dA[p][b][n] = sum_col dgates_m[t][b][col] * Wp[col][n] with p = 0: U_l, 1: V_l, 2: U_a, 3: V_a (m = p>>1).
+struct LsthmBwdB {
+  const float* Wp; int n0, H;
+  __device__ __forceinline__ void operator()(int n, int k, float* bb) const {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bb[j] = Wp[(long)(k + j) * H + n0 + n];
+  }
+};
+
+template <bool PS, int NP>
+__device__ __forceinline__ void lsthm_bwd_mat_body(const CellK& P, const DirP& D, int t, int p, int n0, int mb,
+                                                   const float (*bpre)[8], float* red, float* tile) {
+  const int m = p >> 1;
   const int H = P.H, B = P.B, T = P.T;
   const float* Wp = (p & 1) ? D.V[m] : D.U[m];
   const float* dg = D.dgates + ((long)m * T * B + (long)t * B) * 4 * H;
   auto aload = [&](int r, int k, float* a) {
     const int b = mb * 32 + r;
     if (b >= B) { zero8(a); return; }
-    load8(dg + (long)b * 4 * H + k, a);
+    load8x<PS>(dg + (long)b * 4 * H + k, a);
   };
-  auto bload = [&](int n, int k, float* bb) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bb[j] = Wp[(long)(k + j) * H + n0 + n];
-  };
-  wg_mm32(4 * H, aload, bload, red, tile);
+  wg_mm32<NP>(4 * H, aload, LsthmBwdB{Wp, n0, H}, bpre, red, tile);
   const int rr = threadIdx.x >> 5, n = threadIdx.x & 31;
   const int b = mb * 32 + rr;
-  if (b < B) D.dA[((long)p * B + b) * H + n0 + n] = tile[threadIdx.x];
+  if (b < B) stx<PS>(D.dA + ((long)p * B + b) * H + n0 + n, tile[threadIdx.x]);
 }
 
-// ================================================================================================ speaker backward
-// grid (H/32, 4 products, ndir*nmb), block 1024, one launch per step (descending t).
-// product p: cell c = p>>1, (p&1) ? W_hh : W_ih.  Prologue: every workgroup rebuilds the LSTMCell gate gradients of its
-// cell for its 32 slots (element-wise, cheap, keeps the step at ONE launch); then raw = dsg @ W.
-// Ping-pong buffers by step parity: raw_ih/dhprev/dcprev [2][2][B][H], dh0 [2][B][H].
-__global__ __launch_bounds__(1024) void spk_bwd_step(CellK P, int t) {
+// per-step launches: row grid (B, ndir) x NT threads; mat grid (H/32, 4, ndir*nmb) x 1024
+__global__ __launch_bounds__(1024) void lsthm_bwd_row(CellK P, int t) {
+  extern __shared__ float smem[];
+  lsthm_bwd_row_body<false>(P, P.d[blockIdx.y], t, blockIdx.x, smem);
+}
+__global__ __launch_bounds__(1024) void lsthm_bwd_mat(CellK P, int t) {
+  extern __shared__ float smem[];
+  const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
+  lsthm_bwd_mat_body<false, 0>(P, P.d[dir], t, blockIdx.y, blockIdx.x * 32, mb, nullptr, smem, smem + RED_FLOATS);
+}
+
+// persistent launch: grid (nwg, 1, ndir), nwg >= (H/32)*4*nmb.  Row phase: rows round-robin over all nwg workgroups;
+// matvec phase: the first (H/32)*4*nmb workgroups.  Two barriers per step.
+template <int NP>
+__global__ __launch_bounds__(1024) void lsthm_bwd_persist(CellK P) {
   extern __shared__ float smem[];
   float* red = smem;
   float* tile = smem + RED_FLOATS;
-  float* dsg_s = tile + 1024;                 // [32][4H + 4]
-  const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
+  int* lds_ok = (int*)(tile + 1024);
+  const int dir = blockIdx.z;
   const DirP& D = P.d[dir];
-  const int p = blockIdx.y, c = p >> 1, n0 = blockIdx.x * 32;
+  const int H = P.H;
+  const unsigned nwg = gridDim.x;
+  const int w = blockIdx.x;
+  const int nsl = H / 32;
+  const bool has_mat = w < nsl * 4 * P.nmb;
+  const int mb = w / (nsl * 4), p = (w / nsl) % 4, n0 = (w % nsl) * 32;
+  float bpre[NP][8];
+  if (has_mat) preload_b<NP>(4 * H, LsthmBwdB{(p & 1) ? D.V[p >> 1] : D.U[p >> 1], n0, H}, bpre);
+  unsigned nbar = 0;
+  for (int t = P.T - 1; t >= 0; --t) {
+    for (int b = w; b < P.B; b += (int)nwg) lsthm_bwd_row_body<true>(P, D, t, b, smem);
+    if (t == 0) break;
+    if (!dir_barrier(P.sync + SYNC_LSTHM_BWD + dir, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
+    if (has_mat) lsthm_bwd_mat_body<true, NP>(P, D, t, p, n0, mb, bpre, red, tile);
+    if (!dir_barrier(P.sync + SYNC_LSTHM_BWD + dir, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
+  }
+}
+
+// ================================================================================================ speaker backward
+// Role (product p, output slice n0, slot block mb), one phase per step (descending t).
+// product p: cell c = p>>1, (p&1) ? W_hh : W_ih.  Prologue: every workgroup rebuilds the LSTMCell gate gradients of its
+// cell for its 32 slots (element-wise, cheap, keeps the step at ONE phase); then raw = dsg @ W.
+// Ping-pong buffers by step parity: raw_ih/dhprev/dcprev [2][2][B][H], dh0 [2][B][H].
+template <bool PS, int NP>
+__device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, int t, int p, int n0, int mb, bool first_slice,
+                                             const float (*bpre)[8], float* red, float* tile, float* dsg_s) {
+  const int c = p >> 1;
   const int H = P.H, B = P.B, T = P.T;
   const int LDS_LD = 4 * H + 4;
   const long SB = (long)B * H;
@@ -513,7 +708,7 @@ __global__ __launch_bounds__(1024) void spk_bwd_step(CellK P, int t) {
   float* dhprev_c = D.dhprev + (long)cur * 2 * SB + (long)c * SB;
   float* dcprev_c = D.dcprev + (long)cur * 2 * SB + (long)c * SB;
   float* dh0_c = D.dh0 + (long)cur * SB;
-  const bool w_elem = (blockIdx.x == 0) && ((p & 1) == 0);    // writes dsg / dcprev of its cell
+  const bool w_elem = first_slice && ((p & 1) == 0);          // writes dsg / dcprev of its cell
   const bool w_dh0 = w_elem && (c == 0);                      // writes dh0 rows of this slot block
   const int N0n = last ? 0 : D.n0[t + 1];
   const int tid = threadIdx.x;
@@ -529,7 +724,7 @@ __global__ __launch_bounds__(1024) void spk_bwd_step(CellK P, int t) {
     const int rown = D.rowof[(long)(t + 1) * B + r];
     const int slotn = rown - (Pn ? N0n : 0);
     mP = D.qm[((long)t * B + r) * 2 + Pn];
-    return raw_ih_n[(long)Pn * SB + (long)slotn * H + u] + dh0_n[(long)rown * H + u];
+    return ldx<PS>(raw_ih_n + (long)Pn * SB + (long)slotn * H + u) + ldx<PS>(dh0_n + (long)rown * H + u);
   };
 
   for (int e = tid; e < 32 * H; e += 1024) {
@@ -541,10 +736,10 @@ __global__ __launch_bounds__(1024) void spk_bwd_step(CellK P, int t) {
       if (w_dh0) {
         float mP;
         const float X = Xnext(slot, u, mP);
-        dh0_c[(long)slot * H + u] = (1.f - mP) * X;
+        stx<PS>(dh0_c + (long)slot * H + u, (1.f - mP) * X);
       }
-      float dh = last ? 0.f : dhprev_n[(long)slot * H + u];
-      const float dc_in = last ? 0.f : dcprev_n[(long)slot * H + u];
+      float dh = last ? 0.f : ldx<PS>(dhprev_n + (long)slot * H + u);
+      const float dc_in = last ? 0.f : ldx<PS>(dcprev_n + (long)slot * H + u);
       if (slot < Nc) {
         const int r = off + slot;
         float mP;
@@ -554,9 +749,9 @@ __global__ __launch_bounds__(1024) void spk_bwd_step(CellK P, int t) {
       if (Nc == 0) {
         // skipped cell: identity on (h, c)
         if (w_elem) {
-          dcprev_c[(long)slot * H + u] = dc_in;
-          dhprev_c[(long)slot * H + u] = dh;
-          raw_ih_c[(long)slot * H + u] = 0.f;
+          stx<PS>(dcprev_c + (long)slot * H + u, dc_in);
+          stx<PS>(dhprev_c + (long)slot * H + u, dh);
+          stx<PS>(raw_ih_c + (long)slot * H + u, 0.f);
         }
       } else {
         const float* g = sg + (long)slot * 4 * H + u;
@@ -567,7 +762,7 @@ __global__ __launch_bounds__(1024) void spk_bwd_step(CellK P, int t) {
         d_f = dcn * cq_old[(long)slot * H + u] * gf * (1.f - gf);
         d_g = dcn * gi * (1.f - gg * gg);
         d_o = dh * tc * go * (1.f - go);
-        if (w_elem) dcprev_c[(long)slot * H + u] = dcn * gf;
+        if (w_elem) stx<PS>(dcprev_c + (long)slot * H + u, dcn * gf);
       }
       if (w_elem) {
         float* o = dsg_g + (long)slot * 4 * H + u;
@@ -582,16 +777,42 @@ __global__ __launch_bounds__(1024) void spk_bwd_step(CellK P, int t) {
 
   const float* Wp = (p & 1) ? D.Whh[c] : D.Wih[c];
   auto aload = [&](int r, int k, float* a) { load8(dsg_s + r * LDS_LD + k, a); };
-  auto bload = [&](int n, int k, float* bb) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bb[j] = Wp[(long)(k + j) * H + n0 + n];
-  };
-  wg_mm32(4 * H, aload, bload, red, tile);
+  wg_mm32<NP>(4 * H, aload, LsthmBwdB{Wp, n0, H}, bpre, red, tile);
   const int rr = tid >> 5, n = tid & 31;
   const int slot = mb * 32 + rr;
   if (slot < B) {
     float* dst = (p & 1) ? dhprev_c : raw_ih_c;
-    dst[(long)slot * H + n0 + n] = tile[tid];
+    stx<PS>(dst + (long)slot * H + n0 + n, tile[tid]);
+  }
+}
+
+// per-step launch: grid (H/32, 4 products, ndir*nmb), block 1024
+__global__ __launch_bounds__(1024) void spk_bwd_step(CellK P, int t) {
+  extern __shared__ float smem[];
+  const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
+  spk_bwd_body<false, 0>(P, P.d[dir], t, blockIdx.y, blockIdx.x * 32, mb, blockIdx.x == 0, nullptr, smem, smem + RED_FLOATS,
+                         smem + RED_FLOATS + 1024);
+}
+
+// persistent launch: same grid, one barrier per step
+template <int NP>
+__global__ __launch_bounds__(1024) void spk_bwd_persist(CellK P) {
+  extern __shared__ float smem[];
+  float* red = smem;
+  float* tile = smem + RED_FLOATS;
+  float* dsg_s = tile + 1024;
+  int* lds_ok = (int*)(dsg_s + 32 * (4 * P.H + 4));
+  const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
+  const DirP& D = P.d[dir];
+  const int p = blockIdx.y, n0 = blockIdx.x * 32;
+  const unsigned nwg = gridDim.x * gridDim.y * P.nmb;
+  float bpre[NP][8];
+  preload_b<NP>(4 * P.H, LsthmBwdB{(p & 1) ? D.Whh[p >> 1] : D.Wih[p >> 1], n0, P.H}, bpre);
+  unsigned nbar = 0;
+  for (int t = P.T - 1; t >= 0; --t) {
+    spk_bwd_body<true, NP>(P, D, t, p, n0, mb, blockIdx.x == 0, bpre, red, tile, dsg_s);
+    if (t == 0) break;
+    if (!dir_barrier(P.sync + SYNC_SPK_BWD + dir, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
   }
 }
 
@@ -678,6 +899,7 @@ static void carve_dir(Carver& cv, DirP& d, int T, int B, int D, int H) {
 
 struct CellHost {
   CellK k;
+  unsigned* sync;
   float* xrev[2];     // reversed x_l / x_a for the backward direction [T*B, D]
   float* dxtmp;       // [T*B, D]
 };
@@ -686,6 +908,8 @@ static size_t carve_all(char* base, const mser_cell_desc& d, CellHost* out) {
   Carver cv{base, 0};
   CellHost h;
   h.k.T = d.T; h.k.B = d.B; h.k.D = d.D; h.k.H = d.H; h.k.ndir = d.ndir; h.k.nmb = cdiv(d.B, 32); h.k.ldo = d.ldo;
+  h.sync = cv.take<unsigned>(SYNC_WORDS);
+  h.k.sync = h.sync;
   for (int i = 0; i < d.ndir; ++i) carve_dir(cv, h.k.d[i], d.T, d.B, d.D, d.H);
   const size_t TBD = (size_t)d.T * d.B * d.D;
   h.xrev[0] = cv.take<float>(TBD);
@@ -760,6 +984,25 @@ static int allow_lds(const void* kernel, size_t bytes) {
 
 static size_t row_lds_bytes(int H, int NT, int narr) { return ((size_t)narr * H + 3 * (size_t)NT + 16) * sizeof(float); }
 
+// ---- launch mode ---------------------------------------------------------------------------------------------------------
+static int g_opt_persistent = 1;      // MSER_OPT_PERSISTENT
+static int g_num_cus = 0;
+constexpr size_t PERSIST_MIN_LDS = 84 * 1024;     // > half of the 160 KiB LDS: at most ONE persistent workgroup per CU
+
+static int num_cus() {
+  if (g_num_cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) g_num_cus = n;
+    if (g_num_cus <= 0) g_num_cus = 1;
+  }
+  return g_num_cus;
+}
+// A persistent launch needs every workgroup co-resident (one per CU) and its weight slice in registers (H = 128 or 256).
+static bool persist_ok(int H, long total_wgs) {
+  return g_opt_persistent && (H == 128 || H == 256) && total_wgs <= num_cus();
+}
+static size_t persist_lds(size_t need) { return need > PERSIST_MIN_LDS ? need : PERSIST_MIN_LDS; }
+
 int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s) {
   MSER_TRY(validate(d, false));
   CellHost h;
@@ -784,14 +1027,28 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s) {
       MSER_CHECK_HIP(hipMemset2DAsync(k.out, d.ldo * sizeof(float), 0, 4 * (size_t)H * sizeof(float), TB, s));
   }
   const size_t mm_lds = (RED_FLOATS + 1024) * sizeof(float);
-  MSER_TRY(allow_lds((const void*)spk_fwd_step, mm_lds));
-  MSER_TRY(allow_lds((const void*)lsthm_fwd_gates, mm_lds));
+  MSER_CHECK_HIP(hipMemsetAsync(h.sync, 0, SYNC_WORDS * sizeof(unsigned), s));
+  const long fwd_wgs = (long)(H / 8) * 2 * d.ndir * K.nmb;
+  const bool persist = persist_ok(H, fwd_wgs);
+  const size_t p_lds = persist_lds(mm_lds + 64);
   // ---- speaker chain
-  for (int t = 0; t < T; ++t) {
+  if (persist) {
     ProfScope ps(MSER_PROF_SPK_FWD, s);
-    hipLaunchKernelGGL(spk_fwd_step, dim3(H / 8, 2, d.ndir * K.nmb), dim3(1024), mm_lds, s, K, t);
+    if (H == 128) {
+      MSER_TRY(allow_lds((const void*)spk_fwd_persist<1>, p_lds));
+      hipLaunchKernelGGL(spk_fwd_persist<1>, dim3(H / 8, 2, d.ndir * K.nmb), dim3(1024), p_lds, s, K);
+    } else {
+      MSER_TRY(allow_lds((const void*)spk_fwd_persist<2>, p_lds));
+      hipLaunchKernelGGL(spk_fwd_persist<2>, dim3(H / 8, 2, d.ndir * K.nmb), dim3(1024), p_lds, s, K);
+    }
+  } else {
+    MSER_TRY(allow_lds((const void*)spk_fwd_step, mm_lds));
+    for (int t = 0; t < T; ++t) {
+      ProfScope ps(MSER_PROF_SPK_FWD, s);
+      hipLaunchKernelGGL(spk_fwd_step, dim3(H / 8, 2, d.ndir * K.nmb), dim3(1024), mm_lds, s, K, t);
+    }
   }
-  MSER_TRY(check_launch("spk_fwd_step"));
+  MSER_TRY(check_launch("spk_fwd"));
   // ---- hoisted pre-activations: pre_m = xdir W_m^T + W.bias + HQ S_m^T + S.bias
   for (int i = 0; i < d.ndir; ++i) {
     DirP& k = K.d[i];
@@ -816,14 +1073,26 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s) {
   // ---- LSTHM chain
   const int NT = H > 512 ? H : 512;
   const size_t z_lds = row_lds_bytes(H, NT, 2);
-  for (int t = 0; t < T; ++t) {
-    {
-      ProfScope ps(MSER_PROF_LSTHM_FWD_GATES, s);
-      hipLaunchKernelGGL(lsthm_fwd_gates, dim3(H / 8, 2, d.ndir * K.nmb), dim3(1024), mm_lds, s, K, t);
+  if (persist) {
+    ProfScope ps(MSER_PROF_LSTHM_FWD_GATES, s);
+    if (H == 128) {
+      MSER_TRY(allow_lds((const void*)lsthm_fwd_persist<1>, p_lds));
+      hipLaunchKernelGGL(lsthm_fwd_persist<1>, dim3(H / 8, 2, d.ndir * K.nmb), dim3(1024), p_lds, s, K);
+    } else {
+      MSER_TRY(allow_lds((const void*)lsthm_fwd_persist<2>, p_lds));
+      hipLaunchKernelGGL(lsthm_fwd_persist<2>, dim3(H / 8, 2, d.ndir * K.nmb), dim3(1024), p_lds, s, K);
     }
-    {
-      ProfScope ps(MSER_PROF_LSTHM_FWD_Z, s);
-      hipLaunchKernelGGL(lsthm_fwd_z, dim3(B, d.ndir), dim3(NT), z_lds, s, K, t);
+  } else {
+    MSER_TRY(allow_lds((const void*)lsthm_fwd_gates, mm_lds));
+    for (int t = 0; t < T; ++t) {
+      {
+        ProfScope ps(MSER_PROF_LSTHM_FWD_GATES, s);
+        hipLaunchKernelGGL(lsthm_fwd_gates, dim3(H / 8, 2, d.ndir * K.nmb), dim3(1024), mm_lds, s, K, t);
+      }
+      {
+        ProfScope ps(MSER_PROF_LSTHM_FWD_Z, s);
+        hipLaunchKernelGGL(lsthm_fwd_z, dim3(B, d.ndir), dim3(NT), z_lds, s, K, t);
+      }
     }
   }
   return check_launch("lsthm_fwd");
@@ -845,16 +1114,32 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s) {
   const size_t mm_lds = (RED_FLOATS + 1024) * sizeof(float);
   const int NT = H > 512 ? H : 512;
   const size_t row_lds = row_lds_bytes(H, NT, 9);
-  MSER_TRY(allow_lds((const void*)lsthm_bwd_mat, mm_lds));
+  MSER_CHECK_HIP(hipMemsetAsync(h.sync, 0, SYNC_WORDS * sizeof(unsigned), s));
+  const int mat_wgs = (H / 32) * 4 * K.nmb;
+  const int bwd_nwg = mat_wgs > 32 ? mat_wgs : 32;          // row phase spreads the B rows over all of them
+  const bool persist = persist_ok(H, (long)bwd_nwg * d.ndir);
+  const size_t p_lds = persist_lds(mm_lds + 64);
   // ---- LSTHM chain, reverse time
-  for (int t = T - 1; t >= 0; --t) {
-    {
-      ProfScope ps(MSER_PROF_LSTHM_BWD_ROW, s);
-      hipLaunchKernelGGL(lsthm_bwd_row, dim3(B, d.ndir), dim3(NT), row_lds, s, K, t);
+  if (persist) {
+    ProfScope ps(MSER_PROF_LSTHM_BWD_ROW, s);
+    if (H == 128) {
+      MSER_TRY(allow_lds((const void*)lsthm_bwd_persist<2>, p_lds));
+      hipLaunchKernelGGL(lsthm_bwd_persist<2>, dim3(bwd_nwg, 1, d.ndir), dim3(1024), p_lds, s, K);
+    } else {
+      MSER_TRY(allow_lds((const void*)lsthm_bwd_persist<4>, p_lds));
+      hipLaunchKernelGGL(lsthm_bwd_persist<4>, dim3(bwd_nwg, 1, d.ndir), dim3(1024), p_lds, s, K);
     }
-    if (t > 0) {
-      ProfScope ps(MSER_PROF_LSTHM_BWD_MAT, s);
-      hipLaunchKernelGGL(lsthm_bwd_mat, dim3(H / 32, 4, d.ndir * K.nmb), dim3(1024), mm_lds, s, K, t);
+  } else {
+    MSER_TRY(allow_lds((const void*)lsthm_bwd_mat, mm_lds));
+    for (int t = T - 1; t >= 0; --t) {
+      {
+        ProfScope ps(MSER_PROF_LSTHM_BWD_ROW, s);
+        hipLaunchKernelGGL(lsthm_bwd_row, dim3(B, d.ndir), dim3(NT), row_lds, s, K, t);
+      }
+      if (t > 0) {
+        ProfScope ps(MSER_PROF_LSTHM_BWD_MAT, s);
+        hipLaunchKernelGGL(lsthm_bwd_mat, dim3(H / 32, 4, d.ndir * K.nmb), dim3(1024), mm_lds, s, K, t);
+      }
     }
   }
   MSER_TRY(check_launch("lsthm_bwd"));
@@ -909,12 +1194,24 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s) {
   }
   // ---- speaker chain, reverse time
   const size_t spk_lds = mm_lds + 32 * (4 * (size_t)H + 4) * sizeof(float);
-  MSER_TRY(allow_lds((const void*)spk_bwd_step, spk_lds));
-  for (int t = T - 1; t >= 0; --t) {
+  if (persist_ok(H, (long)mat_wgs * d.ndir)) {
+    const size_t ps_lds = persist_lds(spk_lds + 64);
     ProfScope ps(MSER_PROF_SPK_BWD, s);
-    hipLaunchKernelGGL(spk_bwd_step, dim3(H / 32, 4, d.ndir * K.nmb), dim3(1024), spk_lds, s, K, t);
+    if (H == 128) {
+      MSER_TRY(allow_lds((const void*)spk_bwd_persist<2>, ps_lds));
+      hipLaunchKernelGGL(spk_bwd_persist<2>, dim3(H / 32, 4, d.ndir * K.nmb), dim3(1024), ps_lds, s, K);
+    } else {
+      MSER_TRY(allow_lds((const void*)spk_bwd_persist<4>, ps_lds));
+      hipLaunchKernelGGL(spk_bwd_persist<4>, dim3(H / 32, 4, d.ndir * K.nmb), dim3(1024), ps_lds, s, K);
+    }
+  } else {
+    MSER_TRY(allow_lds((const void*)spk_bwd_step, spk_lds));
+    for (int t = T - 1; t >= 0; --t) {
+      ProfScope ps(MSER_PROF_SPK_BWD, s);
+      hipLaunchKernelGGL(spk_bwd_step, dim3(H / 32, 4, d.ndir * K.nmb), dim3(1024), spk_lds, s, K, t);
+    }
   }
-  MSER_TRY(check_launch("spk_bwd_step"));
+  MSER_TRY(check_launch("spk_bwd"));
   for (int i = 0; i < d.ndir; ++i) {
     DirP& k = K.d[i];
     const mser_cell_params& G = d.dir[i].g;
@@ -999,6 +1296,31 @@ __global__ __launch_bounds__(1024) void rank1_attention_kernel(const float* x1, 
 using namespace mser;
 
 extern "C" {
+
+int mser_set_option(int32_t key, int32_t value) {
+  switch (key) {
+    case MSER_OPT_PERSISTENT: g_opt_persistent = value ? 1 : 0; return 0;
+    default: set_error("mser_set_option: unknown key %d", key); return -1;
+  }
+}
+
+int mser_marn_cell_status(const mser_cell_desc* d, mser_stream_t stream) {
+  if (!d || !d->workspace) { set_error("mser_marn_cell_status: null descriptor/workspace"); return -1; }
+  CellHost h;
+  carve_all((char*)d->workspace, *d, &h);
+  unsigned words[SYNC_WORDS];
+  MSER_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  MSER_CHECK_HIP(hipMemcpy(words, h.sync, sizeof(words), hipMemcpyDeviceToHost));
+#ifdef MSER_STAMPS
+  fprintf(stderr, "[stamps lsthm_fwd_persist, 10ns ticks/step] gates %u barrier1 %u z %u barrier2 %u\n", words[10], words[11], words[12], words[13]);
+#endif
+  if (words[SYNC_ABORT] != 0) {
+    set_error("marn_cell: a persistent kernel gave up waiting at an inter-workgroup barrier (counters: spk_fwd %u/%u lsthm_fwd %u/%u "
+              "lsthm_bwd %u/%u spk_bwd %u/%u)", words[0], words[1], words[2], words[3], words[4], words[5], words[6], words[7]);
+    return -2;
+  }
+  return 0;
+}
 
 int mser_prof_enable(int32_t kernel_id, int32_t max_launches) {
   for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);

@@ -86,6 +86,8 @@ SIGNATURES = {
     "mser_adam_flat": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
     "mser_adam_flat_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _f32, _vp, _f32, _vp]),
     "mser_dp_pack": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "mser_set_option": (C.c_int, [_i32, _i32]),
+    "mser_marn_cell_status": (C.c_int, [C.POINTER(CellDesc), _vp]),
     "mser_prof_enable": (C.c_int, [_i32, _i32]),
     "mser_prof_collect": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
 }

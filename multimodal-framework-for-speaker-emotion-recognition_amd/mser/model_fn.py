@@ -48,6 +48,7 @@ class ModelCtx:
     Hcat: Tensor = None
     cell_ws: Tensor = None
     cell_dirs: list = None
+    cell_desc: object = None
     A1: Tensor = None
     A2: Tensor = None
     xa: list = None
@@ -132,6 +133,7 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
     ]
     desc = ops.make_cell_desc(Ln, B, D, H, c.x_l, c.x_a, c.cell_dirs, 10 * H, c.cell_ws)
     ops.marn_cell_fwd(desc)
+    c.cell_desc = desc
 
     # ---- sequence-level cross-modal attention (:377-383)
     w, v, v1, v2 = P("w"), P("v"), P("v1"), P("v2")
@@ -212,6 +214,7 @@ def marn1_backward(c: ModelCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: Opt
         r["dout"] = dH[:, sl]
     desc = ops.make_cell_desc(Ln, B, D, H, c.x_l, c.x_a, c.cell_dirs, 10 * H, c.cell_ws, dx_l=dx_l, dx_a=dx_a)
     ops.marn_cell_bwd(desc)
+    c.cell_desc = desc
     # ---- encoders (two passes with shared weights) + linear_in
     Pl, Pa, Gl, Ga = _sub(P, "encoder_l."), _sub(P, "encoder_a."), _sub(G, "encoder_l."), _sub(G, "encoder_a.")
     cur = torch.cuda.current_stream()

@@ -263,3 +263,15 @@ def marn_cell_fwd(desc: L.CellDesc) -> None:
 
 def marn_cell_bwd(desc: L.CellDesc) -> None:
     L.check(L.load().mser_marn_cell_bwd(C.byref(desc), _stream()), "marn_cell_bwd")
+
+
+def marn_cell_status(desc: L.CellDesc) -> None:
+    """Synchronising diagnostic: raises if a persistent recurrent kernel gave up at one of its bounded barriers."""
+    L.check(L.load().mser_marn_cell_status(C.byref(desc), _stream()), "marn_cell_status")
+
+
+MSER_OPT_PERSISTENT = 1
+
+
+def set_option(key: int, value: int) -> None:
+    L.check(L.load().mser_set_option(key, value), "set_option")

@@ -153,3 +153,52 @@ def test_model_determinism_and_no_grad(O):
         b = net(x, qmask, umask)[0].clone()
     assert torch.equal(a, b)                       # forward is bit-reproducible (fixed-order reductions)
     assert torch.isfinite(a).all()
+
+
+def test_persistent_vs_per_step_launches(O):
+    """The persistent recurrent kernels (time loop inside, counter barriers, write-through hand-offs) against the per-step
+    launches: same arithmetic and the same data flow, only the synchronisation differs -- plus the partial-sum grouping of
+    the rank-1 attention rows (1024 vs 512 threads per row), hence ulp-level (not bitwise) agreement: 2e-6 on log-probs.
+    A stale hand-off would show up as an O(1e-2) error.  Repeated launches keep consumers L1-warm."""
+    from models.lsthm_sps import MARN1_sps
+    from loss import MaskedLoss
+    from mser import ops
+    res = {}
+    for mode in (0, 1):
+        ops.set_option(ops.MSER_OPT_PERSISTENT, mode)
+        net = MARN1_sps(6, d_r=768).cuda().eval()
+        load_params(net, O.seeded_params(seed=11, d_r=768))
+        x, qmask, umask, label = (t.cuda() for t in O.seeded_batch(32, 40, d_r=768, seed=12, ragged=True))
+        for rep in range(3):                                   # repeated launches: L1-warm consumers, reused workspace
+            net.zero_grad()
+            lp, _, _ = net(x, qmask, umask)
+            loss = MaskedLoss(torch.nn.NLLLoss)(lp, label.view(-1), umask)
+            loss.backward()
+        g = net.flat_store.grad.clone()
+        res[mode] = (lp.detach().clone(), g)
+    ops.set_option(ops.MSER_OPT_PERSISTENT, 1)
+    assert float((res[0][0] - res[1][0]).abs().max()) < 2e-6, float((res[0][0] - res[1][0]).abs().max())
+    # gradients pass through split-K float atomics (order-dependent rounding), so compare with a tight tolerance
+    d = float((res[0][1] - res[1][1]).abs().max())
+    assert d < 1e-5 * max(1.0, float(res[0][1].abs().max())), d
+
+
+def test_persistent_status_clean(O):
+    from models.lsthm_sps import MARN_cell
+    from mser import ops
+    m = MARN_cell(128, 128, 100, 100).cuda()
+    T, N = 50, 32
+    rs = np.random.RandomState(0)
+    x_l = torch.tensor(rs.standard_normal((T, N, 100)).astype(np.float32)).cuda()
+    x_a = torch.tensor(rs.standard_normal((T, N, 100)).astype(np.float32)).cuda()
+    qmask = torch.tensor(np.eye(2, dtype=np.float32)[rs.randint(0, 2, (T, N))]).cuda()
+    xl2, xa2 = x_l.view(T * N, 100), x_a.view(T * N, 100)
+    out = torch.empty(T * N, 512, device="cuda")
+    ws = torch.empty(ops.cell_workspace_bytes(T, N, 100, 128, 1), device="cuda", dtype=torch.uint8)
+    P = dict(m.named_parameters())
+    dirs = [dict(p=ops.cell_param_struct(lambda n: P[n].detach()), qmask=qmask, rev=None, out=out)]
+    desc = ops.make_cell_desc(T, N, 100, 128, xl2, xa2, dirs, 512, ws)
+    for _ in range(5):
+        ops.marn_cell_fwd(desc)
+    ops.marn_cell_status(desc)                                  # raises if any barrier timed out
+    assert torch.isfinite(out).all()
