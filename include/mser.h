@@ -145,6 +145,11 @@ typedef struct mser_cell_desc {
 size_t mser_marn_cell_workspace_bytes(int32_t T, int32_t B, int32_t D, int32_t H, int32_t ndir);
 int mser_marn_cell_fwd(const mser_cell_desc* d, mser_stream_t stream);
 int mser_marn_cell_bwd(const mser_cell_desc* d, mser_stream_t stream);
+/* The same work in separately schedulable phases, so that the caller can overlap independent parts on different streams:
+ * the speaker chain depends on qmask only (overlaps the encoders); its backward touches only speaker-cell gradients (overlaps
+ * the encoder backward).  fwd = SPEAKER_FWD then LSTHM_FWD; bwd = LSTHM_BWD then SPEAKER_BWD (the caller orders them). */
+enum { MSER_PHASE_SPEAKER_FWD = 1, MSER_PHASE_LSTHM_FWD = 2, MSER_PHASE_LSTHM_BWD = 4, MSER_PHASE_SPEAKER_BWD = 8 };
+int mser_marn_cell_run(const mser_cell_desc* d, int32_t phases, mser_stream_t stream);
 
 /* Launch mode of the recurrent chains.  MSER_OPT_PERSISTENT = 1 (default): each chain is ONE persistent launch with the time
  * loop inside (weights in registers, per-direction counter barriers, write-through hand-offs) whenever every workgroup can be

@@ -6,8 +6,12 @@
 //
 // Tile: 64x64 per 256-thread workgroup (4 waves as 2x2, one 32x32 accumulator each), BK = 16.
 // LDS tiles are k-major ([BK][64+pad]) so an MFMA operand fetch is one conflict-free ds_read_b32 per lane.
-// The matrices on this path are small (M = B*L <= 64k rows, N <= 1280) and the job is latency/launch bound,
-// so the kernel favours generality (any strides, two batch levels, split-K, fused bias/ReLU/residual epilogue).
+// The matrices on this path are small (M = B*L = 4096 rows, N <= 1280, K <= 1280 or a 4096-long split reduction) and every
+// call is latency bound, not bandwidth bound: what matters is (1) cheap addressing -- per-thread base pointers are computed
+// once, the k-loop only adds one offset -- and (2) memory-level parallelism -- global loads run TWO tiles ahead of the MFMAs
+// (register staging: tile i is computed from LDS while tile i+1 waits in registers and tile i+2 is in flight).
+// Generality (any strides, two batch levels, split-K with float atomics, fused bias/ReLU/residual epilogue) is kept because
+// every transposed / strided / head-interleaved product of the forward and backward pass goes through this one kernel.
 #include "common.h"
 #include "../../include/mser.h"
 
@@ -25,7 +29,7 @@ struct GemmArgs {
   const float* R1; const float* R2; long ldr1, ldr2, sR1, sR2;
 };
 
-// AMODE / BMODE: 0 = k contiguous, 1 = m (n) contiguous, 2 = generic
+// AMODE / BMODE: 0 = k contiguous (threads walk k fastest), 1 = m (n) contiguous (threads walk m / n fastest), 2 = generic
 template <int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   __shared__ float As[2][BK][BM + PAD];
@@ -38,59 +42,82 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   int z = blockIdx.z;
   const int ks = z % g.splitk; z /= g.splitk;
   const int z2 = z % g.batch2, z1 = z / g.batch2;
-  const float* A = g.A + z1 * g.sA1 + z2 * g.sA2;
-  const float* B = g.B + z1 * g.sB1 + z2 * g.sB2;
   const int kbeg = ks * g.kchunk;
   const int kend = min(g.K, kbeg + g.kchunk);
+  const float* A = g.A + z1 * g.sA1 + z2 * g.sA2 + (long)kbeg * g.sAk;
+  const float* B = g.B + z1 * g.sB1 + z2 * g.sB2 + (long)kbeg * g.sBk;
+  const int klen = kend - kbeg;
 
-  // per-thread load coordinates: 4 elements of the 64x16 A tile and of the 16x64 B tile
+  // per-thread element coordinates inside a tile and the matching base pointers (computed once)
   int am[4], ak[4], bn[4], bk[4];
+  const float* pa[4];
+  const float* pb[4];
+  bool va[4], vb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    if (AMODE == 1) { int e = tid + i * 256; ak[i] = e >> 6; am[i] = e & 63; }   // m fastest
-    else            { int e = tid + i * 256; am[i] = e >> 4; ak[i] = e & 15; }   // k fastest
-    if (BMODE == 1) { int e = tid + i * 256; bk[i] = e >> 6; bn[i] = e & 63; }   // n fastest
-    else            { int e = tid + i * 256; bn[i] = e >> 4; bk[i] = e & 15; }   // k fastest
+    const int e = tid + i * 256;
+    if (AMODE == 1) { ak[i] = e >> 6; am[i] = e & 63; } else { am[i] = e >> 4; ak[i] = e & 15; }
+    if (BMODE == 1) { bk[i] = e >> 6; bn[i] = e & 63; } else { bn[i] = e >> 4; bk[i] = e & 15; }
+    va[i] = (m0 + am[i]) < g.M;
+    vb[i] = (n0 + bn[i]) < g.N;
+    pa[i] = A + (long)(va[i] ? m0 + am[i] : 0) * g.sAm + (long)ak[i] * g.sAk;
+    pb[i] = B + (long)(vb[i] ? n0 + bn[i] : 0) * g.sBn + (long)bk[i] * g.sBk;
   }
 
   f32x16 acc = {0};
-  float ra[4], rb[4];
-  auto gload = [&](int k0) {
+  const int nt = (klen + BK - 1) / BK;
+  auto gload = [&](int t, float* ra, float* rb) {
+    const int k0 = t * BK;
+    const long oa = (long)k0 * g.sAk, ob = (long)k0 * g.sBk;
+    if (k0 + BK <= klen) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int m = m0 + am[i], k = k0 + ak[i];
-      ra[i] = (m < g.M && k < kend) ? A[(long)m * g.sAm + (long)k * g.sAk] : 0.f;
-      int n = n0 + bn[i]; k = k0 + bk[i];
-      rb[i] = (n < g.N && k < kend) ? B[(long)k * g.sBk + (long)n * g.sBn] : 0.f;
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = va[i] ? pa[i][oa] : 0.f;
+        rb[i] = vb[i] ? pb[i][ob] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = (va[i] && k0 + ak[i] < klen) ? pa[i][oa] : 0.f;
+        rb[i] = (vb[i] && k0 + bk[i] < klen) ? pb[i][ob] : 0.f;
+      }
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, const float* ra, const float* rb) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       As[buf][ak[i]][am[i]] = ra[i];
       Bs[buf][bk[i]][bn[i]] = rb[i];
     }
   };
-
-  int buf = 0;
-  if (kbeg < kend) {
-    gload(kbeg);
-    lstore(0);
-  }
-  __syncthreads();
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    const bool more = (k0 + BK) < kend;
-    if (more) gload(k0 + BK);
-    const int half = lane >> 5, l31 = lane & 31;
+  const int half = lane >> 5, l31 = lane & 31;
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      float a = As[buf][kk + half][wr * 32 + l31];
-      float b = Bs[buf][kk + half][wc * 32 + l31];
+      const float a = As[buf][kk + half][wr * 32 + l31];
+      const float b = Bs[buf][kk + half][wc * 32 + l31];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
-    if (more) lstore(buf ^ 1);
+  };
+
+  float ra0[4], rb0[4], ra1[4], rb1[4];
+  if (nt > 0) {
+    gload(0, ra0, rb0);
+    if (nt > 1) gload(1, ra1, rb1);
+    lstore(0, ra0, rb0);
+  }
+  __syncthreads();
+  // tile t lives in LDS buffer t&1; registers set (t+1)&1 holds tile t+1; tile t+2 is requested into the freed set
+  for (int t = 0; t < nt; t += 2) {
+    if (t + 2 < nt) gload(t + 2, ra0, rb0);
+    compute(0);
+    if (t + 1 < nt) lstore(1, ra1, rb1);
     __syncthreads();
-    buf ^= 1;
+    if (t + 1 >= nt) break;
+    if (t + 3 < nt) gload(t + 3, ra1, rb1);
+    compute(1);
+    if (t + 2 < nt) lstore(0, ra0, rb0);
+    __syncthreads();
   }
 
   // epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)

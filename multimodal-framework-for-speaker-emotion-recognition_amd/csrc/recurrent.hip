@@ -40,18 +40,20 @@ struct DirP {
   const float* dout;
   // backward scratch
   float *dgates, *dc_carry, *dA, *attacc, *dHQ;
-  float *dsg, *raw_ih, *dhprev, *dcprev, *dh0;
+  float *dsg, *Xb, *dhprev, *dcprev;   // Xb[2][B][H]: grad wrt q_{t-1}[b, party_t[b]], ping-pong by step parity
+  float* mnext;                        // [T][B]: qmask_t[r][party_{t+1}[r]] (0 at the last step)
 };
 
 struct CellK {
   int T, B, D, H, ndir, nmb;
   long ldo;
+  void* wsbase;        // the cell workspace: one buffer descriptor spans it (sc1 hand-off accesses)
+  unsigned wsbytes;
   unsigned* sync;      // persistent-kernel counters: [SYNC_*] words, zeroed by a memset node before every launch
   DirP d[2];
 };
-enum { SYNC_SPK_FWD = 0, SYNC_LSTHM_FWD = 2, SYNC_LSTHM_BWD = 4, SYNC_SPK_BWD = 6, SYNC_ABORT = 8, SYNC_WORDS = 16 };
+enum { SYNC_SPK_FWD = 0, SYNC_LSTHM_FWD = 2, SYNC_LSTHM_BWD = 4, SYNC_SPK_BWD = 6, SYNC_ABORT = 8, SYNC_WORDS = 64 };
 
-constexpr int RED_FLOATS = 16 * 1024;
 
 // ---- optional per-kernel timing with HIP events (bench.py's live roofline measurement; off by default) ----------------------
 struct Prof {
@@ -78,16 +80,31 @@ struct ProfScope {
 // add per workgroup behind s_waitcnt vmcnt(0) + barrier, sc1-load poll, workgroup barrier, sc1 loads).  PS = false in the
 // per-step launches, where the kernel boundary orders everything and plain accesses are correct.
 typedef __attribute__((address_space(1))) unsigned int gu32;
-typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// The hand-off payload goes through ONE buffer descriptor that spans the whole cell workspace: raw buffer loads/stores with
+// aux = 16 are `buffer_load/store_dword[x4] ... sc1` (L1-bypassing / write-through), they are ordinary (non-atomic) memory
+// operations for the compiler, so it can issue a phase's loads back to back and wait once, and they come 16 bytes wide.
+struct WS {
+  __amdgpu_buffer_rsrc_t r;
+  const char* base;
+};
+__device__ __forceinline__ WS make_ws(void* base, unsigned bytes) {
+  WS w;
+  w.base = (const char*)base;
+  w.r = __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);
+  return w;
+}
+constexpr int AUX_SC1 = 16;
 
 template <bool PS>
-__device__ __forceinline__ float ldx(const float* p) {
-  if constexpr (PS) return __uint_as_float(__hip_atomic_load((const gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+__device__ __forceinline__ float ldx(const WS& w, const float* p) {
+  if constexpr (PS) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(w.r, (int)((const char*)p - w.base), 0, AUX_SC1));
   else return *p;
 }
 template <bool PS>
-__device__ __forceinline__ void stx(float* p, float v) {
-  if constexpr (PS) __hip_atomic_store((gu32*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void stx(const WS& w, float* p, float v) {
+  if constexpr (PS) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), w.r, (int)((const char*)p - w.base), 0, AUX_SC1);
   else *p = v;
 }
 __device__ __forceinline__ void load8(const float* p, float* a) {
@@ -97,17 +114,29 @@ __device__ __forceinline__ void load8(const float* p, float* a) {
   a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
 }
 template <bool PS>
-__device__ __forceinline__ void load8x(const float* p, float* a) {
+__device__ __forceinline__ void load8x(const WS& w, const float* p, float* a) {
   if constexpr (PS) {
-    const gu64* q = (const gu64*)p;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const unsigned long long v = __hip_atomic_load(q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      a[2 * i] = __uint_as_float((unsigned)v);
-      a[2 * i + 1] = __uint_as_float((unsigned)(v >> 32));
-    }
+    const int off = (int)((const char*)p - w.base);
+    const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(w.r, off, 0, AUX_SC1);
+    const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(w.r, off + 16, 0, AUX_SC1);
+    a[0] = __uint_as_float(v0.x); a[1] = __uint_as_float(v0.y); a[2] = __uint_as_float(v0.z); a[3] = __uint_as_float(v0.w);
+    a[4] = __uint_as_float(v1.x); a[5] = __uint_as_float(v1.y); a[6] = __uint_as_float(v1.z); a[7] = __uint_as_float(v1.w);
   } else {
     load8(p, a);
+  }
+}
+template <bool PS>
+__device__ __forceinline__ void store8x(const WS& w, float* p, const float* a) {
+  if constexpr (PS) {
+    const int off = (int)((const char*)p - w.base);
+    u32x4 v0, v1;
+    v0.x = __float_as_uint(a[0]); v0.y = __float_as_uint(a[1]); v0.z = __float_as_uint(a[2]); v0.w = __float_as_uint(a[3]);
+    v1.x = __float_as_uint(a[4]); v1.y = __float_as_uint(a[5]); v1.z = __float_as_uint(a[6]); v1.w = __float_as_uint(a[7]);
+    __builtin_amdgcn_raw_buffer_store_b128(v0, w.r, off, 0, AUX_SC1);
+    __builtin_amdgcn_raw_buffer_store_b128(v1, w.r, off + 16, 0, AUX_SC1);
+  } else {
+    *reinterpret_cast<float4*>(p) = make_float4(a[0], a[1], a[2], a[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(a[4], a[5], a[6], a[7]);
   }
 }
 __device__ __forceinline__ void zero8(float* a) {
@@ -142,29 +171,59 @@ __device__ __forceinline__ bool dir_barrier(unsigned* cnt, unsigned* abortw, uns
   return *lds_ok != 0;
 }
 
-// 32 x 32 x K product by one 1024-thread workgroup; result (row-major [32][32]) left in tile[], all threads synced.
-// aload(r, k, a[8]) must return A[row r][k..k+7]; bload(n, k, b[8]) must return B[k..k+7][col n].
-// NP > 0: the B fragments of this wave's NP k-passes were loaded once into bpre[][] (persistent kernels keep the weights
-// in registers across the whole time loop).
+// ---- workgroup geometry of the recurrent kernels ----------------------------------------------------------------------------
+// 512 threads = 8 waves = 2 per SIMD.  The fp32 MFMA is paced per SIMD (64 cycles per 32x32x2), so the matvec phases need only
+// one or two waves per SIMD; the row phases (rank-1 attention: ~16k exp2 per dialogue row) want more VALU issue slots.
+constexpr int NT = 512, NW = 8;
+
+// ---- diagnostic phase stamps (compiled only with -DMSER_STAMPS; never in the product build) -----------------------------------
+#ifdef MSER_STAMPS
+__shared__ unsigned long long st_acc[17];      // 16 accumulators + last stamp; 18*8 = 144 B keeps the dynamic LDS base 16-B aligned
+__shared__ unsigned long long st_pad;
+#define STAMP_INIT() do { if (threadIdx.x == 0) { for (int _i = 0; _i < 16; ++_i) st_acc[_i] = 0; st_acc[16] = __builtin_amdgcn_s_memrealtime(); st_pad = 0; } } while (0)
+#define STAMP_ACC(k) do { if (threadIdx.x == 0) { unsigned long long _n = __builtin_amdgcn_s_memrealtime(); st_acc[k] += _n - st_acc[16]; st_acc[16] = _n; } } while (0)
+#define STAMP_DUMP(P, base, sel) do { if (threadIdx.x == 0 && (sel)) for (int _i = 0; _i < 8; ++_i) (P).sync[(base) + _i] = (unsigned)(st_acc[_i] / (unsigned)(P).T); } while (0)
+#else
+#define STAMP_INIT()
+#define STAMP_ACC(k)
+#define STAMP_DUMP(P, base, sel)
+#endif
+constexpr int RED_FLOATS = NW * 1024;       // K-split partial tiles, reused as scratch by the row phases
+constexpr float LOG2E = 1.4426950408889634f;
+
+// 32 x 32 x K product by one workgroup: the 8 waves split K, each runs a chain of v_mfma_f32_32x32x2_f32, partials are
+// reduced through LDS in a fixed order.  Result (row-major [32][32]) left in tile[], all threads synced.
+// aload(r, k, a[8]) returns A[row r][k..k+7]; bload(n, k, b[8]) returns B[k..k+7][col n].
+// NP > 0: the B fragments of this wave's NP k-passes were loaded once into bpre[][] (persistent kernels keep the weights in
+// registers across the whole time loop) and all A fragments are fetched before the first MFMA.
 template <int NP, class ALoad, class BLoad>
 __device__ __forceinline__ void wg_mm32(int K, ALoad aload, BLoad bload, const float (*bpre)[8], float* red, float* tile) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
-  const int KC = ((K + 255) / 256) * 16;   // per-wave K chunk (multiple of 16)
+  const int KC = ((K + NW * 16 - 1) / (NW * 16)) * 16;   // per-wave K chunk (multiple of 16)
   f32x16 acc = {0};
-  const int kend = min(K, (wave + 1) * KC);
-  int pass = 0;
-  for (int kb = wave * KC; kb < kend; kb += 16, ++pass) {
-    float a[8], b[8];
-    aload(r, kb + half * 8, a);
-    if constexpr (NP > 0) {
+  const int kbeg = wave * KC;
+  const int kend = min(K, kbeg + KC);
+  if constexpr (NP > 0) {
+    float a[NP][8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) b[j] = bpre[pass < NP ? pass : NP - 1][j];
-    } else {
-      bload(r, kb + half * 8, b);
+    for (int p = 0; p < NP; ++p) {
+      if (kbeg + p * 16 < kend) aload(r, kbeg + p * 16 + half * 8, a[p]);
+      else zero8(a[p]);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][j], bpre[p][j], acc, 0, 0, 0);
+    }
+  } else {
+    for (int kb = kbeg; kb < kend; kb += 16) {
+      float a[8], b[8];
+      aload(r, kb + half * 8, a);
+      bload(r, kb + half * 8, b);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -172,17 +231,20 @@ __device__ __forceinline__ void wg_mm32(int K, ALoad aload, BLoad bload, const f
     red[wave * 1024 + row * 32 + r] = acc[i];
   }
   __syncthreads();
-  float s = 0.f;
 #pragma unroll
-  for (int w = 0; w < 16; ++w) s += red[w * 1024 + tid];
-  tile[tid] = s;
+  for (int e = 0; e < 1024 / NT; ++e) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w * 1024 + tid + e * NT];
+    tile[tid + e * NT] = s;
+  }
   __syncthreads();
 }
 template <int NP, class BLoad>
 __device__ __forceinline__ void preload_b(int K, BLoad bload, float (*bpre)[8]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, half = lane >> 5;
-  const int KC = ((K + 255) / 256) * 16;
+  const int KC = ((K + NW * 16 - 1) / (NW * 16)) * 16;
   const int kend = min(K, (wave + 1) * KC);
 #pragma unroll
   for (int pass = 0; pass < NP; ++pass) {
@@ -191,6 +253,46 @@ __device__ __forceinline__ void preload_b(int K, BLoad bload, float (*bpre)[8]) 
     else zero8(bpre[pass]);
   }
 }
+
+// block-wide helpers (NT threads)
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) s += sh[w];
+  return s;
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = -INFINITY;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) s = fmaxf(s, sh[w]);
+  return s;
+}
+
+// Rank-1 attention constants of one direction in LDS: att[0..H) = Wk, att[H..2H) = Wq, att[2H] = max(Wk), att[2H+1] = min(Wk).
+// (softmax_j(u * Wk[j]) has its maximum at u*max(Wk) for u >= 0 and u*min(Wk) otherwise: no running max needed.)
+__device__ __forceinline__ void att_prepare(const DirP& D, int H, float* att, float* sh) {
+  float wmx = -INFINITY, wmn = INFINITY;
+  for (int k = threadIdx.x; k < H; k += NT) {
+    const float w = D.attWk[k];
+    att[k] = w;
+    att[H + k] = D.attWq[k];
+    wmx = fmaxf(wmx, w);
+    wmn = fminf(wmn, w);
+  }
+  wmx = block_max(wmx, sh);
+  wmn = -block_max(-wmn, sh);
+  if (threadIdx.x == 0) { att[2 * H] = wmx; att[2 * H + 1] = wmn; }
+  __syncthreads();
+}
+__device__ __forceinline__ int att_floats(int H) { return 2 * H + 16; }
 
 // ================================================================================================ speaker forward
 // Role: (cell c, units u0..u0+7, slot block mb) of direction D.  One nn.LSTMCell (gate order i,f,g,o) step for 8 hidden
@@ -206,7 +308,7 @@ struct SpkFwdB {
 };
 
 template <bool PS, int NP>
-__device__ __forceinline__ void spk_fwd_body(const CellK& P, const DirP& D, int t, int c, int u0, int mb, bool writer,
+__device__ __forceinline__ void spk_fwd_body(const CellK& P, const DirP& D, const WS& ws, int t, int c, int u0, int mb, bool writer,
                                              const float (*bpre)[8], float* red, float* tile) {
   const int H = P.H, B = P.B, T = P.T;
   const int N0 = D.n0[t];
@@ -224,20 +326,28 @@ __device__ __forceinline__ void spk_fwd_body(const CellK& P, const DirP& D, int 
     if (tid < 256) {
       const int slot = mb * 32 + (tid >> 3), u = u0 + (tid & 7);
       if (slot < B) {
-        stx<PS>(hq_new + (long)slot * H + u, ldx<PS>(hq_old + (long)slot * H + u));
-        stx<PS>(cq_new + (long)slot * H + u, ldx<PS>(cq_old + (long)slot * H + u));
+        stx<PS>(ws, hq_new + (long)slot * H + u, ldx<PS>(ws, hq_old + (long)slot * H + u));
+        stx<PS>(ws, cq_new + (long)slot * H + u, ldx<PS>(ws, cq_old + (long)slot * H + u));
 #pragma unroll
         for (int g = 0; g < 4; ++g) sg[(long)slot * 4 * H + g * H + u] = 0.f;
       }
     }
     if (writer)
-      for (int e = tid; e < 32 * H; e += 1024) {
+      for (int e = tid; e < 32 * H; e += NT) {
         const int slot = mb * 32 + e / H;
-        if (slot < B) stx<PS>(qs + (long)slot * H + e % H, 0.f);
+        if (slot < B) stx<PS>(ws, qs + (long)slot * H + e % H, 0.f);
       }
     return;
   }
 
+  // epilogue operands that do not depend on the matvec: fetch them first
+  float cq_prev = 0.f, bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (tid < 256) {
+    const int slot = mb * 32 + (tid >> 3), u = u0 + (tid & 7);
+    if (slot < B) cq_prev = ldx<PS>(ws, cq_old + (long)slot * H + u);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[g] = D.bih[c][g * H + u] + D.bhh[c][g * H + u];
+  }
   const int N0p = t > 0 ? D.n0[t - 1] : 0;
   auto aload = [&](int r, int k, float* a) {
     const int slot = mb * 32 + r;
@@ -250,59 +360,59 @@ __device__ __forceinline__ void spk_fwd_body(const CellK& P, const DirP& D, int 
                                     : D.qsel + ((long)(1 * T + t - 1) * B + (b - N0p)) * H;
         const float* hq = D.HQ + ((long)(t - 1) * B + b) * H;
         float x0[8], x1[8];
-        load8x<PS>(h0 + k, x0);
-        load8x<PS>(hq + k, x1);
+        load8x<PS>(ws, h0 + k, x0);
+        load8x<PS>(ws, hq + k, x1);
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] = x0[j] * (1.f - m) + x1[j] * m;
       } else {
         zero8(a);
       }
-      if (writer) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) stx<PS>(qs + (long)slot * H + k + j, a[j]);
-      }
+      if (writer) store8x<PS>(ws, qs + (long)slot * H + k, a);
     } else {
-      load8x<PS>(hq_old + (long)slot * H + (k - H), a);
+      load8x<PS>(ws, hq_old + (long)slot * H + (k - H), a);
     }
   };
+  STAMP_ACC(0);
   wg_mm32<NP>(2 * H, aload, SpkFwdB{D, c, u0, H}, bpre, red, tile);
-
-  {
-    const int n = tid & 31;
-    const long wrow = (long)(n >> 3) * H + u0 + (n & 7);
-    tile[tid] += D.bih[c][wrow] + D.bhh[c][wrow];
-  }
-  __syncthreads();
+  STAMP_ACC(1);
   if (tid < 256) {
     const int rr = tid >> 3, uu = tid & 7;
     const int slot = mb * 32 + rr, u = u0 + uu;
     if (slot < B) {
-      const float gi = sigmoidf_(tile[rr * 32 + 0 + uu]);
-      const float gf = sigmoidf_(tile[rr * 32 + 8 + uu]);
-      const float gg = tanhf(tile[rr * 32 + 16 + uu]);
-      const float go = sigmoidf_(tile[rr * 32 + 24 + uu]);
-      const float cn = gf * ldx<PS>(cq_old + (long)slot * H + u) + gi * gg;
+      const float gi = sigmoidf_(tile[rr * 32 + 0 + uu] + bias4[0]);
+      const float gf = sigmoidf_(tile[rr * 32 + 8 + uu] + bias4[1]);
+      const float gg = tanhf(tile[rr * 32 + 16 + uu] + bias4[2]);
+      const float go = sigmoidf_(tile[rr * 32 + 24 + uu] + bias4[3]);
+      const float cn = gf * cq_prev + gi * gg;
       const float hn = go * tanhf(cn);
-      stx<PS>(cq_new + (long)slot * H + u, cn);
-      stx<PS>(hq_new + (long)slot * H + u, hn);
+      stx<PS>(ws, cq_new + (long)slot * H + u, cn);
+      stx<PS>(ws, hq_new + (long)slot * H + u, hn);
       float* g = sg + (long)slot * 4 * H + u;
       g[0] = gi; g[H] = gf; g[2 * H] = gg; g[3 * H] = go;
-      if (slot < Nc) stx<PS>(D.HQ + ((long)t * B + off + slot) * H + u, hn);   // h_q = cat[h_q0[:N0], h_q1[:N1]] (:192)
+      if (slot < Nc) {                                        // h_q = cat[h_q0[:N0], h_q1[:N1]] (:192)
+        const int r = off + slot;
+        stx<PS>(ws, D.HQ + ((long)t * B + r) * H + u, hn);
+        const int tau = D.rev ? D.rev[(long)t * B + r] : t;   // all_hs = cat[h_l, h_a, z_l, h_q] (:218): the h_q quarter
+        if (tau >= 0) D.out[((long)tau * B + r) * P.ldo + 3 * H + u] = hn;
+      }
     }
   }
+  STAMP_ACC(2);
 }
 
-// per-step launch: grid (H/8, 2 cells, ndir*nmb), block 1024
-__global__ __launch_bounds__(1024) void spk_fwd_step(CellK P, int t) {
-  extern __shared__ float smem[];
+// per-step launch: grid (H/8, 2 cells, ndir*nmb), block NT
+__global__ __launch_bounds__(NT) void spk_fwd_step(CellK P, int t) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WS ws = make_ws(P.wsbase, P.wsbytes);
   const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
-  spk_fwd_body<false, 0>(P, P.d[dir], t, blockIdx.y, blockIdx.x * 8, mb, blockIdx.x == 0, nullptr, smem, smem + RED_FLOATS);
+  spk_fwd_body<false, 0>(P, P.d[dir], ws, t, blockIdx.y, blockIdx.x * 8, mb, blockIdx.x == 0, nullptr, smem, smem + RED_FLOATS);
 }
 
 // persistent launch: same grid, the whole time loop inside; weights of this workgroup's slice stay in registers.
 template <int NP>
-__global__ __launch_bounds__(1024) void spk_fwd_persist(CellK P) {
-  extern __shared__ float smem[];
+__global__ __launch_bounds__(NT) void spk_fwd_persist(CellK P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WS ws = make_ws(P.wsbase, P.wsbytes);
   float* red = smem;
   float* tile = smem + RED_FLOATS;
   int* lds_ok = (int*)(tile + 1024);
@@ -312,10 +422,15 @@ __global__ __launch_bounds__(1024) void spk_fwd_persist(CellK P) {
   const unsigned nwg = gridDim.x * gridDim.y * P.nmb;
   float bpre[NP][8];
   preload_b<NP>(2 * P.H, SpkFwdB{D, c, u0, P.H}, bpre);
+  STAMP_INIT();
   for (int t = 0; t < P.T; ++t) {
-    spk_fwd_body<true, NP>(P, D, t, c, u0, mb, blockIdx.x == 0, bpre, red, tile);
+    spk_fwd_body<true, NP>(P, D, ws, t, c, u0, mb, blockIdx.x == 0, bpre, red, tile);
+    if (t + 1 == P.T) break;
     if (!dir_barrier(P.sync + SYNC_SPK_FWD + dir, P.sync + SYNC_ABORT, nwg * (unsigned)(t + 1), lds_ok)) return;
+    STAMP_ACC(3);
   }
+  STAMP_DUMP(P, 16, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
+  STAMP_DUMP(P, 56, blockIdx.x == 5 && blockIdx.y == 1 && blockIdx.z == 0);
 }
 
 // ================================================================================================ LSTHM forward
@@ -330,7 +445,7 @@ struct LsthmFwdB {
 };
 
 template <bool PS, int NP>
-__device__ __forceinline__ void lsthm_gates_body(const CellK& P, const DirP& D, int t, int m, int u0, int mb,
+__device__ __forceinline__ void lsthm_gates_body(const CellK& P, const DirP& D, const WS& ws, int t, int m, int u0, int mb,
                                                  const float (*bpre)[8], float* red, float* tile) {
   const int H = P.H, B = P.B, T = P.T;
   const float* hz_old = D.hz + (long)t * B * 3 * H;
@@ -340,134 +455,123 @@ __device__ __forceinline__ void lsthm_gates_body(const CellK& P, const DirP& D, 
   const int tid = threadIdx.x;
 
   // epilogue operands that do not depend on the matvec: issue their loads first so their latency hides behind it
-  float pre_v = 0.f;
-  {
-    const int rr = tid >> 5, n = tid & 31;
-    const int b = mb * 32 + rr;
-    const long wrow = (long)(n >> 3) * H + u0 + (n & 7);
-    if (b < B) pre_v = D.pre[((long)m * T * B + (long)t * B + b) * 4 * H + wrow] + D.Ub[m][wrow] + D.Vb[m][wrow];
+  float pre4[4] = {0.f, 0.f, 0.f, 0.f}, c_prev = 0.f;
+  int tau = -1;
+  if (tid < 256) {
+    const int b = mb * 32 + (tid >> 3), u = u0 + (tid & 7);
+    if (b < B) {
+      const float* pr = D.pre + ((long)m * T * B + (long)t * B + b) * 4 * H + u;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pre4[g] = pr[g * H] + D.Ub[m][g * H + u] + D.Vb[m][g * H + u];
+      c_prev = ldx<PS>(ws, c_old + (long)b * H + u);
+      tau = D.rev ? D.rev[(long)t * B + b] : t;
+    }
   }
   auto aload = [&](int r, int k, float* a) {
     const int b = mb * 32 + r;
     if (b >= B) { zero8(a); return; }
     const float* row = hz_old + (long)b * 3 * H;
-    if (k < H) load8x<PS>(row + m * H + k, a);
-    else load8x<PS>(row + 2 * H + (k - H), a);
+    if (k < H) load8x<PS>(ws, row + m * H + k, a);
+    else load8x<PS>(ws, row + 2 * H + (k - H), a);
   };
+  STAMP_ACC(0);
   wg_mm32<NP>(2 * H, aload, LsthmFwdB{D, m, u0, H}, bpre, red, tile);
-  tile[tid] += pre_v;
-  __syncthreads();
+  STAMP_ACC(1);
   if (tid < 256) {
     const int rr = tid >> 3, uu = tid & 7;
     const int b = mb * 32 + rr, u = u0 + uu;
     if (b < B) {
-      const float gf = sigmoidf_(tile[rr * 32 + 0 + uu]);
-      const float gi = sigmoidf_(tile[rr * 32 + 8 + uu]);
-      const float go = sigmoidf_(tile[rr * 32 + 16 + uu]);
-      const float gc = tanhf(tile[rr * 32 + 24 + uu]);
-      const float cn = gf * ldx<PS>(c_old + (long)b * H + u) + gi * gc;
+      const float gf = sigmoidf_(tile[rr * 32 + 0 + uu] + pre4[0]);
+      const float gi = sigmoidf_(tile[rr * 32 + 8 + uu] + pre4[1]);
+      const float go = sigmoidf_(tile[rr * 32 + 16 + uu] + pre4[2]);
+      const float gc = tanhf(tile[rr * 32 + 24 + uu] + pre4[3]);
+      const float cn = gf * c_prev + gi * gc;
       const float hn = tanhf(cn) * go;
-      stx<PS>(c_new + (long)b * H + u, cn);
-      stx<PS>(hz_new + (long)b * 3 * H + m * H + u, hn);
+      stx<PS>(ws, c_new + (long)b * H + u, cn);
+      stx<PS>(ws, hz_new + (long)b * 3 * H + m * H + u, hn);
       float* g = D.gates + ((long)m * T * B + (long)t * B + b) * 4 * H + u;
       g[0] = gf; g[H] = gi; g[2 * H] = go; g[3 * H] = gc;
-      const int tau = D.rev ? D.rev[(long)t * B + b] : t;
       if (tau >= 0) D.out[((long)tau * B + b) * P.ldo + m * H + u] = hn;
     }
   }
+  STAMP_ACC(2);
 }
 
-// block-wide helpers for the row phases (NT threads, NT/64 waves)
-__device__ __forceinline__ float block_sum(float v, float* sh, int nw) {
-  v = wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float s = 0.f;
-  for (int w = 0; w < nw; ++w) s += sh[w];
-  return s;
-}
-__device__ __forceinline__ float block_max(float v, float* sh, int nw) {
-  v = wave_max(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float s = -INFINITY;
-  for (int w = 0; w < nw; ++w) s = fmaxf(s, sh[w]);
-  return s;
-}
-
-// Row phase, one dialogue row b per call, NT = blockDim.x threads.
-// z[b,i] = sum_j softmax_j(c_l[i] * s_b * Wk[j]) c_a[j]   (:59-72, rank-1 form).  LDS floats: ca[H] wk[H] part[2][NT] sh[16]
+// Row phase, one dialogue row b per call (NT threads): z[b,i] = sum_j softmax_j(c_l[i] * s_b * Wk[j]) c_a[j]  (:59-72, rank-1 form)
+// thread (i = tid % H, q = tid / H) covers keys j in [q*JC, (q+1)*JC).  scr: ca[H] pZ[NT] pN[NT] sh[16]
 template <bool PS>
-__device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, int t, int b, float* smem) {
+__device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, const WS& ws, int t, int b, const float* att, float* scr) {
   const int H = P.H, B = P.B, T = P.T;
-  const int NT = blockDim.x, Q = NT / H, JC = H / Q;
-  float* ca = smem;
-  float* wk = ca + H;
-  float* pZ = wk + H;
+  const int Q = NT / H, JC = H / Q;
+  float* ca = scr;
+  float* pZ = ca + H;
   float* pN = pZ + NT;
   float* sh = pN + NT;
-  const int tid = threadIdx.x, nw = NT >> 6;
+  const float* wk = att;
+  const float* wq = att + H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* c_l = D.cstate + ((long)0 * (T + 1) + t + 1) * B * H + (long)b * H;
   const float* c_a = D.cstate + ((long)1 * (T + 1) + t + 1) * B * H + (long)b * H;
-  float sp = 0.f, wmx = -INFINITY, wmn = INFINITY;
-  for (int k = tid; k < H; k += NT) {
-    const float cv = ldx<PS>(c_a + k), w = D.attWk[k];
-    ca[k] = cv;
-    wk[k] = w;
-    sp += D.attWq[k] * cv;
-    wmx = fmaxf(wmx, w);
-    wmn = fminf(wmn, w);
+  const int i = tid & (H - 1), q = tid / H;
+  float sp = 0.f;
+  if (tid < H) {
+    const float cv = ldx<PS>(ws, c_a + tid);
+    ca[tid] = cv;
+    sp = wq[tid] * cv;
   }
-  const int i = tid % H, q = tid / H;
-  const float cli = ldx<PS>(c_l + i);
-  const float s = block_sum(sp, sh, nw) / sqrtf((float)H);
-  wmx = block_max(wmx, sh, nw);
-  wmn = -block_max(-wmn, sh, nw);
+  const float cli = ldx<PS>(ws, c_l + i);
+  const int tau = D.rev ? D.rev[(long)t * B + b] : t;
+  sp = wave_sum(sp);
+  if (lane == 0) sh[wave] = sp;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) s += sh[w];
+  s /= sqrtf((float)H);
   const float u = cli * s;
-  const float mx = (u >= 0.f) ? u * wmx : u * wmn;
+  const float mx = (u >= 0.f) ? u * att[2 * H] : u * att[2 * H + 1];
+  const float u2 = u * LOG2E, m2 = mx * LOG2E;
   float Z = 0.f, N = 0.f;
   for (int j = q * JC; j < (q + 1) * JC; ++j) {
-    const float e = expf(u * wk[j] - mx);
+    const float e = __builtin_amdgcn_exp2f(fmaf(u2, wk[j], -m2));
     Z += e;
-    N += e * ca[j];
+    N = fmaf(e, ca[j], N);
   }
-  pZ[tid] = Z;
-  pN[tid] = N;
+  if (q > 0) { pZ[tid] = Z; pN[tid] = N; }
   __syncthreads();
   if (q == 0) {
     for (int qq = 1; qq < Q; ++qq) { Z += pZ[qq * H + i]; N += pN[qq * H + i]; }
     const float z = N / Z;
-    stx<PS>(D.hz + ((long)(t + 1) * B + b) * 3 * H + 2 * H + i, z);
-    const int tau = D.rev ? D.rev[(long)t * B + b] : t;
-    if (tau >= 0) {
-      float* o = D.out + ((long)tau * B + b) * P.ldo;
-      o[2 * H + i] = z;
-      o[3 * H + i] = D.HQ[((long)t * B + b) * H + i];      // all_hs = cat[h_l, h_a, z_l, h_q] (:218)
-    }
+    stx<PS>(ws, D.hz + ((long)(t + 1) * B + b) * 3 * H + 2 * H + i, z);
+    if (tau >= 0) D.out[((long)tau * B + b) * P.ldo + 2 * H + i] = z;
   }
-  __syncthreads();     // LDS is reused by the next row / phase
+  __syncthreads();     // scratch is reused by the next row / phase
 }
 
 // per-step launches
-__global__ __launch_bounds__(1024) void lsthm_fwd_gates(CellK P, int t) {
-  extern __shared__ float smem[];
+__global__ __launch_bounds__(NT) void lsthm_fwd_gates(CellK P, int t) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WS ws = make_ws(P.wsbase, P.wsbytes);
   const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
-  lsthm_gates_body<false, 0>(P, P.d[dir], t, blockIdx.y, blockIdx.x * 8, mb, nullptr, smem, smem + RED_FLOATS);
+  lsthm_gates_body<false, 0>(P, P.d[dir], ws, t, blockIdx.y, blockIdx.x * 8, mb, nullptr, smem, smem + RED_FLOATS);
 }
-__global__ __launch_bounds__(1024) void lsthm_fwd_z(CellK P, int t) {
-  extern __shared__ float smem[];
-  lsthm_z_body<false>(P, P.d[blockIdx.y], t, blockIdx.x, smem);
+__global__ __launch_bounds__(NT) void lsthm_fwd_z(CellK P, int t) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WS ws = make_ws(P.wsbase, P.wsbytes);
+  float* att = smem + RED_FLOATS;
+  att_prepare(P.d[blockIdx.y], P.H, att, smem);
+  lsthm_z_body<false>(P, P.d[blockIdx.y], ws, t, blockIdx.x, att, smem);
 }
 
 // persistent launch: grid (H/8, 2 streams, ndir*nmb); two barriers per step (gates -> z -> next gates)
 template <int NP>
-__global__ __launch_bounds__(1024) void lsthm_fwd_persist(CellK P) {
-  extern __shared__ float smem[];
+__global__ __launch_bounds__(NT) void lsthm_fwd_persist(CellK P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WS ws = make_ws(P.wsbase, P.wsbytes);
   float* red = smem;
   float* tile = smem + RED_FLOATS;
-  int* lds_ok = (int*)(tile + 1024);
+  float* att = tile + 1024;
+  int* lds_ok = (int*)(att + att_floats(P.H));
   const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
   const DirP& D = P.d[dir];
   const int m = blockIdx.y, u0 = blockIdx.x * 8;
@@ -475,47 +579,36 @@ __global__ __launch_bounds__(1024) void lsthm_fwd_persist(CellK P) {
   const int w = (mb * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;    // linear workgroup index inside the direction
   float bpre[NP][8];
   preload_b<NP>(2 * P.H, LsthmFwdB{D, m, u0, P.H}, bpre);
+  att_prepare(D, P.H, att, red);
   unsigned nbar = 0;
-#ifdef MSER_STAMPS
-  unsigned long long acc4[4] = {0, 0, 0, 0};
-#define STAMP(v) unsigned long long v = __builtin_amdgcn_s_memrealtime()
-#else
-#define STAMP(v)
-#endif
+  STAMP_INIT();
   for (int t = 0; t < P.T; ++t) {
-    STAMP(s0);
-    lsthm_gates_body<true, NP>(P, D, t, m, u0, mb, bpre, red, tile);
-    STAMP(s1);
+    lsthm_gates_body<true, NP>(P, D, ws, t, m, u0, mb, bpre, red, tile);   // stamps 0 (loads) 1 (mm) 2 (epilogue)
     if (!dir_barrier(P.sync + SYNC_LSTHM_FWD + dir, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
-    STAMP(s2);
-    for (int b = w; b < P.B; b += (int)nwg) lsthm_z_body<true>(P, D, t, b, smem);
-    STAMP(s3);
+    STAMP_ACC(3);
+    for (int b = w; b < P.B; b += (int)nwg) lsthm_z_body<true>(P, D, ws, t, b, att, red);
+    STAMP_ACC(4);
+    if (t + 1 == P.T) break;
     if (!dir_barrier(P.sync + SYNC_LSTHM_FWD + dir, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
-#ifdef MSER_STAMPS
-    STAMP(s4);
-    acc4[0] += s1 - s0; acc4[1] += s2 - s1; acc4[2] += s3 - s2; acc4[3] += s4 - s3;
-#endif
+    STAMP_ACC(5);
   }
-#ifdef MSER_STAMPS
-  if (threadIdx.x == 0 && blockIdx.x == 3 && blockIdx.y == 1 && blockIdx.z == 0)
-    for (int i = 0; i < 4; ++i) P.sync[10 + i] = (unsigned)(acc4[i] / P.T);     // 10 ns ticks per step
-#endif
-#undef STAMP
+  STAMP_DUMP(P, 24, blockIdx.x == 3 && blockIdx.y == 1 && blockIdx.z == 0);
 }
 
 // ================================================================================================ LSTHM backward
-// Row phase (one dialogue row per call): attention backward (recomputing the softmax), then the gate backward for both
-// streams.  Writes dgates[t], the dc carry, dHQ[t] (the h_q part of dout) and accumulates the attention-vector grads of
+// Row phase (one dialogue row per call): attention backward (recomputing the softmax with exp2), then the gate backward for
+// both streams.  Writes dgates[t], the dc carry, dHQ[t] (the h_q part of dout) and accumulates the attention-vector grads of
 // its own row (reduced over rows once after the chain).
-// LDS floats: ca cl wk wq ua ma aa wa za (9H) + part[3][NT] + sh[16]
+// scr floats: ca[H] cl[H] cw[H] coef[H][8] p[3][NT] sh[16]
 template <bool PS>
-__device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D, int t, int b, float* smem) {
+__device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D, const WS& ws, int t, int b, const float* att, float* scr) {
   const int H = P.H, B = P.B, T = P.T;
-  const int NT = blockDim.x, Q = NT / H, JC = H / Q;
-  float* ca = smem;          float* cl = ca + H;   float* wk = cl + H;   float* wq = wk + H;
-  float* ua = wq + H;        float* ma = ua + H;   float* aa = ma + H;   float* wa = aa + H;   float* za = wa + H;
-  float* p0 = za + H;        float* p1 = p0 + NT;  float* p2 = p1 + NT;  float* sh = p2 + NT;
-  const int tid = threadIdx.x, nw = NT >> 6;
+  const int Q = NT / H, JC = H / Q;
+  float* ca = scr;           float* cl = ca + H;   float* cw = cl + H;   float* coef = cw + H;
+  float* p0 = coef + 8 * H;  float* p1 = p0 + NT;  float* p2 = p1 + NT;  float* sh = p2 + NT;
+  const float* wk = att;
+  const float* wq = att + H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long rowt = (long)t * B + b;
   const float* c_l = D.cstate + ((long)0 * (T + 1) + t + 1) * B * H + (long)b * H;
   const float* c_a = D.cstate + ((long)1 * (T + 1) + t + 1) * B * H + (long)b * H;
@@ -526,95 +619,108 @@ __device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D
   const float* dA = D.dA + (long)b * H;          // [4][B][H]: U_l, V_l, U_a, V_a products of step t+1
   const long SA = (long)B * H;
   const float rsH = 1.0f / sqrtf((float)H);
+  const int i = tid & (H - 1), q = tid / H;
 
-  float sp = 0.f, wmx = -INFINITY, wmn = INFINITY;
-  for (int k = tid; k < H; k += NT) {
-    const float cv = c_a[k], w = D.attWk[k], wqv = D.attWq[k];
-    ca[k] = cv; wk[k] = w; wq[k] = wqv; cl[k] = c_l[k];
-    sp += wqv * cv;
-    wmx = fmaxf(wmx, w);
-    wmn = fminf(wmn, w);
+  float sp = 0.f;
+  if (tid < H) {
+    const float cv = c_a[tid], w = wk[tid];
+    ca[tid] = cv; cl[tid] = c_l[tid]; cw[tid] = cv * w;
+    sp = wq[tid] * cv;
   }
-  const int i = tid % H, q = tid / H;
-  // operands of the per-unit epilogue: issue the loads early (they do not depend on the reductions)
-  float dz_in = 0.f, zi = 0.f;
+  // operands of the per-unit epilogue (threads q == 0): issue the loads early, they do not depend on the reductions
+  float dz_in = 0.f, zi = 0.f, dh2[2] = {0.f, 0.f}, gsv[2][4], cprev2[2] = {0.f, 0.f}, carry2[2] = {0.f, 0.f}, dhq = 0.f;
   if (q == 0) {
     dz_in = dorow ? dorow[2 * H + i] : 0.f;
-    if (!last) dz_in += ldx<PS>(dA + 1 * SA + i) + ldx<PS>(dA + 3 * SA + i);
+    if (!last) dz_in += ldx<PS>(ws, dA + 1 * SA + i) + ldx<PS>(ws, dA + 3 * SA + i);
     zi = zrow[i];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const float* g = D.gates + ((long)m * T * B + rowt) * 4 * H + i;
+      gsv[m][0] = g[0]; gsv[m][1] = g[H]; gsv[m][2] = g[2 * H]; gsv[m][3] = g[3 * H];
+      dh2[m] = dorow ? dorow[m * H + i] : 0.f;
+      if (!last) dh2[m] += ldx<PS>(ws, dA + (2 * m) * SA + i);
+      cprev2[m] = D.cstate[((long)m * (T + 1) + t) * B * H + (long)b * H + i];
+      carry2[m] = D.dc_carry[(long)m * SA + (long)b * H + i];
+    }
+    dhq = dorow ? dorow[3 * H + i] : 0.f;
   }
-  const float s = block_sum(sp, sh, nw) * rsH;
-  wmx = block_max(wmx, sh, nw);
-  wmn = -block_max(-wmn, sh, nw);
+  sp = wave_sum(sp);
+  if (lane == 0) sh[wave] = sp;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) s += sh[w];
+  s *= rsH;
 
-  // ---- pass 1: per output unit i, sums over j
+  // ---- pass 1: per output unit i, sums over the keys j of chunk q
   const float u = cl[i] * s;
-  const float mx = (u >= 0.f) ? u * wmx : u * wmn;
+  const float mx = (u >= 0.f) ? u * att[2 * H] : u * att[2 * H + 1];
+  const float u2 = u * LOG2E, m2 = mx * LOG2E;
   float Z = 0.f, N2 = 0.f, N3 = 0.f;
   for (int j = q * JC; j < (q + 1) * JC; ++j) {
-    const float e = expf(u * wk[j] - mx);
+    const float e = __builtin_amdgcn_exp2f(fmaf(u2, wk[j], -m2));
     Z += e;
-    N2 += e * ca[j] * wk[j];
-    N3 += e * wk[j];
+    N2 = fmaf(e, cw[j], N2);
+    N3 = fmaf(e, wk[j], N3);
   }
-  p0[tid] = Z; p1[tid] = N2; p2[tid] = N3;
+  if (q > 0) { p0[tid] = Z; p1[tid] = N2; p2[tid] = N3; }
   __syncthreads();
-  float du_cl = 0.f;   // du_i * c_l[i], for ds
-  float dcl_att = 0.f;
+  float du_cl = 0.f, dcl_att = 0.f;
   if (q == 0) {
     for (int qq = 1; qq < Q; ++qq) { Z += p0[qq * H + i]; N2 += p1[qq * H + i]; N3 += p2[qq * H + i]; }
     const float du = dz_in * (N2 - zi * N3) / Z;
     const float a = dz_in / Z;
-    ua[i] = u; ma[i] = mx; aa[i] = a; wa[i] = a * u; za[i] = a * u * zi;
+    float* cf = coef + 8 * i;
+    cf[0] = u2; cf[1] = m2; cf[2] = a; cf[3] = a * u; cf[4] = a * u * zi;
     du_cl = du * cl[i];
     dcl_att = du * s;
   }
-  const float ds = block_sum(du_cl, sh, nw);      // includes the barrier that publishes ua..za
-  // ---- pass 2: per key index j, sums over i
+  du_cl = wave_sum(du_cl);
+  __syncthreads();               // pass-1 partials consumed; coef published
+  if (lane == 0) sh[wave] = du_cl;
+  // ---- pass 2: per key index j (= i), sums over the units ii of chunk q
   const int j = i;
   float S1 = 0.f, S2 = 0.f, S3 = 0.f;
   {
     const float wkj = wk[j];
     for (int ii = q * JC; ii < (q + 1) * JC; ++ii) {
-      const float e = expf(ua[ii] * wkj - ma[ii]);
-      S1 += aa[ii] * e;
-      S2 += wa[ii] * e;
-      S3 += za[ii] * e;
+      const float4 c4 = *reinterpret_cast<const float4*>(coef + 8 * ii);
+      const float c5 = coef[8 * ii + 4];
+      const float e = __builtin_amdgcn_exp2f(fmaf(c4.x, wkj, -c4.y));
+      S1 = fmaf(c4.z, e, S1);
+      S2 = fmaf(c4.w, e, S2);
+      S3 = fmaf(c5, e, S3);
     }
   }
-  p0[tid] = S1; p1[tid] = S2; p2[tid] = S3;
+  if (q > 0) { p0[tid] = S1; p1[tid] = S2; p2[tid] = S3; }
   __syncthreads();
   if (q == 0) {
-    float S1t = 0.f, S2t = 0.f, S3t = 0.f;
-    for (int qq = 0; qq < Q; ++qq) { S1t += p0[qq * H + j]; S2t += p1[qq * H + j]; S3t += p2[qq * H + j]; }
-    const float dca_att = S1t + ds * wq[j] * rsH;
+    float ds = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) ds += sh[w];
+    for (int qq = 1; qq < Q; ++qq) { S1 += p0[qq * H + j]; S2 += p1[qq * H + j]; S3 += p2[qq * H + j]; }
+    const float dca_att = S1 + ds * wq[j] * rsH;
     float* acc = D.attacc + (long)b * 2 * H;
     acc[j] += ds * ca[j] * rsH;                  // dWq[j]
-    acc[H + j] += ca[j] * S2t - S3t;             // dWk[j]
+    acc[H + j] += ca[j] * S2 - S3;               // dWk[j]
     // ---- gate backward, both streams (unit i == j)
-    const float* cprev_l = D.cstate + ((long)0 * (T + 1) + t) * B * H + (long)b * H;
-    const float* cprev_a = D.cstate + ((long)1 * (T + 1) + t) * B * H + (long)b * H;
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      const float* g = D.gates + ((long)m * T * B + rowt) * 4 * H + i;
-      const float gf = g[0], gi = g[H], go = g[2 * H], gc = g[3 * H];
-      float dh = dorow ? dorow[m * H + i] : 0.f;
-      if (!last) dh += ldx<PS>(dA + (2 * m) * SA + i);
+      const float gf = gsv[m][0], gi = gsv[m][1], go = gsv[m][2], gc = gsv[m][3];
+      const float dh = dh2[m];
       const float cc = m ? ca[i] : cl[i];
       const float tc = tanhf(cc);
-      float* carry = D.dc_carry + (long)m * SA + (long)b * H + i;
-      const float dc = *carry + dh * go * (1.f - tc * tc) + (m ? dca_att : dcl_att);
-      const float cp = m ? cprev_a[i] : cprev_l[i];
+      const float dc = carry2[m] + dh * go * (1.f - tc * tc) + (m ? dca_att : dcl_att);
       float* dg = D.dgates + ((long)m * T * B + rowt) * 4 * H + i;
-      stx<PS>(dg, dc * cp * gf * (1.f - gf));
-      stx<PS>(dg + H, dc * gc * gi * (1.f - gi));
-      stx<PS>(dg + 2 * H, dh * tc * go * (1.f - go));
-      stx<PS>(dg + 3 * H, dc * gi * (1.f - gc * gc));
-      *carry = dc * gf;
+      stx<PS>(ws, dg, dc * cprev2[m] * gf * (1.f - gf));
+      stx<PS>(ws, dg + H, dc * gc * gi * (1.f - gi));
+      stx<PS>(ws, dg + 2 * H, dh * tc * go * (1.f - go));
+      stx<PS>(ws, dg + 3 * H, dc * gi * (1.f - gc * gc));
+      D.dc_carry[(long)m * SA + (long)b * H + i] = dc * gf;
     }
-    D.dHQ[rowt * H + i] = dorow ? dorow[3 * H + i] : 0.f;
+    D.dHQ[rowt * H + i] = dhq;
   }
-  __syncthreads();     // LDS is reused by the next row / phase
+  __syncthreads();     // scratch is reused by the next row / phase
 }
 
 // Matvec phase, role (product p, output slice n0..n0+31, row block mb):
@@ -628,7 +734,7 @@ struct LsthmBwdB {
 };
 
 template <bool PS, int NP>
-__device__ __forceinline__ void lsthm_bwd_mat_body(const CellK& P, const DirP& D, int t, int p, int n0, int mb,
+__device__ __forceinline__ void lsthm_bwd_mat_body(const CellK& P, const DirP& D, const WS& ws, int t, int p, int n0, int mb,
                                                    const float (*bpre)[8], float* red, float* tile) {
   const int m = p >> 1;
   const int H = P.H, B = P.B, T = P.T;
@@ -637,33 +743,43 @@ __device__ __forceinline__ void lsthm_bwd_mat_body(const CellK& P, const DirP& D
   auto aload = [&](int r, int k, float* a) {
     const int b = mb * 32 + r;
     if (b >= B) { zero8(a); return; }
-    load8x<PS>(dg + (long)b * 4 * H + k, a);
+    load8x<PS>(ws, dg + (long)b * 4 * H + k, a);
   };
   wg_mm32<NP>(4 * H, aload, LsthmBwdB{Wp, n0, H}, bpre, red, tile);
-  const int rr = threadIdx.x >> 5, n = threadIdx.x & 31;
-  const int b = mb * 32 + rr;
-  if (b < B) stx<PS>(D.dA + ((long)p * B + b) * H + n0 + n, tile[threadIdx.x]);
+#pragma unroll
+  for (int e = 0; e < 1024 / NT; ++e) {
+    const int idx = threadIdx.x + e * NT;
+    const int rr = idx >> 5, n = idx & 31;
+    const int b = mb * 32 + rr;
+    if (b < B) stx<PS>(ws, D.dA + ((long)p * B + b) * H + n0 + n, tile[idx]);
+  }
 }
 
-// per-step launches: row grid (B, ndir) x NT threads; mat grid (H/32, 4, ndir*nmb) x 1024
-__global__ __launch_bounds__(1024) void lsthm_bwd_row(CellK P, int t) {
-  extern __shared__ float smem[];
-  lsthm_bwd_row_body<false>(P, P.d[blockIdx.y], t, blockIdx.x, smem);
+// per-step launches: row grid (B, ndir); mat grid (H/32, 4, ndir*nmb)
+__global__ __launch_bounds__(NT) void lsthm_bwd_row(CellK P, int t) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WS ws = make_ws(P.wsbase, P.wsbytes);
+  float* att = smem + RED_FLOATS;
+  att_prepare(P.d[blockIdx.y], P.H, att, smem);
+  lsthm_bwd_row_body<false>(P, P.d[blockIdx.y], ws, t, blockIdx.x, att, smem);
 }
-__global__ __launch_bounds__(1024) void lsthm_bwd_mat(CellK P, int t) {
-  extern __shared__ float smem[];
+__global__ __launch_bounds__(NT) void lsthm_bwd_mat(CellK P, int t) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WS ws = make_ws(P.wsbase, P.wsbytes);
   const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
-  lsthm_bwd_mat_body<false, 0>(P, P.d[dir], t, blockIdx.y, blockIdx.x * 32, mb, nullptr, smem, smem + RED_FLOATS);
+  lsthm_bwd_mat_body<false, 0>(P, P.d[dir], ws, t, blockIdx.y, blockIdx.x * 32, mb, nullptr, smem, smem + RED_FLOATS);
 }
 
 // persistent launch: grid (nwg, 1, ndir), nwg >= (H/32)*4*nmb.  Row phase: rows round-robin over all nwg workgroups;
 // matvec phase: the first (H/32)*4*nmb workgroups.  Two barriers per step.
 template <int NP>
-__global__ __launch_bounds__(1024) void lsthm_bwd_persist(CellK P) {
-  extern __shared__ float smem[];
+__global__ __launch_bounds__(NT) void lsthm_bwd_persist(CellK P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WS ws = make_ws(P.wsbase, P.wsbytes);
   float* red = smem;
   float* tile = smem + RED_FLOATS;
-  int* lds_ok = (int*)(tile + 1024);
+  float* att = tile + 1024;
+  int* lds_ok = (int*)(att + att_floats(P.H));
   const int dir = blockIdx.z;
   const DirP& D = P.d[dir];
   const int H = P.H;
@@ -674,23 +790,35 @@ __global__ __launch_bounds__(1024) void lsthm_bwd_persist(CellK P) {
   const int mb = w / (nsl * 4), p = (w / nsl) % 4, n0 = (w % nsl) * 32;
   float bpre[NP][8];
   if (has_mat) preload_b<NP>(4 * H, LsthmBwdB{(p & 1) ? D.V[p >> 1] : D.U[p >> 1], n0, H}, bpre);
+  att_prepare(D, H, att, red);
   unsigned nbar = 0;
+  STAMP_INIT();
   for (int t = P.T - 1; t >= 0; --t) {
-    for (int b = w; b < P.B; b += (int)nwg) lsthm_bwd_row_body<true>(P, D, t, b, smem);
+    for (int b = w; b < P.B; b += (int)nwg) lsthm_bwd_row_body<true>(P, D, ws, t, b, att, red);
+    STAMP_ACC(0);
     if (t == 0) break;
     if (!dir_barrier(P.sync + SYNC_LSTHM_BWD + dir, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
-    if (has_mat) lsthm_bwd_mat_body<true, NP>(P, D, t, p, n0, mb, bpre, red, tile);
+    STAMP_ACC(1);
+    if (has_mat) lsthm_bwd_mat_body<true, NP>(P, D, ws, t, p, n0, mb, bpre, red, tile);
+    STAMP_ACC(2);
     if (!dir_barrier(P.sync + SYNC_LSTHM_BWD + dir, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
+    STAMP_ACC(3);
   }
+  STAMP_DUMP(P, 32, blockIdx.x == 1 && blockIdx.z == 0);
 }
 
 // ================================================================================================ speaker backward
 // Role (product p, output slice n0, slot block mb), one phase per step (descending t).
-// product p: cell c = p>>1, (p&1) ? W_hh : W_ih.  Prologue: every workgroup rebuilds the LSTMCell gate gradients of its
-// cell for its 32 slots (element-wise, cheap, keeps the step at ONE phase); then raw = dsg @ W.
-// Ping-pong buffers by step parity: raw_ih/dhprev/dcprev [2][2][B][H], dh0 [2][B][H].
+// product p: cell c = p>>1, (p&1) ? W_hh : W_ih.
+//   X_t[b]  := grad wrt q_{t-1}[b, party_t[b]]                         (dialogue-row indexed, ping-pong buffer Xb)
+//   dh_q_t[r] = dHQ[t][r] + mnext[t][r] * X_{t+1}[r]                   (blend, :204-207, h_q branch)
+//   dh_0_t[r] =            (1 - mnext[t][r]) * X_{t+1}[r]              (blend, h_0 branch: flows straight into q_sel_t)
+//   X_t[perm_t[off+k]] = (dgates_t[c][k] @ W_ih)[.] + dh_0_t[off+k]    (gather of q_sel, :242-257)
+// Prologue: every workgroup of the cell rebuilds the LSTMCell gate gradients for its 32 slots (element-wise, all loads issued
+// up front: one memory round trip), then raw = dsg @ W on the MFMA.  The redundant element-wise results are written to
+// global memory by exactly one workgroup per iteration slice (wsel), so no workgroup carries all the stores.
 template <bool PS, int NP>
-__device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, int t, int p, int n0, int mb, bool first_slice,
+__device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, const WS& ws, int t, int p, int n0, int mb, int wsel,
                                              const float (*bpre)[8], float* red, float* tile, float* dsg_s) {
   const int c = p >> 1;
   const int H = P.H, B = P.B, T = P.T;
@@ -700,104 +828,135 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, int 
   const int Nc = c ? B - N0 : N0, off = c ? N0 : 0;
   const bool last = (t == T - 1);
   const int cur = t & 1, nxt = cur ^ 1;       // buffers written at step t / step t+1
-  const float* raw_ih_n = D.raw_ih + (long)nxt * 2 * SB;
+  const float* X_n = D.Xb + (long)nxt * SB;
   const float* dhprev_n = D.dhprev + (long)nxt * 2 * SB + (long)c * SB;
   const float* dcprev_n = D.dcprev + (long)nxt * 2 * SB + (long)c * SB;
-  const float* dh0_n = D.dh0 + (long)nxt * SB;
-  float* raw_ih_c = D.raw_ih + (long)cur * 2 * SB + (long)c * SB;
+  float* X_c = D.Xb + (long)cur * SB;
   float* dhprev_c = D.dhprev + (long)cur * 2 * SB + (long)c * SB;
   float* dcprev_c = D.dcprev + (long)cur * 2 * SB + (long)c * SB;
-  float* dh0_c = D.dh0 + (long)cur * SB;
-  const bool w_elem = first_slice && ((p & 1) == 0);          // writes dsg / dcprev of its cell
-  const bool w_dh0 = w_elem && (c == 0);                      // writes dh0 rows of this slot block
-  const int N0n = last ? 0 : D.n0[t + 1];
   const int tid = threadIdx.x;
   const float* sg = D.sgates + ((long)c * T + t) * B * 4 * H;
   const float* cq_old = D.cq_state + ((long)c * (T + 1) + t) * SB;
   const float* cq_new = cq_old + SB;
   float* dsg_g = D.dsg + ((long)c * T + t) * B * 4 * H;
+  const float* mn = D.mnext + (long)t * B;
 
-  // X_{t+1}[r] = grad wrt q_t[r, party_{t+1}[r]]  = raw_ih_{t+1}[P][slot] + dh0_{t+1}[row]
-  auto Xnext = [&](int r, int u, float& mP) -> float {
-    if (last) { mP = 0.f; return 0.f; }
-    const int Pn = D.party[(long)(t + 1) * B + r];
-    const int rown = D.rowof[(long)(t + 1) * B + r];
-    const int slotn = rown - (Pn ? N0n : 0);
-    mP = D.qm[((long)t * B + r) * 2 + Pn];
-    return ldx<PS>(raw_ih_n + (long)Pn * SB + (long)slotn * H + u) + ldx<PS>(dh0_n + (long)rown * H + u);
-  };
-
-  for (int e = tid; e < 32 * H; e += 1024) {
-    const int rr = e / H, u = e % H;
+  // operands of the matvec epilogue (W_ih products only): dh_0 of this slice, fetched before anything else
+  float dh0e[1024 / NT];
+  int be[1024 / NT];
+#pragma unroll
+  for (int e = 0; e < 1024 / NT; ++e) {
+    const int idx = tid + e * NT;
+    const int rr = idx >> 5, n = idx & 31;
     const int slot = mb * 32 + rr;
-    float d_i = 0.f, d_f = 0.f, d_g = 0.f, d_o = 0.f;
-    if (slot < B) {
-      // dh0 of row `slot` (cell-independent), written once per slot block
-      if (w_dh0) {
-        float mP;
-        const float X = Xnext(slot, u, mP);
-        stx<PS>(dh0_c + (long)slot * H + u, (1.f - mP) * X);
-      }
-      float dh = last ? 0.f : ldx<PS>(dhprev_n + (long)slot * H + u);
-      const float dc_in = last ? 0.f : ldx<PS>(dcprev_n + (long)slot * H + u);
-      if (slot < Nc) {
-        const int r = off + slot;
-        float mP;
-        const float X = Xnext(r, u, mP);
-        dh += D.dHQ[((long)t * B + r) * H + u] + mP * X;
-      }
-      if (Nc == 0) {
-        // skipped cell: identity on (h, c)
-        if (w_elem) {
-          stx<PS>(dcprev_c + (long)slot * H + u, dc_in);
-          stx<PS>(dhprev_c + (long)slot * H + u, dh);
-          stx<PS>(raw_ih_c + (long)slot * H + u, 0.f);
+    dh0e[e] = 0.f;
+    be[e] = -1;
+    if ((p & 1) == 0 && slot < Nc) {
+      const int r = off + slot;
+      be[e] = D.perm[(long)t * B + r];
+      if (!last) dh0e[e] = (1.f - mn[r]) * ldx<PS>(ws, X_n + (long)r * H + n0 + n);
+    }
+  }
+
+  constexpr int MAXIT = 8;                       // 32*H/NT iterations of the element-wise prologue, H <= 128 fully unrolled
+  const int nit = 32 * H / NT;
+  for (int it0 = 0; it0 < nit; it0 += MAXIT) {
+    float v_dh[MAXIT], v_dc[MAXIT], v_x[MAXIT], v_hq[MAXIT], v_m[MAXIT], v_g[MAXIT][4], v_cn[MAXIT], v_co[MAXIT];
+#pragma unroll
+    for (int ii = 0; ii < MAXIT; ++ii) {
+      const int e = tid + (it0 + ii) * NT;
+      const int rr = e / H, u = e % H;
+      const int slot = mb * 32 + rr;
+      v_dh[ii] = v_dc[ii] = v_x[ii] = v_hq[ii] = v_m[ii] = v_cn[ii] = v_co[ii] = 0.f;
+      v_g[ii][0] = v_g[ii][1] = v_g[ii][2] = v_g[ii][3] = 0.f;
+      if (it0 + ii < nit && slot < B) {
+        if (!last) {
+          v_dh[ii] = ldx<PS>(ws, dhprev_n + (long)slot * H + u);
+          v_dc[ii] = ldx<PS>(ws, dcprev_n + (long)slot * H + u);
         }
-      } else {
-        const float* g = sg + (long)slot * 4 * H + u;
-        const float gi = g[0], gf = g[H], gg = g[2 * H], go = g[3 * H];
-        const float tc = tanhf(cq_new[(long)slot * H + u]);
-        const float dcn = dc_in + dh * go * (1.f - tc * tc);
-        d_i = dcn * gg * gi * (1.f - gi);
-        d_f = dcn * cq_old[(long)slot * H + u] * gf * (1.f - gf);
-        d_g = dcn * gi * (1.f - gg * gg);
-        d_o = dh * tc * go * (1.f - go);
-        if (w_elem) stx<PS>(dcprev_c + (long)slot * H + u, dcn * gf);
-      }
-      if (w_elem) {
-        float* o = dsg_g + (long)slot * 4 * H + u;
-        o[0] = d_i; o[H] = d_f; o[2 * H] = d_g; o[3 * H] = d_o;
+        if (slot < Nc) {
+          const int r = off + slot;
+          if (!last) { v_x[ii] = ldx<PS>(ws, X_n + (long)r * H + u); v_m[ii] = mn[r]; }
+          v_hq[ii] = D.dHQ[((long)t * B + r) * H + u];
+        }
+        if (Nc != 0) {
+          const float* g = sg + (long)slot * 4 * H + u;
+          v_g[ii][0] = g[0]; v_g[ii][1] = g[H]; v_g[ii][2] = g[2 * H]; v_g[ii][3] = g[3 * H];
+          v_cn[ii] = cq_new[(long)slot * H + u];
+          v_co[ii] = cq_old[(long)slot * H + u];
+        }
       }
     }
-    float* l = dsg_s + rr * LDS_LD + u;
-    l[0] = d_i; l[H] = d_f; l[2 * H] = d_g; l[3 * H] = d_o;
+#pragma unroll
+    for (int ii = 0; ii < MAXIT; ++ii) {
+      if (it0 + ii >= nit) break;
+      const int e = tid + (it0 + ii) * NT;
+      const int rr = e / H, u = e % H;
+      const int slot = mb * 32 + rr;
+      const bool wr = ((it0 + ii) % (2 * (H / 32))) == wsel;      // this workgroup publishes this iteration's results
+      float d_i = 0.f, d_f = 0.f, d_g = 0.f, d_o = 0.f;
+      if (slot < B) {
+        const float dh = v_dh[ii] + v_hq[ii] + v_m[ii] * v_x[ii];
+        if (Nc == 0) {
+          // skipped cell: identity on (h, c)
+          if (wr) {
+            stx<PS>(ws, dcprev_c + (long)slot * H + u, v_dc[ii]);
+            stx<PS>(ws, dhprev_c + (long)slot * H + u, dh);
+          }
+        } else {
+          const float gi = v_g[ii][0], gf = v_g[ii][1], gg = v_g[ii][2], go = v_g[ii][3];
+          const float tc = tanhf(v_cn[ii]);
+          const float dcn = v_dc[ii] + dh * go * (1.f - tc * tc);
+          d_i = dcn * gg * gi * (1.f - gi);
+          d_f = dcn * v_co[ii] * gf * (1.f - gf);
+          d_g = dcn * gi * (1.f - gg * gg);
+          d_o = dh * tc * go * (1.f - go);
+          if (wr) stx<PS>(ws, dcprev_c + (long)slot * H + u, dcn * gf);
+        }
+        if (wr) {
+          float* o = dsg_g + (long)slot * 4 * H + u;
+          o[0] = d_i; o[H] = d_f; o[2 * H] = d_g; o[3 * H] = d_o;
+        }
+      }
+      float* l = dsg_s + rr * LDS_LD + u;
+      l[0] = d_i; l[H] = d_f; l[2 * H] = d_g; l[3 * H] = d_o;
+    }
   }
   if (Nc == 0) return;     // uniform per workgroup
   __syncthreads();
+  STAMP_ACC(0);
 
   const float* Wp = (p & 1) ? D.Whh[c] : D.Wih[c];
   auto aload = [&](int r, int k, float* a) { load8(dsg_s + r * LDS_LD + k, a); };
   wg_mm32<NP>(4 * H, aload, LsthmBwdB{Wp, n0, H}, bpre, red, tile);
-  const int rr = tid >> 5, n = tid & 31;
-  const int slot = mb * 32 + rr;
-  if (slot < B) {
-    float* dst = (p & 1) ? dhprev_c : raw_ih_c;
-    stx<PS>(dst + (long)slot * H + n0 + n, tile[tid]);
+  STAMP_ACC(1);
+#pragma unroll
+  for (int e = 0; e < 1024 / NT; ++e) {
+    const int idx = tid + e * NT;
+    const int rr = idx >> 5, n = idx & 31;
+    const int slot = mb * 32 + rr;
+    if (p & 1) {
+      if (slot < B) stx<PS>(ws, dhprev_c + (long)slot * H + n0 + n, tile[idx]);
+    } else if (be[e] >= 0) {
+      stx<PS>(ws, X_c + (long)be[e] * H + n0 + n, tile[idx] + dh0e[e]);
+    }
   }
 }
 
-// per-step launch: grid (H/32, 4 products, ndir*nmb), block 1024
-__global__ __launch_bounds__(1024) void spk_bwd_step(CellK P, int t) {
-  extern __shared__ float smem[];
+// per-step launch: grid (H/32, 4 products, ndir*nmb), block NT
+__global__ __launch_bounds__(NT) void spk_bwd_step(CellK P, int t) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WS ws = make_ws(P.wsbase, P.wsbytes);
   const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
-  spk_bwd_body<false, 0>(P, P.d[dir], t, blockIdx.y, blockIdx.x * 32, mb, blockIdx.x == 0, nullptr, smem, smem + RED_FLOATS,
+  spk_bwd_body<false, 0>(P, P.d[dir], ws, t, blockIdx.y, blockIdx.x * 32, mb, (int)((blockIdx.y & 1) * gridDim.x + blockIdx.x), nullptr, smem, smem + RED_FLOATS,
                          smem + RED_FLOATS + 1024);
 }
 
 // persistent launch: same grid, one barrier per step
 template <int NP>
-__global__ __launch_bounds__(1024) void spk_bwd_persist(CellK P) {
-  extern __shared__ float smem[];
+__global__ __launch_bounds__(NT) void spk_bwd_persist(CellK P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WS ws = make_ws(P.wsbase, P.wsbytes);
   float* red = smem;
   float* tile = smem + RED_FLOATS;
   float* dsg_s = tile + 1024;
@@ -809,14 +968,27 @@ __global__ __launch_bounds__(1024) void spk_bwd_persist(CellK P) {
   float bpre[NP][8];
   preload_b<NP>(4 * P.H, LsthmBwdB{(p & 1) ? D.Whh[p >> 1] : D.Wih[p >> 1], n0, P.H}, bpre);
   unsigned nbar = 0;
+  STAMP_INIT();
   for (int t = P.T - 1; t >= 0; --t) {
-    spk_bwd_body<true, NP>(P, D, t, p, n0, mb, blockIdx.x == 0, bpre, red, tile, dsg_s);
+    spk_bwd_body<true, NP>(P, D, ws, t, p, n0, mb, (int)((p & 1) * gridDim.x + blockIdx.x), bpre, red, tile, dsg_s);
+    STAMP_ACC(2);
     if (t == 0) break;
     if (!dir_barrier(P.sync + SYNC_SPK_BWD + dir, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
+    STAMP_ACC(3);
   }
+  STAMP_DUMP(P, 40, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
+  STAMP_DUMP(P, 48, blockIdx.x == 2 && blockIdx.y == 1 && blockIdx.z == 0);
 }
 
 // ================================================================================================ small helpers
+// mnext[t][r] = qm[t][r][party[t+1][r]]: the blend weight with which row r's h_q feeds the state that dialogue r reads at t+1
+__global__ void mnext_kernel(const float* qm, const int* party, float* mnext, int T, int B) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)T * B) return;
+  const long t = i / B;
+  mnext[i] = (t + 1 < T) ? qm[i * 2 + party[i + B]] : 0.f;
+}
+
 __global__ void rowof_kernel(const int* perm, int* rowof, long TB, int B) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= TB) return;
@@ -891,10 +1063,10 @@ static void carve_dir(Carver& cv, DirP& d, int T, int B, int D, int H) {
   d.attacc = cv.take<float>((size_t)B * 2 * H);
   d.dHQ = cv.take<float>(TB * H);
   d.dsg = cv.take<float>(2 * TB * 4 * H);
-  d.raw_ih = cv.take<float>(2 * 2 * SB);
+  d.Xb = cv.take<float>(2 * SB);
   d.dhprev = cv.take<float>(2 * 2 * SB);
   d.dcprev = cv.take<float>(2 * 2 * SB);
-  d.dh0 = cv.take<float>(2 * SB);
+  d.mnext = cv.take<float>(TB);
 }
 
 struct CellHost {
@@ -910,6 +1082,8 @@ static size_t carve_all(char* base, const mser_cell_desc& d, CellHost* out) {
   h.k.T = d.T; h.k.B = d.B; h.k.D = d.D; h.k.H = d.H; h.k.ndir = d.ndir; h.k.nmb = cdiv(d.B, 32); h.k.ldo = d.ldo;
   h.sync = cv.take<unsigned>(SYNC_WORDS);
   h.k.sync = h.sync;
+  h.k.wsbase = base;
+  h.k.wsbytes = (unsigned)(d.workspace_bytes < 0x7fffffffULL ? d.workspace_bytes : 0x7fffffffULL);
   for (int i = 0; i < d.ndir; ++i) carve_dir(cv, h.k.d[i], d.T, d.B, d.D, d.H);
   const size_t TBD = (size_t)d.T * d.B * d.D;
   h.xrev[0] = cv.take<float>(TBD);
@@ -921,7 +1095,7 @@ static size_t carve_all(char* base, const mser_cell_desc& d, CellHost* out) {
 
 static int validate(const mser_cell_desc& d, bool bwd) {
   MSER_REQUIRE(d.T > 0 && d.B > 0 && d.D > 0, "marn_cell: bad sizes T=%d B=%d D=%d", d.T, d.B, d.D);
-  MSER_REQUIRE(d.H >= 32 && d.H <= 1024 && (d.H & (d.H - 1)) == 0, "marn_cell: H=%d must be a power of two in [32,1024]", d.H);
+  MSER_REQUIRE(d.H >= 32 && d.H <= 512 && (d.H & (d.H - 1)) == 0, "marn_cell: H=%d must be a power of two in [32,512]", d.H);
   MSER_REQUIRE(d.ndir == 1 || d.ndir == 2, "marn_cell: ndir=%d", d.ndir);
   MSER_REQUIRE(d.x_l && d.x_a && d.workspace, "marn_cell: null input/workspace");
   MSER_REQUIRE(((uintptr_t)d.workspace & 255) == 0, "marn_cell: workspace must be 256-byte aligned");
@@ -929,6 +1103,7 @@ static int validate(const mser_cell_desc& d, bool bwd) {
                "marn_cell: workspace too small (%zu < %zu)", d.workspace_bytes,
                mser_marn_cell_workspace_bytes(d.T, d.B, d.D, d.H, d.ndir));
   MSER_REQUIRE(d.ldo >= 4L * d.H, "marn_cell: ldo=%ld < 4H", (long)d.ldo);
+  MSER_REQUIRE(d.workspace_bytes < 0x7fffffffULL, "marn_cell: workspace of %zu bytes exceeds the 2 GiB addressable through one buffer descriptor", d.workspace_bytes);
   if (bwd) MSER_REQUIRE(d.H <= 256, "marn_cell_bwd: H=%d > 256 not supported yet (LDS gate-gradient tile)", d.H);
   for (int i = 0; i < d.ndir; ++i) {
     const mser_cell_dir& r = d.dir[i];
@@ -982,7 +1157,7 @@ static int allow_lds(const void* kernel, size_t bytes) {
   return 0;
 }
 
-static size_t row_lds_bytes(int H, int NT, int narr) { return ((size_t)narr * H + 3 * (size_t)NT + 16) * sizeof(float); }
+static size_t row_lds_bytes(int H) { return ((size_t)RED_FLOATS + 2 * (size_t)H + 16) * sizeof(float); }
 
 // ---- launch mode ---------------------------------------------------------------------------------------------------------
 static int g_opt_persistent = 1;      // MSER_OPT_PERSISTENT
@@ -1003,19 +1178,28 @@ static bool persist_ok(int H, long total_wgs) {
 }
 static size_t persist_lds(size_t need) { return need > PERSIST_MIN_LDS ? need : PERSIST_MIN_LDS; }
 
-int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s) {
+// phases: MSER_PHASE_SPEAKER_FWD builds the tables, zeroes the initial states and runs the speaker chain (needs only qmask / rev:
+// it can overlap the encoders on another stream); MSER_PHASE_LSTHM_FWD runs the pre-activation GEMMs and the LSTHM chain.
+int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   MSER_TRY(validate(d, false));
   CellHost h;
   carve_all((char*)d.workspace, d, &h);
   CellK& K = h.k;
   const int T = d.T, B = d.B, D = d.D, H = d.H;
   const long TB = (long)T * B, SB = (long)B * H;
+  for (int i = 0; i < d.ndir; ++i) fill_params(K.d[i], d.dir[i]);
+  const size_t mm_lds = (RED_FLOATS + 1024) * sizeof(float);
+  const long fwd_wgs = (long)(H / 8) * 2 * d.ndir * K.nmb;
+  const bool persist = persist_ok(H, fwd_wgs);
+  const size_t p_lds = persist_lds(mm_lds + (2 * (size_t)H + 16) * sizeof(float) + 64);
+  if (phases & MSER_PHASE_SPEAKER_FWD) {
+  MSER_CHECK_HIP(hipMemsetAsync(h.sync, 0, SYNC_WORDS * sizeof(unsigned), s));
   for (int i = 0; i < d.ndir; ++i) {
     DirP& k = K.d[i];
-    fill_params(k, d.dir[i]);
     MSER_TRY(mser_build_slot_tables(d.dir[i].qmask, k.rev, T, B, k.party, k.perm, k.n0, k.qm, s));
     hipLaunchKernelGGL(rowof_kernel, dim3(cdiv(TB, 256)), dim3(256), 0, s, k.perm, k.rowof, TB, B);
-    MSER_TRY(check_launch("rowof"));
+    hipLaunchKernelGGL(mnext_kernel, dim3(cdiv(TB, 256)), dim3(256), 0, s, k.qm, k.party, k.mnext, T, B);
+    MSER_TRY(check_launch("rowof/mnext"));
     // zero initial states (index 0 of the (T+1)-long state arrays, both cells / streams)
     for (int c = 0; c < 2; ++c) {
       MSER_CHECK_HIP(hipMemsetAsync(k.hq_state + (long)c * (T + 1) * SB, 0, SB * sizeof(float), s));
@@ -1026,29 +1210,26 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s) {
     if (k.rev)   // rows at and beyond len_b stay zero in the reversed output (pad_sequence, :410)
       MSER_CHECK_HIP(hipMemset2DAsync(k.out, d.ldo * sizeof(float), 0, 4 * (size_t)H * sizeof(float), TB, s));
   }
-  const size_t mm_lds = (RED_FLOATS + 1024) * sizeof(float);
-  MSER_CHECK_HIP(hipMemsetAsync(h.sync, 0, SYNC_WORDS * sizeof(unsigned), s));
-  const long fwd_wgs = (long)(H / 8) * 2 * d.ndir * K.nmb;
-  const bool persist = persist_ok(H, fwd_wgs);
-  const size_t p_lds = persist_lds(mm_lds + 64);
   // ---- speaker chain
   if (persist) {
     ProfScope ps(MSER_PROF_SPK_FWD, s);
     if (H == 128) {
-      MSER_TRY(allow_lds((const void*)spk_fwd_persist<1>, p_lds));
-      hipLaunchKernelGGL(spk_fwd_persist<1>, dim3(H / 8, 2, d.ndir * K.nmb), dim3(1024), p_lds, s, K);
-    } else {
       MSER_TRY(allow_lds((const void*)spk_fwd_persist<2>, p_lds));
-      hipLaunchKernelGGL(spk_fwd_persist<2>, dim3(H / 8, 2, d.ndir * K.nmb), dim3(1024), p_lds, s, K);
+      hipLaunchKernelGGL(spk_fwd_persist<2>, dim3(H / 8, 2, d.ndir * K.nmb), dim3(NT), p_lds, s, K);
+    } else {
+      MSER_TRY(allow_lds((const void*)spk_fwd_persist<4>, p_lds));
+      hipLaunchKernelGGL(spk_fwd_persist<4>, dim3(H / 8, 2, d.ndir * K.nmb), dim3(NT), p_lds, s, K);
     }
   } else {
     MSER_TRY(allow_lds((const void*)spk_fwd_step, mm_lds));
     for (int t = 0; t < T; ++t) {
       ProfScope ps(MSER_PROF_SPK_FWD, s);
-      hipLaunchKernelGGL(spk_fwd_step, dim3(H / 8, 2, d.ndir * K.nmb), dim3(1024), mm_lds, s, K, t);
+      hipLaunchKernelGGL(spk_fwd_step, dim3(H / 8, 2, d.ndir * K.nmb), dim3(NT), mm_lds, s, K, t);
     }
   }
   MSER_TRY(check_launch("spk_fwd"));
+  }
+  if (!(phases & MSER_PHASE_LSTHM_FWD)) return 0;
   // ---- hoisted pre-activations: pre_m = xdir W_m^T + W.bias + HQ S_m^T + S.bias
   for (int i = 0; i < d.ndir; ++i) {
     DirP& k = K.d[i];
@@ -1071,23 +1252,22 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s) {
     }
   }
   // ---- LSTHM chain
-  const int NT = H > 512 ? H : 512;
-  const size_t z_lds = row_lds_bytes(H, NT, 2);
+  const size_t z_lds = row_lds_bytes(H);
   if (persist) {
     ProfScope ps(MSER_PROF_LSTHM_FWD_GATES, s);
     if (H == 128) {
-      MSER_TRY(allow_lds((const void*)lsthm_fwd_persist<1>, p_lds));
-      hipLaunchKernelGGL(lsthm_fwd_persist<1>, dim3(H / 8, 2, d.ndir * K.nmb), dim3(1024), p_lds, s, K);
-    } else {
       MSER_TRY(allow_lds((const void*)lsthm_fwd_persist<2>, p_lds));
-      hipLaunchKernelGGL(lsthm_fwd_persist<2>, dim3(H / 8, 2, d.ndir * K.nmb), dim3(1024), p_lds, s, K);
+      hipLaunchKernelGGL(lsthm_fwd_persist<2>, dim3(H / 8, 2, d.ndir * K.nmb), dim3(NT), p_lds, s, K);
+    } else {
+      MSER_TRY(allow_lds((const void*)lsthm_fwd_persist<4>, p_lds));
+      hipLaunchKernelGGL(lsthm_fwd_persist<4>, dim3(H / 8, 2, d.ndir * K.nmb), dim3(NT), p_lds, s, K);
     }
   } else {
     MSER_TRY(allow_lds((const void*)lsthm_fwd_gates, mm_lds));
     for (int t = 0; t < T; ++t) {
       {
         ProfScope ps(MSER_PROF_LSTHM_FWD_GATES, s);
-        hipLaunchKernelGGL(lsthm_fwd_gates, dim3(H / 8, 2, d.ndir * K.nmb), dim3(1024), mm_lds, s, K, t);
+        hipLaunchKernelGGL(lsthm_fwd_gates, dim3(H / 8, 2, d.ndir * K.nmb), dim3(NT), mm_lds, s, K, t);
       }
       {
         ProfScope ps(MSER_PROF_LSTHM_FWD_Z, s);
@@ -1098,36 +1278,40 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s) {
   return check_launch("lsthm_fwd");
 }
 
-int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s) {
+// phases: MSER_PHASE_LSTHM_BWD = BPTT of the LSTHM chain + its deferred gradient GEMMs (produces dx_l / dx_a and dHQ);
+// MSER_PHASE_SPEAKER_BWD = BPTT of the speaker chain + its deferred GEMMs (touches only speaker-cell gradients: it can overlap
+// the encoder backward on another stream once the LSTHM phase has finished).
+int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   MSER_TRY(validate(d, true));
   CellHost h;
   carve_all((char*)d.workspace, d, &h);
   CellK& K = h.k;
   const int T = d.T, B = d.B, D = d.D, H = d.H;
   const long TB = (long)T * B, SB = (long)B * H;
+  for (int i = 0; i < d.ndir; ++i) fill_params(K.d[i], d.dir[i]);
+  const size_t mm_lds = (RED_FLOATS + 1024) * sizeof(float);
+  const size_t row_lds = row_lds_bytes(H);
+  const int mat_wgs = (H / 32) * 4 * K.nmb;
+  const int SPLITK = 16;
+  if (phases & MSER_PHASE_LSTHM_BWD) {
   for (int i = 0; i < d.ndir; ++i) {
     DirP& k = K.d[i];
-    fill_params(k, d.dir[i]);
     MSER_CHECK_HIP(hipMemsetAsync(k.dc_carry, 0, 2 * SB * sizeof(float), s));
     MSER_CHECK_HIP(hipMemsetAsync(k.attacc, 0, (size_t)B * 2 * H * sizeof(float), s));
   }
-  const size_t mm_lds = (RED_FLOATS + 1024) * sizeof(float);
-  const int NT = H > 512 ? H : 512;
-  const size_t row_lds = row_lds_bytes(H, NT, 9);
-  MSER_CHECK_HIP(hipMemsetAsync(h.sync, 0, SYNC_WORDS * sizeof(unsigned), s));
-  const int mat_wgs = (H / 32) * 4 * K.nmb;
+  MSER_CHECK_HIP(hipMemsetAsync(h.sync + SYNC_LSTHM_BWD, 0, 4 * sizeof(unsigned), s));
   const int bwd_nwg = mat_wgs > 32 ? mat_wgs : 32;          // row phase spreads the B rows over all of them
   const bool persist = persist_ok(H, (long)bwd_nwg * d.ndir);
-  const size_t p_lds = persist_lds(mm_lds + 64);
+  const size_t p_lds = persist_lds(mm_lds + (2 * (size_t)H + 16) * sizeof(float) + 64);
   // ---- LSTHM chain, reverse time
   if (persist) {
     ProfScope ps(MSER_PROF_LSTHM_BWD_ROW, s);
     if (H == 128) {
-      MSER_TRY(allow_lds((const void*)lsthm_bwd_persist<2>, p_lds));
-      hipLaunchKernelGGL(lsthm_bwd_persist<2>, dim3(bwd_nwg, 1, d.ndir), dim3(1024), p_lds, s, K);
-    } else {
       MSER_TRY(allow_lds((const void*)lsthm_bwd_persist<4>, p_lds));
-      hipLaunchKernelGGL(lsthm_bwd_persist<4>, dim3(bwd_nwg, 1, d.ndir), dim3(1024), p_lds, s, K);
+      hipLaunchKernelGGL(lsthm_bwd_persist<4>, dim3(bwd_nwg, 1, d.ndir), dim3(NT), p_lds, s, K);
+    } else {
+      MSER_TRY(allow_lds((const void*)lsthm_bwd_persist<8>, p_lds));
+      hipLaunchKernelGGL(lsthm_bwd_persist<8>, dim3(bwd_nwg, 1, d.ndir), dim3(NT), p_lds, s, K);
     }
   } else {
     MSER_TRY(allow_lds((const void*)lsthm_bwd_mat, mm_lds));
@@ -1138,13 +1322,12 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s) {
       }
       if (t > 0) {
         ProfScope ps(MSER_PROF_LSTHM_BWD_MAT, s);
-        hipLaunchKernelGGL(lsthm_bwd_mat, dim3(H / 32, 4, d.ndir * K.nmb), dim3(1024), mm_lds, s, K, t);
+        hipLaunchKernelGGL(lsthm_bwd_mat, dim3(H / 32, 4, d.ndir * K.nmb), dim3(NT), mm_lds, s, K, t);
       }
     }
   }
   MSER_TRY(check_launch("lsthm_bwd"));
   // ---- deferred (non-recurrent) gradient GEMMs of the LSTHM streams
-  const int SPLITK = 16;
   for (int i = 0; i < d.ndir; ++i) {
     DirP& k = K.d[i];
     const mser_cell_params& G = d.dir[i].g;
@@ -1192,23 +1375,25 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s) {
       MSER_TRY(colsum4(k.attacc + H, B, H, 2 * H, G.att_Wk, nullptr, nullptr, nullptr, s));
     }
   }
+  }
+  if (!(phases & MSER_PHASE_SPEAKER_BWD)) return 0;
   // ---- speaker chain, reverse time
   const size_t spk_lds = mm_lds + 32 * (4 * (size_t)H + 4) * sizeof(float);
   if (persist_ok(H, (long)mat_wgs * d.ndir)) {
     const size_t ps_lds = persist_lds(spk_lds + 64);
     ProfScope ps(MSER_PROF_SPK_BWD, s);
     if (H == 128) {
-      MSER_TRY(allow_lds((const void*)spk_bwd_persist<2>, ps_lds));
-      hipLaunchKernelGGL(spk_bwd_persist<2>, dim3(H / 32, 4, d.ndir * K.nmb), dim3(1024), ps_lds, s, K);
-    } else {
       MSER_TRY(allow_lds((const void*)spk_bwd_persist<4>, ps_lds));
-      hipLaunchKernelGGL(spk_bwd_persist<4>, dim3(H / 32, 4, d.ndir * K.nmb), dim3(1024), ps_lds, s, K);
+      hipLaunchKernelGGL(spk_bwd_persist<4>, dim3(H / 32, 4, d.ndir * K.nmb), dim3(NT), ps_lds, s, K);
+    } else {
+      MSER_TRY(allow_lds((const void*)spk_bwd_persist<8>, ps_lds));
+      hipLaunchKernelGGL(spk_bwd_persist<8>, dim3(H / 32, 4, d.ndir * K.nmb), dim3(NT), ps_lds, s, K);
     }
   } else {
     MSER_TRY(allow_lds((const void*)spk_bwd_step, spk_lds));
     for (int t = T - 1; t >= 0; --t) {
       ProfScope ps(MSER_PROF_SPK_BWD, s);
-      hipLaunchKernelGGL(spk_bwd_step, dim3(H / 32, 4, d.ndir * K.nmb), dim3(1024), spk_lds, s, K, t);
+      hipLaunchKernelGGL(spk_bwd_step, dim3(H / 32, 4, d.ndir * K.nmb), dim3(NT), spk_lds, s, K, t);
     }
   }
   MSER_TRY(check_launch("spk_bwd"));
@@ -1257,12 +1442,12 @@ __global__ void lsthm_step_kernel(const float* x, const float* c, const float* h
   }
 }
 
-__global__ __launch_bounds__(1024) void rank1_attention_kernel(const float* x1, const float* x2, const float* Wq, const float* Wk,
-                                                               float* out, int B, int H) {
-  extern __shared__ float smem[];
-  const int NT = blockDim.x, Q = NT / H, JC = H / Q;
+__global__ __launch_bounds__(NT) void rank1_attention_kernel(const float* x1, const float* x2, const float* Wq, const float* Wk,
+                                                             float* out, int B, int H) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int Q = NT / H, JC = H / Q;
   float* ca = smem; float* wk = ca + H; float* pZ = wk + H; float* pN = pZ + NT; float* sh = pN + NT;
-  const int b = blockIdx.x, tid = threadIdx.x, nw = NT >> 6;
+  const int b = blockIdx.x, tid = threadIdx.x;
   float sp = 0.f, wmx = -INFINITY, wmn = INFINITY;
   for (int k = tid; k < H; k += NT) {
     const float cv = x2[(long)b * H + k], w = Wk[k];
@@ -1271,17 +1456,18 @@ __global__ __launch_bounds__(1024) void rank1_attention_kernel(const float* x1, 
     wmx = fmaxf(wmx, w);
     wmn = fminf(wmn, w);
   }
-  const float s = block_sum(sp, sh, nw) / sqrtf((float)H);
-  wmx = block_max(wmx, sh, nw);
-  wmn = -block_max(-wmn, sh, nw);
-  const int i = tid % H, q = tid / H;
+  const float s = block_sum(sp, sh) / sqrtf((float)H);
+  wmx = block_max(wmx, sh);
+  wmn = -block_max(-wmn, sh);
+  const int i = tid & (H - 1), q = tid / H;
   const float u = x1[(long)b * H + i] * s;
   const float mx = (u >= 0.f) ? u * wmx : u * wmn;
+  const float u2 = u * LOG2E, m2 = mx * LOG2E;
   float Z = 0.f, N = 0.f;
   for (int j = q * JC; j < (q + 1) * JC; ++j) {
-    const float e = expf(u * wk[j] - mx);
+    const float e = __builtin_amdgcn_exp2f(fmaf(u2, wk[j], -m2));
     Z += e;
-    N += e * ca[j];
+    N = fmaf(e, ca[j], N);
   }
   pZ[tid] = Z; pN[tid] = N;
   __syncthreads();
@@ -1312,7 +1498,14 @@ int mser_marn_cell_status(const mser_cell_desc* d, mser_stream_t stream) {
   MSER_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
   MSER_CHECK_HIP(hipMemcpy(words, h.sync, sizeof(words), hipMemcpyDeviceToHost));
 #ifdef MSER_STAMPS
-  fprintf(stderr, "[stamps lsthm_fwd_persist, 10ns ticks/step] gates %u barrier1 %u z %u barrier2 %u\n", words[10], words[11], words[12], words[13]);
+  {
+    const char* names[6] = {"spk_fwd wg(0,0)", "lsthm_fwd wg(3,1)", "lsthm_bwd wg 1", "spk_bwd wg(0,0)", "spk_bwd wg(2,1)", "spk_fwd wg(5,1)"};
+    for (int k = 0; k < 6; ++k) {
+      fprintf(stderr, "[stamps %-18s 10ns ticks/step]", names[k]);
+      for (int i = 0; i < 8; ++i) fprintf(stderr, " %u", words[16 + 8 * k + i]);
+      fprintf(stderr, "\n");
+    }
+  }
 #endif
   if (words[SYNC_ABORT] != 0) {
     set_error("marn_cell: a persistent kernel gave up waiting at an inter-workgroup barrier (counters: spk_fwd %u/%u lsthm_fwd %u/%u "
@@ -1358,12 +1551,21 @@ size_t mser_marn_cell_workspace_bytes(int32_t T, int32_t B, int32_t D, int32_t H
 
 int mser_marn_cell_fwd(const mser_cell_desc* d, mser_stream_t stream) {
   if (!d) { set_error("mser_marn_cell_fwd: null descriptor"); return -1; }
-  return marn_cell_fwd(*d, (hipStream_t)stream);
+  return marn_cell_fwd(*d, (hipStream_t)stream, MSER_PHASE_SPEAKER_FWD | MSER_PHASE_LSTHM_FWD);
 }
 
 int mser_marn_cell_bwd(const mser_cell_desc* d, mser_stream_t stream) {
   if (!d) { set_error("mser_marn_cell_bwd: null descriptor"); return -1; }
-  return marn_cell_bwd(*d, (hipStream_t)stream);
+  return marn_cell_bwd(*d, (hipStream_t)stream, MSER_PHASE_LSTHM_BWD | MSER_PHASE_SPEAKER_BWD);
+}
+
+int mser_marn_cell_run(const mser_cell_desc* d, int32_t phases, mser_stream_t stream) {
+  if (!d) { set_error("mser_marn_cell_run: null descriptor"); return -1; }
+  if (phases & (MSER_PHASE_SPEAKER_FWD | MSER_PHASE_LSTHM_FWD))
+    MSER_TRY(marn_cell_fwd(*d, (hipStream_t)stream, phases));
+  if (phases & (MSER_PHASE_LSTHM_BWD | MSER_PHASE_SPEAKER_BWD))
+    MSER_TRY(marn_cell_bwd(*d, (hipStream_t)stream, phases));
+  return 0;
 }
 
 int mser_lsthm_step_fwd(const float* x, const float* c, const float* h, const float* z, const float* s, const float* W,
@@ -1380,10 +1582,10 @@ int mser_lsthm_step_fwd(const float* x, const float* c, const float* h, const fl
 int mser_rank1_attention_fwd(const float* x1, const float* x2, const float* Wq, const float* Wk, float* out, int32_t B, int32_t H,
                              mser_stream_t stream) {
   MSER_REQUIRE(x1 && x2 && Wq && Wk && out, "mser_rank1_attention_fwd: null pointer");
-  MSER_REQUIRE(H >= 32 && H <= 1024 && (H & (H - 1)) == 0, "mser_rank1_attention_fwd: H=%d must be a power of two in [32,1024]", H);
+  MSER_REQUIRE(H >= 32 && H <= 512 && (H & (H - 1)) == 0, "mser_rank1_attention_fwd: H=%d must be a power of two in [32,512]", H);
   if (B <= 0) return 0;
-  const int NT = H > 512 ? H : 512;
-  hipLaunchKernelGGL(rank1_attention_kernel, dim3(B), dim3(NT), row_lds_bytes(H, NT, 2), (hipStream_t)stream, x1, x2, Wq, Wk, out, B, H);
+  hipLaunchKernelGGL(rank1_attention_kernel, dim3(B), dim3(NT), (2 * (size_t)H + 2 * NT + 16) * sizeof(float), (hipStream_t)stream, x1, x2,
+                     Wq, Wk, out, B, H);
   return check_launch("mser_rank1_attention_fwd");
 }
 

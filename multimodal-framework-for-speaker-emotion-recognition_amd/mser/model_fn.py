@@ -113,17 +113,7 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
     c.lens = torch.empty(B, device=x.device, dtype=torch.int32)
     c.rev = torch.empty(Ln, B, device=x.device, dtype=torch.int32)
     ops.build_reverse_index(umask, c.lens, c.rev)
-    if side is not None:
-        side[0].wait_stream(cur)
-        with torch.cuda.stream(side[0]):
-            audio_branch()
-        text_branch()
-        cur.wait_stream(side[0])
-    else:
-        text_branch()
-        audio_branch()
-
-    # ---- bidirectional MARN cell (both directions share every launch)
+    # the bidirectional MARN cell: both directions share every launch; its speaker chain depends on qmask only
     c.Hcat = torch.empty(N, 10 * H, device=x.device)
     nbytes = ops.cell_workspace_bytes(Ln, B, D, H, 2)
     c.cell_ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
@@ -132,8 +122,22 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
         dict(p=ops.cell_param_struct(_sub(P, "marn_cell_b.")), qmask=qmask, rev=c.rev, out=c.Hcat[:, 4 * H:8 * H]),
     ]
     desc = ops.make_cell_desc(Ln, B, D, H, c.x_l, c.x_a, c.cell_dirs, 10 * H, c.cell_ws)
-    ops.marn_cell_fwd(desc)
     c.cell_desc = desc
+    if side is not None:
+        side[0].wait_stream(cur)
+        side[1].wait_stream(cur)
+        with torch.cuda.stream(side[1]):
+            ops.marn_cell_run(desc, ops.PHASE_SPEAKER_FWD)      # overlaps the encoders
+        with torch.cuda.stream(side[0]):
+            audio_branch()
+        text_branch()
+        cur.wait_stream(side[0])
+        cur.wait_stream(side[1])
+    else:
+        ops.marn_cell_run(desc, ops.PHASE_SPEAKER_FWD)
+        text_branch()
+        audio_branch()
+    ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD)
 
     # ---- sequence-level cross-modal attention (:377-383)
     w, v, v1, v2 = P("w"), P("v"), P("v1"), P("v2")
@@ -213,9 +217,9 @@ def marn1_backward(c: ModelCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: Opt
         r["g"] = ops.cell_param_struct(_sub(G, pre))
         r["dout"] = dH[:, sl]
     desc = ops.make_cell_desc(Ln, B, D, H, c.x_l, c.x_a, c.cell_dirs, 10 * H, c.cell_ws, dx_l=dx_l, dx_a=dx_a)
-    ops.marn_cell_bwd(desc)
     c.cell_desc = desc
-    # ---- encoders (two passes with shared weights) + linear_in
+    ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD)
+    # ---- speaker-chain BPTT (side stream 1) overlaps the encoders' backward (two passes with shared weights) + linear_in
     Pl, Pa, Gl, Ga = _sub(P, "encoder_l."), _sub(P, "encoder_a."), _sub(G, "encoder_l."), _sub(G, "encoder_a.")
     cur = torch.cuda.current_stream()
     side = _Streams.get(dev) if use_streams else None
@@ -233,10 +237,15 @@ def marn1_backward(c: ModelCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: Opt
 
     if side is not None:
         side[0].wait_stream(cur)
+        side[1].wait_stream(cur)
+        with torch.cuda.stream(side[1]):
+            ops.marn_cell_run(desc, ops.PHASE_SPEAKER_BWD)
         with torch.cuda.stream(side[0]):
             audio_branch()
         text_branch()
         cur.wait_stream(side[0])
+        cur.wait_stream(side[1])
     else:
+        ops.marn_cell_run(desc, ops.PHASE_SPEAKER_BWD)
         text_branch()
         audio_branch()

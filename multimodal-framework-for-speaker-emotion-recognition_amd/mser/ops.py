@@ -275,3 +275,10 @@ MSER_OPT_PERSISTENT = 1
 
 def set_option(key: int, value: int) -> None:
     L.check(L.load().mser_set_option(key, value), "set_option")
+
+
+PHASE_SPEAKER_FWD, PHASE_LSTHM_FWD, PHASE_LSTHM_BWD, PHASE_SPEAKER_BWD = 1, 2, 4, 8
+
+
+def marn_cell_run(desc: L.CellDesc, phases: int) -> None:
+    L.check(L.load().mser_marn_cell_run(C.byref(desc), phases, _stream()), "marn_cell_run")
