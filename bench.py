@@ -10,7 +10,7 @@ backward, (N>1: ONE RCCL all-reduce of the flat gradient buffer), fused Adam.  I
 region.  Weak scaling: every rank owns its own 32 dialogues, global batch = 32*N.  value = N*B*L / step time.
 
 The single JSON line also carries
-  roofline     -- the dominant kernel (lsthm_fwd_gates: the LSTHM time-step matvec+gates) measured live with HIP events
+  roofline     -- the dominant kernel (the LSTHM backward chain; the forward chain rides along) measured live with HIP events
                   around each of its launches (eager pass after the timed region), against the HBM roofline;
   cpu_baseline -- the CPU oracle (torch fp32 restatement of the reference, eval-mode fwd+bwd, same shapes) timed on this
                   host's cores (rank 0, N=1 only).
@@ -56,13 +56,18 @@ def init_attention_weights(model, seed=0):
                 p.copy_(torch.tensor((rs.standard_normal(tuple(p.shape)) * s).astype(np.float32)))
 
 
-def lsthm_fwd_gates_bytes(ndir=2):
-    """Algorithmic bytes of ONE lsthm_fwd_gates launch (one time step, both streams, `ndir` directions) -- DESIGN.md.
-    read: U,V [4H,H] x2 streams + their biases, pre-activations [B,4H] x2, h_l|h_a|z [B,3H], c [B,H] x2
-    write: gates [B,4H] x2, c [B,H] x2, h [B,H] x2 (state) + h [B,H] x2 (output rows)."""
-    per_dir = 4 * (2 * 2 * 4 * H * H + 2 * 2 * 4 * H + 2 * B * 4 * H + B * 3 * H + 2 * B * H
-                   + 2 * B * 4 * H + 2 * B * H + 2 * B * H + 2 * B * H)
-    return per_dir * ndir
+def lsthm_step_bytes(backward):
+    """Algorithmic bytes of ONE LSTHM time step of ONE direction (both streams) -- the streaming model of DESIGN.md 5.
+    forward : read U,V [4H,H] x2 + biases, pre-activations [B,4H] x2, h_l|h_a|z [B,3H], c [B,H] x2;
+              write gates [B,4H] x2, c x2, h x2 (state) + h,z output rows.
+    backward: read U,V x2, saved gates x2, c_t and c_{t-1} x2, z row, dout row [B,4H], dA [4][B,H], dc carry x2;
+              write dgates x2 (and read them back in the matvec phase), dA, dHQ, dc carry."""
+    f = 4
+    if not backward:
+        return f * (2 * 2 * 4 * H * H + 2 * 2 * 4 * H + 2 * B * 4 * H + B * 3 * H + 2 * B * H
+                    + 2 * B * 4 * H + 2 * B * H + 2 * B * H + 3 * B * H)
+    return f * (2 * 2 * 4 * H * H + 2 * B * 4 * H + 4 * B * H + B * H + B * 4 * H + 4 * B * H + 2 * B * H
+                + 2 * 2 * B * 4 * H + 4 * B * H + B * H + 2 * B * H)
 
 
 def cpu_baseline(steps=3):
@@ -183,23 +188,32 @@ def main():
     ms_per_step = float(ms)
     log(f"timed region done: {ms_per_step:.3f} ms/step")
 
-    # ---- live roofline measurement of the dominant kernel: HIP events around each of its launches (eager pass)
+    # ---- live roofline measurement: HIP events around every launch of the LSTHM chain kernels (eager pass, same inputs)
     roofline = None
     if rank == 0 and not args.no_roofline:
-        steps_prof = 3
-        _lib.check(lib.mser_prof_enable(2, 2 * L * steps_prof + 16), "prof_enable")    # MSER_PROF_LSTHM_FWD_GATES
-        for _ in range(steps_prof):
-            tr.forward_backward(x, qmask, umask, label)
-        torch.cuda.synchronize()
-        tot, cnt = ctypes.c_float(0), ctypes.c_int32(0)
-        _lib.check(lib.mser_prof_collect(ctypes.byref(tot), ctypes.byref(cnt)), "prof_collect")
-        lib.mser_prof_enable(0, 0)
-        avg_us = tot.value * 1e3 / max(cnt.value, 1)
-        by = lsthm_fwd_gates_bytes()
-        achieved = by / (avg_us * 1e-6) / 1e9
-        roofline = dict(bound="hbm", kernel="lsthm_fwd_gates", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, bytes_per_launch=by,
-                        avg_launch_us=round(avg_us, 3), launches_timed=cnt.value)
+        def timed(kernel_id, steps_prof=5):
+            _lib.check(lib.mser_prof_enable(kernel_id, 4 * L * steps_prof + 16), "prof_enable")
+            for _ in range(steps_prof):
+                tr.forward_backward(x, qmask, umask, label)
+            torch.cuda.synchronize()
+            tot, cnt = ctypes.c_float(0), ctypes.c_int32(0)
+            _lib.check(lib.mser_prof_collect(ctypes.byref(tot), ctypes.byref(cnt)), "prof_collect")
+            lib.mser_prof_enable(0, 0)
+            return tot.value * 1e3 / max(cnt.value, 1), cnt.value      # us per launch, launches
+
+        def entry(name, us, launches, backward):
+            steps_per_launch = 2 * L if us > 200 else 2                 # persistent launch = T steps x 2 directions
+            by = lsthm_step_bytes(backward) * steps_per_launch
+            ach = by / (us * 1e-6) / 1e9
+            return dict(bound="hbm", kernel=name, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, bytes_per_launch=by, avg_launch_us=round(us, 2),
+                        launches_timed=launches, steps_per_launch=steps_per_launch,
+                        note="dependency-latency bound recurrence (2 inter-workgroup hand-offs per time step); weights are "
+                             "register-resident, so real HBM traffic is far below this streaming model")
+        us_b, n_b = timed(4)     # MSER_PROF_LSTHM_BWD_ROW: brackets lsthm_bwd_persist (or each lsthm_bwd_row launch)
+        us_f, n_f = timed(2)     # MSER_PROF_LSTHM_FWD_GATES: brackets lsthm_fwd_persist (or each lsthm_fwd_gates launch)
+        roofline = entry("lsthm_bwd_persist" if us_b > 200 else "lsthm_bwd_row", us_b, n_b, True)
+        roofline["lsthm_forward"] = entry("lsthm_fwd_persist" if us_f > 200 else "lsthm_fwd_gates", us_f, n_f, False)
 
     log("roofline pass done")
     cpu = None

@@ -202,3 +202,48 @@ def test_persistent_status_clean(O):
         ops.marn_cell_fwd(desc)
     ops.marn_cell_status(desc)                                  # raises if any barrier timed out
     assert torch.isfinite(out).all()
+
+
+def test_trainer_three_steps_vs_reference_golden(O, golden_dir):
+    """ModelTrainer.train_network (MaskedLoss + fused flat Adam with L2 decay + closed-form StepLR) against the reference's own
+    trainer run with every Dropout p = 0 (tests/golden/make_golden.py::trainer_case): 2 epochs x 3 ragged batches."""
+    from model_trainer import ModelTrainer
+    g = _g(golden_dir, "trainer.npz")
+    tr = ModelTrainer(torch.device("cuda:0"), lr=1e-3, test_step=1, lr_decay=0.98, model="MARN1_sps", loss="NLL", n_classes=6,
+                      dataset="IEMOCAP", quiet=True)
+    load_params(tr.model, O.seeded_params(seed=5, d_r=1024))
+    B, L = 3, 10
+    batches = []
+    for s in range(3):
+        x, qmask, umask, label = O.seeded_batch(B, L, d_r=1024, seed=40 + s, ragged=True)
+        r = x[:, :, :1024]
+        d = torch.tensor(np.random.RandomState(s).standard_normal(tuple(r.shape)).astype(np.float32)) * 0.1
+        batches.append([r + d, r - d, r + 2 * d, r - 2 * d, torch.zeros(L, B, 4), x[:, :, 1024:], qmask, umask, label, ["v"] * B])
+    for ep in (1, 2):
+        lr, avg = tr.train_network(ep, batches)
+        assert lr == pytest.approx(float(g[f"lr{ep}"]), rel=1e-9)
+        assert abs(avg - float(g[f"avg_loss{ep}"])) <= 2e-4, (ep, avg, float(g[f"avg_loss{ep}"]))
+    sd = tr.model.state_dict()
+    worst = 0.0
+    for k in g.files:
+        if k.startswith("p/"):
+            got = sd[k[2:]].detach().cpu().numpy().reshape(-1)[:16]
+            worst = max(worst, float(np.abs(got - g[k]).max()))
+    # six Adam steps of lr 1e-3: parameters moved by up to ~6e-3; agreement to 3e-4 pins the optimiser arithmetic
+    assert worst < 3e-4, worst
+
+
+def test_checkpoint_roundtrip(O, tmp_path):
+    from model_trainer import ModelTrainer
+    a = ModelTrainer(torch.device("cuda:0"), 1e-3, 1, 0.98, "MARN1_sps", "NLL", 6, "IEMOCAP", quiet=True)
+    load_params(a.model, O.seeded_params(seed=7))
+    path = str(tmp_path / "model_0001.model")
+    a.save_parameters(path)
+    keys = list(torch.load(path, weights_only=True).keys())
+    assert keys[0] == "model.w" and len(keys) == 120          # reference files carry the 'model.' prefix (SURVEY 5)
+    b = ModelTrainer(torch.device("cuda:0"), 1e-3, 1, 0.98, "MARN1_sps", "NLL", 6, "IEMOCAP", quiet=True)
+    b.load_parameters(path)
+    x, qmask, umask, _ = (t.cuda() for t in O.seeded_batch(2, 8, seed=3))
+    a.eval(); b.eval()
+    with torch.no_grad():
+        assert torch.equal(a.model(x, qmask, umask)[0], b.model(x, qmask, umask)[0])

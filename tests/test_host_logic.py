@@ -1,0 +1,118 @@
+"""CPU: host-side logic of the drop-in mirrors (no kernels run): parameter names/shapes/initialisers, flat storage layout,
+learning-rate schedule, constructor signatures, and the loud failure on CPU tensors (no fallback on the product path)."""
+import inspect
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+
+
+def test_state_dict_keys_and_shapes_match_reference():
+    from models.lsthm_sps import MARN1_sps
+    net = MARN1_sps(6)
+    sd = net.state_dict()
+    shapes = O.param_shapes(d_r=1024)
+    assert list(sd.keys()) == list(shapes.keys())            # the reference's registration order
+    for k, v in sd.items():
+        assert tuple(v.shape) == shapes[k], k
+    assert sum(p.numel() for p in net.parameters()) == 2488786   # SURVEY: 2,488,786 parameters
+
+
+def test_initialisers():
+    from models.lsthm_sps import MARN1_sps, CrossAttention2
+    from attention.SelfAttention import ScaledDotProductAttention
+    net = MARN1_sps(6)
+    for n in ("w", "v", "v1", "v2", "crossatt_l2a.Wq", "crossatt_a2l_1.Wv", "marn_cell_f.crossatt_l2a.Wk"):
+        assert torch.all(net.state_dict()[n] == 1.0), n           # ones, model/lsthm_sps.py:53-55,82-84,340-346
+    sa = ScaledDotProductAttention(64, 16, 16, 4)
+    assert float(sa.fc_q.weight.std()) < 2e-3 and float(sa.fc_q.bias.abs().max()) == 0.0   # N(0, 0.001), zero bias (:35-47)
+
+
+@pytest.mark.parametrize("cls,args", [
+    ("models.lsthm_sps:LSTHM1", ["cell_size", "in_size", "hybrid_in_size", "speaker_dim"]),
+    ("models.lsthm_sps:CrossAttention", ["attn_dropout"]),
+    ("models.lsthm_sps:CrossAttention2", ["dh", "dk", "dv", "attn_dropout"]),
+    ("models.lsthm_sps:CrossAttention3", ["dh", "dk", "dv", "attn_dropout"]),
+    ("models.lsthm_sps:MARN_cell", ["dh_l", "dh_a", "d_l", "d_a", "dropout"]),
+    ("models.lsthm_sps:MARN1_sps", ["n_classes"]),
+    ("models.encoder:MultiHeadAttention", ["n_head", "d_model", "d_model2", "d_k", "d_v", "dropout"]),
+    ("models.encoder:ScaledDotProductAttention", ["temperature", "attn_dropout"]),
+    ("models.encoder:PositionwiseFeedForward", ["d_in", "d_hid", "dropout"]),
+    ("models.encoder:EncoderLayer", ["d_model", "d_inner", "n_head", "d_k", "d_v", "dropout"]),
+    ("attention.SelfAttention:ScaledDotProductAttention", ["d_model", "d_k", "d_v", "h", "dropout"]),
+    ("loss:MaskedLoss", ["losser", "weight"]),
+    ("model_trainer:ModelTrainer", ["device", "lr", "test_step", "lr_decay", "model", "loss", "n_classes", "dataset"]),
+])
+def test_constructor_signatures(cls, args):
+    import importlib
+    mod, name = cls.split(":")
+    c = getattr(importlib.import_module(mod), name)
+    pos = [p.name for p in inspect.signature(c.__init__).parameters.values()
+           if p.kind in (p.POSITIONAL_OR_KEYWORD,) and p.name != "self"]
+    assert pos == args, (cls, pos)
+
+
+def test_forward_signatures():
+    from models.lsthm_sps import MARN1_sps, MARN_cell, LSTHM1
+    from model_trainer import ModelTrainer
+    assert list(inspect.signature(MARN1_sps.forward).parameters)[1:] == ["x", "qmask", "umask"]
+    assert list(inspect.signature(MARN_cell.forward).parameters)[1:] == ["x", "x_l", "x_a", "qmask"]
+    assert list(inspect.signature(LSTHM1.forward).parameters)[1:] == ["x", "ctm", "htm", "ztm", "speaker_affine"]
+    for m in ("train_network", "eval_network", "save_parameters", "load_parameters"):
+        assert hasattr(ModelTrainer, m)
+
+
+def test_no_cpu_fallback():
+    from models.lsthm_sps import MARN1_sps
+    from models.encoder import EncoderLayer
+    net = MARN1_sps(6)
+    x, qmask, umask, _ = O.seeded_batch(2, 4)
+    with pytest.raises(RuntimeError, match="HIP path only"):
+        net(x, qmask, umask)
+    with pytest.raises(RuntimeError, match="HIP path only"):
+        EncoderLayer(100, 40, 8, 40, 40)(torch.zeros(1, 3, 100))
+
+
+def test_flat_store_layout_and_dead_parameters():
+    from models.lsthm_sps import MARN1_sps
+    from mser.flat import ALIGN
+    net = MARN1_sps(6)
+    st = net.flat_store
+    assert all(off % ALIGN == 0 for off in st.offsets.values())
+    live = sum(int(np.prod(st.shapes[n])) for n in st.names if n not in st.dead)
+    assert live == 2203370                                       # SURVEY: 2,203,370 scalars receive a gradient
+    assert len(st.dead) == 20                                    # 20 tensors never do (SURVEY 7 "Dead parameters")
+    # q/k/v projection weights of an encoder are adjacent in the flat buffer (enables one fused N=960 GEMM later)
+    o = st.offsets
+    assert o["encoder_l.slf_attn.w_ks.weight"] - o["encoder_l.slf_attn.w_qs.weight"] == 320 * 100
+    st.attach(torch.device("cpu"))                               # the storage logic itself is device-agnostic
+    sd = net.state_dict()
+    assert sd["fc.0.weight"].data_ptr() == st.data.data_ptr() + 4 * o["fc.0.weight"]
+    sd["w"].fill_(3.0)
+    assert float(st.data[o["w"]]) == 3.0                         # parameters are views of the flat buffer
+
+
+def test_step_lr_closed_form(golden_dir):
+    from mser.optim import StepLR
+
+    class _Opt:
+        param_groups = [dict(lr=1e-3, initial_lr=1e-3)]
+    sch = StepLR(_Opt(), step_size=1, gamma=0.98)
+    g = np.load(os.path.join(golden_dir, "trainer.npz"))
+    sch.step(0)
+    assert _Opt.param_groups[0]["lr"] == pytest.approx(float(g["lr1"]), rel=1e-12)
+    sch.step(1)
+    assert _Opt.param_groups[0]["lr"] == pytest.approx(float(g["lr2"]), rel=1e-12)
+    sch2 = StepLR(_Opt(), step_size=3, gamma=0.5)
+    for ep in range(1, 10):
+        sch2.step(ep - 1)
+        assert _Opt.param_groups[0]["lr"] == pytest.approx(O.step_lr(1e-3, 0.5, 3, ep))
+
+
+def test_out_of_scope_models_are_refused_loudly():
+    from model_trainer import ModelTrainer
+    with pytest.raises(NotImplementedError):
+        ModelTrainer("cpu", 1e-3, 1, 0.98, "DialogueRNN", "NLL", 6, "IEMOCAP", quiet=True)
