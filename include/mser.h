@@ -147,8 +147,10 @@ int mser_marn_cell_fwd(const mser_cell_desc* d, mser_stream_t stream);
 int mser_marn_cell_bwd(const mser_cell_desc* d, mser_stream_t stream);
 /* The same work in separately schedulable phases, so that the caller can overlap independent parts on different streams:
  * the speaker chain depends on qmask only (overlaps the encoders); its backward touches only speaker-cell gradients (overlaps
- * the encoder backward).  fwd = SPEAKER_FWD then LSTHM_FWD; bwd = LSTHM_BWD then SPEAKER_BWD (the caller orders them). */
-enum { MSER_PHASE_SPEAKER_FWD = 1, MSER_PHASE_LSTHM_FWD = 2, MSER_PHASE_LSTHM_BWD = 4, MSER_PHASE_SPEAKER_BWD = 8 };
+ * the encoder backward).  fwd = SPEAKER_FWD then LSTHM_FWD; bwd = LSTHM_BWD, LSTHM_BWD_DX, then SPEAKER_BWD and LSTHM_WGRAD in any order (the caller orders them). */
+enum { MSER_PHASE_SPEAKER_FWD = 1, MSER_PHASE_LSTHM_FWD = 2, MSER_PHASE_LSTHM_BWD = 4 /* BPTT chain only */, MSER_PHASE_SPEAKER_BWD = 8,
+       MSER_PHASE_LSTHM_BWD_DX = 16 /* dHQ, dx_l, dx_a GEMMs: after the chain, before SPEAKER_BWD / the encoders */,
+       MSER_PHASE_LSTHM_WGRAD = 32 /* LSTHM parameter gradients: after the chain, independent of everything else */ };
 int mser_marn_cell_run(const mser_cell_desc* d, int32_t phases, mser_stream_t stream);
 
 /* Launch mode of the recurrent chains.  MSER_OPT_PERSISTENT = 1 (default): each chain is ONE persistent launch with the time

@@ -1013,10 +1013,12 @@ __global__ __launch_bounds__(256) void colsum4_kernel(const float* X, long rows,
   __shared__ float part[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
-  const long r0 = (long)blockIdx.y * 512;
+  const long r0 = (long)blockIdx.y * 64;
   float s = 0.f;
-  if (c < n)
-    for (long r = r0 + rl; r < min(rows, r0 + 512); r += 4) s += X[r * ld + c];
+  if (c < n) {
+#pragma unroll 8
+    for (long r = r0 + rl; r < min(rows, r0 + 64); r += 4) s += X[r * ld + c];
+  }
   part[rl][threadIdx.x & 63] = s;
   __syncthreads();
   if (rl == 0 && c < n) {
@@ -1029,7 +1031,7 @@ __global__ __launch_bounds__(256) void colsum4_kernel(const float* X, long rows,
 }
 
 static int colsum4(const float* X, long rows, int n, long ld, float* o0, float* o1, float* o2, float* o3, hipStream_t s) {
-  hipLaunchKernelGGL(colsum4_kernel, dim3(cdiv(n, 64), cdiv(rows, 512)), dim3(256), 0, s, X, rows, n, ld, o0, o1, o2, o3);
+  hipLaunchKernelGGL(colsum4_kernel, dim3(cdiv(n, 64), cdiv(rows, 64)), dim3(256), 0, s, X, rows, n, ld, o0, o1, o2, o3);
   return check_launch("colsum4");
 }
 
@@ -1327,7 +1329,9 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
     }
   }
   MSER_TRY(check_launch("lsthm_bwd"));
-  // ---- deferred (non-recurrent) gradient GEMMs of the LSTHM streams
+  }
+  // ---- deferred (non-recurrent) GEMMs of the LSTHM streams.  DX: what the rest of the backward waits for (dHQ for the speaker
+  // chain, dx_l / dx_a for the encoders).  WGRAD: parameter gradients only -- nothing downstream reads them in this step.
   for (int i = 0; i < d.ndir; ++i) {
     DirP& k = K.d[i];
     const mser_cell_params& G = d.dir[i].g;
@@ -1338,22 +1342,24 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
     for (int m = 0; m < 2; ++m) {
       const float* dg = k.dgates + (long)m * TB * 4 * H;
       mser_gemm_desc g;
-      // dHQ += dg S_m
-      g = gd(dg, 4 * H, 1, k.S[m], H, 1, k.dHQ, H, (int)TB, H, 4 * H);
-      g.flags = MSER_GEMM_ACCUM;
-      MSER_TRY(gemm(g, s));
-      // dx (direction order) = dg W_m
-      if (!k.rev) {
-        g = gd(dg, 4 * H, 1, k.W[m], D, 1, dxs[m], D, (int)TB, D, 4 * H);
+      if (phases & MSER_PHASE_LSTHM_BWD_DX) {
+        // dHQ += dg S_m
+        g = gd(dg, 4 * H, 1, k.S[m], H, 1, k.dHQ, H, (int)TB, H, 4 * H);
         g.flags = MSER_GEMM_ACCUM;
         MSER_TRY(gemm(g, s));
-      } else {
-        g = gd(dg, 4 * H, 1, k.W[m], D, 1, h.dxtmp, D, (int)TB, D, 4 * H);
-        MSER_TRY(gemm(g, s));
-        hipLaunchKernelGGL(reverse_acc_kernel, dim3(cdiv(TB * D, 256)), dim3(256), 0, s, h.dxtmp, k.rev, dxs[m], (long)D, T, B, D);
-        MSER_TRY(check_launch("reverse_acc"));
+        // dx (direction order) = dg W_m
+        if (!k.rev) {
+          g = gd(dg, 4 * H, 1, k.W[m], D, 1, dxs[m], D, (int)TB, D, 4 * H);
+          g.flags = MSER_GEMM_ACCUM;
+          MSER_TRY(gemm(g, s));
+        } else {
+          g = gd(dg, 4 * H, 1, k.W[m], D, 1, h.dxtmp, D, (int)TB, D, 4 * H);
+          MSER_TRY(gemm(g, s));
+          hipLaunchKernelGGL(reverse_acc_kernel, dim3(cdiv(TB * D, 256)), dim3(256), 0, s, h.dxtmp, k.rev, dxs[m], (long)D, T, B, D);
+          MSER_TRY(check_launch("reverse_acc"));
+        }
       }
-      if (G.lsthm_W[m]) {
+      if ((phases & MSER_PHASE_LSTHM_WGRAD) && G.lsthm_W[m]) {
         // dW_m += dg^T xdir ; dS_m += dg^T HQ ; dU_m += dg^T h_prev ; dV_m += dg^T z_prev
         g = gd(dg, 1, 4 * H, xs[m], lds[m], 1, G.lsthm_W[m], D, 4 * H, D, (int)TB);
         g.splitk = SPLITK;
@@ -1370,11 +1376,10 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
         MSER_TRY(colsum4(dg, TB, 4 * H, 4 * H, G.lsthm_Wb[m], G.lsthm_Ub[m], G.lsthm_Vb[m], G.lsthm_Sb[m], s));
       }
     }
-    if (G.att_Wq) {
+    if ((phases & MSER_PHASE_LSTHM_WGRAD) && G.att_Wq) {
       MSER_TRY(colsum4(k.attacc, B, H, 2 * H, G.att_Wq, nullptr, nullptr, nullptr, s));
       MSER_TRY(colsum4(k.attacc + H, B, H, 2 * H, G.att_Wk, nullptr, nullptr, nullptr, s));
     }
-  }
   }
   if (!(phases & MSER_PHASE_SPEAKER_BWD)) return 0;
   // ---- speaker chain, reverse time
@@ -1556,14 +1561,14 @@ int mser_marn_cell_fwd(const mser_cell_desc* d, mser_stream_t stream) {
 
 int mser_marn_cell_bwd(const mser_cell_desc* d, mser_stream_t stream) {
   if (!d) { set_error("mser_marn_cell_bwd: null descriptor"); return -1; }
-  return marn_cell_bwd(*d, (hipStream_t)stream, MSER_PHASE_LSTHM_BWD | MSER_PHASE_SPEAKER_BWD);
+  return marn_cell_bwd(*d, (hipStream_t)stream, MSER_PHASE_LSTHM_BWD | MSER_PHASE_LSTHM_BWD_DX | MSER_PHASE_LSTHM_WGRAD | MSER_PHASE_SPEAKER_BWD);
 }
 
 int mser_marn_cell_run(const mser_cell_desc* d, int32_t phases, mser_stream_t stream) {
   if (!d) { set_error("mser_marn_cell_run: null descriptor"); return -1; }
   if (phases & (MSER_PHASE_SPEAKER_FWD | MSER_PHASE_LSTHM_FWD))
     MSER_TRY(marn_cell_fwd(*d, (hipStream_t)stream, phases));
-  if (phases & (MSER_PHASE_LSTHM_BWD | MSER_PHASE_SPEAKER_BWD))
+  if (phases & (MSER_PHASE_LSTHM_BWD | MSER_PHASE_LSTHM_BWD_DX | MSER_PHASE_LSTHM_WGRAD | MSER_PHASE_SPEAKER_BWD))
     MSER_TRY(marn_cell_bwd(*d, (hipStream_t)stream, phases));
   return 0;
 }

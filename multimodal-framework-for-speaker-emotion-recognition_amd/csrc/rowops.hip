@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64 * WPB) void add_layernorm_fwd_kernel(const float
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.  dgamma / dbeta: per-block partial sums in
 // LDS, then one float atomic per column per block.
-constexpr int LN_ROWS_PER_BLOCK = 32;
+constexpr int LN_ROWS_PER_BLOCK = 16;
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dy, const float* xsum, const float* mean,
                                                             const float* rstd, const float* gamma, float* dx,
                                                             float* dgamma, float* dbeta, long rows, int D) {
@@ -178,10 +178,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* X, long rows, 
   __shared__ float part[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
-  const long r0 = (long)blockIdx.y * 256;
+  const long r0 = (long)blockIdx.y * 64;
   float s = 0.f;
-  if (c < n)
-    for (long r = r0 + rl; r < min(rows, r0 + 256); r += 4) s += X[r * ld + c];
+  if (c < n) {
+#pragma unroll 8
+    for (long r = r0 + rl; r < min(rows, r0 + 64); r += 4) s += X[r * ld + c];
+  }
   part[rl][threadIdx.x & 63] = s;
   __syncthreads();
   if (rl == 0 && c < n) atomicAdd(&out[c], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
@@ -448,7 +450,7 @@ int mser_layernorm_bwd(const float* dy, const float* xsum, const float* mean, co
 int mser_colsum_acc(const float* X, int64_t rows, int32_t n, int64_t ld, float* out, mser_stream_t stream) {
   MSER_REQUIRE(X && out, "mser_colsum_acc: null pointer");
   if (rows <= 0 || n <= 0) return 0;
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(n, 64), cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, X, (long)rows, n,
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(n, 64), cdiv(rows, 64)), dim3(256), 0, (hipStream_t)stream, X, (long)rows, n,
                      (long)ld, out);
   return check_launch("mser_colsum_acc");
 }
@@ -473,7 +475,7 @@ int mser_scale_acc_dot(float* acc, int64_t ldacc, const float* t, int64_t ldt, c
                        float* ds, int64_t rows, int32_t D, mser_stream_t stream) {
   MSER_REQUIRE(acc && t && (!ds || x), "mser_scale_acc_dot: null pointer");
   if (rows <= 0 || D <= 0) return 0;
-  const int blocks = (int)fmin((double)cdiv(rows * D, 256), 1024.0);
+  const int blocks = (int)fmin((double)cdiv(rows * D, 1024), 128.0);      // one same-address float atomic per block
   hipLaunchKernelGGL(scale_acc_dot_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, acc, (long)ldacc, t, (long)ldt, x,
                      (long)ldx, s_dev, ds, (long)rows, D);
   return check_launch("mser_scale_acc_dot");

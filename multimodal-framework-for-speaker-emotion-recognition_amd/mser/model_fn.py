@@ -70,7 +70,7 @@ class _Streams:
     @classmethod
     def get(cls, dev):
         if cls._s is None or cls._s[0].device != dev:
-            cls._s = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            cls._s = [torch.cuda.Stream(device=dev) for _ in range(4)]
         return cls._s
 
 
@@ -123,34 +123,50 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
     ]
     desc = ops.make_cell_desc(Ln, B, D, H, c.x_l, c.x_a, c.cell_dirs, 10 * H, c.cell_ws)
     c.cell_desc = desc
-    if side is not None:
-        side[0].wait_stream(cur)
-        side[1].wait_stream(cur)
-        with torch.cuda.stream(side[1]):
-            ops.marn_cell_run(desc, ops.PHASE_SPEAKER_FWD)      # overlaps the encoders
-        with torch.cuda.stream(side[0]):
-            audio_branch()
-        text_branch()
-        cur.wait_stream(side[0])
-        cur.wait_stream(side[1])
-    else:
-        ops.marn_cell_run(desc, ops.PHASE_SPEAKER_FWD)
-        text_branch()
-        audio_branch()
-    ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD)
-
-    # ---- sequence-level cross-modal attention (:377-383)
     w, v, v1, v2 = P("w"), P("v"), P("v1"), P("v2")
     c.A1 = torch.empty(N, H, device=x.device)
     c.A2 = torch.empty(N, H, device=x.device)
     hh = d.xattn_heads
     c.xa = [None] * 4
-    c.xa[0] = F_.xattn_fwd(c.x_l, w, c.x_a, v, P("crossatt_l2a.Wq"), P("crossatt_l2a.Wk"), P("crossatt_l2a.Wv"), lay, lay, c.A1, hh)
-    c.xa[1] = F_.xattn_fwd(c.x_a, v, c.x_l, w, P("crossatt_a2l.Wq"), P("crossatt_a2l.Wk"), P("crossatt_a2l.Wv"), lay, lay, c.A2, hh)
-    c.xa[2] = F_.xattn_fwd(c.x_a, v, c.A1, v1, P("crossatt_l2a_1.Wq"), P("crossatt_l2a_1.Wk"), P("crossatt_l2a_1.Wv"), lay, lay,
-                           c.Hcat[:, 8 * H:9 * H], hh)
-    c.xa[3] = F_.xattn_fwd(c.x_l, w, c.A2, v2, P("crossatt_a2l_1.Wq"), P("crossatt_a2l_1.Wk"), P("crossatt_a2l_1.Wv"), lay, lay,
-                           c.Hcat[:, 9 * H:10 * H], hh)
+
+    # sequence-level cross-modal attention (:377-383): needs only the encoder outputs, so it runs beside the LSTHM chain
+    def xattn_a():      # attn1 path
+        c.xa[0] = F_.xattn_fwd(c.x_l, w, c.x_a, v, P("crossatt_l2a.Wq"), P("crossatt_l2a.Wk"), P("crossatt_l2a.Wv"), lay, lay, c.A1, hh)
+        c.xa[2] = F_.xattn_fwd(c.x_a, v, c.A1, v1, P("crossatt_l2a_1.Wq"), P("crossatt_l2a_1.Wk"), P("crossatt_l2a_1.Wv"), lay, lay,
+                               c.Hcat[:, 8 * H:9 * H], hh)
+
+    def xattn_b():      # attn2 path
+        c.xa[1] = F_.xattn_fwd(c.x_a, v, c.x_l, w, P("crossatt_a2l.Wq"), P("crossatt_a2l.Wk"), P("crossatt_a2l.Wv"), lay, lay, c.A2, hh)
+        c.xa[3] = F_.xattn_fwd(c.x_l, w, c.A2, v2, P("crossatt_a2l_1.Wq"), P("crossatt_a2l_1.Wk"), P("crossatt_a2l_1.Wv"), lay, lay,
+                               c.Hcat[:, 9 * H:10 * H], hh)
+
+    if side is not None:
+        s_audio, s_spk, s_xa, s_xb = side
+        for st in side:
+            st.wait_stream(cur)
+        with torch.cuda.stream(s_spk):
+            ops.marn_cell_run(desc, ops.PHASE_SPEAKER_FWD)      # qmask-only chain: overlaps the encoders
+        with torch.cuda.stream(s_audio):
+            audio_branch()
+        text_branch()
+        cur.wait_stream(s_audio)                                # x_l and x_a are final
+        s_xa.wait_stream(cur)
+        s_xb.wait_stream(cur)
+        with torch.cuda.stream(s_xa):
+            xattn_a()
+        with torch.cuda.stream(s_xb):
+            xattn_b()
+        cur.wait_stream(s_spk)
+        ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD)            # 64 persistent workgroups; the attention GEMMs fill the other CUs
+        cur.wait_stream(s_xa)
+        cur.wait_stream(s_xb)
+    else:
+        ops.marn_cell_run(desc, ops.PHASE_SPEAKER_FWD)
+        text_branch()
+        audio_branch()
+        ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD)
+        xattn_a()
+        xattn_b()
 
     # ---- fusion head (:390-393)
     c.y1 = torch.empty(N, D, device=x.device)
@@ -199,27 +215,32 @@ def marn1_backward(c: ModelCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: Opt
     ops.matmul(dy1, P("fc.0.weight"), dH)
     ops.grad_weight(dy1, c.Hcat, G("fc.0.weight"))
     ops.colsum_acc(dy1, G("fc.0.bias"))
-    # ---- sequence-level attention, reverse order
+    # ---- the four sequence-level attention modules (two independent chains, side streams) run beside the LSTHM BPTT chain.
+    # Each chain accumulates its x_l / x_a gradients into its own buffers (no cross-stream read-modify-write).
     w, v, v1, v2 = P("w"), P("v"), P("v1"), P("v2")
     dA1 = torch.zeros(N, H, device=dev)
     dA2 = torch.zeros(N, H, device=dev)
+    dxl_a, dxa_a = torch.zeros(N, D, device=dev), torch.zeros(N, D, device=dev)
+    dxl_b, dxa_b = torch.zeros(N, D, device=dev), torch.zeros(N, D, device=dev)
+    # the learnable scalars w, v receive contributions from both chains: float atomics on one word each, order-insensitive
 
     def xb(i, name, dout, dx1, dx2, ga1, ga2):
         F_.xattn_bwd(c.xa[i], dout, P(name + ".Wq"), P(name + ".Wk"), P(name + ".Wv"), G(name + ".Wq"), G(name + ".Wk"),
                      G(name + ".Wv"), dx1, dx2, ga1, ga2)
 
-    xb(3, "crossatt_a2l_1", dH[:, 9 * H:10 * H], dx_l, dA2, G("w"), G("v2"))
-    xb(2, "crossatt_l2a_1", dH[:, 8 * H:9 * H], dx_a, dA1, G("v"), G("v1"))
-    xb(1, "crossatt_a2l", dA2, dx_a, dx_l, G("v"), G("w"))
-    xb(0, "crossatt_l2a", dA1, dx_l, dx_a, G("w"), G("v"))
-    # ---- MARN cell
+    def xattn_a_bwd():     # attn1 path: crossatt_l2a_1(v x_a, v1 A1) <- crossatt_l2a(w x_l, v x_a)
+        xb(2, "crossatt_l2a_1", dH[:, 8 * H:9 * H], dxa_a, dA1, G("v"), G("v1"))
+        xb(0, "crossatt_l2a", dA1, dxl_a, dxa_a, G("w"), G("v"))
+
+    def xattn_b_bwd():     # attn2 path: crossatt_a2l_1(w x_l, v2 A2) <- crossatt_a2l(v x_a, w x_l)
+        xb(3, "crossatt_a2l_1", dH[:, 9 * H:10 * H], dxl_b, dA2, G("w"), G("v2"))
+        xb(1, "crossatt_a2l", dA2, dxa_b, dxl_b, G("v"), G("w"))
+
     for r, pre, sl in ((c.cell_dirs[0], "marn_cell_f.", slice(0, 4 * H)), (c.cell_dirs[1], "marn_cell_b.", slice(4 * H, 8 * H))):
         r["g"] = ops.cell_param_struct(_sub(G, pre))
         r["dout"] = dH[:, sl]
     desc = ops.make_cell_desc(Ln, B, D, H, c.x_l, c.x_a, c.cell_dirs, 10 * H, c.cell_ws, dx_l=dx_l, dx_a=dx_a)
     c.cell_desc = desc
-    ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD)
-    # ---- speaker-chain BPTT (side stream 1) overlaps the encoders' backward (two passes with shared weights) + linear_in
     Pl, Pa, Gl, Ga = _sub(P, "encoder_l."), _sub(P, "encoder_a."), _sub(G, "encoder_l."), _sub(G, "encoder_a.")
     cur = torch.cuda.current_stream()
     side = _Streams.get(dev) if use_streams else None
@@ -235,17 +256,42 @@ def marn1_backward(c: ModelCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: Opt
         d2 = F_.encoder_layer_bwd(c.enc[3], dx_a, Pa, Ga)
         F_.encoder_layer_bwd(c.enc[2], d2, Pa, Ga)                 # input features need no gradient
 
+    def merge_dx():
+        ops.add_rows(dxl_a, dxl_a, dxl_b)
+        ops.add_rows(dx_l, dx_l, dxl_a)
+        ops.add_rows(dxa_a, dxa_a, dxa_b)
+        ops.add_rows(dx_a, dx_a, dxa_a)
+
     if side is not None:
-        side[0].wait_stream(cur)
-        side[1].wait_stream(cur)
-        with torch.cuda.stream(side[1]):
-            ops.marn_cell_run(desc, ops.PHASE_SPEAKER_BWD)
-        with torch.cuda.stream(side[0]):
+        s_audio, s_spk, s_xa, s_xb = side
+        for st in side:
+            st.wait_stream(cur)
+        with torch.cuda.stream(s_xa):
+            xattn_a_bwd()
+        with torch.cuda.stream(s_xb):
+            xattn_b_bwd()
+        ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD)               # BPTT chain (persistent kernel, 64 CUs)
+        cur.wait_stream(s_xa)
+        cur.wait_stream(s_xb)
+        merge_dx()
+        ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD_DX)            # dHQ, dx_l += dg W_l, dx_a += dg W_a
+        s_spk.wait_stream(cur)
+        s_audio.wait_stream(cur)
+        s_xa.wait_stream(cur)
+        with torch.cuda.stream(s_spk):
+            ops.marn_cell_run(desc, ops.PHASE_SPEAKER_BWD)         # speaker BPTT: touches only speaker-cell gradients
+        with torch.cuda.stream(s_xa):
+            ops.marn_cell_run(desc, ops.PHASE_LSTHM_WGRAD)         # LSTHM parameter gradients: nothing downstream reads them
+        with torch.cuda.stream(s_audio):
             audio_branch()
         text_branch()
-        cur.wait_stream(side[0])
-        cur.wait_stream(side[1])
+        for st in (s_audio, s_spk, s_xa):
+            cur.wait_stream(st)
     else:
-        ops.marn_cell_run(desc, ops.PHASE_SPEAKER_BWD)
+        xattn_a_bwd()
+        xattn_b_bwd()
+        ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD)
+        merge_dx()
+        ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD_DX | ops.PHASE_LSTHM_WGRAD | ops.PHASE_SPEAKER_BWD)
         text_branch()
         audio_branch()

@@ -277,7 +277,7 @@ def set_option(key: int, value: int) -> None:
     L.check(L.load().mser_set_option(key, value), "set_option")
 
 
-PHASE_SPEAKER_FWD, PHASE_LSTHM_FWD, PHASE_LSTHM_BWD, PHASE_SPEAKER_BWD = 1, 2, 4, 8
+PHASE_SPEAKER_FWD, PHASE_LSTHM_FWD, PHASE_LSTHM_BWD, PHASE_SPEAKER_BWD, PHASE_LSTHM_BWD_DX, PHASE_LSTHM_WGRAD = 1, 2, 4, 8, 16, 32
 
 
 def marn_cell_run(desc: L.CellDesc, phases: int) -> None:
