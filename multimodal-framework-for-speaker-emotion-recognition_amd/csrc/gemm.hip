@@ -4,8 +4,9 @@
 // fp32; on CDNA4 the f32 MFMA is a k-ordered fmaf chain (bit-identical to a scalar fp32 loop) at the f32 vector peak
 // but needs one VGPR per operand and leaves the VALU free for the epilogue (guide: "FP32-input MFMA").
 //
-// Tile: 64x64 per 256-thread workgroup (4 waves as 2x2, one 32x32 accumulator each), BK = 16.
-// LDS tiles are k-major ([BK][64+pad]) so an MFMA operand fetch is one conflict-free ds_read_b32 per lane.
+// Tile: 64x64 per 256-thread workgroup (4 waves as 2x2, one 32x32 accumulator each), BK = 32, float4 staging where aligned.
+// LDS tiles are laid out [k parity][row][k/2] so that the 16 operands a lane feeds to the 16 MFMAs of a tile are contiguous
+// (4 conflict-free ds_read_b128 per operand), fetched before the MFMA chain starts.
 // The matrices on this path are small (M = B*L = 4096 rows, N <= 1280, K <= 1280 or a 4096-long split reduction) and every
 // call is latency bound, not bandwidth bound: what matters is (1) cheap addressing -- per-thread base pointers are computed
 // once, the k-loop only adds one offset -- and (2) memory-level parallelism -- global loads run TWO tiles ahead of the MFMAs
@@ -17,7 +18,8 @@
 
 namespace mser {
 
-constexpr int BM = 64, BN = 64, BK = 16, PAD = 4;
+constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int KH = BK / 2, LROW = KH + 4;      // LDS tile [k parity][m][k/2 (+4 pad)]: a lane's 16 MFMA operands are contiguous
 
 struct GemmArgs {
   const float* A; const float* B; float* C;
@@ -29,11 +31,72 @@ struct GemmArgs {
   const float* R1; const float* R2; long ldr1, ldr2, sR1, sR2;
 };
 
-// AMODE / BMODE: 0 = k contiguous (threads walk k fastest), 1 = m (n) contiguous (threads walk m / n fastest), 2 = generic
+// One operand tile (64 rows/cols x 32 k) staged global -> registers -> LDS (k-major [BK][64+PAD]).
+// MODE 0: k contiguous, float4 along k (host guarantees 16-B alignment, stride % 4 == 0, K-chunk % 4 == 0)
+// MODE 1: m/n contiguous, float4 along m/n (alignment, stride % 4 == 0, extent % 4 == 0)
+// MODE 2: any strides, scalar loads.
+// Loads are UNCONDITIONAL: addresses are clamped into the matrix and the value is zeroed by a select afterwards -- a load
+// inside a per-element branch makes hipcc wait vmcnt(0) per element (serial memory round trips).
+template <int MODE>
+struct TileLoader {
+  static constexpr int NV = (MODE == 2) ? 8 : 2;       // register slots: 8 scalars or 2 float4
+  const float* p[NV];
+  int mm[NV], kk[NV];
+  bool ok[NV];
+  long sk;                                             // element stride along k
+
+  __device__ __forceinline__ void init(const float* base, long sm, long sk_, int m0, int M) {
+    sk = sk_;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = tid + i * 256;
+      if (MODE == 0) { mm[i] = e >> 3; kk[i] = (e & 7) * 4; }
+      else if (MODE == 1) { mm[i] = (e & 15) * 4; kk[i] = e >> 4; }
+      else { mm[i] = e >> 5; kk[i] = e & 31; }
+      ok[i] = (m0 + mm[i]) < M;
+      p[i] = base + (long)(ok[i] ? m0 + mm[i] : 0) * sm + (long)kk[i] * sk;
+    }
+  }
+  // r: NV*4 floats (vector modes) or NV floats (scalar mode).  load() ONLY issues the loads (no use of the data: any use would
+  // make the compiler wait for them right here and defeat the two-tile prefetch); invalid rows / k are zeroed in store().
+  __device__ __forceinline__ void load(int k0, int klen, float* r) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int k = k0 + kk[i];
+      // clamped so that the (possibly 4-wide) access stays inside [0, klen): vector modes have klen % 4 == 0
+      const int kc = (k < klen ? k : klen - (MODE == 0 ? 4 : 1)) - kk[i];
+      const float* q = p[i] + (long)kc * sk;
+      if (MODE == 2) {
+        r[i] = *q;
+      } else {
+        const float4 v = *reinterpret_cast<const float4*>(q);
+        r[4 * i + 0] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
+      }
+    }
+  }
+  // T: [2][64][LROW]; element (k, m) lives at T[k & 1][m][k >> 1]
+  __device__ __forceinline__ void store(float (*T)[BM][LROW], const float* r, int k0, int klen) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const bool good = ok[i] && (k0 + kk[i]) < klen;     // vectors never straddle the valid range (host checks % 4)
+      if (MODE == 0) {            // k .. k+3 of one row, k % 4 == 0
+        *reinterpret_cast<float2*>(&T[0][mm[i]][kk[i] >> 1]) = make_float2(good ? r[4 * i + 0] : 0.f, good ? r[4 * i + 2] : 0.f);
+        *reinterpret_cast<float2*>(&T[1][mm[i]][kk[i] >> 1]) = make_float2(good ? r[4 * i + 1] : 0.f, good ? r[4 * i + 3] : 0.f);
+      } else if (MODE == 1) {     // rows m .. m+3 at one k
+#pragma unroll
+        for (int j = 0; j < 4; ++j) T[kk[i] & 1][mm[i] + j][kk[i] >> 1] = good ? r[4 * i + j] : 0.f;
+      } else {
+        T[kk[i] & 1][mm[i]][kk[i] >> 1] = good ? r[i] : 0.f;
+      }
+    }
+  }
+};
+
 template <int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-  __shared__ float As[2][BK][BM + PAD];
-  __shared__ float Bs[2][BK][BN + PAD];
+  __shared__ __attribute__((aligned(16))) float As[2][2][BM][LROW];
+  __shared__ __attribute__((aligned(16))) float Bs[2][2][BN][LROW];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -44,79 +107,51 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int z2 = z % g.batch2, z1 = z / g.batch2;
   const int kbeg = ks * g.kchunk;
   const int kend = min(g.K, kbeg + g.kchunk);
-  const float* A = g.A + z1 * g.sA1 + z2 * g.sA2 + (long)kbeg * g.sAk;
-  const float* B = g.B + z1 * g.sB1 + z2 * g.sB2 + (long)kbeg * g.sBk;
   const int klen = kend - kbeg;
 
-  // per-thread element coordinates inside a tile and the matching base pointers (computed once)
-  int am[4], ak[4], bn[4], bk[4];
-  const float* pa[4];
-  const float* pb[4];
-  bool va[4], vb[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int e = tid + i * 256;
-    if (AMODE == 1) { ak[i] = e >> 6; am[i] = e & 63; } else { am[i] = e >> 4; ak[i] = e & 15; }
-    if (BMODE == 1) { bk[i] = e >> 6; bn[i] = e & 63; } else { bn[i] = e >> 4; bk[i] = e & 15; }
-    va[i] = (m0 + am[i]) < g.M;
-    vb[i] = (n0 + bn[i]) < g.N;
-    pa[i] = A + (long)(va[i] ? m0 + am[i] : 0) * g.sAm + (long)ak[i] * g.sAk;
-    pb[i] = B + (long)(vb[i] ? n0 + bn[i] : 0) * g.sBn + (long)bk[i] * g.sBk;
-  }
+  TileLoader<AMODE> la;
+  TileLoader<BMODE> lb;
+  la.init(g.A + z1 * g.sA1 + z2 * g.sA2 + (long)kbeg * g.sAk, g.sAm, g.sAk, m0, g.M);
+  lb.init(g.B + z1 * g.sB1 + z2 * g.sB2 + (long)kbeg * g.sBk, g.sBn, g.sBk, n0, g.N);
 
   f32x16 acc = {0};
   const int nt = (klen + BK - 1) / BK;
-  auto gload = [&](int t, float* ra, float* rb) {
-    const int k0 = t * BK;
-    const long oa = (long)k0 * g.sAk, ob = (long)k0 * g.sBk;
-    if (k0 + BK <= klen) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ra[i] = va[i] ? pa[i][oa] : 0.f;
-        rb[i] = vb[i] ? pb[i][ob] : 0.f;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ra[i] = (va[i] && k0 + ak[i] < klen) ? pa[i][oa] : 0.f;
-        rb[i] = (vb[i] && k0 + bk[i] < klen) ? pb[i][ob] : 0.f;
-      }
-    }
-  };
-  auto lstore = [&](int buf, const float* ra, const float* rb) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      As[buf][ak[i]][am[i]] = ra[i];
-      Bs[buf][bk[i]][bn[i]] = rb[i];
-    }
-  };
   const int half = lane >> 5, l31 = lane & 31;
+  // all 16 A and 16 B operands of the tile are fetched with 8 ds_read_b128 BEFORE the MFMA chain (just-in-time scalar LDS
+  // reads expose the LDS latency once per MFMA and ran the chain at ~35 % of its issue rate)
   auto compute = [&](int buf) {
+    float a[KH], b[KH];
+    const float* pa = &As[buf][half][wr * 32 + l31][0];
+    const float* pb = &Bs[buf][half][wc * 32 + l31][0];
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const float a = As[buf][kk + half][wr * 32 + l31];
-      const float b = Bs[buf][kk + half][wc * 32 + l31];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    for (int q = 0; q < KH / 4; ++q) {
+      const float4 va4 = *reinterpret_cast<const float4*>(pa + 4 * q);
+      const float4 vb4 = *reinterpret_cast<const float4*>(pb + 4 * q);
+      a[4 * q] = va4.x; a[4 * q + 1] = va4.y; a[4 * q + 2] = va4.z; a[4 * q + 3] = va4.w;
+      b[4 * q] = vb4.x; b[4 * q + 1] = vb4.y; b[4 * q + 2] = vb4.z; b[4 * q + 3] = vb4.w;
     }
+    // straight-line chain of 16 MFMAs (a short last tile multiplies stored zeros: cheaper than a branch per MFMA)
+#pragma unroll
+    for (int i = 0; i < KH; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
   };
 
-  float ra0[4], rb0[4], ra1[4], rb1[4];
+  float ra0[8], rb0[8], ra1[8], rb1[8];
   if (nt > 0) {
-    gload(0, ra0, rb0);
-    if (nt > 1) gload(1, ra1, rb1);
-    lstore(0, ra0, rb0);
+    la.load(0, klen, ra0); lb.load(0, klen, rb0);
+    if (nt > 1) { la.load(BK, klen, ra1); lb.load(BK, klen, rb1); }
+    la.store(As[0], ra0, 0, klen); lb.store(Bs[0], rb0, 0, klen);
   }
   __syncthreads();
-  // tile t lives in LDS buffer t&1; registers set (t+1)&1 holds tile t+1; tile t+2 is requested into the freed set
+  // tile t lives in LDS buffer t&1; register set (t+1)&1 holds tile t+1; tile t+2 is requested into the freed set
   for (int t = 0; t < nt; t += 2) {
-    if (t + 2 < nt) gload(t + 2, ra0, rb0);
+    if (t + 2 < nt) { la.load((t + 2) * BK, klen, ra0); lb.load((t + 2) * BK, klen, rb0); }
     compute(0);
-    if (t + 1 < nt) lstore(1, ra1, rb1);
+    if (t + 1 < nt) { la.store(As[1], ra1, (t + 1) * BK, klen); lb.store(Bs[1], rb1, (t + 1) * BK, klen); }
     __syncthreads();
     if (t + 1 >= nt) break;
-    if (t + 3 < nt) gload(t + 3, ra1, rb1);
+    if (t + 3 < nt) { la.load((t + 3) * BK, klen, ra1); lb.load((t + 3) * BK, klen, rb1); }
     compute(1);
-    if (t + 2 < nt) lstore(0, ra0, rb0);
+    if (t + 2 < nt) { la.store(As[0], ra0, (t + 2) * BK, klen); lb.store(Bs[0], rb0, (t + 2) * BK, klen); }
     __syncthreads();
   }
 
@@ -181,8 +216,16 @@ int gemm(const mser_gemm_desc& d, hipStream_t s) {
   a.R1 = d.R1; a.R2 = d.R2; a.ldr1 = d.ldr1; a.ldr2 = d.ldr2; a.sR1 = d.sR1_1; a.sR2 = d.sR1_2;
   dim3 grid(cdiv(d.N, BN), cdiv(d.M, BM), b1 * b2 * splitk);
   MSER_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "mser_gemm: grid too large (M=%d batch=%d)", d.M, b1 * b2);
-  const int amode = d.sAk == 1 ? 0 : (d.sAm == 1 ? 1 : 2);
-  const int bmode = d.sBk == 1 ? 0 : (d.sBn == 1 ? 1 : 2);
+  // vector (float4) staging needs: unit stride along the vector, every other stride % 4 == 0, a 16-byte aligned base, and
+  // extents such that no vector straddles the valid range
+  auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  auto m4 = [](long v) { return (v & 3) == 0; };
+  const bool kvec_ok = m4(d.K) && m4(a.kchunk);
+  int amode = 2, bmode = 2;
+  if (d.sAk == 1 && m4(d.sAm) && m4(d.sA1) && m4(d.sA2) && al16(d.A) && kvec_ok) amode = 0;
+  else if (d.sAm == 1 && m4(d.sAk) && m4(d.sA1) && m4(d.sA2) && al16(d.A) && m4(d.M)) amode = 1;
+  if (d.sBk == 1 && m4(d.sBn) && m4(d.sB1) && m4(d.sB2) && al16(d.B) && kvec_ok) bmode = 0;
+  else if (d.sBn == 1 && m4(d.sBk) && m4(d.sB1) && m4(d.sB2) && al16(d.B) && m4(d.N)) bmode = 1;
   switch (amode) {
     case 0: launch_b<0>(bmode, grid, s, a); break;
     case 1: launch_b<1>(bmode, grid, s, a); break;
