@@ -34,7 +34,7 @@ struct DirP {
   const int* rev;
   float* qm;
   // saved by the forward
-  float *qsel, *hq_state, *cq_state, *sgates, *HQ;
+  float *qsel, *hq_state, *cq_state, *sgates, *HQ, *tcq;   // tcq[2][T][B][H] = tanh(c_new) (saves the backward a tanhf per element)
   float *pre, *gates, *cstate, *hz;
   float* out;
   const float* dout;
@@ -137,6 +137,25 @@ __device__ __forceinline__ void store8x(const WS& w, float* p, const float* a) {
   } else {
     *reinterpret_cast<float4*>(p) = make_float4(a[0], a[1], a[2], a[3]);
     *reinterpret_cast<float4*>(p + 4) = make_float4(a[4], a[5], a[6], a[7]);
+  }
+}
+template <bool PS>
+__device__ __forceinline__ float4 ld4x(const WS& w, const float* p) {
+  if constexpr (PS) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w.r, (int)((const char*)p - w.base), 0, AUX_SC1);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  } else {
+    return *reinterpret_cast<const float4*>(p);
+  }
+}
+template <bool PS>
+__device__ __forceinline__ void st4x(const WS& w, float* p, float4 v) {
+  if constexpr (PS) {
+    u32x4 u;
+    u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(u, w.r, (int)((const char*)p - w.base), 0, AUX_SC1);
+  } else {
+    *reinterpret_cast<float4*>(p) = v;
   }
 }
 __device__ __forceinline__ void zero8(float* a) {
@@ -384,7 +403,9 @@ __device__ __forceinline__ void spk_fwd_body(const CellK& P, const DirP& D, cons
       const float gg = tanhf(tile[rr * 32 + 16 + uu] + bias4[2]);
       const float go = sigmoidf_(tile[rr * 32 + 24 + uu] + bias4[3]);
       const float cn = gf * cq_prev + gi * gg;
-      const float hn = go * tanhf(cn);
+      const float tcn = tanhf(cn);
+      const float hn = go * tcn;
+      D.tcq[((long)c * T + t) * SB + (long)slot * H + u] = tcn;
       stx<PS>(ws, cq_new + (long)slot * H + u, cn);
       stx<PS>(ws, hq_new + (long)slot * H + u, hn);
       float* g = sg + (long)slot * 4 * H + u;
@@ -499,10 +520,10 @@ __device__ __forceinline__ void lsthm_gates_body(const CellK& P, const DirP& D, 
 
 // Row phase, one dialogue row b per call (NT threads): z[b,i] = sum_j softmax_j(c_l[i] * s_b * Wk[j]) c_a[j]  (:59-72, rank-1 form)
 // thread (i = tid % H, q = tid / H) covers keys j in [q*JC, (q+1)*JC).  scr: ca[H] pZ[NT] pN[NT] sh[16]
-template <bool PS>
+template <bool PS, int JCT>       // JCT = keys per thread chunk when known at compile time (fully unrolled loops), 0 = runtime
 __device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, const WS& ws, int t, int b, const float* att, float* scr) {
   const int H = P.H, B = P.B, T = P.T;
-  const int Q = NT / H, JC = H / Q;
+  const int Q = NT / H, JC = JCT ? JCT : H / Q;
   float* ca = scr;
   float* pZ = ca + H;
   float* pN = pZ + NT;
@@ -532,10 +553,15 @@ __device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, cons
   const float mx = (u >= 0.f) ? u * att[2 * H] : u * att[2 * H + 1];
   const float u2 = u * LOG2E, m2 = mx * LOG2E;
   float Z = 0.f, N = 0.f;
-  for (int j = q * JC; j < (q + 1) * JC; ++j) {
-    const float e = __builtin_amdgcn_exp2f(fmaf(u2, wk[j], -m2));
-    Z += e;
-    N = fmaf(e, ca[j], N);
+  {
+    const float* wkc = wk + q * JC;
+    const float* cac = ca + q * JC;
+#pragma unroll
+    for (int jj = 0; jj < (JCT ? JCT : JC); ++jj) {
+      const float e = __builtin_amdgcn_exp2f(fmaf(u2, wkc[jj], -m2));
+      Z += e;
+      N = fmaf(e, cac[jj], N);
+    }
   }
   if (q > 0) { pZ[tid] = Z; pN[tid] = N; }
   __syncthreads();
@@ -560,7 +586,7 @@ __global__ __launch_bounds__(NT) void lsthm_fwd_z(CellK P, int t) {
   const WS ws = make_ws(P.wsbase, P.wsbytes);
   float* att = smem + RED_FLOATS;
   att_prepare(P.d[blockIdx.y], P.H, att, smem);
-  lsthm_z_body<false>(P, P.d[blockIdx.y], ws, t, blockIdx.x, att, smem);
+  lsthm_z_body<false, 0>(P, P.d[blockIdx.y], ws, t, blockIdx.x, att, smem);
 }
 
 // persistent launch: grid (H/8, 2 streams, ndir*nmb); two barriers per step (gates -> z -> next gates)
@@ -586,7 +612,7 @@ __global__ __launch_bounds__(NT) void lsthm_fwd_persist(CellK P) {
     lsthm_gates_body<true, NP>(P, D, ws, t, m, u0, mb, bpre, red, tile);   // stamps 0 (loads) 1 (mm) 2 (epilogue)
     if (!dir_barrier(P.sync + SYNC_LSTHM_FWD + dir, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
     STAMP_ACC(3);
-    for (int b = w; b < P.B; b += (int)nwg) lsthm_z_body<true>(P, D, ws, t, b, att, red);
+    for (int b = w; b < P.B; b += (int)nwg) lsthm_z_body<true, 8 * NP * NP>(P, D, ws, t, b, att, red);   // NP = H/64, JC = H*H/NT = 8 NP^2
     STAMP_ACC(4);
     if (t + 1 == P.T) break;
     if (!dir_barrier(P.sync + SYNC_LSTHM_FWD + dir, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
@@ -600,10 +626,10 @@ __global__ __launch_bounds__(NT) void lsthm_fwd_persist(CellK P) {
 // both streams.  Writes dgates[t], the dc carry, dHQ[t] (the h_q part of dout) and accumulates the attention-vector grads of
 // its own row (reduced over rows once after the chain).
 // scr floats: ca[H] cl[H] cw[H] coef[H][8] p[3][NT] sh[16]
-template <bool PS>
+template <bool PS, int JCT>
 __device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D, const WS& ws, int t, int b, const float* att, float* scr) {
   const int H = P.H, B = P.B, T = P.T;
-  const int Q = NT / H, JC = H / Q;
+  const int Q = NT / H, JC = JCT ? JCT : H / Q;
   float* ca = scr;           float* cl = ca + H;   float* cw = cl + H;   float* coef = cw + H;
   float* p0 = coef + 8 * H;  float* p1 = p0 + NT;  float* p2 = p1 + NT;  float* sh = p2 + NT;
   const float* wk = att;
@@ -657,11 +683,17 @@ __device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D
   const float mx = (u >= 0.f) ? u * att[2 * H] : u * att[2 * H + 1];
   const float u2 = u * LOG2E, m2 = mx * LOG2E;
   float Z = 0.f, N2 = 0.f, N3 = 0.f;
-  for (int j = q * JC; j < (q + 1) * JC; ++j) {
-    const float e = __builtin_amdgcn_exp2f(fmaf(u2, wk[j], -m2));
-    Z += e;
-    N2 = fmaf(e, cw[j], N2);
-    N3 = fmaf(e, wk[j], N3);
+  {
+    const float* wkc = wk + q * JC;
+    const float* cwc = cw + q * JC;
+#pragma unroll
+    for (int jj = 0; jj < (JCT ? JCT : JC); ++jj) {
+      const float wj = wkc[jj];
+      const float e = __builtin_amdgcn_exp2f(fmaf(u2, wj, -m2));
+      Z += e;
+      N2 = fmaf(e, cwc[jj], N2);
+      N3 = fmaf(e, wj, N3);
+    }
   }
   if (q > 0) { p0[tid] = Z; p1[tid] = N2; p2[tid] = N3; }
   __syncthreads();
@@ -683,9 +715,11 @@ __device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D
   float S1 = 0.f, S2 = 0.f, S3 = 0.f;
   {
     const float wkj = wk[j];
-    for (int ii = q * JC; ii < (q + 1) * JC; ++ii) {
-      const float4 c4 = *reinterpret_cast<const float4*>(coef + 8 * ii);
-      const float c5 = coef[8 * ii + 4];
+    const float* cfc = coef + 8 * q * JC;
+#pragma unroll
+    for (int ii = 0; ii < (JCT ? JCT : JC); ++ii) {
+      const float4 c4 = *reinterpret_cast<const float4*>(cfc + 8 * ii);
+      const float c5 = cfc[8 * ii + 4];
       const float e = __builtin_amdgcn_exp2f(fmaf(c4.x, wkj, -c4.y));
       S1 = fmaf(c4.z, e, S1);
       S2 = fmaf(c4.w, e, S2);
@@ -761,7 +795,7 @@ __global__ __launch_bounds__(NT) void lsthm_bwd_row(CellK P, int t) {
   const WS ws = make_ws(P.wsbase, P.wsbytes);
   float* att = smem + RED_FLOATS;
   att_prepare(P.d[blockIdx.y], P.H, att, smem);
-  lsthm_bwd_row_body<false>(P, P.d[blockIdx.y], ws, t, blockIdx.x, att, smem);
+  lsthm_bwd_row_body<false, 0>(P, P.d[blockIdx.y], ws, t, blockIdx.x, att, smem);
 }
 __global__ __launch_bounds__(NT) void lsthm_bwd_mat(CellK P, int t) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -794,7 +828,7 @@ __global__ __launch_bounds__(NT) void lsthm_bwd_persist(CellK P) {
   unsigned nbar = 0;
   STAMP_INIT();
   for (int t = P.T - 1; t >= 0; --t) {
-    for (int b = w; b < P.B; b += (int)nwg) lsthm_bwd_row_body<true>(P, D, ws, t, b, att, red);
+    for (int b = w; b < P.B; b += (int)nwg) lsthm_bwd_row_body<true, 2 * NP * NP>(P, D, ws, t, b, att, red);   // NP = H/32, JC = H*H/NT = 2 NP^2
     STAMP_ACC(0);
     if (t == 0) break;
     if (!dir_barrier(P.sync + SYNC_LSTHM_BWD + dir, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
@@ -837,7 +871,7 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, cons
   const int tid = threadIdx.x;
   const float* sg = D.sgates + ((long)c * T + t) * B * 4 * H;
   const float* cq_old = D.cq_state + ((long)c * (T + 1) + t) * SB;
-  const float* cq_new = cq_old + SB;
+  const float* tcq_t = D.tcq + ((long)c * T + t) * SB;
   float* dsg_g = D.dsg + ((long)c * T + t) * B * 4 * H;
   const float* mn = D.mnext + (long)t * B;
 
@@ -858,68 +892,82 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, cons
     }
   }
 
-  constexpr int MAXIT = 8;                       // 32*H/NT iterations of the element-wise prologue, H <= 128 fully unrolled
-  const int nit = 32 * H / NT;
+  // element-wise prologue over 32 slots x H units, 4 consecutive units per thread-iteration (16-byte accesses: the phase is
+  // bound by vector-memory instruction throughput, not by arithmetic).  All loads of an iteration batch are issued first.
+  constexpr int MAXIT = 4;
+  const int G4 = H / 4;                          // float4 groups per slot row
+  const int nit = 32 * G4 / NT;                  // = H/64
+  const int npub = 2 * (H / 32);                 // workgroups of this cell; group g is published by workgroup (g % G4) % npub
+  auto f4 = [](float4 v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; };
   for (int it0 = 0; it0 < nit; it0 += MAXIT) {
-    float v_dh[MAXIT], v_dc[MAXIT], v_x[MAXIT], v_hq[MAXIT], v_m[MAXIT], v_g[MAXIT][4], v_cn[MAXIT], v_co[MAXIT];
+    float4 v_dh[MAXIT], v_dc[MAXIT], v_x[MAXIT], v_hq[MAXIT], v_g[MAXIT][4], v_tc[MAXIT], v_co[MAXIT];
+    float v_m[MAXIT];
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int ii = 0; ii < MAXIT; ++ii) {
-      const int e = tid + (it0 + ii) * NT;
-      const int rr = e / H, u = e % H;
+      const int g = tid + (it0 + ii) * NT;
+      const int rr = g / G4, u = (g % G4) * 4;
       const int slot = mb * 32 + rr;
-      v_dh[ii] = v_dc[ii] = v_x[ii] = v_hq[ii] = v_m[ii] = v_cn[ii] = v_co[ii] = 0.f;
-      v_g[ii][0] = v_g[ii][1] = v_g[ii][2] = v_g[ii][3] = 0.f;
+      v_dh[ii] = v_dc[ii] = v_x[ii] = v_hq[ii] = v_tc[ii] = v_co[ii] = z4;
+      v_g[ii][0] = v_g[ii][1] = v_g[ii][2] = v_g[ii][3] = z4;
+      v_m[ii] = 0.f;
       if (it0 + ii < nit && slot < B) {
         if (!last) {
-          v_dh[ii] = ldx<PS>(ws, dhprev_n + (long)slot * H + u);
-          v_dc[ii] = ldx<PS>(ws, dcprev_n + (long)slot * H + u);
+          v_dh[ii] = ld4x<PS>(ws, dhprev_n + (long)slot * H + u);
+          v_dc[ii] = ld4x<PS>(ws, dcprev_n + (long)slot * H + u);
         }
         if (slot < Nc) {
           const int r = off + slot;
-          if (!last) { v_x[ii] = ldx<PS>(ws, X_n + (long)r * H + u); v_m[ii] = mn[r]; }
-          v_hq[ii] = D.dHQ[((long)t * B + r) * H + u];
+          if (!last) { v_x[ii] = ld4x<PS>(ws, X_n + (long)r * H + u); v_m[ii] = mn[r]; }
+          v_hq[ii] = *reinterpret_cast<const float4*>(D.dHQ + ((long)t * B + r) * H + u);
         }
         if (Nc != 0) {
-          const float* g = sg + (long)slot * 4 * H + u;
-          v_g[ii][0] = g[0]; v_g[ii][1] = g[H]; v_g[ii][2] = g[2 * H]; v_g[ii][3] = g[3 * H];
-          v_cn[ii] = cq_new[(long)slot * H + u];
-          v_co[ii] = cq_old[(long)slot * H + u];
+          const float* g0 = sg + (long)slot * 4 * H + u;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v_g[ii][k] = *reinterpret_cast<const float4*>(g0 + k * H);
+          v_tc[ii] = *reinterpret_cast<const float4*>(tcq_t + (long)slot * H + u);
+          v_co[ii] = *reinterpret_cast<const float4*>(cq_old + (long)slot * H + u);
         }
       }
     }
 #pragma unroll
     for (int ii = 0; ii < MAXIT; ++ii) {
       if (it0 + ii >= nit) break;
-      const int e = tid + (it0 + ii) * NT;
-      const int rr = e / H, u = e % H;
+      const int g = tid + (it0 + ii) * NT;
+      const int rr = g / G4, u = (g % G4) * 4;
       const int slot = mb * 32 + rr;
-      const bool wr = ((it0 + ii) % (2 * (H / 32))) == wsel;      // this workgroup publishes this iteration's results
-      float d_i = 0.f, d_f = 0.f, d_g = 0.f, d_o = 0.f;
-      if (slot < B) {
-        const float dh = v_dh[ii] + v_hq[ii] + v_m[ii] * v_x[ii];
-        if (Nc == 0) {
-          // skipped cell: identity on (h, c)
-          if (wr) {
-            stx<PS>(ws, dcprev_c + (long)slot * H + u, v_dc[ii]);
-            stx<PS>(ws, dhprev_c + (long)slot * H + u, dh);
-          }
+      const bool wr = ((g % G4) % npub) == wsel;          // this workgroup publishes this group's results
+      float d4[4][4];                                     // [gate][j]
+      float dcp[4], dhp[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float dh = f4(v_dh[ii], j) + f4(v_hq[ii], j) + v_m[ii] * f4(v_x[ii], j);
+        const float dc_in = f4(v_dc[ii], j);
+        dhp[j] = dh;
+        if (Nc == 0) {                                    // skipped cell: identity on (h, c)
+          dcp[j] = dc_in;
+          d4[0][j] = d4[1][j] = d4[2][j] = d4[3][j] = 0.f;
         } else {
-          const float gi = v_g[ii][0], gf = v_g[ii][1], gg = v_g[ii][2], go = v_g[ii][3];
-          const float tc = tanhf(v_cn[ii]);
-          const float dcn = v_dc[ii] + dh * go * (1.f - tc * tc);
-          d_i = dcn * gg * gi * (1.f - gi);
-          d_f = dcn * v_co[ii] * gf * (1.f - gf);
-          d_g = dcn * gi * (1.f - gg * gg);
-          d_o = dh * tc * go * (1.f - go);
-          if (wr) stx<PS>(ws, dcprev_c + (long)slot * H + u, dcn * gf);
-        }
-        if (wr) {
-          float* o = dsg_g + (long)slot * 4 * H + u;
-          o[0] = d_i; o[H] = d_f; o[2 * H] = d_g; o[3 * H] = d_o;
+          const float gi = f4(v_g[ii][0], j), gf = f4(v_g[ii][1], j), gg = f4(v_g[ii][2], j), go = f4(v_g[ii][3], j);
+          const float tc = f4(v_tc[ii], j);               // tanh(c_new), saved by the forward
+          const float dcn = dc_in + dh * go * (1.f - tc * tc);
+          d4[0][j] = dcn * gg * gi * (1.f - gi);
+          d4[1][j] = dcn * f4(v_co[ii], j) * gf * (1.f - gf);
+          d4[2][j] = dcn * gi * (1.f - gg * gg);
+          d4[3][j] = dh * tc * go * (1.f - go);
+          dcp[j] = dcn * gf;
         }
       }
+      if (slot < B && wr) {
+        st4x<PS>(ws, dcprev_c + (long)slot * H + u, make_float4(dcp[0], dcp[1], dcp[2], dcp[3]));
+        if (Nc == 0) st4x<PS>(ws, dhprev_c + (long)slot * H + u, make_float4(dhp[0], dhp[1], dhp[2], dhp[3]));
+        float* o = dsg_g + (long)slot * 4 * H + u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(o + k * H) = make_float4(d4[k][0], d4[k][1], d4[k][2], d4[k][3]);
+      }
       float* l = dsg_s + rr * LDS_LD + u;
-      l[0] = d_i; l[H] = d_f; l[2 * H] = d_g; l[3 * H] = d_o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(l + k * H) = make_float4(d4[k][0], d4[k][1], d4[k][2], d4[k][3]);
     }
   }
   if (Nc == 0) return;     // uniform per workgroup
@@ -1055,6 +1103,7 @@ static void carve_dir(Carver& cv, DirP& d, int T, int B, int D, int H) {
   d.cq_state = cv.take<float>(2 * (T + 1) * SB);
   d.sgates = cv.take<float>(2 * TB * 4 * H);
   d.HQ = cv.take<float>(TB * H);
+  d.tcq = cv.take<float>(2 * TB * H);
   d.pre = cv.take<float>(2 * TB * 4 * H);
   d.gates = cv.take<float>(2 * TB * 4 * H);
   d.cstate = cv.take<float>(2 * (T + 1) * SB);
