@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--graph", action="store_true", help="force hipGraph replay (default: whichever of eager / graph is faster)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -171,6 +172,27 @@ def main():
         else:
             tr.train_step(x, qmask, umask, label)
 
+    # Eager launches keep the speaker / LSTHM chains as concurrent counter-linked kernels on separate streams; under capture they
+    # are ordered (a graph executor may serialise branches).  Pick the faster launch mode unless one was forced.
+    if graph is not None and not args.graph:
+        def probe(fn, n=6):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n
+        t_graph = probe(step)
+        t_eager = probe(lambda: tr.train_step(x, qmask, umask, label))
+        flag = torch.tensor([1.0 if t_eager < t_graph else 0.0], device=device)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)        # every rank must take the same path
+        if float(flag) > 0:
+            graph = None
+            use_graph = False
+        log(f"probe: graph {t_graph * 1e3:.3f} ms/step, eager {t_eager * 1e3:.3f} ms/step -> {'graph' if use_graph else 'eager'}")
     log("graph captured" if graph is not None else "eager mode")
     for _ in range(max(0, args.warmup - n_eager_warm)):
         step()

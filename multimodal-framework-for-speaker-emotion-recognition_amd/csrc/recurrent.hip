@@ -39,7 +39,7 @@ struct DirP {
   float* out;
   const float* dout;
   // backward scratch
-  float *dgates, *dc_carry, *dA, *attacc, *dHQ;
+  float *dgates, *dc_carry, *dA, *attacc, *dHQ, *dHQp;   // dHQp[2][T][B][H]: dgates_m @ S_m per step (pipelined mode)
   float *dsg, *Xb, *dhprev, *dcprev;   // Xb[2][B][H]: grad wrt q_{t-1}[b, party_t[b]], ping-pong by step parity
   float* mnext;                        // [T][B]: qmask_t[r][party_{t+1}[r]] (0 at the last step)
 };
@@ -167,14 +167,21 @@ __device__ __forceinline__ void zero8(float* a) {
 // (zeroed by a memset node before the launch); `target` = nwg * (index of this barrier + 1).  Every spin is bounded: on
 // time-out (or when another workgroup has already given up) the abort word is set and every workgroup leaves the kernel.
 constexpr unsigned SPIN_LIMIT = 1u << 22;
-__device__ __forceinline__ bool dir_barrier(unsigned* cnt, unsigned* abortw, unsigned target, int* lds_ok) {
+// `cnt2 / target2` (optional): additionally wait until ANOTHER kernel's counter has reached target2 -- the cross-kernel link
+// of the pipelined chains (the LSTHM chain consumes h_q[t] from the concurrently running speaker chain; the speaker BPTT
+// consumes dHQ[t] from the LSTHM BPTT).  `wait` = false: arrive only (last step of a producer).
+__device__ __forceinline__ bool dir_barrier(unsigned* cnt, unsigned* abortw, unsigned target, int* lds_ok,
+                                            const unsigned* cnt2 = nullptr, unsigned target2 = 0, bool wait = true) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its write-through stores
   __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add((gu32*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cnt) __hip_atomic_fetch_add((gu32*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int ok = 1;
     unsigned spins = 0;
-    while (__hip_atomic_load((const gu32*)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    while (wait) {
+      const bool a = !cnt || __hip_atomic_load((const gu32*)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
+      const bool b = !cnt2 || __hip_atomic_load((const gu32*)cnt2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target2;
+      if (a && b) break;
       __builtin_amdgcn_s_sleep(1);
       if ((++spins & 255u) == 0u) {
         if (spins > SPIN_LIMIT || __hip_atomic_load((const gu32*)abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
@@ -446,8 +453,8 @@ __global__ __launch_bounds__(NT) void spk_fwd_persist(CellK P) {
   STAMP_INIT();
   for (int t = 0; t < P.T; ++t) {
     spk_fwd_body<true, NP>(P, D, ws, t, c, u0, mb, blockIdx.x == 0, bpre, red, tile);
-    if (t + 1 == P.T) break;
-    if (!dir_barrier(P.sync + SYNC_SPK_FWD + dir, P.sync + SYNC_ABORT, nwg * (unsigned)(t + 1), lds_ok)) return;
+    // the counter also tells the concurrently running LSTHM kernel that h_q[t] is published: arrive after the last step too
+    if (!dir_barrier(P.sync + SYNC_SPK_FWD + dir, P.sync + SYNC_ABORT, nwg * (unsigned)(t + 1), lds_ok, nullptr, 0, t + 1 < P.T)) return;
     STAMP_ACC(3);
   }
   STAMP_DUMP(P, 16, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
@@ -461,11 +468,14 @@ struct LsthmFwdB {
   __device__ __forceinline__ void operator()(int n, int k, float* b) const {
     const long wrow = (long)(n >> 3) * H + u0 + (n & 7);
     if (k < H) load8(D.U[m] + wrow * H + k, b);
-    else load8(D.V[m] + wrow * H + (k - H), b);
+    else if (k < 2 * H) load8(D.V[m] + wrow * H + (k - H), b);
+    else load8(D.S[m] + wrow * H + (k - 2 * H), b);          // WITHS only (K = 3H)
   }
 };
 
-template <bool PS, int NP>
+// WITHS: the speaker term S h_q[t] is part of the step (K = 3H) instead of the hoisted pre-activation GEMM, so that the chain
+// can run CONCURRENTLY with the speaker chain that produces h_q (pipelined persistent kernels).
+template <bool PS, int NP, bool WITHS = false>
 __device__ __forceinline__ void lsthm_gates_body(const CellK& P, const DirP& D, const WS& ws, int t, int m, int u0, int mb,
                                                  const float (*bpre)[8], float* red, float* tile) {
   const int H = P.H, B = P.B, T = P.T;
@@ -483,7 +493,10 @@ __device__ __forceinline__ void lsthm_gates_body(const CellK& P, const DirP& D, 
     if (b < B) {
       const float* pr = D.pre + ((long)m * T * B + (long)t * B + b) * 4 * H + u;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) pre4[g] = pr[g * H] + D.Ub[m][g * H + u] + D.Vb[m][g * H + u];
+      for (int g = 0; g < 4; ++g) {
+        pre4[g] = pr[g * H] + D.Ub[m][g * H + u] + D.Vb[m][g * H + u];
+        if (WITHS) pre4[g] += D.Sb[m][g * H + u];
+      }
       c_prev = ldx<PS>(ws, c_old + (long)b * H + u);
       tau = D.rev ? D.rev[(long)t * B + b] : t;
     }
@@ -493,10 +506,11 @@ __device__ __forceinline__ void lsthm_gates_body(const CellK& P, const DirP& D, 
     if (b >= B) { zero8(a); return; }
     const float* row = hz_old + (long)b * 3 * H;
     if (k < H) load8x<PS>(ws, row + m * H + k, a);
-    else load8x<PS>(ws, row + 2 * H + (k - H), a);
+    else if (k < 2 * H) load8x<PS>(ws, row + 2 * H + (k - H), a);
+    else load8x<PS>(ws, D.HQ + ((long)t * B + b) * H + (k - 2 * H), a);
   };
   STAMP_ACC(0);
-  wg_mm32<NP>(2 * H, aload, LsthmFwdB{D, m, u0, H}, bpre, red, tile);
+  wg_mm32<NP>(WITHS ? 3 * H : 2 * H, aload, LsthmFwdB{D, m, u0, H}, bpre, red, tile);
   STAMP_ACC(1);
   if (tid < 256) {
     const int rr = tid >> 3, uu = tid & 7;
@@ -589,7 +603,8 @@ __global__ __launch_bounds__(NT) void lsthm_fwd_z(CellK P, int t) {
   lsthm_z_body<false, 0>(P, P.d[blockIdx.y], ws, t, blockIdx.x, att, smem);
 }
 
-// persistent launch: grid (H/8, 2 streams, ndir*nmb); two barriers per step (gates -> z -> next gates)
+// persistent launch: grid (H/8, 2 streams, ndir*nmb); two barriers per step (gates -> z -> next gates).  Runs concurrently with
+// spk_fwd_persist: step t starts only once the speaker counter shows h_q[t] published (checked inside the previous barrier).
 template <int NP>
 __global__ __launch_bounds__(NT) void lsthm_fwd_persist(CellK P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -602,20 +617,24 @@ __global__ __launch_bounds__(NT) void lsthm_fwd_persist(CellK P) {
   const DirP& D = P.d[dir];
   const int m = blockIdx.y, u0 = blockIdx.x * 8;
   const unsigned nwg = gridDim.x * gridDim.y * P.nmb;
+  const unsigned nwg_spk = nwg;                                          // spk_fwd_persist uses the same grid
   const int w = (mb * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;    // linear workgroup index inside the direction
   float bpre[NP][8];
-  preload_b<NP>(2 * P.H, LsthmFwdB{D, m, u0, P.H}, bpre);
+  preload_b<NP>(3 * P.H, LsthmFwdB{D, m, u0, P.H}, bpre);
   att_prepare(D, P.H, att, red);
+  unsigned* cnt = P.sync + SYNC_LSTHM_FWD + dir;
+  const unsigned* spk = P.sync + SYNC_SPK_FWD + dir;
   unsigned nbar = 0;
+  if (!dir_barrier(nullptr, P.sync + SYNC_ABORT, 0, lds_ok, spk, nwg_spk)) return;      // h_q[0] published
   STAMP_INIT();
   for (int t = 0; t < P.T; ++t) {
-    lsthm_gates_body<true, NP>(P, D, ws, t, m, u0, mb, bpre, red, tile);   // stamps 0 (loads) 1 (mm) 2 (epilogue)
-    if (!dir_barrier(P.sync + SYNC_LSTHM_FWD + dir, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
+    lsthm_gates_body<true, NP, true>(P, D, ws, t, m, u0, mb, bpre, red, tile);   // stamps 0 (loads) 1 (mm) 2 (epilogue)
+    if (!dir_barrier(cnt, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
     STAMP_ACC(3);
-    for (int b = w; b < P.B; b += (int)nwg) lsthm_z_body<true, 8 * NP * NP>(P, D, ws, t, b, att, red);   // NP = H/64, JC = H*H/NT = 8 NP^2
+    for (int b = w; b < P.B; b += (int)nwg) lsthm_z_body<true, (128 * NP / 3) * (128 * NP / 3) / NT>(P, D, ws, t, b, att, red);   // NP = 3H/128, JC = H*H/NT
     STAMP_ACC(4);
     if (t + 1 == P.T) break;
-    if (!dir_barrier(P.sync + SYNC_LSTHM_FWD + dir, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
+    if (!dir_barrier(cnt, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok, spk, nwg_spk * (unsigned)(t + 2))) return;
     STAMP_ACC(5);
   }
   STAMP_DUMP(P, 24, blockIdx.x == 3 && blockIdx.y == 1 && blockIdx.z == 0);
@@ -752,13 +771,15 @@ __device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D
       stx<PS>(ws, dg + 3 * H, dc * gi * (1.f - gc * gc));
       D.dc_carry[(long)m * SA + (long)b * H + i] = dc * gf;
     }
-    D.dHQ[rowt * H + i] = dhq;
+    stx<PS>(ws, D.dHQ + rowt * H + i, dhq);
   }
   __syncthreads();     // scratch is reused by the next row / phase
 }
 
 // Matvec phase, role (product p, output slice n0..n0+31, row block mb):
-// dA[p][b][n] = sum_col dgates_m[t][b][col] * Wp[col][n] with p = 0: U_l, 1: V_l, 2: U_a, 3: V_a (m = p>>1).
+// dA[p][b][n] = sum_col dgates_m[t][b][col] * Wp[col][n] with p = 0: U_l, 1: V_l, 2: U_a, 3: V_a (m = p>>1);
+// p = 4, 5 (pipelined persistent mode only): dHQp[m][t][b][n] = dgates_m[t] @ S_m, the speaker-state gradient that the
+// concurrently running speaker BPTT consumes (instead of a hoisted GEMM after the chain).
 struct LsthmBwdB {
   const float* Wp; int n0, H;
   __device__ __forceinline__ void operator()(int n, int k, float* bb) const {
@@ -770,9 +791,9 @@ struct LsthmBwdB {
 template <bool PS, int NP>
 __device__ __forceinline__ void lsthm_bwd_mat_body(const CellK& P, const DirP& D, const WS& ws, int t, int p, int n0, int mb,
                                                    const float (*bpre)[8], float* red, float* tile) {
-  const int m = p >> 1;
+  const int m = p < 4 ? p >> 1 : p - 4;
   const int H = P.H, B = P.B, T = P.T;
-  const float* Wp = (p & 1) ? D.V[m] : D.U[m];
+  const float* Wp = p >= 4 ? D.S[m] : ((p & 1) ? D.V[m] : D.U[m]);
   const float* dg = D.dgates + ((long)m * T * B + (long)t * B) * 4 * H;
   auto aload = [&](int r, int k, float* a) {
     const int b = mb * 32 + r;
@@ -785,7 +806,10 @@ __device__ __forceinline__ void lsthm_bwd_mat_body(const CellK& P, const DirP& D
     const int idx = threadIdx.x + e * NT;
     const int rr = idx >> 5, n = idx & 31;
     const int b = mb * 32 + rr;
-    if (b < B) stx<PS>(ws, D.dA + ((long)p * B + b) * H + n0 + n, tile[idx]);
+    if (b < B) {
+      float* dst = p < 4 ? D.dA + ((long)p * B + b) * H : D.dHQp + (((long)m * T + t) * B + b) * H;
+      stx<PS>(ws, dst + n0 + n, tile[idx]);
+    }
   }
 }
 
@@ -804,8 +828,9 @@ __global__ __launch_bounds__(NT) void lsthm_bwd_mat(CellK P, int t) {
   lsthm_bwd_mat_body<false, 0>(P, P.d[dir], ws, t, blockIdx.y, blockIdx.x * 32, mb, nullptr, smem, smem + RED_FLOATS);
 }
 
-// persistent launch: grid (nwg, 1, ndir), nwg >= (H/32)*4*nmb.  Row phase: rows round-robin over all nwg workgroups;
-// matvec phase: the first (H/32)*4*nmb workgroups.  Two barriers per step.
+// persistent launch: grid (nwg, 1, ndir), nwg >= (H/32)*6*nmb.  Row phase: rows round-robin over all nwg workgroups;
+// matvec phase: the first (H/32)*6*nmb workgroups (4 carry products + 2 speaker-gradient products).  Two barriers per step;
+// the counter doubles as the "dHQ[t] is complete" signal for the concurrently running speaker BPTT (value 2*(T-t)*nwg).
 template <int NP>
 __global__ __launch_bounds__(NT) void lsthm_bwd_persist(CellK P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -820,22 +845,24 @@ __global__ __launch_bounds__(NT) void lsthm_bwd_persist(CellK P) {
   const unsigned nwg = gridDim.x;
   const int w = blockIdx.x;
   const int nsl = H / 32;
-  const bool has_mat = w < nsl * 4 * P.nmb;
-  const int mb = w / (nsl * 4), p = (w / nsl) % 4, n0 = (w % nsl) * 32;
+  const bool has_mat = w < nsl * 6 * P.nmb;
+  const int mb = w / (nsl * 6), p = (w / nsl) % 6, n0 = (w % nsl) * 32;
   float bpre[NP][8];
-  if (has_mat) preload_b<NP>(4 * H, LsthmBwdB{(p & 1) ? D.V[p >> 1] : D.U[p >> 1], n0, H}, bpre);
+  if (has_mat) {
+    const float* Wp = p >= 4 ? D.S[p - 4] : ((p & 1) ? D.V[p >> 1] : D.U[p >> 1]);
+    preload_b<NP>(4 * H, LsthmBwdB{Wp, n0, H}, bpre);
+  }
   att_prepare(D, H, att, red);
   unsigned nbar = 0;
   STAMP_INIT();
   for (int t = P.T - 1; t >= 0; --t) {
     for (int b = w; b < P.B; b += (int)nwg) lsthm_bwd_row_body<true, 2 * NP * NP>(P, D, ws, t, b, att, red);   // NP = H/32, JC = H*H/NT = 2 NP^2
     STAMP_ACC(0);
-    if (t == 0) break;
     if (!dir_barrier(P.sync + SYNC_LSTHM_BWD + dir, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
     STAMP_ACC(1);
-    if (has_mat) lsthm_bwd_mat_body<true, NP>(P, D, ws, t, p, n0, mb, bpre, red, tile);
+    if (has_mat && (t > 0 || p >= 4)) lsthm_bwd_mat_body<true, NP>(P, D, ws, t, p, n0, mb, bpre, red, tile);
     STAMP_ACC(2);
-    if (!dir_barrier(P.sync + SYNC_LSTHM_BWD + dir, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
+    if (!dir_barrier(P.sync + SYNC_LSTHM_BWD + dir, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok, nullptr, 0, t > 0)) return;
     STAMP_ACC(3);
   }
   STAMP_DUMP(P, 32, blockIdx.x == 1 && blockIdx.z == 0);
@@ -851,7 +878,7 @@ __global__ __launch_bounds__(NT) void lsthm_bwd_persist(CellK P) {
 // Prologue: every workgroup of the cell rebuilds the LSTMCell gate gradients for its 32 slots (element-wise, all loads issued
 // up front: one memory round trip), then raw = dsg @ W on the MFMA.  The redundant element-wise results are written to
 // global memory by exactly one workgroup per iteration slice (wsel), so no workgroup carries all the stores.
-template <bool PS, int NP>
+template <bool PS, int NP, bool WITHP = false>
 __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, const WS& ws, int t, int p, int n0, int mb, int wsel,
                                              const float (*bpre)[8], float* red, float* tile, float* dsg_s) {
   const int c = p >> 1;
@@ -919,7 +946,14 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, cons
         if (slot < Nc) {
           const int r = off + slot;
           if (!last) { v_x[ii] = ld4x<PS>(ws, X_n + (long)r * H + u); v_m[ii] = mn[r]; }
-          v_hq[ii] = *reinterpret_cast<const float4*>(D.dHQ + ((long)t * B + r) * H + u);
+          if (WITHP) {       // pipelined: dHQ[t] = dout_hq (row phase) + dgates_l S_l + dgates_a S_a (matvec phase), all just published
+            const float4 q0 = ld4x<PS>(ws, D.dHQ + ((long)t * B + r) * H + u);
+            const float4 q1 = ld4x<PS>(ws, D.dHQp + (((long)0 * T + t) * B + r) * H + u);
+            const float4 q2 = ld4x<PS>(ws, D.dHQp + (((long)1 * T + t) * B + r) * H + u);
+            v_hq[ii] = make_float4(q0.x + q1.x + q2.x, q0.y + q1.y + q2.y, q0.z + q1.z + q2.z, q0.w + q1.w + q2.w);
+          } else {
+            v_hq[ii] = *reinterpret_cast<const float4*>(D.dHQ + ((long)t * B + r) * H + u);
+          }
         }
         if (Nc != 0) {
           const float* g0 = sg + (long)slot * 4 * H + u;
@@ -1000,9 +1034,10 @@ __global__ __launch_bounds__(NT) void spk_bwd_step(CellK P, int t) {
                          smem + RED_FLOATS + 1024);
 }
 
-// persistent launch: same grid, one barrier per step
+// persistent launch: same grid, one barrier per step.  Runs concurrently with lsthm_bwd_persist: step t starts once that kernel's
+// counter shows dHQ[t] complete (value 2*(T-t)*nwg_l; checked inside the previous step's barrier).
 template <int NP>
-__global__ __launch_bounds__(NT) void spk_bwd_persist(CellK P) {
+__global__ __launch_bounds__(NT) void spk_bwd_persist(CellK P, unsigned nwg_l) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const WS ws = make_ws(P.wsbase, P.wsbytes);
   float* red = smem;
@@ -1015,13 +1050,16 @@ __global__ __launch_bounds__(NT) void spk_bwd_persist(CellK P) {
   const unsigned nwg = gridDim.x * gridDim.y * P.nmb;
   float bpre[NP][8];
   preload_b<NP>(4 * P.H, LsthmBwdB{(p & 1) ? D.Whh[p >> 1] : D.Wih[p >> 1], n0, P.H}, bpre);
+  unsigned* cnt = P.sync + SYNC_SPK_BWD + dir;
+  const unsigned* lcnt = P.sync + SYNC_LSTHM_BWD + dir;
   unsigned nbar = 0;
+  if (!dir_barrier(nullptr, P.sync + SYNC_ABORT, 0, lds_ok, lcnt, 2u * nwg_l)) return;          // dHQ[T-1] complete
   STAMP_INIT();
   for (int t = P.T - 1; t >= 0; --t) {
-    spk_bwd_body<true, NP>(P, D, ws, t, p, n0, mb, (int)((p & 1) * gridDim.x + blockIdx.x), bpre, red, tile, dsg_s);
+    spk_bwd_body<true, NP, true>(P, D, ws, t, p, n0, mb, (int)((p & 1) * gridDim.x + blockIdx.x), bpre, red, tile, dsg_s);
     STAMP_ACC(2);
     if (t == 0) break;
-    if (!dir_barrier(P.sync + SYNC_SPK_BWD + dir, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
+    if (!dir_barrier(cnt, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok, lcnt, 2u * nwg_l * (unsigned)(P.T - t + 1))) return;
     STAMP_ACC(3);
   }
   STAMP_DUMP(P, 40, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
@@ -1113,6 +1151,7 @@ static void carve_dir(Carver& cv, DirP& d, int T, int B, int D, int H) {
   d.dA = cv.take<float>(4 * SB);
   d.attacc = cv.take<float>((size_t)B * 2 * H);
   d.dHQ = cv.take<float>(TB * H);
+  d.dHQp = cv.take<float>(2 * TB * H);
   d.dsg = cv.take<float>(2 * TB * 4 * H);
   d.Xb = cv.take<float>(2 * SB);
   d.dhprev = cv.take<float>(2 * 2 * SB);
@@ -1241,9 +1280,9 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   for (int i = 0; i < d.ndir; ++i) fill_params(K.d[i], d.dir[i]);
   const size_t mm_lds = (RED_FLOATS + 1024) * sizeof(float);
   const long fwd_wgs = (long)(H / 8) * 2 * d.ndir * K.nmb;
-  const bool persist = persist_ok(H, fwd_wgs);
+  const bool persist = persist_ok(H, 2 * fwd_wgs);        // speaker and LSTHM kernels run concurrently (pipelined)
   const size_t p_lds = persist_lds(mm_lds + (2 * (size_t)H + 16) * sizeof(float) + 64);
-  if (phases & MSER_PHASE_SPEAKER_FWD) {
+  if (phases & MSER_PHASE_FWD_PREP) {
   MSER_CHECK_HIP(hipMemsetAsync(h.sync, 0, SYNC_WORDS * sizeof(unsigned), s));
   for (int i = 0; i < d.ndir; ++i) {
     DirP& k = K.d[i];
@@ -1261,6 +1300,8 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
     if (k.rev)   // rows at and beyond len_b stay zero in the reversed output (pad_sequence, :410)
       MSER_CHECK_HIP(hipMemset2DAsync(k.out, d.ldo * sizeof(float), 0, 4 * (size_t)H * sizeof(float), TB, s));
   }
+  }
+  if (phases & MSER_PHASE_SPEAKER_FWD) {
   // ---- speaker chain
   if (persist) {
     ProfScope ps(MSER_PROF_SPK_FWD, s);
@@ -1296,10 +1337,12 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       mser_gemm_desc g = gd(xs[m], lds[m], 1, k.W[m], 1, D, pre, 4 * H, (int)TB, 4 * H, D);
       g.bias = k.Wb[m];
       MSER_TRY(gemm(g, s));
-      g = gd(k.HQ, H, 1, k.S[m], 1, H, pre, 4 * H, (int)TB, 4 * H, H);
-      g.bias = k.Sb[m];
-      g.flags = MSER_GEMM_ACCUM;
-      MSER_TRY(gemm(g, s));
+      if (!persist) {      // the pipelined persistent kernel adds S h_q[t] (+ S.bias) inside the step instead
+        g = gd(k.HQ, H, 1, k.S[m], 1, H, pre, 4 * H, (int)TB, 4 * H, H);
+        g.bias = k.Sb[m];
+        g.flags = MSER_GEMM_ACCUM;
+        MSER_TRY(gemm(g, s));
+      }
     }
   }
   // ---- LSTHM chain
@@ -1307,11 +1350,11 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   if (persist) {
     ProfScope ps(MSER_PROF_LSTHM_FWD_GATES, s);
     if (H == 128) {
-      MSER_TRY(allow_lds((const void*)lsthm_fwd_persist<2>, p_lds));
-      hipLaunchKernelGGL(lsthm_fwd_persist<2>, dim3(H / 8, 2, d.ndir * K.nmb), dim3(NT), p_lds, s, K);
+      MSER_TRY(allow_lds((const void*)lsthm_fwd_persist<3>, p_lds));
+      hipLaunchKernelGGL(lsthm_fwd_persist<3>, dim3(H / 8, 2, d.ndir * K.nmb), dim3(NT), p_lds, s, K);
     } else {
-      MSER_TRY(allow_lds((const void*)lsthm_fwd_persist<4>, p_lds));
-      hipLaunchKernelGGL(lsthm_fwd_persist<4>, dim3(H / 8, 2, d.ndir * K.nmb), dim3(NT), p_lds, s, K);
+      MSER_TRY(allow_lds((const void*)lsthm_fwd_persist<6>, p_lds));
+      hipLaunchKernelGGL(lsthm_fwd_persist<6>, dim3(H / 8, 2, d.ndir * K.nmb), dim3(NT), p_lds, s, K);
     }
   } else {
     MSER_TRY(allow_lds((const void*)lsthm_fwd_gates, mm_lds));
@@ -1342,18 +1385,22 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   for (int i = 0; i < d.ndir; ++i) fill_params(K.d[i], d.dir[i]);
   const size_t mm_lds = (RED_FLOATS + 1024) * sizeof(float);
   const size_t row_lds = row_lds_bytes(H);
-  const int mat_wgs = (H / 32) * 4 * K.nmb;
-  const int SPLITK = 16;
-  if (phases & MSER_PHASE_LSTHM_BWD) {
-  for (int i = 0; i < d.ndir; ++i) {
-    DirP& k = K.d[i];
-    MSER_CHECK_HIP(hipMemsetAsync(k.dc_carry, 0, 2 * SB * sizeof(float), s));
-    MSER_CHECK_HIP(hipMemsetAsync(k.attacc, 0, (size_t)B * 2 * H * sizeof(float), s));
-  }
-  MSER_CHECK_HIP(hipMemsetAsync(h.sync + SYNC_LSTHM_BWD, 0, 4 * sizeof(unsigned), s));
-  const int bwd_nwg = mat_wgs > 32 ? mat_wgs : 32;          // row phase spreads the B rows over all of them
-  const bool persist = persist_ok(H, (long)bwd_nwg * d.ndir);
+  const int spk_wgs = (H / 32) * 4 * K.nmb;                  // speaker BPTT: 4 products
+  const int mat_wgs = (H / 32) * 6 * K.nmb;                  // LSTHM BPTT matvec phase: 4 carry products + 2 speaker-gradient products
+  const int bwd_nwg = mat_wgs > 32 ? mat_wgs : 32;           // row phase spreads the B rows over all of them
+  // both BPTT kernels run concurrently (pipelined): all their workgroups must be co-resident
+  const bool persist = persist_ok(H, ((long)bwd_nwg + spk_wgs) * d.ndir);
   const size_t p_lds = persist_lds(mm_lds + (2 * (size_t)H + 16) * sizeof(float) + 64);
+  const int SPLITK = 16;
+  if (phases & MSER_PHASE_BWD_PREP) {
+    for (int i = 0; i < d.ndir; ++i) {
+      DirP& k = K.d[i];
+      MSER_CHECK_HIP(hipMemsetAsync(k.dc_carry, 0, 2 * SB * sizeof(float), s));
+      MSER_CHECK_HIP(hipMemsetAsync(k.attacc, 0, (size_t)B * 2 * H * sizeof(float), s));
+    }
+    MSER_CHECK_HIP(hipMemsetAsync(h.sync + SYNC_LSTHM_BWD, 0, 4 * sizeof(unsigned), s));
+  }
+  if (phases & MSER_PHASE_LSTHM_BWD) {
   // ---- LSTHM chain, reverse time
   if (persist) {
     ProfScope ps(MSER_PROF_LSTHM_BWD_ROW, s);
@@ -1392,10 +1439,11 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       const float* dg = k.dgates + (long)m * TB * 4 * H;
       mser_gemm_desc g;
       if (phases & MSER_PHASE_LSTHM_BWD_DX) {
-        // dHQ += dg S_m
-        g = gd(dg, 4 * H, 1, k.S[m], H, 1, k.dHQ, H, (int)TB, H, 4 * H);
-        g.flags = MSER_GEMM_ACCUM;
-        MSER_TRY(gemm(g, s));
+        if (!persist) {    // dHQ += dg S_m (the pipelined persistent kernels exchange this per step instead)
+          g = gd(dg, 4 * H, 1, k.S[m], H, 1, k.dHQ, H, (int)TB, H, 4 * H);
+          g.flags = MSER_GEMM_ACCUM;
+          MSER_TRY(gemm(g, s));
+        }
         // dx (direction order) = dg W_m
         if (!k.rev) {
           g = gd(dg, 4 * H, 1, k.W[m], D, 1, dxs[m], D, (int)TB, D, 4 * H);
@@ -1433,15 +1481,15 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   if (!(phases & MSER_PHASE_SPEAKER_BWD)) return 0;
   // ---- speaker chain, reverse time
   const size_t spk_lds = mm_lds + 32 * (4 * (size_t)H + 4) * sizeof(float);
-  if (persist_ok(H, (long)mat_wgs * d.ndir)) {
+  if (persist) {
     const size_t ps_lds = persist_lds(spk_lds + 64);
     ProfScope ps(MSER_PROF_SPK_BWD, s);
     if (H == 128) {
       MSER_TRY(allow_lds((const void*)spk_bwd_persist<4>, ps_lds));
-      hipLaunchKernelGGL(spk_bwd_persist<4>, dim3(H / 32, 4, d.ndir * K.nmb), dim3(NT), ps_lds, s, K);
+      hipLaunchKernelGGL(spk_bwd_persist<4>, dim3(H / 32, 4, d.ndir * K.nmb), dim3(NT), ps_lds, s, K, (unsigned)bwd_nwg);
     } else {
       MSER_TRY(allow_lds((const void*)spk_bwd_persist<8>, ps_lds));
-      hipLaunchKernelGGL(spk_bwd_persist<8>, dim3(H / 32, 4, d.ndir * K.nmb), dim3(NT), ps_lds, s, K);
+      hipLaunchKernelGGL(spk_bwd_persist<8>, dim3(H / 32, 4, d.ndir * K.nmb), dim3(NT), ps_lds, s, K, (unsigned)bwd_nwg);
     }
   } else {
     MSER_TRY(allow_lds((const void*)spk_bwd_step, spk_lds));
@@ -1605,19 +1653,27 @@ size_t mser_marn_cell_workspace_bytes(int32_t T, int32_t B, int32_t D, int32_t H
 
 int mser_marn_cell_fwd(const mser_cell_desc* d, mser_stream_t stream) {
   if (!d) { set_error("mser_marn_cell_fwd: null descriptor"); return -1; }
-  return marn_cell_fwd(*d, (hipStream_t)stream, MSER_PHASE_SPEAKER_FWD | MSER_PHASE_LSTHM_FWD);
+  return marn_cell_fwd(*d, (hipStream_t)stream, MSER_PHASE_FWD_PREP | MSER_PHASE_SPEAKER_FWD | MSER_PHASE_LSTHM_FWD);
 }
 
 int mser_marn_cell_bwd(const mser_cell_desc* d, mser_stream_t stream) {
   if (!d) { set_error("mser_marn_cell_bwd: null descriptor"); return -1; }
-  return marn_cell_bwd(*d, (hipStream_t)stream, MSER_PHASE_LSTHM_BWD | MSER_PHASE_LSTHM_BWD_DX | MSER_PHASE_LSTHM_WGRAD | MSER_PHASE_SPEAKER_BWD);
+  return marn_cell_bwd(*d, (hipStream_t)stream, MSER_PHASE_BWD_PREP | MSER_PHASE_LSTHM_BWD | MSER_PHASE_LSTHM_BWD_DX | MSER_PHASE_LSTHM_WGRAD | MSER_PHASE_SPEAKER_BWD);
+}
+
+int mser_marn_cell_pipelined(int32_t B, int32_t H, int32_t ndir) {
+  const int nmb = cdiv(B, 32);
+  const long fwd = 2L * (H / 8) * 2 * ndir * nmb;
+  const int mat = (H / 32) * 6 * nmb;
+  const long bwd = ((long)(mat > 32 ? mat : 32) + (H / 32) * 4 * nmb) * ndir;
+  return (persist_ok(H, fwd) && persist_ok(H, bwd)) ? 1 : 0;
 }
 
 int mser_marn_cell_run(const mser_cell_desc* d, int32_t phases, mser_stream_t stream) {
   if (!d) { set_error("mser_marn_cell_run: null descriptor"); return -1; }
-  if (phases & (MSER_PHASE_SPEAKER_FWD | MSER_PHASE_LSTHM_FWD))
+  if (phases & (MSER_PHASE_FWD_PREP | MSER_PHASE_SPEAKER_FWD | MSER_PHASE_LSTHM_FWD))
     MSER_TRY(marn_cell_fwd(*d, (hipStream_t)stream, phases));
-  if (phases & (MSER_PHASE_LSTHM_BWD | MSER_PHASE_LSTHM_BWD_DX | MSER_PHASE_LSTHM_WGRAD | MSER_PHASE_SPEAKER_BWD))
+  if (phases & (MSER_PHASE_BWD_PREP | MSER_PHASE_LSTHM_BWD | MSER_PHASE_LSTHM_BWD_DX | MSER_PHASE_LSTHM_WGRAD | MSER_PHASE_SPEAKER_BWD))
     MSER_TRY(marn_cell_bwd(*d, (hipStream_t)stream, phases));
   return 0;
 }

@@ -78,6 +78,7 @@ SIGNATURES = {
     "mser_marn_cell_fwd": (C.c_int, [C.POINTER(CellDesc), _vp]),
     "mser_marn_cell_bwd": (C.c_int, [C.POINTER(CellDesc), _vp]),
     "mser_marn_cell_run": (C.c_int, [C.POINTER(CellDesc), _i32, _vp]),
+    "mser_marn_cell_pipelined": (C.c_int, [_i32, _i32, _i32]),
     "mser_lsthm_step_fwd": (C.c_int, [_vp] * 16 + [_i32] * 5 + [_vp]),
     "mser_rank1_attention_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "mser_logsoftmax_tb_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),

@@ -49,6 +49,7 @@ class ModelCtx:
     cell_ws: Tensor = None
     cell_dirs: list = None
     cell_desc: object = None
+    pipelined: bool = False
     A1: Tensor = None
     A2: Tensor = None
     xa: list = None
@@ -140,12 +141,17 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
         c.xa[3] = F_.xattn_fwd(c.x_l, w, c.A2, v2, P("crossatt_a2l_1.Wq"), P("crossatt_a2l_1.Wk"), P("crossatt_a2l_1.Wv"), lay, lay,
                                c.Hcat[:, 9 * H:10 * H], hh)
 
+    # Counter-linked concurrent kernels need REAL concurrency: a hipGraph executor may serialise parallel branches in an order that
+    # starts the consumer first (it would spin until its bounded time-out), so under stream capture the phases are ordered instead.
+    pipelined = (side is not None and ops.marn_cell_pipelined(B, H, 2) and not torch.cuda.is_current_stream_capturing())
+    c.pipelined = pipelined
+    ops.marn_cell_run(desc, ops.PHASE_FWD_PREP)
     if side is not None:
         s_audio, s_spk, s_xa, s_xb = side
         for st in side:
             st.wait_stream(cur)
         with torch.cuda.stream(s_spk):
-            ops.marn_cell_run(desc, ops.PHASE_SPEAKER_FWD)      # qmask-only chain: overlaps the encoders
+            ops.marn_cell_run(desc, ops.PHASE_SPEAKER_FWD)      # qmask-only chain: overlaps the encoders AND the LSTHM chain
         with torch.cuda.stream(s_audio):
             audio_branch()
         text_branch()
@@ -156,8 +162,12 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
             xattn_a()
         with torch.cuda.stream(s_xb):
             xattn_b()
+        if not pipelined:
+            cur.wait_stream(s_spk)
+        # pipelined: the LSTHM kernel follows the speaker kernel step by step through a device-side counter; both are
+        # persistent (64 + 64 workgroups), the attention GEMMs fill the other CUs
+        ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD)
         cur.wait_stream(s_spk)
-        ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD)            # 64 persistent workgroups; the attention GEMMs fill the other CUs
         cur.wait_stream(s_xa)
         cur.wait_stream(s_xb)
     else:
@@ -270,16 +280,23 @@ def marn1_backward(c: ModelCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: Opt
             xattn_a_bwd()
         with torch.cuda.stream(s_xb):
             xattn_b_bwd()
+        ops.marn_cell_run(desc, ops.PHASE_BWD_PREP)
+        if c.pipelined:
+            s_spk.wait_stream(cur)
         ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD)               # BPTT chain (persistent kernel, 64 CUs)
+        if c.pipelined:
+            with torch.cuda.stream(s_spk):                         # speaker BPTT follows the LSTHM BPTT step by step (counter-linked)
+                ops.marn_cell_run(desc, ops.PHASE_SPEAKER_BWD)
         cur.wait_stream(s_xa)
         cur.wait_stream(s_xb)
         merge_dx()
-        ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD_DX)            # dHQ, dx_l += dg W_l, dx_a += dg W_a
-        s_spk.wait_stream(cur)
+        ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD_DX)            # dx_l += dg W_l, dx_a += dg W_a (and dHQ when not pipelined)
         s_audio.wait_stream(cur)
         s_xa.wait_stream(cur)
-        with torch.cuda.stream(s_spk):
-            ops.marn_cell_run(desc, ops.PHASE_SPEAKER_BWD)         # speaker BPTT: touches only speaker-cell gradients
+        if not c.pipelined:
+            s_spk.wait_stream(cur)
+            with torch.cuda.stream(s_spk):
+                ops.marn_cell_run(desc, ops.PHASE_SPEAKER_BWD)     # speaker BPTT: touches only speaker-cell gradients
         with torch.cuda.stream(s_xa):
             ops.marn_cell_run(desc, ops.PHASE_LSTHM_WGRAD)         # LSTHM parameter gradients: nothing downstream reads them
         with torch.cuda.stream(s_audio):
@@ -290,7 +307,7 @@ def marn1_backward(c: ModelCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: Opt
     else:
         xattn_a_bwd()
         xattn_b_bwd()
-        ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD)
+        ops.marn_cell_run(desc, ops.PHASE_BWD_PREP | ops.PHASE_LSTHM_BWD)
         merge_dx()
         ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD_DX | ops.PHASE_LSTHM_WGRAD | ops.PHASE_SPEAKER_BWD)
         text_branch()

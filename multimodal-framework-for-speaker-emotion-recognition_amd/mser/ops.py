@@ -278,6 +278,11 @@ def set_option(key: int, value: int) -> None:
 
 
 PHASE_SPEAKER_FWD, PHASE_LSTHM_FWD, PHASE_LSTHM_BWD, PHASE_SPEAKER_BWD, PHASE_LSTHM_BWD_DX, PHASE_LSTHM_WGRAD = 1, 2, 4, 8, 16, 32
+PHASE_FWD_PREP, PHASE_BWD_PREP = 64, 128
+
+
+def marn_cell_pipelined(B: int, H: int, ndir: int) -> bool:
+    return bool(L.load().mser_marn_cell_pipelined(B, H, ndir))
 
 
 def marn_cell_run(desc: L.CellDesc, phases: int) -> None:
