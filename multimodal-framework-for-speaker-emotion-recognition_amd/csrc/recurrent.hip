@@ -167,6 +167,33 @@ __device__ __forceinline__ void zero8(float* a) {
 // (zeroed by a memset node before the launch); `target` = nwg * (index of this barrier + 1).  Every spin is bounded: on
 // time-out (or when another workgroup has already given up) the abort word is set and every workgroup leaves the kernel.
 constexpr unsigned SPIN_LIMIT = 1u << 22;
+// Split-phase form: barrier_arrive() then (independent work, e.g. prefetching the next step's saved operands) then
+// barrier_wait().  Loads issued between the two overlap the hand-off latency.
+__device__ __forceinline__ void barrier_arrive(unsigned* cnt) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its write-through stores
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add((gu32*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool barrier_wait(const unsigned* cnt, unsigned* abortw, unsigned target, int* lds_ok) {
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    unsigned spins = 0;
+    while (__hip_atomic_load((const gu32*)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 255u) == 0u) {
+        if (spins > SPIN_LIMIT || __hip_atomic_load((const gu32*)abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          ok = 0;
+          break;
+        }
+      }
+    }
+    if (!ok) __hip_atomic_store((gu32*)abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *lds_ok = ok;
+  }
+  __syncthreads();
+  return *lds_ok != 0;
+}
+
 // `cnt2 / target2` (optional): additionally wait until ANOTHER kernel's counter has reached target2 -- the cross-kernel link
 // of the pipelined chains (the LSTHM chain consumes h_q[t] from the concurrently running speaker chain; the speaker BPTT
 // consumes dHQ[t] from the LSTHM BPTT).  `wait` = false: arrive only (last step of a producer).
@@ -645,8 +672,42 @@ __global__ __launch_bounds__(NT) void lsthm_fwd_persist(CellK P) {
 // both streams.  Writes dgates[t], the dc carry, dHQ[t] (the h_q part of dout) and accumulates the attention-vector grads of
 // its own row (reduced over rows once after the chain).
 // scr floats: ca[H] cl[H] cw[H] coef[H][8] p[3][NT] sh[16]
+// Saved-state operands of one row's backward step: everything that does NOT come from another workgroup in this launch, so it
+// can be fetched while the inter-workgroup barrier of the previous phase is still in flight (threads tid < H hold unit tid).
+struct RowPre {
+  float cav, clv, dz_out, zi, dh_out[2], gsv[2][4], cprev[2], carry[2], dhq;
+};
+__device__ __forceinline__ RowPre lsthm_bwd_row_prefetch(const CellK& P, const DirP& D, int t, int b) {
+  RowPre r;
+  const int H = P.H, B = P.B, T = P.T;
+  const int i = threadIdx.x;
+  r.cav = r.clv = r.dz_out = r.zi = r.dhq = 0.f;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) { r.dh_out[m] = r.cprev[m] = r.carry[m] = 0.f; r.gsv[m][0] = r.gsv[m][1] = r.gsv[m][2] = r.gsv[m][3] = 0.f; }
+  if (i < H) {
+    const long rowt = (long)t * B + b;
+    const long SA = (long)B * H;
+    const int tau = D.rev ? D.rev[rowt] : t;
+    const float* dorow = (tau >= 0) ? D.dout + ((long)tau * B + b) * P.ldo : nullptr;
+    r.clv = D.cstate[((long)0 * (T + 1) + t + 1) * B * H + (long)b * H + i];
+    r.cav = D.cstate[((long)1 * (T + 1) + t + 1) * B * H + (long)b * H + i];
+    r.zi = D.hz[((long)(t + 1) * B + b) * 3 * H + 2 * H + i];
+    if (dorow) { r.dz_out = dorow[2 * H + i]; r.dhq = dorow[3 * H + i]; }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const float* g = D.gates + ((long)m * T * B + rowt) * 4 * H + i;
+      r.gsv[m][0] = g[0]; r.gsv[m][1] = g[H]; r.gsv[m][2] = g[2 * H]; r.gsv[m][3] = g[3 * H];
+      if (dorow) r.dh_out[m] = dorow[m * H + i];
+      r.cprev[m] = D.cstate[((long)m * (T + 1) + t) * B * H + (long)b * H + i];
+      r.carry[m] = D.dc_carry[(long)m * SA + (long)b * H + i];
+    }
+  }
+  return r;
+}
+
 template <bool PS, int JCT>
-__device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D, const WS& ws, int t, int b, const float* att, float* scr) {
+__device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D, const WS& ws, int t, int b, const float* att, float* scr,
+                                                   const RowPre& pre) {
   const int H = P.H, B = P.B, T = P.T;
   const int Q = NT / H, JC = JCT ? JCT : H / Q;
   float* ca = scr;           float* cl = ca + H;   float* cw = cl + H;   float* coef = cw + H;
@@ -655,43 +716,29 @@ __device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D
   const float* wq = att + H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long rowt = (long)t * B + b;
-  const float* c_l = D.cstate + ((long)0 * (T + 1) + t + 1) * B * H + (long)b * H;
-  const float* c_a = D.cstate + ((long)1 * (T + 1) + t + 1) * B * H + (long)b * H;
-  const float* zrow = D.hz + ((long)(t + 1) * B + b) * 3 * H + 2 * H;
-  const int tau = D.rev ? D.rev[rowt] : t;
-  const float* dorow = (tau >= 0) ? D.dout + ((long)tau * B + b) * P.ldo : nullptr;
   const bool last = (t == T - 1);
   const float* dA = D.dA + (long)b * H;          // [4][B][H]: U_l, V_l, U_a, V_a products of step t+1
   const long SA = (long)B * H;
   const float rsH = 1.0f / sqrtf((float)H);
   const int i = tid & (H - 1), q = tid / H;
 
+  // the only operands that come from other workgroups of this launch: the four carry products of step t+1
+  float dz_in = pre.dz_out, zi = pre.zi, dh2[2] = {pre.dh_out[0], pre.dh_out[1]}, dhq = pre.dhq;
+  if (q == 0 && !last) {
+    dz_in += ldx<PS>(ws, dA + 1 * SA + i) + ldx<PS>(ws, dA + 3 * SA + i);
+    dh2[0] += ldx<PS>(ws, dA + 0 * SA + i);
+    dh2[1] += ldx<PS>(ws, dA + 2 * SA + i);
+  }
   float sp = 0.f;
   if (tid < H) {
-    const float cv = c_a[tid], w = wk[tid];
-    ca[tid] = cv; cl[tid] = c_l[tid]; cw[tid] = cv * w;
+    const float cv = pre.cav, w = wk[tid];
+    ca[tid] = cv; cl[tid] = pre.clv; cw[tid] = cv * w;
     sp = wq[tid] * cv;
-  }
-  // operands of the per-unit epilogue (threads q == 0): issue the loads early, they do not depend on the reductions
-  float dz_in = 0.f, zi = 0.f, dh2[2] = {0.f, 0.f}, gsv[2][4], cprev2[2] = {0.f, 0.f}, carry2[2] = {0.f, 0.f}, dhq = 0.f;
-  if (q == 0) {
-    dz_in = dorow ? dorow[2 * H + i] : 0.f;
-    if (!last) dz_in += ldx<PS>(ws, dA + 1 * SA + i) + ldx<PS>(ws, dA + 3 * SA + i);
-    zi = zrow[i];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const float* g = D.gates + ((long)m * T * B + rowt) * 4 * H + i;
-      gsv[m][0] = g[0]; gsv[m][1] = g[H]; gsv[m][2] = g[2 * H]; gsv[m][3] = g[3 * H];
-      dh2[m] = dorow ? dorow[m * H + i] : 0.f;
-      if (!last) dh2[m] += ldx<PS>(ws, dA + (2 * m) * SA + i);
-      cprev2[m] = D.cstate[((long)m * (T + 1) + t) * B * H + (long)b * H + i];
-      carry2[m] = D.dc_carry[(long)m * SA + (long)b * H + i];
-    }
-    dhq = dorow ? dorow[3 * H + i] : 0.f;
   }
   sp = wave_sum(sp);
   if (lane == 0) sh[wave] = sp;
   __syncthreads();
+  STAMP_ACC(4);
   float s = 0.f;
 #pragma unroll
   for (int w = 0; w < NW; ++w) s += sh[w];
@@ -716,6 +763,7 @@ __device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D
   }
   if (q > 0) { p0[tid] = Z; p1[tid] = N2; p2[tid] = N3; }
   __syncthreads();
+  STAMP_ACC(5);
   float du_cl = 0.f, dcl_att = 0.f;
   if (q == 0) {
     for (int qq = 1; qq < Q; ++qq) { Z += p0[qq * H + i]; N2 += p1[qq * H + i]; N3 += p2[qq * H + i]; }
@@ -729,6 +777,7 @@ __device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D
   du_cl = wave_sum(du_cl);
   __syncthreads();               // pass-1 partials consumed; coef published
   if (lane == 0) sh[wave] = du_cl;
+  STAMP_ACC(6);
   // ---- pass 2: per key index j (= i), sums over the units ii of chunk q
   const int j = i;
   float S1 = 0.f, S2 = 0.f, S3 = 0.f;
@@ -747,6 +796,7 @@ __device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D
   }
   if (q > 0) { p0[tid] = S1; p1[tid] = S2; p2[tid] = S3; }
   __syncthreads();
+  STAMP_ACC(7);
   if (q == 0) {
     float ds = 0.f;
 #pragma unroll
@@ -759,13 +809,13 @@ __device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D
     // ---- gate backward, both streams (unit i == j)
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      const float gf = gsv[m][0], gi = gsv[m][1], go = gsv[m][2], gc = gsv[m][3];
+      const float gf = pre.gsv[m][0], gi = pre.gsv[m][1], go = pre.gsv[m][2], gc = pre.gsv[m][3];
       const float dh = dh2[m];
-      const float cc = m ? ca[i] : cl[i];
+      const float cc = m ? pre.cav : pre.clv;
       const float tc = tanhf(cc);
-      const float dc = carry2[m] + dh * go * (1.f - tc * tc) + (m ? dca_att : dcl_att);
+      const float dc = pre.carry[m] + dh * go * (1.f - tc * tc) + (m ? dca_att : dcl_att);
       float* dg = D.dgates + ((long)m * T * B + rowt) * 4 * H + i;
-      stx<PS>(ws, dg, dc * cprev2[m] * gf * (1.f - gf));
+      stx<PS>(ws, dg, dc * pre.cprev[m] * gf * (1.f - gf));
       stx<PS>(ws, dg + H, dc * gc * gi * (1.f - gi));
       stx<PS>(ws, dg + 2 * H, dh * tc * go * (1.f - go));
       stx<PS>(ws, dg + 3 * H, dc * gi * (1.f - gc * gc));
@@ -819,7 +869,7 @@ __global__ __launch_bounds__(NT) void lsthm_bwd_row(CellK P, int t) {
   const WS ws = make_ws(P.wsbase, P.wsbytes);
   float* att = smem + RED_FLOATS;
   att_prepare(P.d[blockIdx.y], P.H, att, smem);
-  lsthm_bwd_row_body<false, 0>(P, P.d[blockIdx.y], ws, t, blockIdx.x, att, smem);
+  lsthm_bwd_row_body<false, 0>(P, P.d[blockIdx.y], ws, t, blockIdx.x, att, smem, lsthm_bwd_row_prefetch(P, P.d[blockIdx.y], t, blockIdx.x));
 }
 __global__ __launch_bounds__(NT) void lsthm_bwd_mat(CellK P, int t) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -854,15 +904,26 @@ __global__ __launch_bounds__(NT) void lsthm_bwd_persist(CellK P) {
   }
   att_prepare(D, H, att, red);
   unsigned nbar = 0;
+  unsigned* cnt = P.sync + SYNC_LSTHM_BWD + dir;
   STAMP_INIT();
+  RowPre pre = lsthm_bwd_row_prefetch(P, D, P.T - 1, w < P.B ? w : 0);
   for (int t = P.T - 1; t >= 0; --t) {
-    for (int b = w; b < P.B; b += (int)nwg) lsthm_bwd_row_body<true, 2 * NP * NP>(P, D, ws, t, b, att, red);   // NP = H/32, JC = H*H/NT = 2 NP^2
+    for (int b = w; b < P.B; b += (int)nwg) {           // NP = H/32, JC = H*H/NT = 2 NP^2
+      if (b != w) pre = lsthm_bwd_row_prefetch(P, D, t, b);
+      lsthm_bwd_row_body<true, 2 * NP * NP>(P, D, ws, t, b, att, red, pre);
+    }
     STAMP_ACC(0);
-    if (!dir_barrier(P.sync + SYNC_LSTHM_BWD + dir, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
+    if (!dir_barrier(cnt, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
     STAMP_ACC(1);
     if (has_mat && (t > 0 || p >= 4)) lsthm_bwd_mat_body<true, NP>(P, D, ws, t, p, n0, mb, bpre, red, tile);
     STAMP_ACC(2);
-    if (!dir_barrier(P.sync + SYNC_LSTHM_BWD + dir, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok, nullptr, 0, t > 0)) return;
+    // split-phase barrier: the saved-state operands of step t-1 are fetched while the hand-off is in flight
+    barrier_arrive(cnt);
+    ++nbar;
+    if (t > 0) {
+      pre = lsthm_bwd_row_prefetch(P, D, t - 1, w < P.B ? w : 0);
+      if (!barrier_wait(cnt, P.sync + SYNC_ABORT, nwg * nbar, lds_ok)) return;
+    }
     STAMP_ACC(3);
   }
   STAMP_DUMP(P, 32, blockIdx.x == 1 && blockIdx.z == 0);

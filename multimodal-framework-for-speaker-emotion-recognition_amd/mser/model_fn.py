@@ -145,33 +145,40 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
     # starts the consumer first (it would spin until its bounded time-out), so under stream capture the phases are ordered instead.
     pipelined = (side is not None and ops.marn_cell_pipelined(B, H, 2) and not torch.cuda.is_current_stream_capturing())
     c.pipelined = pipelined
-    ops.marn_cell_run(desc, ops.PHASE_FWD_PREP)
     if side is not None:
         s_audio, s_spk, s_xa, s_xb = side
         for st in side:
             st.wait_stream(cur)
+        ev_prep = torch.cuda.Event()
         with torch.cuda.stream(s_spk):
+            ops.marn_cell_run(desc, ops.PHASE_FWD_PREP)         # tables, initial states, counters: off the encoders' stream
+            ev_prep.record(s_spk)
             ops.marn_cell_run(desc, ops.PHASE_SPEAKER_FWD)      # qmask-only chain: overlaps the encoders AND the LSTHM chain
         with torch.cuda.stream(s_audio):
             audio_branch()
         text_branch()
         cur.wait_stream(s_audio)                                # x_l and x_a are final
-        s_xa.wait_stream(cur)
-        s_xb.wait_stream(cur)
+        ev_x = torch.cuda.Event()
+        ev_x.record(cur)
+        if pipelined:
+            cur.wait_event(ev_prep)
+        else:
+            cur.wait_stream(s_spk)
+        # The critical chain is ISSUED first (the host needs ~10 us per launch): pipelined, the LSTHM kernel follows the speaker
+        # kernel step by step through a device-side counter; both are persistent (64 + 64 workgroups) and the attention GEMMs,
+        # issued afterwards on two side streams, fill the other CUs.
+        ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD)
+        s_xa.wait_event(ev_x)
+        s_xb.wait_event(ev_x)
         with torch.cuda.stream(s_xa):
             xattn_a()
         with torch.cuda.stream(s_xb):
             xattn_b()
-        if not pipelined:
-            cur.wait_stream(s_spk)
-        # pipelined: the LSTHM kernel follows the speaker kernel step by step through a device-side counter; both are
-        # persistent (64 + 64 workgroups), the attention GEMMs fill the other CUs
-        ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD)
         cur.wait_stream(s_spk)
         cur.wait_stream(s_xa)
         cur.wait_stream(s_xb)
     else:
-        ops.marn_cell_run(desc, ops.PHASE_SPEAKER_FWD)
+        ops.marn_cell_run(desc, ops.PHASE_FWD_PREP | ops.PHASE_SPEAKER_FWD)
         text_branch()
         audio_branch()
         ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD)
@@ -274,12 +281,9 @@ def marn1_backward(c: ModelCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: Opt
 
     if side is not None:
         s_audio, s_spk, s_xa, s_xb = side
-        for st in side:
-            st.wait_stream(cur)
-        with torch.cuda.stream(s_xa):
-            xattn_a_bwd()
-        with torch.cuda.stream(s_xb):
-            xattn_b_bwd()
+        ev_h = torch.cuda.Event()
+        ev_h.record(cur)                                           # dH and the initial dx_l / dx_a are ready
+        # critical chain first (host issue order matters: ~10 us per launch)
         ops.marn_cell_run(desc, ops.PHASE_BWD_PREP)
         if c.pipelined:
             s_spk.wait_stream(cur)
@@ -287,6 +291,12 @@ def marn1_backward(c: ModelCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: Opt
         if c.pipelined:
             with torch.cuda.stream(s_spk):                         # speaker BPTT follows the LSTHM BPTT step by step (counter-linked)
                 ops.marn_cell_run(desc, ops.PHASE_SPEAKER_BWD)
+        s_xa.wait_event(ev_h)
+        s_xb.wait_event(ev_h)
+        with torch.cuda.stream(s_xa):
+            xattn_a_bwd()
+        with torch.cuda.stream(s_xb):
+            xattn_b_bwd()
         cur.wait_stream(s_xa)
         cur.wait_stream(s_xb)
         merge_dx()
