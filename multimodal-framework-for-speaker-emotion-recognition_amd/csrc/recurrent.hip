@@ -39,6 +39,7 @@ struct DirP {
   float* out;
   const float* dout;
   // backward scratch
+  float* dxc;          // [2 streams][T*B][D]: dgates_m @ W_m of THIS direction at natural time rows (pipelined persistent mode)
   float *dgates, *dc_carry, *dA, *attacc, *dHQ, *dHQp;   // dHQp[2][T][B][H]: dgates_m @ S_m per step (pipelined mode)
   float *dsg, *Xb, *dhprev, *dcprev;   // Xb[2][B][H]: grad wrt q_{t-1}[b, party_t[b]], ping-pong by step parity
   float* mnext;                        // [T][B]: qmask_t[r][party_{t+1}[r]] (0 at the last step)
@@ -831,34 +832,46 @@ __device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D
 // p = 4, 5 (pipelined persistent mode only): dHQp[m][t][b][n] = dgates_m[t] @ S_m, the speaker-state gradient that the
 // concurrently running speaker BPTT consumes (instead of a hoisted GEMM after the chain).
 struct LsthmBwdB {
-  const float* Wp; int n0, H;
+  const float* Wp; int n0, H;      // H = leading dimension of Wp ([K][H] row-major)
+  int ncols = 1 << 30;             // valid output columns (columns >= ncols read as zero)
   __device__ __forceinline__ void operator()(int n, int k, float* bb) const {
+    const int col = n0 + n;
+    const int cc = col < ncols ? col : 0;       // clamped address, value zeroed afterwards (no load inside a branch)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) bb[j] = Wp[(long)(k + j) * H + n0 + n];
+    for (int j = 0; j < 8; ++j) bb[j] = Wp[(long)(k + j) * H + cc];
+    if (col >= ncols) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bb[j] = 0.f;
+    }
   }
 };
 
 template <bool PS, int NP>
 __device__ __forceinline__ void lsthm_bwd_mat_body(const CellK& P, const DirP& D, const WS& ws, int t, int p, int n0, int mb,
                                                    const float (*bpre)[8], float* red, float* tile) {
-  const int m = p < 4 ? p >> 1 : p - 4;
+  const int m = p < 4 ? p >> 1 : (p - 4) & 1;
   const int H = P.H, B = P.B, T = P.T;
-  const float* Wp = p >= 4 ? D.S[m] : ((p & 1) ? D.V[m] : D.U[m]);
+  const float* Wp = p >= 6 ? D.W[m] : (p >= 4 ? D.S[m] : ((p & 1) ? D.V[m] : D.U[m]));
   const float* dg = D.dgates + ((long)m * T * B + (long)t * B) * 4 * H;
   auto aload = [&](int r, int k, float* a) {
     const int b = mb * 32 + r;
     if (b >= B) { zero8(a); return; }
     load8x<PS>(ws, dg + (long)b * 4 * H + k, a);
   };
-  wg_mm32<NP>(4 * H, aload, LsthmBwdB{Wp, n0, H}, bpre, red, tile);
+  wg_mm32<NP>(4 * H, aload, LsthmBwdB{Wp, n0, p >= 6 ? P.D : H, p >= 6 ? P.D : H}, bpre, red, tile);
 #pragma unroll
   for (int e = 0; e < 1024 / NT; ++e) {
     const int idx = threadIdx.x + e * NT;
     const int rr = idx >> 5, n = idx & 31;
     const int b = mb * 32 + rr;
     if (b < B) {
-      float* dst = p < 4 ? D.dA + ((long)p * B + b) * H : D.dHQp + (((long)m * T + t) * B + b) * H;
-      stx<PS>(ws, dst + n0 + n, tile[idx]);
+      if (p >= 6) {              // dx of this direction at the natural time position (consumed after the launch: plain store)
+        const int tau = D.rev ? D.rev[(long)t * B + b] : t;
+        if (tau >= 0 && n0 + n < P.D) D.dxc[((long)m * T * B + (long)tau * B + b) * P.D + n0 + n] = tile[idx];
+      } else {
+        float* dst = p < 4 ? D.dA + ((long)p * B + b) * H : D.dHQp + (((long)m * T + t) * B + b) * H;
+        stx<PS>(ws, dst + n0 + n, tile[idx]);
+      }
     }
   }
 }
@@ -894,13 +907,18 @@ __global__ __launch_bounds__(NT) void lsthm_bwd_persist(CellK P) {
   const int H = P.H;
   const unsigned nwg = gridDim.x;
   const int w = blockIdx.x;
-  const int nsl = H / 32;
-  const bool has_mat = w < nsl * 6 * P.nmb;
-  const int mb = w / (nsl * 6), p = (w / nsl) % 6, n0 = (w % nsl) * 32;
+  // matvec roles: 6 products x H/32 slices (carries + speaker gradient), then 2 products x ceil(D/32) slices (dx = dgates W)
+  const int nsl = H / 32, nslx = (P.D + 31) / 32;
+  const int per_mb = 6 * nsl + 2 * nslx;
+  const bool has_mat = w < per_mb * P.nmb;
+  const int mb = w / per_mb, wr = w % per_mb;
+  const int p = wr < 6 * nsl ? wr / nsl : 6 + (wr - 6 * nsl) / nslx;
+  const int n0 = (wr < 6 * nsl ? wr % nsl : (wr - 6 * nsl) % nslx) * 32;
   float bpre[NP][8];
   if (has_mat) {
-    const float* Wp = p >= 4 ? D.S[p - 4] : ((p & 1) ? D.V[p >> 1] : D.U[p >> 1]);
-    preload_b<NP>(4 * H, LsthmBwdB{Wp, n0, H}, bpre);
+    const int m = p < 4 ? p >> 1 : (p - 4) & 1;
+    const float* Wp = p >= 6 ? D.W[m] : (p >= 4 ? D.S[m] : ((p & 1) ? D.V[m] : D.U[m]));
+    preload_b<NP>(4 * H, LsthmBwdB{Wp, n0, p >= 6 ? P.D : H, p >= 6 ? P.D : H}, bpre);
   }
   att_prepare(D, H, att, red);
   unsigned nbar = 0;
@@ -915,7 +933,7 @@ __global__ __launch_bounds__(NT) void lsthm_bwd_persist(CellK P) {
     STAMP_ACC(0);
     if (!dir_barrier(cnt, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
     STAMP_ACC(1);
-    if (has_mat && (t > 0 || p >= 4)) lsthm_bwd_mat_body<true, NP>(P, D, ws, t, p, n0, mb, bpre, red, tile);
+    if (has_mat && (t > 0 || p >= 4)) lsthm_bwd_mat_body<true, NP>(P, D, ws, t, p, n0, mb, bpre, red, tile);   // t == 0: no carries needed
     STAMP_ACC(2);
     // split-phase barrier: the saved-state operands of step t-1 are fetched while the hand-off is in flight
     barrier_arrive(cnt);
@@ -1213,6 +1231,7 @@ static void carve_dir(Carver& cv, DirP& d, int T, int B, int D, int H) {
   d.attacc = cv.take<float>((size_t)B * 2 * H);
   d.dHQ = cv.take<float>(TB * H);
   d.dHQp = cv.take<float>(2 * TB * H);
+  d.dxc = cv.take<float>(2 * TB * D);
   d.dsg = cv.take<float>(2 * TB * 4 * H);
   d.Xb = cv.take<float>(2 * SB);
   d.dhprev = cv.take<float>(2 * 2 * SB);
@@ -1447,7 +1466,7 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   const size_t mm_lds = (RED_FLOATS + 1024) * sizeof(float);
   const size_t row_lds = row_lds_bytes(H);
   const int spk_wgs = (H / 32) * 4 * K.nmb;                  // speaker BPTT: 4 products
-  const int mat_wgs = (H / 32) * 6 * K.nmb;                  // LSTHM BPTT matvec phase: 4 carry products + 2 speaker-gradient products
+  const int mat_wgs = ((H / 32) * 6 + ((D + 31) / 32) * 2) * K.nmb;   // LSTHM BPTT matvec roles: 4 carries + 2 speaker-gradient + 2 dx products
   const int bwd_nwg = mat_wgs > 32 ? mat_wgs : 32;           // row phase spreads the B rows over all of them
   // both BPTT kernels run concurrently (pipelined): all their workgroups must be co-resident
   const bool persist = persist_ok(H, ((long)bwd_nwg + spk_wgs) * d.ndir);
@@ -1458,6 +1477,8 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       DirP& k = K.d[i];
       MSER_CHECK_HIP(hipMemsetAsync(k.dc_carry, 0, 2 * SB * sizeof(float), s));
       MSER_CHECK_HIP(hipMemsetAsync(k.attacc, 0, (size_t)B * 2 * H * sizeof(float), s));
+      if (persist && k.rev)    // rows at and beyond len_b receive no gradient from the reversed direction
+        MSER_CHECK_HIP(hipMemsetAsync(k.dxc, 0, 2 * (size_t)TB * D * sizeof(float), s));
     }
     MSER_CHECK_HIP(hipMemsetAsync(h.sync + SYNC_LSTHM_BWD, 0, 4 * sizeof(unsigned), s));
   }
@@ -1506,7 +1527,9 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
           MSER_TRY(gemm(g, s));
         }
         // dx (direction order) = dg W_m
-        if (!k.rev) {
+        if (persist) {       // produced inside the BPTT kernel at natural time rows: just add it
+          MSER_TRY(mser_add_rows(dxs[m], D, dxs[m], D, k.dxc + (long)m * TB * D, D, TB, D, s));
+        } else if (!k.rev) {
           g = gd(dg, 4 * H, 1, k.W[m], D, 1, dxs[m], D, (int)TB, D, 4 * H);
           g.flags = MSER_GEMM_ACCUM;
           MSER_TRY(gemm(g, s));
@@ -1725,7 +1748,7 @@ int mser_marn_cell_bwd(const mser_cell_desc* d, mser_stream_t stream) {
 int mser_marn_cell_pipelined(int32_t B, int32_t H, int32_t ndir) {
   const int nmb = cdiv(B, 32);
   const long fwd = 2L * (H / 8) * 2 * ndir * nmb;
-  const int mat = (H / 32) * 6 * nmb;
+  const int mat = ((H / 32) * 6 + 8) * nmb;      // + dx roles (D <= 128 assumed for this estimate)
   const long bwd = ((long)(mat > 32 ? mat : 32) + (H / 32) * 4 * nmb) * ndir;
   return (persist_ok(H, fwd) && persist_ok(H, bwd)) ? 1 : 0;
 }
