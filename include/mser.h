@@ -146,16 +146,18 @@ size_t mser_marn_cell_workspace_bytes(int32_t T, int32_t B, int32_t D, int32_t H
 int mser_marn_cell_fwd(const mser_cell_desc* d, mser_stream_t stream);
 int mser_marn_cell_bwd(const mser_cell_desc* d, mser_stream_t stream);
 /* The same work in separately schedulable phases, so that the caller can overlap independent parts on different streams.
- *   forward : FWD_PREP (tables, initial states, counters) -> SPEAKER_FWD and LSTHM_FWD
- *   backward: BWD_PREP -> LSTHM_BWD (BPTT chain) -> LSTHM_BWD_DX (dx_l, dx_a [, dHQ]) ; LSTHM_WGRAD any time after LSTHM_BWD ;
- *             SPEAKER_BWD (chain + its parameter gradients)
- * When mser_marn_cell_pipelined() returns 1 the chains are persistent kernels linked by device-side step counters:
- * SPEAKER_FWD may run CONCURRENTLY with LSTHM_FWD, and SPEAKER_BWD concurrently with LSTHM_BWD (issue the PREP phase first,
- * then the two phases on different streams; the producer kernel must be issued, not necessarily finished).  Otherwise the
- * speaker phase must have completed before LSTHM_FWD, and LSTHM_BWD + LSTHM_BWD_DX before SPEAKER_BWD.  Issuing everything in
- * the listed order on ONE stream is always valid. */
+ *   forward : FWD_PREP (tables, initial states, counters) -> SPEAKER_FWD -> LSTHM_FWD
+ *   backward: BWD_PREP -> LSTHM_BWD (BPTT chains) -> LSTHM_BWD_DX (dx_l, dx_a [, dHQ]) -> SPEAKER_BWD ;
+ *             LSTHM_WGRAD any time after LSTHM_BWD
+ * In persistent mode (MSER_OPT_PERSISTENT, H in {128,256}, all workgroups co-resident) both chains of a pass run inside ONE
+ * fused launch issued by LSTHM_FWD / LSTHM_BWD (speaker and LSTHM workgroups linked by device-side step counters); SPEAKER_FWD
+ * is then empty and SPEAKER_BWD only computes the speaker-cell parameter gradients.  Otherwise the chains are per-step launches
+ * and SPEAKER_FWD (which needs only qmask) can overlap the encoders on another stream. */
 enum { MSER_PHASE_SPEAKER_FWD = 1, MSER_PHASE_LSTHM_FWD = 2, MSER_PHASE_LSTHM_BWD = 4, MSER_PHASE_SPEAKER_BWD = 8,
-       MSER_PHASE_LSTHM_BWD_DX = 16, MSER_PHASE_LSTHM_WGRAD = 32, MSER_PHASE_FWD_PREP = 64, MSER_PHASE_BWD_PREP = 128 };
+       MSER_PHASE_LSTHM_BWD_DX = 16, MSER_PHASE_LSTHM_WGRAD = 32, MSER_PHASE_FWD_PREP = 64, MSER_PHASE_BWD_PREP = 128,
+       /* modifier for SPEAKER_FWD and LSTHM_FWD (pass it to both): keep the forward chains as two persistent launches so that the
+        * speaker chain, issued on another REAL stream, starts before the encoders finish.  Never inside stream capture. */
+       MSER_PHASE_SEPARATE_SPEAKER = 256 };
 int mser_marn_cell_pipelined(int32_t B, int32_t H, int32_t ndir);
 int mser_marn_cell_run(const mser_cell_desc* d, int32_t phases, mser_stream_t stream);
 

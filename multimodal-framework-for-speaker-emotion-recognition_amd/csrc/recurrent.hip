@@ -348,6 +348,10 @@ __device__ __forceinline__ void att_prepare(const DirP& D, int H, float* att, fl
 }
 __device__ __forceinline__ int att_floats(int H) { return 2 * H + 16; }
 
+// A workgroup's coordinates inside its chain's logical grid (the chains were separate launches; the fused kernels below give every
+// chain a contiguous range of blockIdx.x and decode it into these coordinates).
+struct Role { int x, y, z, gx, gy; };
+
 // ================================================================================================ speaker forward
 // Role: (cell c, units u0..u0+7, slot block mb) of direction D.  One nn.LSTMCell (gate order i,f,g,o) step for 8 hidden
 // units of one party cell over a block of 32 compaction slots.  q_sel is rebuilt on the fly from the previous step's rows:
@@ -466,27 +470,25 @@ __global__ __launch_bounds__(NT) void spk_fwd_step(CellK P, int t) {
 
 // persistent launch: same grid, the whole time loop inside; weights of this workgroup's slice stay in registers.
 template <int NP>
-__global__ __launch_bounds__(NT) void spk_fwd_persist(CellK P) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const WS ws = make_ws(P.wsbase, P.wsbytes);
+__device__ __forceinline__ void spk_fwd_role(const CellK& P, const Role R, float* smem, const WS& ws) {
   float* red = smem;
   float* tile = smem + RED_FLOATS;
   int* lds_ok = (int*)(tile + 1024);
-  const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
+  const int dir = R.z / P.nmb, mb = R.z % P.nmb;
   const DirP& D = P.d[dir];
-  const int c = blockIdx.y, u0 = blockIdx.x * 8;
-  const unsigned nwg = gridDim.x * gridDim.y * P.nmb;
+  const int c = R.y, u0 = R.x * 8;
+  const unsigned nwg = R.gx * R.gy * P.nmb;
   float bpre[NP][8];
   preload_b<NP>(2 * P.H, SpkFwdB{D, c, u0, P.H}, bpre);
   STAMP_INIT();
   for (int t = 0; t < P.T; ++t) {
-    spk_fwd_body<true, NP>(P, D, ws, t, c, u0, mb, blockIdx.x == 0, bpre, red, tile);
+    spk_fwd_body<true, NP>(P, D, ws, t, c, u0, mb, R.x == 0, bpre, red, tile);
     // the counter also tells the concurrently running LSTHM kernel that h_q[t] is published: arrive after the last step too
     if (!dir_barrier(P.sync + SYNC_SPK_FWD + dir, P.sync + SYNC_ABORT, nwg * (unsigned)(t + 1), lds_ok, nullptr, 0, t + 1 < P.T)) return;
     STAMP_ACC(3);
   }
-  STAMP_DUMP(P, 16, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
-  STAMP_DUMP(P, 56, blockIdx.x == 5 && blockIdx.y == 1 && blockIdx.z == 0);
+  STAMP_DUMP(P, 16, R.x == 0 && R.y == 0 && R.z == 0);
+  STAMP_DUMP(P, 56, R.x == 5 && R.y == 1 && R.z == 0);
 }
 
 // ================================================================================================ LSTHM forward
@@ -634,19 +636,17 @@ __global__ __launch_bounds__(NT) void lsthm_fwd_z(CellK P, int t) {
 // persistent launch: grid (H/8, 2 streams, ndir*nmb); two barriers per step (gates -> z -> next gates).  Runs concurrently with
 // spk_fwd_persist: step t starts only once the speaker counter shows h_q[t] published (checked inside the previous barrier).
 template <int NP>
-__global__ __launch_bounds__(NT) void lsthm_fwd_persist(CellK P) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const WS ws = make_ws(P.wsbase, P.wsbytes);
+__device__ __forceinline__ void lsthm_fwd_role(const CellK& P, const Role R, float* smem, const WS& ws) {
   float* red = smem;
   float* tile = smem + RED_FLOATS;
   float* att = tile + 1024;
   int* lds_ok = (int*)(att + att_floats(P.H));
-  const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
+  const int dir = R.z / P.nmb, mb = R.z % P.nmb;
   const DirP& D = P.d[dir];
-  const int m = blockIdx.y, u0 = blockIdx.x * 8;
-  const unsigned nwg = gridDim.x * gridDim.y * P.nmb;
-  const unsigned nwg_spk = nwg;                                          // spk_fwd_persist uses the same grid
-  const int w = (mb * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;    // linear workgroup index inside the direction
+  const int m = R.y, u0 = R.x * 8;
+  const unsigned nwg = R.gx * R.gy * P.nmb;
+  const unsigned nwg_spk = nwg;                                          // the speaker chain uses the same logical grid
+  const int w = (mb * R.gy + R.y) * R.gx + R.x;    // linear workgroup index inside the direction
   float bpre[NP][8];
   preload_b<NP>(3 * P.H, LsthmFwdB{D, m, u0, P.H}, bpre);
   att_prepare(D, P.H, att, red);
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(NT) void lsthm_fwd_persist(CellK P) {
     if (!dir_barrier(cnt, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok, spk, nwg_spk * (unsigned)(t + 2))) return;
     STAMP_ACC(5);
   }
-  STAMP_DUMP(P, 24, blockIdx.x == 3 && blockIdx.y == 1 && blockIdx.z == 0);
+  STAMP_DUMP(P, 24, R.x == 3 && R.y == 1 && R.z == 0);
 }
 
 // ================================================================================================ LSTHM backward
@@ -895,18 +895,16 @@ __global__ __launch_bounds__(NT) void lsthm_bwd_mat(CellK P, int t) {
 // matvec phase: the first (H/32)*6*nmb workgroups (4 carry products + 2 speaker-gradient products).  Two barriers per step;
 // the counter doubles as the "dHQ[t] is complete" signal for the concurrently running speaker BPTT (value 2*(T-t)*nwg).
 template <int NP>
-__global__ __launch_bounds__(NT) void lsthm_bwd_persist(CellK P) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const WS ws = make_ws(P.wsbase, P.wsbytes);
+__device__ __forceinline__ void lsthm_bwd_role(const CellK& P, const Role R, float* smem, const WS& ws) {
   float* red = smem;
   float* tile = smem + RED_FLOATS;
   float* att = tile + 1024;
   int* lds_ok = (int*)(att + att_floats(P.H));
-  const int dir = blockIdx.z;
+  const int dir = R.z;
   const DirP& D = P.d[dir];
   const int H = P.H;
-  const unsigned nwg = gridDim.x;
-  const int w = blockIdx.x;
+  const unsigned nwg = R.gx;
+  const int w = R.x;
   // matvec roles: 6 products x H/32 slices (carries + speaker gradient), then 2 products x ceil(D/32) slices (dx = dgates W)
   const int nsl = H / 32, nslx = (P.D + 31) / 32;
   const int per_mb = 6 * nsl + 2 * nslx;
@@ -944,7 +942,7 @@ __global__ __launch_bounds__(NT) void lsthm_bwd_persist(CellK P) {
     }
     STAMP_ACC(3);
   }
-  STAMP_DUMP(P, 32, blockIdx.x == 1 && blockIdx.z == 0);
+  STAMP_DUMP(P, 32, R.x == 1 && R.z == 0);
 }
 
 // ================================================================================================ speaker backward
@@ -1116,17 +1114,15 @@ __global__ __launch_bounds__(NT) void spk_bwd_step(CellK P, int t) {
 // persistent launch: same grid, one barrier per step.  Runs concurrently with lsthm_bwd_persist: step t starts once that kernel's
 // counter shows dHQ[t] complete (value 2*(T-t)*nwg_l; checked inside the previous step's barrier).
 template <int NP>
-__global__ __launch_bounds__(NT) void spk_bwd_persist(CellK P, unsigned nwg_l) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const WS ws = make_ws(P.wsbase, P.wsbytes);
+__device__ __forceinline__ void spk_bwd_role(const CellK& P, const Role R, float* smem, const WS& ws, unsigned nwg_l) {
   float* red = smem;
   float* tile = smem + RED_FLOATS;
   float* dsg_s = tile + 1024;
   int* lds_ok = (int*)(dsg_s + 32 * (4 * P.H + 4));
-  const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
+  const int dir = R.z / P.nmb, mb = R.z % P.nmb;
   const DirP& D = P.d[dir];
-  const int p = blockIdx.y, n0 = blockIdx.x * 32;
-  const unsigned nwg = gridDim.x * gridDim.y * P.nmb;
+  const int p = R.y, n0 = R.x * 32;
+  const unsigned nwg = R.gx * R.gy * P.nmb;
   float bpre[NP][8];
   preload_b<NP>(4 * P.H, LsthmBwdB{(p & 1) ? D.Whh[p >> 1] : D.Wih[p >> 1], n0, P.H}, bpre);
   unsigned* cnt = P.sync + SYNC_SPK_BWD + dir;
@@ -1135,14 +1131,67 @@ __global__ __launch_bounds__(NT) void spk_bwd_persist(CellK P, unsigned nwg_l) {
   if (!dir_barrier(nullptr, P.sync + SYNC_ABORT, 0, lds_ok, lcnt, 2u * nwg_l)) return;          // dHQ[T-1] complete
   STAMP_INIT();
   for (int t = P.T - 1; t >= 0; --t) {
-    spk_bwd_body<true, NP, true>(P, D, ws, t, p, n0, mb, (int)((p & 1) * gridDim.x + blockIdx.x), bpre, red, tile, dsg_s);
+    spk_bwd_body<true, NP, true>(P, D, ws, t, p, n0, mb, (int)((p & 1) * R.gx + R.x), bpre, red, tile, dsg_s);
     STAMP_ACC(2);
     if (t == 0) break;
     if (!dir_barrier(cnt, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok, lcnt, 2u * nwg_l * (unsigned)(P.T - t + 1))) return;
     STAMP_ACC(3);
   }
-  STAMP_DUMP(P, 40, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
-  STAMP_DUMP(P, 48, blockIdx.x == 2 && blockIdx.y == 1 && blockIdx.z == 0);
+  STAMP_DUMP(P, 40, R.x == 0 && R.y == 0 && R.z == 0);
+  STAMP_DUMP(P, 48, R.x == 2 && R.y == 1 && R.z == 0);
+}
+
+// ================================================================================================ fused persistent launches
+// Both chains of a pass live in ONE launch: blockIdx.x < n_l are the LSTHM-chain workgroups (the critical chain first), the rest
+// the speaker-chain workgroups.  They run concurrently as independent groups linked only by the producer's step counter
+// (forward: h_q[t]; backward: dHQ[t]).  One launch = one residency guarantee (grid <= CUs, one workgroup per CU through the LDS
+// request), independent of how a stream or hipGraph executor would have ordered two separate kernels.
+template <int NPS, int NPL>
+__global__ __launch_bounds__(NT) void cell_fwd_fused(CellK P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WS ws = make_ws(P.wsbase, P.wsbytes);
+  const int gx = P.H / 8, gy = 2;
+  const int n_l = gx * gy * P.ndir * P.nmb;
+  int id = blockIdx.x;
+  const bool lsthm = id < n_l;
+  if (!lsthm) id -= n_l;
+  const Role R{id % gx, (id / gx) % gy, id / (gx * gy), gx, gy};
+  if (lsthm) lsthm_fwd_role<NPL>(P, R, smem, ws);
+  else spk_fwd_role<NPS>(P, R, smem, ws);
+}
+
+// The forward chains as two separate launches (MSER_PHASE_SEPARATE_SPEAKER): the speaker chain needs only qmask, so an eager
+// caller can start it on a side stream long before the encoders have produced the LSTHM inputs; the LSTHM launch follows it
+// through the same step counter.  Only valid when the speaker launch is already executing or queued ahead on another REAL
+// stream (not inside a captured graph, whose executor may serialise branches in any order).
+template <int NP>
+__global__ __launch_bounds__(NT) void spk_fwd_persist(CellK P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WS ws = make_ws(P.wsbase, P.wsbytes);
+  spk_fwd_role<NP>(P, Role{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, smem, ws);
+}
+template <int NP>
+__global__ __launch_bounds__(NT) void lsthm_fwd_persist(CellK P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WS ws = make_ws(P.wsbase, P.wsbytes);
+  lsthm_fwd_role<NP>(P, Role{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, smem, ws);
+}
+
+template <int NPL, int NPS>
+__global__ __launch_bounds__(NT) void cell_bwd_fused(CellK P, unsigned bwd_nwg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WS ws = make_ws(P.wsbase, P.wsbytes);
+  const int n_l = (int)bwd_nwg * P.ndir;
+  int id = blockIdx.x;
+  if (id < n_l) {
+    const Role R{id % (int)bwd_nwg, 0, id / (int)bwd_nwg, (int)bwd_nwg, 1};
+    lsthm_bwd_role<NPL>(P, R, smem, ws);
+  } else {
+    id -= n_l;
+    const int gx = P.H / 32, gy = 4;
+    const Role R{id % gx, (id / gx) % gy, id / (gx * gy), gx, gy};
+    spk_bwd_role<NPS>(P, R, smem, ws, bwd_nwg);
+  }
 }
 
 // ================================================================================================ small helpers
@@ -1360,7 +1409,7 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   for (int i = 0; i < d.ndir; ++i) fill_params(K.d[i], d.dir[i]);
   const size_t mm_lds = (RED_FLOATS + 1024) * sizeof(float);
   const long fwd_wgs = (long)(H / 8) * 2 * d.ndir * K.nmb;
-  const bool persist = persist_ok(H, 2 * fwd_wgs);        // speaker and LSTHM kernels run concurrently (pipelined)
+  const bool persist = persist_ok(H, 2 * fwd_wgs);        // speaker and LSTHM chains share one launch: all workgroups co-resident
   const size_t p_lds = persist_lds(mm_lds + (2 * (size_t)H + 16) * sizeof(float) + 64);
   if (phases & MSER_PHASE_FWD_PREP) {
   MSER_CHECK_HIP(hipMemsetAsync(h.sync, 0, SYNC_WORDS * sizeof(unsigned), s));
@@ -1381,9 +1430,8 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       MSER_CHECK_HIP(hipMemset2DAsync(k.out, d.ldo * sizeof(float), 0, 4 * (size_t)H * sizeof(float), TB, s));
   }
   }
-  if (phases & MSER_PHASE_SPEAKER_FWD) {
-  // ---- speaker chain
-  if (persist) {
+  const bool separate = persist && (phases & MSER_PHASE_SEPARATE_SPEAKER);
+  if ((phases & MSER_PHASE_SPEAKER_FWD) && separate) {
     ProfScope ps(MSER_PROF_SPK_FWD, s);
     if (H == 128) {
       MSER_TRY(allow_lds((const void*)spk_fwd_persist<2>, p_lds));
@@ -1392,14 +1440,16 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       MSER_TRY(allow_lds((const void*)spk_fwd_persist<4>, p_lds));
       hipLaunchKernelGGL(spk_fwd_persist<4>, dim3(H / 8, 2, d.ndir * K.nmb), dim3(NT), p_lds, s, K);
     }
-  } else {
+    MSER_TRY(check_launch("spk_fwd_persist"));
+  }
+  if ((phases & MSER_PHASE_SPEAKER_FWD) && !persist) {
+    // ---- speaker chain as per-step launches (the persistent mode runs it inside the fused launch of the LSTHM phase)
     MSER_TRY(allow_lds((const void*)spk_fwd_step, mm_lds));
     for (int t = 0; t < T; ++t) {
       ProfScope ps(MSER_PROF_SPK_FWD, s);
       hipLaunchKernelGGL(spk_fwd_step, dim3(H / 8, 2, d.ndir * K.nmb), dim3(NT), mm_lds, s, K, t);
     }
-  }
-  MSER_TRY(check_launch("spk_fwd"));
+    MSER_TRY(check_launch("spk_fwd"));
   }
   if (!(phases & MSER_PHASE_LSTHM_FWD)) return 0;
   // ---- hoisted pre-activations: pre_m = xdir W_m^T + W.bias + HQ S_m^T + S.bias
@@ -1427,7 +1477,7 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   }
   // ---- LSTHM chain
   const size_t z_lds = row_lds_bytes(H);
-  if (persist) {
+  if (separate) {
     ProfScope ps(MSER_PROF_LSTHM_FWD_GATES, s);
     if (H == 128) {
       MSER_TRY(allow_lds((const void*)lsthm_fwd_persist<3>, p_lds));
@@ -1435,6 +1485,16 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
     } else {
       MSER_TRY(allow_lds((const void*)lsthm_fwd_persist<6>, p_lds));
       hipLaunchKernelGGL(lsthm_fwd_persist<6>, dim3(H / 8, 2, d.ndir * K.nmb), dim3(NT), p_lds, s, K);
+    }
+  } else if (persist) {
+    // ONE launch for both chains: 2 x fwd_wgs workgroups (LSTHM roles first), linked by the speaker's step counter
+    ProfScope ps(MSER_PROF_LSTHM_FWD_GATES, s);
+    if (H == 128) {
+      MSER_TRY(allow_lds((const void*)cell_fwd_fused<2, 3>, p_lds));
+      hipLaunchKernelGGL((cell_fwd_fused<2, 3>), dim3(2 * fwd_wgs), dim3(NT), p_lds, s, K);
+    } else {
+      MSER_TRY(allow_lds((const void*)cell_fwd_fused<4, 6>, p_lds));
+      hipLaunchKernelGGL((cell_fwd_fused<4, 6>), dim3(2 * fwd_wgs), dim3(NT), p_lds, s, K);
     }
   } else {
     MSER_TRY(allow_lds((const void*)lsthm_fwd_gates, mm_lds));
@@ -1485,13 +1545,16 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   if (phases & MSER_PHASE_LSTHM_BWD) {
   // ---- LSTHM chain, reverse time
   if (persist) {
+    // ONE launch for both BPTT chains: bwd_nwg*ndir LSTHM workgroups + spk_wgs*ndir speaker workgroups
+    const size_t f_lds = persist_lds(mm_lds + 32 * (4 * (size_t)H + 4) * sizeof(float) + 64);
+    const unsigned grid = (unsigned)(((long)bwd_nwg + spk_wgs) * d.ndir);
     ProfScope ps(MSER_PROF_LSTHM_BWD_ROW, s);
     if (H == 128) {
-      MSER_TRY(allow_lds((const void*)lsthm_bwd_persist<4>, p_lds));
-      hipLaunchKernelGGL(lsthm_bwd_persist<4>, dim3(bwd_nwg, 1, d.ndir), dim3(NT), p_lds, s, K);
+      MSER_TRY(allow_lds((const void*)cell_bwd_fused<4, 4>, f_lds));
+      hipLaunchKernelGGL((cell_bwd_fused<4, 4>), dim3(grid), dim3(NT), f_lds, s, K, (unsigned)bwd_nwg);
     } else {
-      MSER_TRY(allow_lds((const void*)lsthm_bwd_persist<8>, p_lds));
-      hipLaunchKernelGGL(lsthm_bwd_persist<8>, dim3(bwd_nwg, 1, d.ndir), dim3(NT), p_lds, s, K);
+      MSER_TRY(allow_lds((const void*)cell_bwd_fused<8, 8>, f_lds));
+      hipLaunchKernelGGL((cell_bwd_fused<8, 8>), dim3(grid), dim3(NT), f_lds, s, K, (unsigned)bwd_nwg);
     }
   } else {
     MSER_TRY(allow_lds((const void*)lsthm_bwd_mat, mm_lds));
@@ -1565,17 +1628,7 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   if (!(phases & MSER_PHASE_SPEAKER_BWD)) return 0;
   // ---- speaker chain, reverse time
   const size_t spk_lds = mm_lds + 32 * (4 * (size_t)H + 4) * sizeof(float);
-  if (persist) {
-    const size_t ps_lds = persist_lds(spk_lds + 64);
-    ProfScope ps(MSER_PROF_SPK_BWD, s);
-    if (H == 128) {
-      MSER_TRY(allow_lds((const void*)spk_bwd_persist<4>, ps_lds));
-      hipLaunchKernelGGL(spk_bwd_persist<4>, dim3(H / 32, 4, d.ndir * K.nmb), dim3(NT), ps_lds, s, K, (unsigned)bwd_nwg);
-    } else {
-      MSER_TRY(allow_lds((const void*)spk_bwd_persist<8>, ps_lds));
-      hipLaunchKernelGGL(spk_bwd_persist<8>, dim3(H / 32, 4, d.ndir * K.nmb), dim3(NT), ps_lds, s, K, (unsigned)bwd_nwg);
-    }
-  } else {
+  if (!persist) {      // persistent mode: the speaker BPTT chain already ran inside the fused launch of the LSTHM_BWD phase
     MSER_TRY(allow_lds((const void*)spk_bwd_step, spk_lds));
     for (int t = T - 1; t >= 0; --t) {
       ProfScope ps(MSER_PROF_SPK_BWD, s);
@@ -1746,11 +1799,10 @@ int mser_marn_cell_bwd(const mser_cell_desc* d, mser_stream_t stream) {
 }
 
 int mser_marn_cell_pipelined(int32_t B, int32_t H, int32_t ndir) {
-  const int nmb = cdiv(B, 32);
-  const long fwd = 2L * (H / 8) * 2 * ndir * nmb;
-  const int mat = ((H / 32) * 6 + 8) * nmb;      // + dx roles (D <= 128 assumed for this estimate)
-  const long bwd = ((long)(mat > 32 ? mat : 32) + (H / 32) * 4 * nmb) * ndir;
-  return (persist_ok(H, fwd) && persist_ok(H, bwd)) ? 1 : 0;
+  // Since the chains of a pass share ONE fused launch, the caller never has to overlap phases itself: always 0 (kept for ABI
+  // stability; the phases may simply be issued in their listed order).
+  (void)B; (void)H; (void)ndir;
+  return 0;
 }
 
 int mser_marn_cell_run(const mser_cell_desc* d, int32_t phases, mser_stream_t stream) {

@@ -135,18 +135,23 @@ def mha_bwd(c: MhaCtx, dout: Tensor, P: Getter, G: Getter, dxq: Tensor, dxk: Ten
     """Accumulates into dxq/dxk/dxv (which may alias).  If ``init_q`` the residual gradient INITIALISES dxq (no prior read)."""
     rows, D = dout.shape
     nh, dk, dv = c.nh, c.dk, c.dv
-    dy1 = dxq if init_q else _empty(rows, D, like=dout)
+    dy1 = _empty(rows, D, like=dout)          # never modified afterwards: the deferred fc weight gradient reads it
     ops.layernorm_bwd(dout, c.y1, c.mean, c.rstd, P("layer_norm.weight"), dy1, G("layer_norm.weight"), G("layer_norm.bias"))
     dO = _empty(rows, nh * dv, like=dout)
     ops.matmul(dy1, P("fc.weight"), dO)
     ops.grad_weight(dy1, c.O, G("fc.weight"))
-    if not init_q:
-        ops.add_rows(dxq, dxq, dy1)
     dq, dk_, dv_ = torch.empty_like(c.q), torch.empty_like(c.k), torch.empty_like(c.v)
     attn_core_bwd(dO, c.q, c.k, c.v, c.P, dq, dk_, dv_, c.lq, c.lk, nh, dk, dv, 1.0 / (dk ** 0.5))
+    first = True
     for nm, dg, xin, dx in (("w_qs.weight", dq, c.xq, dxq), ("w_ks.weight", dk_, c.xk, dxk), ("w_vs.weight", dv_, c.xv, dxv)):
         if dx is not None:
-            ops.matmul(dg, P(nm), dx, accum=True)
+            if first and init_q:
+                ops.matmul(dg, P(nm), dx, R1=dy1)          # dxq = residual gradient + dq Wq (written, not accumulated)
+            else:
+                if first:
+                    ops.add_rows(dx, dx, dy1)
+                ops.matmul(dg, P(nm), dx, accum=True)
+            first = False
         ops.grad_weight(dg, xin, G(nm))
 
 
@@ -184,10 +189,11 @@ def ffn_bwd(c: FfnCtx, dout: Tensor, P: Getter, G: Getter) -> Tensor:
     ops.grad_weight(dy2, c.hdn, G("w_2.weight"))
     ops.colsum_acc(dy2, G("w_2.bias"))
     ops.relu_bwd_(dh, c.hdn)
-    ops.matmul(dh, P("w_1.weight"), dy2, accum=True)                  # dy2 doubles as d(x): residual + FFN input path
+    dx = _empty(rows, D, like=dout)
+    ops.matmul(dh, P("w_1.weight"), dx, R1=dy2)                       # residual + FFN input path (dy2 stays intact for its wgrads)
     ops.grad_weight(dh, c.x, G("w_1.weight"))
     ops.colsum_acc(dh, G("w_1.bias"))
-    return dy2
+    return dx
 
 
 def _sub(P: Getter, prefix: str) -> Getter:

@@ -71,7 +71,7 @@ class _Streams:
     @classmethod
     def get(cls, dev):
         if cls._s is None or cls._s[0].device != dev:
-            cls._s = [torch.cuda.Stream(device=dev) for _ in range(4)]
+            cls._s = [torch.cuda.Stream(device=dev) for _ in range(5)]
         return cls._s
 
 
@@ -143,17 +143,18 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
 
     # Counter-linked concurrent kernels need REAL concurrency: a hipGraph executor may serialise parallel branches in an order that
     # starts the consumer first (it would spin until its bounded time-out), so under stream capture the phases are ordered instead.
-    pipelined = (side is not None and ops.marn_cell_pipelined(B, H, 2) and not torch.cuda.is_current_stream_capturing())
-    c.pipelined = pipelined
+    pipelined = side is not None and not torch.cuda.is_current_stream_capturing()
+    sep = ops.PHASE_SEPARATE_SPEAKER if pipelined else 0
+    c.pipelined = False          # backward: both BPTT chains share one fused launch, nothing to overlap by hand
     if side is not None:
-        s_audio, s_spk, s_xa, s_xb = side
-        for st in side:
+        s_audio, s_spk, s_xa, s_xb = side[:4]
+        for st in side[:4]:
             st.wait_stream(cur)
         ev_prep = torch.cuda.Event()
         with torch.cuda.stream(s_spk):
             ops.marn_cell_run(desc, ops.PHASE_FWD_PREP)         # tables, initial states, counters: off the encoders' stream
             ev_prep.record(s_spk)
-            ops.marn_cell_run(desc, ops.PHASE_SPEAKER_FWD)      # qmask-only chain: overlaps the encoders AND the LSTHM chain
+            ops.marn_cell_run(desc, ops.PHASE_SPEAKER_FWD | sep)   # qmask-only chain: overlaps the encoders AND the LSTHM chain
         with torch.cuda.stream(s_audio):
             audio_branch()
         text_branch()
@@ -167,7 +168,7 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
         # The critical chain is ISSUED first (the host needs ~10 us per launch): pipelined, the LSTHM kernel follows the speaker
         # kernel step by step through a device-side counter; both are persistent (64 + 64 workgroups) and the attention GEMMs,
         # issued afterwards on two side streams, fill the other CUs.
-        ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD)
+        ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD | sep)
         s_xa.wait_event(ev_x)
         s_xb.wait_event(ev_x)
         with torch.cuda.stream(s_xa):
@@ -204,6 +205,15 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
 def marn1_backward(c: ModelCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: Optional[Tensor] = None,
                    dx_a_out: Optional[Tensor] = None, use_streams: bool = True) -> None:
     """Accumulates every parameter gradient into G(name).  dlp [B*L,C]; optional grads of the returned x_l / x_a."""
+    dev = dlp.device
+    # The side stream costs the host an event record + wait per call (~25 us): worth it only when launches are captured into a
+    # hipGraph (no host cost at replay); in eager mode the host would become the bottleneck.
+    wstream = _Streams.get(dev)[4] if (use_streams and torch.cuda.is_current_stream_capturing()) else None
+    with ops.wgrad_scope(wstream):        # parameter gradients run on their own stream, off the activation-gradient chain
+        _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams)
+
+
+def _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams):
     d = c.dims
     Ln, B, N, D, H = c.L, c.B, c.L * c.B, c.dims.D, c.dims.H
     dev = dlp.device
@@ -280,7 +290,7 @@ def marn1_backward(c: ModelCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: Opt
         ops.add_rows(dx_a, dx_a, dxa_a)
 
     if side is not None:
-        s_audio, s_spk, s_xa, s_xb = side
+        s_audio, s_spk, s_xa, s_xb = side[:4]
         ev_h = torch.cuda.Event()
         ev_h.record(cur)                                           # dH and the initial dx_l / dx_a are ready
         # critical chain first (host issue order matters: ~10 us per launch)

@@ -17,6 +17,57 @@ from . import _lib as L
 Tensor = torch.Tensor
 
 
+# ---- deferred parameter-gradient work -----------------------------------------------------------------------------------------
+# Weight/bias gradients are leaves of the backward graph: nothing in the same step reads them before the optimiser.  Inside a
+# ``wgrad_scope`` every grad_weight / colsum_acc is enqueued on a dedicated side stream behind an event recorded at the call
+# site, so the activation-gradient chain (the critical path) never waits for them.  Operands are kept alive until the scope
+# joins; callers must not modify an operand in place after handing it over (functional.py is written accordingly).
+_WG = {"stream": None, "keep": []}
+
+
+class wgrad_scope:
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        _WG["stream"] = self.stream
+        _WG["keep"] = []
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        _WG["stream"] = None
+        _WG["keep"] = []
+        return False
+
+
+class _deferred:
+    """Context: run the enclosed launches on the wgrad stream (if a scope is active) after the work issued so far."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+        self.ctx = None
+
+    def __enter__(self):
+        st = _WG["stream"]
+        if st is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            st.wait_event(ev)
+            _WG["keep"].append(self.tensors)
+            self.ctx = torch.cuda.stream(st)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -72,11 +123,13 @@ def linear(x: Tensor, W: Tensor, out: Tensor, bias: Optional[Tensor] = None, rel
              ldr2=_ld(R2) if R2 is not None else 0)
 
 
-def matmul(x: Tensor, Wkn: Tensor, out: Tensor, accum: bool = False, alpha_dev: Optional[Tensor] = None) -> None:
-    """out[rows,N] (+)= alpha * x[rows,K] @ Wkn[K,N]   -- torch.matmul(x, W) layout (CrossAttention2/3)"""
+def matmul(x: Tensor, Wkn: Tensor, out: Tensor, accum: bool = False, alpha_dev: Optional[Tensor] = None,
+           R1: Optional[Tensor] = None) -> None:
+    """out[rows,N] (+)= alpha * x[rows,K] @ Wkn[K,N] (+ R1)   -- torch.matmul(x, W) layout (CrossAttention2/3)"""
     rows, K = x.shape
     N = Wkn.shape[1]
-    gemm_raw(x, Wkn, out, rows, N, K, _ld(x), 1, Wkn.stride(0), 1, _ld(out), accum=accum, alpha_dev=alpha_dev)
+    gemm_raw(x, Wkn, out, rows, N, K, _ld(x), 1, Wkn.stride(0), 1, _ld(out), accum=accum, alpha_dev=alpha_dev, R1=R1,
+             ldr1=_ld(R1) if R1 is not None else 0)
 
 
 def matmul_nt(dy: Tensor, Wkn: Tensor, out: Tensor, accum: bool = False, alpha_dev: Optional[Tensor] = None) -> None:
@@ -90,12 +143,13 @@ def grad_weight(dy: Tensor, x: Tensor, dW: Tensor, transposed: bool = False, alp
                 splitk: int = 16) -> None:
     """dW += dy^T x (nn.Linear weight [N,K]) or, transposed, dW += x^T dy (matmul weight [K,N]); split-K float atomics."""
     rows = dy.shape[0]
-    if not transposed:
-        N, K = dy.shape[1], x.shape[1]
-        gemm_raw(dy, x, dW, N, K, rows, 1, _ld(dy), _ld(x), 1, dW.stride(0), splitk=splitk, alpha_dev=alpha_dev)
-    else:
-        K, N = x.shape[1], dy.shape[1]
-        gemm_raw(x, dy, dW, K, N, rows, 1, _ld(x), _ld(dy), 1, dW.stride(0), splitk=splitk, alpha_dev=alpha_dev)
+    with _deferred(dy, x):
+        if not transposed:
+            N, K = dy.shape[1], x.shape[1]
+            gemm_raw(dy, x, dW, N, K, rows, 1, _ld(dy), _ld(x), 1, dW.stride(0), splitk=splitk, alpha_dev=alpha_dev)
+        else:
+            K, N = x.shape[1], dy.shape[1]
+            gemm_raw(x, dy, dW, K, N, rows, 1, _ld(x), _ld(dy), 1, dW.stride(0), splitk=splitk, alpha_dev=alpha_dev)
 
 
 def softmax_rows_(S: Tensor, rows: int, n: int, ld: int, mul: Optional[Tensor] = None, mask: Optional[Tensor] = None,
@@ -123,7 +177,8 @@ def layernorm_bwd(dy: Tensor, xsum: Tensor, mean: Tensor, rstd: Tensor, gamma: T
 
 def colsum_acc(X: Tensor, out: Tensor) -> None:
     rows, n = X.shape
-    L.check(L.load().mser_colsum_acc(_p(X), rows, n, _ld(X), _p(out), _stream()), "colsum_acc")
+    with _deferred(X):
+        L.check(L.load().mser_colsum_acc(_p(X), rows, n, _ld(X), _p(out), _stream()), "colsum_acc")
 
 
 def relu_bwd_(dY: Tensor, Y: Tensor) -> None:
@@ -278,7 +333,7 @@ def set_option(key: int, value: int) -> None:
 
 
 PHASE_SPEAKER_FWD, PHASE_LSTHM_FWD, PHASE_LSTHM_BWD, PHASE_SPEAKER_BWD, PHASE_LSTHM_BWD_DX, PHASE_LSTHM_WGRAD = 1, 2, 4, 8, 16, 32
-PHASE_FWD_PREP, PHASE_BWD_PREP = 64, 128
+PHASE_FWD_PREP, PHASE_BWD_PREP, PHASE_SEPARATE_SPEAKER = 64, 128, 256
 
 
 def marn_cell_pipelined(B: int, H: int, ndir: int) -> bool:
