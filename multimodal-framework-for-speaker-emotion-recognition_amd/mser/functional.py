@@ -93,6 +93,7 @@ class MhaCtx:
     q: Tensor = None
     k: Tensor = None
     v: Tensor = None
+    qkv: Tensor = None
     P: Tensor = None
     O: Tensor = None
     y1: Tensor = None
@@ -103,6 +104,31 @@ class MhaCtx:
     dv: int = 0
 
 
+def _fused_qkv(P: Getter, G: Optional[Getter] = None):
+    """If w_qs, w_ks, w_vs sit back to back in one storage (the flat parameter buffer lays them out that way), return a
+    [2*nq+nv, D] view over the three (and the matching gradient view): one N=960 projection GEMM instead of three."""
+    wq, wk, wv = P("w_qs.weight"), P("w_ks.weight"), P("w_vs.weight")
+    D = wq.shape[1]
+    if not (wq.is_contiguous() and wk.is_contiguous() and wv.is_contiguous()):
+        return None, None
+    if wk.data_ptr() != wq.data_ptr() + 4 * wq.numel() or wv.data_ptr() != wk.data_ptr() + 4 * wk.numel():
+        return None, None
+    sq = wq.untyped_storage()
+    if sq.data_ptr() != wk.untyped_storage().data_ptr() or sq.data_ptr() != wv.untyped_storage().data_ptr():
+        return None, None           # merely adjacent allocations, not one storage
+    rows = wq.shape[0] + wk.shape[0] + wv.shape[0]
+    W = wq.as_strided((rows, D), (D, 1))
+    gW = None
+    if G is not None:
+        gq, gk, gv = G("w_qs.weight"), G("w_ks.weight"), G("w_vs.weight")
+        if gq is None or gk.data_ptr() != gq.data_ptr() + 4 * gq.numel() or gv.data_ptr() != gk.data_ptr() + 4 * gk.numel():
+            return None, None
+        if gq.untyped_storage().data_ptr() != gk.untyped_storage().data_ptr() or gq.untyped_storage().data_ptr() != gv.untyped_storage().data_ptr():
+            return None, None
+        gW = gq.as_strided((rows, D), (D, 1))
+    return W, gW
+
+
 def mha_fwd(xq: Tensor, xk: Tensor, xv: Tensor, P: Getter, lq: Layout, lk: Layout, nh: int, dk: int, dv: int,
             mask: Optional[Tensor] = None, out: Optional[Tensor] = None):
     """MultiHeadAttention.forward -- reference model/encoder.py:27-60: bias-free projections, softmax(q/sqrt(dk) k^T) v,
@@ -111,14 +137,20 @@ def mha_fwd(xq: Tensor, xk: Tensor, xv: Tensor, P: Getter, lq: Layout, lk: Layou
     rows, D = xq.shape
     c = MhaCtx(lq=lq, lk=lk, xq=xq, xk=xk, xv=xv, nh=nh, dk=dk, dv=dv)
     nq, nv = nh * dk, nh * dv
+    c.qkv = None
     if xq is xk and xk is xv:                       # self-attention: one [rows, 2nq+nv] buffer
         qkv = _empty(rows, 2 * nq + nv, like=xq)
         c.q, c.k, c.v = qkv[:, :nq], qkv[:, nq:2 * nq], qkv[:, 2 * nq:]
+        Wqkv, _ = _fused_qkv(P)
+        if Wqkv is not None:
+            c.qkv = qkv
+            ops.linear(xq, Wqkv, qkv)               # one N = 2nq+nv projection
     else:
         c.q, c.k, c.v = _empty(rows, nq, like=xq), _empty(xk.shape[0], nq, like=xq), _empty(xv.shape[0], nv, like=xq)
-    ops.linear(xq, P("w_qs.weight"), c.q)
-    ops.linear(xk, P("w_ks.weight"), c.k)
-    ops.linear(xv, P("w_vs.weight"), c.v)
+    if c.qkv is None:
+        ops.linear(xq, P("w_qs.weight"), c.q)
+        ops.linear(xk, P("w_ks.weight"), c.k)
+        ops.linear(xv, P("w_vs.weight"), c.v)
     c.O = _empty(rows, nv, like=xq)
     c.P = attn_core_fwd(c.q, c.k, c.v, c.O, lq, lk, nh, dk, dv, 1.0 / (dk ** 0.5), mask=mask, mask_on=0, fill=-1e9)
     t = _empty(rows, D, like=xq)
@@ -140,6 +172,14 @@ def mha_bwd(c: MhaCtx, dout: Tensor, P: Getter, G: Getter, dxq: Tensor, dxk: Ten
     dO = _empty(rows, nh * dv, like=dout)
     ops.matmul(dy1, P("fc.weight"), dO)
     ops.grad_weight(dy1, c.O, G("fc.weight"))
+    Wqkv, gWqkv = _fused_qkv(P, G) if (c.qkv is not None and dxq is dxk and dxk is dxv and init_q) else (None, None)
+    if Wqkv is not None:
+        nq = nh * dk
+        dqkv = torch.empty_like(c.qkv)
+        attn_core_bwd(dO, c.q, c.k, c.v, c.P, dqkv[:, :nq], dqkv[:, nq:2 * nq], dqkv[:, 2 * nq:], c.lq, c.lk, nh, dk, dv, 1.0 / (dk ** 0.5))
+        ops.matmul(dqkv, Wqkv, dxq, R1=dy1)            # residual gradient + [dq|dk|dv] @ [Wq;Wk;Wv]  (one K = 2nq+nv GEMM)
+        ops.grad_weight(dqkv, c.xq, gWqkv)
+        return
     dq, dk_, dv_ = torch.empty_like(c.q), torch.empty_like(c.k), torch.empty_like(c.v)
     attn_core_bwd(dO, c.q, c.k, c.v, c.P, dq, dk_, dv_, c.lq, c.lk, nh, dk, dv, 1.0 / (dk ** 0.5))
     first = True

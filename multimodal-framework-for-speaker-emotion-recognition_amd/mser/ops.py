@@ -68,8 +68,15 @@ class _deferred:
         return False
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream      # ~0.3 us; torch.cuda.current_stream().cuda_stream costs ~2.8 us per call
+_DEV = {"idx": None}
+
+
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    idx = _DEV["idx"]
+    if idx is None:
+        idx = _DEV["idx"] = torch.cuda.current_device()
+    return _raw_stream(idx)
 
 
 def _p(t: Optional[Tensor]) -> Optional[int]:
