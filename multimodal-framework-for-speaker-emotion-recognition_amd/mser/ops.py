@@ -94,9 +94,22 @@ def _f32(t: Tensor, what: str) -> None:
 
 def _ld(t: Tensor) -> int:
     """leading dimension of a 2-D row view"""
-    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
-        raise RuntimeError(f"expected a 2-D view with unit inner stride, got shape {tuple(t.shape)} stride {t.stride()}")
-    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+    st = t.stride()
+    if len(st) != 2 or (st[1] != 1 and t.shape[1] > 1):
+        raise RuntimeError(f"expected a 2-D view with unit inner stride, got shape {tuple(t.shape)} stride {st}")
+    return st[0] if t.shape[0] > 1 else max(t.shape[1], st[0])
+
+
+_GD = L.GemmDesc()          # one reusable descriptor: the C call reads it synchronously, so it can be refilled per launch
+_GD_REF = C.byref(_GD)
+_LIBH = {"lib": None}
+
+
+def _lib():
+    lib = _LIBH["lib"]
+    if lib is None:
+        lib = _LIBH["lib"] = L.load()
+    return lib
 
 
 def gemm_raw(A: Tensor, B: Tensor, Cm: Tensor, M: int, N: int, K: int, sAm: int, sAk: int, sBk: int, sBn: int, ldc: int,
@@ -104,20 +117,28 @@ def gemm_raw(A: Tensor, B: Tensor, Cm: Tensor, M: int, N: int, K: int, sAm: int,
              alpha: float = 1.0, alpha_dev: Optional[Tensor] = None, relu: bool = False, accum: bool = False,
              splitk: int = 1, R1: Optional[Tensor] = None, ldr1: int = 0, R2: Optional[Tensor] = None, ldr2: int = 0,
              sR=(0, 0)) -> None:
-    d = L.GemmDesc()
-    d.A, d.B, d.C = _p(A), _p(B), _p(Cm)
+    if not (A.is_cuda and B.is_cuda and Cm.is_cuda):
+        raise RuntimeError("mser ops need GPU tensors (the product path has no CPU fallback)")
+    d = _GD
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cm.data_ptr()
     d.M, d.N, d.K = M, N, K
     d.sAm, d.sAk, d.sBk, d.sBn, d.ldc = sAm, sAk, sBk, sBn, ldc
     d.batch1, d.batch2 = batch
     d.sA1, d.sA2 = sA
     d.sB1, d.sB2 = sB
     d.sC1, d.sC2 = sC
-    d.bias, d.alpha_dev, d.alpha = _p(bias), _p(alpha_dev), alpha
-    d.flags = (L.MSER_GEMM_RELU if relu else 0) | (L.MSER_GEMM_ACCUM if accum else 0)
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.alpha_dev = alpha_dev.data_ptr() if alpha_dev is not None else None
+    d.alpha = alpha
+    d.flags = (1 if relu else 0) | (2 if accum else 0)
     d.splitk = splitk
-    d.R1, d.R2, d.ldr1, d.ldr2 = _p(R1), _p(R2), ldr1, ldr2
+    d.R1 = R1.data_ptr() if R1 is not None else None
+    d.R2 = R2.data_ptr() if R2 is not None else None
+    d.ldr1, d.ldr2 = ldr1, ldr2
     d.sR1_1, d.sR1_2 = sR
-    L.check(L.load().mser_gemm(C.byref(d), _stream()), "mser_gemm")
+    rc = _lib().mser_gemm(_GD_REF, _stream())
+    if rc:
+        L.check(rc, "mser_gemm")
 
 
 def linear(x: Tensor, W: Tensor, out: Tensor, bias: Optional[Tensor] = None, relu: bool = False, accum: bool = False,
@@ -125,9 +146,8 @@ def linear(x: Tensor, W: Tensor, out: Tensor, bias: Optional[Tensor] = None, rel
     """out[rows,N] (+)= x[rows,K] @ W[N,K]^T (+bias, relu, +R1 +R2)   -- nn.Linear layout"""
     rows, K = x.shape
     N = W.shape[0]
-    gemm_raw(x, W, out, rows, N, K, _ld(x), 1, 1, W.stride(0), _ld(out), bias=bias, relu=relu, accum=accum,
-             alpha_dev=alpha_dev, R1=R1, ldr1=_ld(R1) if R1 is not None else 0, R2=R2,
-             ldr2=_ld(R2) if R2 is not None else 0)
+    gemm_raw(x, W, out, rows, N, K, _ld(x), 1, 1, W.stride(0), _ld(out), (1, 1), (0, 0), (0, 0), (0, 0), bias, 1.0, alpha_dev,
+             relu, accum, 1, R1, _ld(R1) if R1 is not None else 0, R2, _ld(R2) if R2 is not None else 0)
 
 
 def matmul(x: Tensor, Wkn: Tensor, out: Tensor, accum: bool = False, alpha_dev: Optional[Tensor] = None,
@@ -161,111 +181,111 @@ def grad_weight(dy: Tensor, x: Tensor, dW: Tensor, transposed: bool = False, alp
 
 def softmax_rows_(S: Tensor, rows: int, n: int, ld: int, mul: Optional[Tensor] = None, mask: Optional[Tensor] = None,
                   mask_on: int = 1, fill: float = float("-inf")) -> None:
-    L.check(L.load().mser_softmax_rows(_p(S), rows, n, ld, _p(mul), _p(mask), mask_on, fill, _stream()), "softmax_rows")
+    L.check(_lib().mser_softmax_rows(_p(S), rows, n, ld, _p(mul), _p(mask), mask_on, fill, _stream()), "softmax_rows")
 
 
 def softmax_bwd_rows_(P: Tensor, dP: Tensor, rows: int, n: int, ld: int, mul: Optional[Tensor] = None) -> None:
-    L.check(L.load().mser_softmax_bwd_rows(_p(P), _p(dP), rows, n, ld, _p(mul), _stream()), "softmax_bwd_rows")
+    L.check(_lib().mser_softmax_bwd_rows(_p(P), _p(dP), rows, n, ld, _p(mul), _stream()), "softmax_bwd_rows")
 
 
 def add_layernorm_fwd(x: Tensor, res: Optional[Tensor], gamma: Tensor, beta: Tensor, y: Tensor, sum_out: Optional[Tensor],
                       mean: Tensor, rstd: Tensor, eps: float) -> None:
     rows, D = x.shape
-    L.check(L.load().mser_add_layernorm_fwd(_p(x), _ld(x), _p(res), _ld(res) if res is not None else 0, _p(gamma), _p(beta),
+    L.check(_lib().mser_add_layernorm_fwd(_p(x), _ld(x), _p(res), _ld(res) if res is not None else 0, _p(gamma), _p(beta),
                                             _p(y), _p(sum_out), _p(mean), _p(rstd), rows, D, eps, _stream()), "add_layernorm_fwd")
 
 
 def layernorm_bwd(dy: Tensor, xsum: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, dx: Tensor, dgamma: Tensor,
                   dbeta: Tensor) -> None:
     rows, D = dy.shape
-    L.check(L.load().mser_layernorm_bwd(_p(dy), _p(xsum), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), rows, D,
+    L.check(_lib().mser_layernorm_bwd(_p(dy), _p(xsum), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), rows, D,
                                         _stream()), "layernorm_bwd")
 
 
 def colsum_acc(X: Tensor, out: Tensor) -> None:
     rows, n = X.shape
     with _deferred(X):
-        L.check(L.load().mser_colsum_acc(_p(X), rows, n, _ld(X), _p(out), _stream()), "colsum_acc")
+        L.check(_lib().mser_colsum_acc(_p(X), rows, n, _ld(X), _p(out), _stream()), "colsum_acc")
 
 
 def relu_bwd_(dY: Tensor, Y: Tensor) -> None:
-    L.check(L.load().mser_relu_bwd(_p(dY), _p(Y), dY.numel(), _stream()), "relu_bwd")
+    L.check(_lib().mser_relu_bwd(_p(dY), _p(Y), dY.numel(), _stream()), "relu_bwd")
 
 
 def add_rows(out: Tensor, a: Tensor, b: Optional[Tensor] = None) -> None:
     rows, D = a.shape
-    L.check(L.load().mser_add_rows(_p(out), _ld(out), _p(a), _ld(a), _p(b), _ld(b) if b is not None else 0, rows, D, _stream()),
+    L.check(_lib().mser_add_rows(_p(out), _ld(out), _p(a), _ld(a), _p(b), _ld(b) if b is not None else 0, rows, D, _stream()),
             "add_rows")
 
 
 def scale_acc_dot(acc: Tensor, t: Tensor, x: Optional[Tensor], s_dev: Optional[Tensor], ds: Optional[Tensor]) -> None:
     rows, D = t.shape
-    L.check(L.load().mser_scale_acc_dot(_p(acc), _ld(acc), _p(t), _ld(t), _p(x), _ld(x) if x is not None else 0, _p(s_dev), _p(ds),
+    L.check(_lib().mser_scale_acc_dot(_p(acc), _ld(acc), _p(t), _ld(t), _p(x), _ld(x) if x is not None else 0, _p(s_dev), _p(ds),
                                         rows, D, _stream()), "scale_acc_dot")
 
 
 def build_reverse_index(umask: Tensor, lens: Tensor, rev: Tensor) -> None:
     B, Ln = umask.shape
-    L.check(L.load().mser_build_reverse_index(_p(umask), B, Ln, _p(lens), _p(rev), _stream()), "build_reverse_index")
+    L.check(_lib().mser_build_reverse_index(_p(umask), B, Ln, _p(lens), _p(rev), _stream()), "build_reverse_index")
 
 
 def reverse_by_length(X: Tensor, rev: Tensor, out: Tensor, Ln: int, B: int) -> None:
     D = X.shape[1]
-    L.check(L.load().mser_reverse_by_length(_p(X), _ld(X), _p(rev), _p(out), _ld(out), Ln, B, D, _stream()), "reverse_by_length")
+    L.check(_lib().mser_reverse_by_length(_p(X), _ld(X), _p(rev), _p(out), _ld(out), Ln, B, D, _stream()), "reverse_by_length")
 
 
 def build_slot_tables(qmask: Tensor, rev: Optional[Tensor], party: Tensor, perm: Tensor, n0: Tensor, qm_out: Tensor) -> None:
     T, B = qmask.shape[0], qmask.shape[1]
-    L.check(L.load().mser_build_slot_tables(_p(qmask), _p(rev), T, B, _p(party), _p(perm), _p(n0), _p(qm_out), _stream()),
+    L.check(_lib().mser_build_slot_tables(_p(qmask), _p(rev), T, B, _p(party), _p(perm), _p(n0), _p(qm_out), _stream()),
             "build_slot_tables")
 
 
 def logsoftmax_tb_fwd(y: Tensor, lp: Tensor, Ln: int, B: int) -> None:
-    L.check(L.load().mser_logsoftmax_tb_fwd(_p(y), _p(lp), Ln, B, y.shape[-1], _stream()), "logsoftmax_tb_fwd")
+    L.check(_lib().mser_logsoftmax_tb_fwd(_p(y), _p(lp), Ln, B, y.shape[-1], _stream()), "logsoftmax_tb_fwd")
 
 
 def logsoftmax_tb_bwd(dlp: Tensor, lp: Tensor, dy: Tensor, Ln: int, B: int) -> None:
-    L.check(L.load().mser_logsoftmax_tb_bwd(_p(dlp), _p(lp), _p(dy), Ln, B, lp.shape[-1], _stream()), "logsoftmax_tb_bwd")
+    L.check(_lib().mser_logsoftmax_tb_bwd(_p(dlp), _p(lp), _p(dy), Ln, B, lp.shape[-1], _stream()), "logsoftmax_tb_bwd")
 
 
 def masked_nll_fwd(pred: Tensor, target: Tensor, mask: Tensor, loss_out: Tensor) -> None:
     rows, Cn = pred.shape
-    L.check(L.load().mser_masked_nll_fwd(_p(pred), _p(target), _p(mask), rows, Cn, _p(loss_out), _stream()), "masked_nll_fwd")
+    L.check(_lib().mser_masked_nll_fwd(_p(pred), _p(target), _p(mask), rows, Cn, _p(loss_out), _stream()), "masked_nll_fwd")
 
 
 def masked_nll_bwd(target: Tensor, mask: Tensor, loss_out: Tensor, gscale: Optional[Tensor], dpred: Tensor) -> None:
     rows, Cn = dpred.shape
-    L.check(L.load().mser_masked_nll_bwd(_p(target), _p(mask), _p(loss_out), _p(gscale), _p(dpred), rows, Cn, _stream()),
+    L.check(_lib().mser_masked_nll_bwd(_p(target), _p(mask), _p(loss_out), _p(gscale), _p(dpred), rows, Cn, _stream()),
             "masked_nll_bwd")
 
 
 def adam_flat(p: Tensor, g: Tensor, m: Tensor, v: Tensor, live: Optional[Tensor], step: int, lr: float, beta1: float = 0.9,
               beta2: float = 0.999, eps: float = 1e-8, wd: float = 0.0, gscale: float = 1.0) -> None:
-    L.check(L.load().mser_adam_flat(_p(p), _p(g), _p(m), _p(v), _p(live), p.numel(), step, lr, beta1, beta2, eps, wd, gscale,
+    L.check(_lib().mser_adam_flat(_p(p), _p(g), _p(m), _p(v), _p(live), p.numel(), step, lr, beta1, beta2, eps, wd, gscale,
                                     _stream()), "adam_flat")
 
 
 def adam_flat_dev(p: Tensor, g: Tensor, m: Tensor, v: Tensor, live: Optional[Tensor], step_dev: Tensor, hp_dev: Tensor,
                   sched_dev: Tensor, eps: float = 1e-8, wd: float = 0.0, gscale_div_dev: Optional[Tensor] = None,
                   gscale: float = 1.0) -> None:
-    L.check(L.load().mser_adam_flat_dev(_p(p), _p(g), _p(m), _p(v), _p(live), p.numel(), _p(step_dev), _p(hp_dev), _p(sched_dev),
+    L.check(_lib().mser_adam_flat_dev(_p(p), _p(g), _p(m), _p(v), _p(live), p.numel(), _p(step_dev), _p(hp_dev), _p(sched_dev),
                                         eps, wd, _p(gscale_div_dev), gscale, _stream()), "adam_flat_dev")
 
 
 def dp_pack(buf: Tensor, g: Tensor, cnt_dev: Tensor) -> None:
-    L.check(L.load().mser_dp_pack(_p(buf), _p(g), _p(cnt_dev), g.numel(), _stream()), "dp_pack")
+    L.check(_lib().mser_dp_pack(_p(buf), _p(g), _p(cnt_dev), g.numel(), _stream()), "dp_pack")
 
 
 def lsthm_step_fwd(x, c, h, z, s, W, Wb, U, Ub, V, Vb, S, Sb, c_out, h_out, gates=None) -> None:
     B, D = x.shape
     H, Hz, Hs = c.shape[1], z.shape[1], s.shape[1]
-    L.check(L.load().mser_lsthm_step_fwd(_p(x), _p(c), _p(h), _p(z), _p(s), _p(W), _p(Wb), _p(U), _p(Ub), _p(V), _p(Vb), _p(S),
+    L.check(_lib().mser_lsthm_step_fwd(_p(x), _p(c), _p(h), _p(z), _p(s), _p(W), _p(Wb), _p(U), _p(Ub), _p(V), _p(Vb), _p(S),
                                          _p(Sb), _p(c_out), _p(h_out), _p(gates), B, D, H, Hz, Hs, _stream()), "lsthm_step_fwd")
 
 
 def rank1_attention_fwd(x1: Tensor, x2: Tensor, Wq: Tensor, Wk: Tensor, out: Tensor) -> None:
     B, H = x1.shape
-    L.check(L.load().mser_rank1_attention_fwd(_p(x1), _p(x2), _p(Wq), _p(Wk), _p(out), B, H, _stream()), "rank1_attention_fwd")
+    L.check(_lib().mser_rank1_attention_fwd(_p(x1), _p(x2), _p(Wq), _p(Wk), _p(out), B, H, _stream()), "rank1_attention_fwd")
 
 
 # ---------------------------------------------------------------------------------------------- MARN cell
@@ -320,23 +340,23 @@ def make_cell_desc(T: int, B: int, D: int, H: int, x_l: Tensor, x_a: Tensor, dir
 
 
 def marn_cell_fwd(desc: L.CellDesc) -> None:
-    L.check(L.load().mser_marn_cell_fwd(C.byref(desc), _stream()), "marn_cell_fwd")
+    L.check(_lib().mser_marn_cell_fwd(C.byref(desc), _stream()), "marn_cell_fwd")
 
 
 def marn_cell_bwd(desc: L.CellDesc) -> None:
-    L.check(L.load().mser_marn_cell_bwd(C.byref(desc), _stream()), "marn_cell_bwd")
+    L.check(_lib().mser_marn_cell_bwd(C.byref(desc), _stream()), "marn_cell_bwd")
 
 
 def marn_cell_status(desc: L.CellDesc) -> None:
     """Synchronising diagnostic: raises if a persistent recurrent kernel gave up at one of its bounded barriers."""
-    L.check(L.load().mser_marn_cell_status(C.byref(desc), _stream()), "marn_cell_status")
+    L.check(_lib().mser_marn_cell_status(C.byref(desc), _stream()), "marn_cell_status")
 
 
 MSER_OPT_PERSISTENT = 1
 
 
 def set_option(key: int, value: int) -> None:
-    L.check(L.load().mser_set_option(key, value), "set_option")
+    L.check(_lib().mser_set_option(key, value), "set_option")
 
 
 PHASE_SPEAKER_FWD, PHASE_LSTHM_FWD, PHASE_LSTHM_BWD, PHASE_SPEAKER_BWD, PHASE_LSTHM_BWD_DX, PHASE_LSTHM_WGRAD = 1, 2, 4, 8, 16, 32
@@ -348,4 +368,4 @@ def marn_cell_pipelined(B: int, H: int, ndir: int) -> bool:
 
 
 def marn_cell_run(desc: L.CellDesc, phases: int) -> None:
-    L.check(L.load().mser_marn_cell_run(C.byref(desc), phases, _stream()), "marn_cell_run")
+    L.check(_lib().mser_marn_cell_run(C.byref(desc), phases, _stream()), "marn_cell_run")
