@@ -4,22 +4,27 @@
 // fp32; on CDNA4 the f32 MFMA is a k-ordered fmaf chain (bit-identical to a scalar fp32 loop) at the f32 vector peak
 // but needs one VGPR per operand and leaves the VALU free for the epilogue (guide: "FP32-input MFMA").
 //
-// Tile: 64x64 per 256-thread workgroup (4 waves as 2x2, one 32x32 accumulator each), BK = 32, float4 staging where aligned.
-// LDS tiles are laid out [k parity][row][k/2] so that the 16 operands a lane feeds to the 16 MFMAs of a tile are contiguous
-// (4 conflict-free ds_read_b128 per operand), fetched before the MFMA chain starts.
-// The matrices on this path are small (M = B*L = 4096 rows, N <= 1280, K <= 1280 or a 4096-long split reduction) and every
-// call is latency bound, not bandwidth bound: what matters is (1) cheap addressing -- per-thread base pointers are computed
-// once, the k-loop only adds one offset -- and (2) memory-level parallelism -- global loads run TWO tiles ahead of the MFMAs
-// (register staging: tile i is computed from LDS while tile i+1 waits in registers and tile i+2 is in flight).
-// Generality (any strides, two batch levels, split-K with float atomics, fused bias/ReLU/residual epilogue) is kept because
-// every transposed / strided / head-interleaved product of the forward and backward pass goes through this one kernel.
+// The matrices on this path are small (M = B*L = 4096 rows, N <= 1280, K <= 1280, or a 4096-long split reduction into a
+// small weight-gradient) and the fp32 MFMA is paced per SIMD (64 cycles per 32x32x2), so a call is bound by (a) how many of
+// the chip's 1024 SIMDs it keeps busy and (b) the fixed cost per k-tile around the MFMA chain.  Hence:
+//  * two tile configurations, both 4 waves / 256 threads with ONE 32x32 accumulator per wave:
+//      C0  64x64 tile, waves 2x2,            BK = 32  -- grids that already fill the chip
+//      C1  64x32 tile, waves 2x1 x 2 k-halves, BK = 64  -- twice the workgroups for the many M=4096, N<=128 products
+//    (the k-halves of C1 are summed through LDS before the epilogue);  split-K over workgroups (float atomics) for the
+//    K = 4096 weight-gradient reductions, with the split chosen here so that the grid fills the chip;
+//  * k-major LDS tiles [k][rows + 2]: operand reads are 32 consecutive words (conflict-free ds_read_b32, all 32 fetched
+//    before the MFMA chain starts), and the staging stores of all three load modes are at worst 2-way conflicted
+//    (the previous [parity][row][k/2] layout made the row-contiguous mode 8-way conflicted: 2.7 us per k-tile);
+//  * a branch-free software pipeline: global loads run TWO tiles ahead of the MFMAs (register staging), issued
+//    unconditionally with clamped addresses -- a load under a condition gets copies (and a wait) right behind it.
+// Generality (any strides, two batch levels, fused bias/ReLU/residual epilogue) is kept because every transposed / strided /
+// head-interleaved product of the forward and backward pass goes through this one kernel.
+#include <cstdio>
+#include <cstdlib>
 #include "common.h"
 #include "../../include/mser.h"
 
 namespace mser {
-
-constexpr int BM = 64, BN = 64, BK = 32;
-constexpr int KH = BK / 2, LROW = KH + 4;      // LDS tile [k parity][m][k/2 (+4 pad)]: a lane's 16 MFMA operands are contiguous
 
 struct GemmArgs {
   const float* A; const float* B; float* C;
@@ -31,15 +36,17 @@ struct GemmArgs {
   const float* R1; const float* R2; long ldr1, ldr2, sR1, sR2;
 };
 
-// One operand tile (64 rows/cols x 32 k) staged global -> registers -> LDS (k-major [BK][64+PAD]).
+// One operand tile (TR rows/cols x BKT k) staged global -> registers -> LDS (k-major [BKT][TR + 2]).
 // MODE 0: k contiguous, float4 along k (host guarantees 16-B alignment, stride % 4 == 0, K-chunk % 4 == 0)
 // MODE 1: m/n contiguous, float4 along m/n (alignment, stride % 4 == 0, extent % 4 == 0)
 // MODE 2: any strides, scalar loads.
-// Loads are UNCONDITIONAL: addresses are clamped into the matrix and the value is zeroed by a select afterwards -- a load
-// inside a per-element branch makes hipcc wait vmcnt(0) per element (serial memory round trips).
-template <int MODE>
+// Loads are UNCONDITIONAL: addresses are clamped into the matrix and the value is zeroed by a select at the LDS store -- a
+// load inside a per-element branch makes hipcc wait vmcnt(0) per element (serial memory round trips).
+template <int MODE, int TR, int BKT>
 struct TileLoader {
-  static constexpr int NV = (MODE == 2) ? 8 : 2;       // register slots: 8 scalars or 2 float4
+  static constexpr int NF = TR * BKT / 256;            // floats per thread
+  static constexpr int NV = (MODE == 2) ? NF : NF / 4; // register slots: scalars or float4
+  static constexpr int LD = TR + 2;
   const float* p[NV];
   int mm[NV], kk[NV];
   bool ok[NV];
@@ -51,15 +58,15 @@ struct TileLoader {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int e = tid + i * 256;
-      if (MODE == 0) { mm[i] = e >> 3; kk[i] = (e & 7) * 4; }
-      else if (MODE == 1) { mm[i] = (e & 15) * 4; kk[i] = e >> 4; }
-      else { mm[i] = e >> 5; kk[i] = e & 31; }
+      if (MODE == 0) { mm[i] = e / (BKT / 4); kk[i] = (e % (BKT / 4)) * 4; }
+      else if (MODE == 1) { mm[i] = (e % (TR / 4)) * 4; kk[i] = e / (TR / 4); }
+      else { mm[i] = e / BKT; kk[i] = e % BKT; }
       ok[i] = (m0 + mm[i]) < M;
       p[i] = base + (long)(ok[i] ? m0 + mm[i] : 0) * sm + (long)kk[i] * sk;
     }
   }
-  // r: NV*4 floats (vector modes) or NV floats (scalar mode).  load() ONLY issues the loads (no use of the data: any use would
-  // make the compiler wait for them right here and defeat the two-tile prefetch); invalid rows / k are zeroed in store().
+  // load() ONLY issues the loads (no use of the data: any use would make the compiler wait for them right here and defeat the
+  // two-tile prefetch); invalid rows / k are zeroed in store().
   __device__ __forceinline__ void load(int k0, int klen, float* r) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -75,33 +82,41 @@ struct TileLoader {
       }
     }
   }
-  // T: [2][64][LROW]; element (k, m) lives at T[k & 1][m][k >> 1]
-  __device__ __forceinline__ void store(float (*T)[BM][LROW], const float* r, int k0, int klen) const {
+  // T: [BKT][LD]; element (k, m) lives at T[k * LD + m]
+  __device__ __forceinline__ void store(float* T, const float* r, int k0, int klen) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const bool good = ok[i] && (k0 + kk[i]) < klen;     // vectors never straddle the valid range (host checks % 4)
-      if (MODE == 0) {            // k .. k+3 of one row, k % 4 == 0
-        *reinterpret_cast<float2*>(&T[0][mm[i]][kk[i] >> 1]) = make_float2(good ? r[4 * i + 0] : 0.f, good ? r[4 * i + 2] : 0.f);
-        *reinterpret_cast<float2*>(&T[1][mm[i]][kk[i] >> 1]) = make_float2(good ? r[4 * i + 1] : 0.f, good ? r[4 * i + 3] : 0.f);
-      } else if (MODE == 1) {     // rows m .. m+3 at one k
+      if (MODE == 0) {            // k .. k+3 of one row
 #pragma unroll
-        for (int j = 0; j < 4; ++j) T[kk[i] & 1][mm[i] + j][kk[i] >> 1] = good ? r[4 * i + j] : 0.f;
+        for (int j = 0; j < 4; ++j) T[(kk[i] + j) * LD + mm[i]] = good ? r[4 * i + j] : 0.f;
+      } else if (MODE == 1) {     // rows m .. m+3 at one k (8-byte aligned: LD even, m % 4 == 0)
+        float2* d = reinterpret_cast<float2*>(&T[kk[i] * LD + mm[i]]);
+        d[0] = make_float2(good ? r[4 * i + 0] : 0.f, good ? r[4 * i + 1] : 0.f);
+        d[1] = make_float2(good ? r[4 * i + 2] : 0.f, good ? r[4 * i + 3] : 0.f);
       } else {
-        T[kk[i] & 1][mm[i]][kk[i] >> 1] = good ? r[i] : 0.f;
+        T[kk[i] * LD + mm[i]] = good ? r[i] : 0.f;
       }
     }
   }
 };
 
-template <int AMODE, int BMODE>
+// WM x WN waves side by side, KS = 4 / (WM * WN) k-slices of every BK tile (one per remaining wave).
+template <int AMODE, int BMODE, int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float As[2][2][BM][LROW];
-  __shared__ __attribute__((aligned(16))) float Bs[2][2][BN][LROW];
+  constexpr int KS = 4 / (WM * WN), TM = 32 * WM, TN = 32 * WN, BKT = 32 * KS;
+  using LA = TileLoader<AMODE, TM, BKT>;
+  using LB = TileLoader<BMODE, TN, BKT>;
+  constexpr int ASZ = BKT * LA::LD, BSZ = BKT * LB::LD;
+  __shared__ __attribute__((aligned(16))) float As[2][ASZ];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BSZ];
+  static_assert(KS == 1 || 2 * ASZ >= (KS - 1) * WM * WN * 1024, "k-slice reduction reuses the A stage buffers");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kh = wave / (WM * WN), wt = wave % (WM * WN);
+  const int wr = wt / WN, wc = wt % WN;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
   int z = blockIdx.z;
   const int ks = z % g.splitk; z /= g.splitk;
   const int z2 = z % g.batch2, z1 = z / g.batch2;
@@ -109,50 +124,57 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int kend = min(g.K, kbeg + g.kchunk);
   const int klen = kend - kbeg;
 
-  TileLoader<AMODE> la;
-  TileLoader<BMODE> lb;
+  LA la;
+  LB lb;
   la.init(g.A + z1 * g.sA1 + z2 * g.sA2 + (long)kbeg * g.sAk, g.sAm, g.sAk, m0, g.M);
   lb.init(g.B + z1 * g.sB1 + z2 * g.sB2 + (long)kbeg * g.sBk, g.sBn, g.sBk, n0, g.N);
 
   f32x16 acc = {0};
-  const int nt = (klen + BK - 1) / BK;
+  const int nt = (klen + BKT - 1) / BKT;
   const int half = lane >> 5, l31 = lane & 31;
-  // all 16 A and 16 B operands of the tile are fetched with 8 ds_read_b128 BEFORE the MFMA chain (just-in-time scalar LDS
-  // reads expose the LDS latency once per MFMA and ran the chain at ~35 % of its issue rate)
+  // all 16 A and 16 B operands of this wave's k-slice are fetched BEFORE the MFMA chain (just-in-time LDS reads expose the
+  // LDS latency once per MFMA)
   auto compute = [&](int buf) {
-    float a[KH], b[KH];
-    const float* pa = &As[buf][half][wr * 32 + l31][0];
-    const float* pb = &Bs[buf][half][wc * 32 + l31][0];
+    float a[16], b[16];
+    const float* pa = &As[buf][(kh * 32 + half) * LA::LD + wr * 32 + l31];
+    const float* pb = &Bs[buf][(kh * 32 + half) * LB::LD + wc * 32 + l31];
 #pragma unroll
-    for (int q = 0; q < KH / 4; ++q) {
-      const float4 va4 = *reinterpret_cast<const float4*>(pa + 4 * q);
-      const float4 vb4 = *reinterpret_cast<const float4*>(pb + 4 * q);
-      a[4 * q] = va4.x; a[4 * q + 1] = va4.y; a[4 * q + 2] = va4.z; a[4 * q + 3] = va4.w;
-      b[4 * q] = vb4.x; b[4 * q + 1] = vb4.y; b[4 * q + 2] = vb4.z; b[4 * q + 3] = vb4.w;
-    }
+    for (int i = 0; i < 16; ++i) { a[i] = pa[2 * i * LA::LD]; b[i] = pb[2 * i * LB::LD]; }
     // straight-line chain of 16 MFMAs (a short last tile multiplies stored zeros: cheaper than a branch per MFMA)
 #pragma unroll
-    for (int i = 0; i < KH; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
+    for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
   };
 
-  float ra0[8], rb0[8], ra1[8], rb1[8];
-  if (nt > 0) {
-    la.load(0, klen, ra0); lb.load(0, klen, rb0);
-    if (nt > 1) { la.load(BK, klen, ra1); lb.load(BK, klen, rb1); }
-    la.store(As[0], ra0, 0, klen); lb.store(Bs[0], rb0, 0, klen);
-  }
+  // Branch-free pipeline: tile t lives in LDS buffer t&1; register set (t+1)&1 holds tile t+1; tile t+2 is requested into the
+  // freed set.  Out-of-range tiles are loaded from clamped addresses, stored as zeros and multiply as zeros.
+  float ra0[LA::NF], rb0[LB::NF], ra1[LA::NF], rb1[LB::NF];
+  la.load(0, klen, ra0); lb.load(0, klen, rb0);
+  la.load(BKT, klen, ra1); lb.load(BKT, klen, rb1);
+  la.store(As[0], ra0, 0, klen); lb.store(Bs[0], rb0, 0, klen);
   __syncthreads();
-  // tile t lives in LDS buffer t&1; register set (t+1)&1 holds tile t+1; tile t+2 is requested into the freed set
   for (int t = 0; t < nt; t += 2) {
-    if (t + 2 < nt) { la.load((t + 2) * BK, klen, ra0); lb.load((t + 2) * BK, klen, rb0); }
+    la.load((t + 2) * BKT, klen, ra0); lb.load((t + 2) * BKT, klen, rb0);
     compute(0);
-    if (t + 1 < nt) { la.store(As[1], ra1, (t + 1) * BK, klen); lb.store(Bs[1], rb1, (t + 1) * BK, klen); }
+    la.store(As[1], ra1, (t + 1) * BKT, klen); lb.store(Bs[1], rb1, (t + 1) * BKT, klen);
     __syncthreads();
-    if (t + 1 >= nt) break;
-    if (t + 3 < nt) { la.load((t + 3) * BK, klen, ra1); lb.load((t + 3) * BK, klen, rb1); }
-    compute(1);
-    if (t + 2 < nt) { la.store(As[0], ra0, (t + 2) * BK, klen); lb.store(Bs[0], rb0, (t + 2) * BK, klen); }
+    la.load((t + 3) * BKT, klen, ra1); lb.load((t + 3) * BKT, klen, rb1);
+    compute(1);                       // odd tile count: the last pass multiplies a zero tile
+    la.store(As[0], ra0, (t + 2) * BKT, klen); lb.store(Bs[0], rb0, (t + 2) * BKT, klen);
     __syncthreads();
+  }
+
+  if (KS > 1) {       // sum the k-slices: slices 1.. park their accumulators in LDS (stage buffers are dead by now)
+    float* red = &As[0][0];
+    if (kh > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(((kh - 1) * WM * WN + wt) * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (kh > 0) return;
+#pragma unroll
+    for (int q = 0; q < KS - 1; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += red[((q * WM * WN + wt) * 16 + r) * 64 + lane];
   }
 
   // epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -181,12 +203,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
 }
 
-template <int AM>
-static void launch_b(int bmode, dim3 grid, hipStream_t s, const GemmArgs& a) {
-  switch (bmode) {
-    case 0: hipLaunchKernelGGL((gemm_kernel<AM, 0>), grid, dim3(256), 0, s, a); break;
-    case 1: hipLaunchKernelGGL((gemm_kernel<AM, 1>), grid, dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL((gemm_kernel<AM, 2>), grid, dim3(256), 0, s, a); break;
+template <int AM, int BM_, int WM, int WN>
+static void launch_one(dim3 grid, hipStream_t s, const GemmArgs& a) {
+  hipLaunchKernelGGL((gemm_kernel<AM, BM_, WM, WN>), grid, dim3(256), 0, s, a);
+}
+template <int WM, int WN>
+static void launch_modes(int amode, int bmode, dim3 grid, hipStream_t s, const GemmArgs& a) {
+  switch (amode * 3 + bmode) {
+    case 0: launch_one<0, 0, WM, WN>(grid, s, a); break;
+    case 1: launch_one<0, 1, WM, WN>(grid, s, a); break;
+    case 2: launch_one<0, 2, WM, WN>(grid, s, a); break;
+    case 3: launch_one<1, 0, WM, WN>(grid, s, a); break;
+    case 4: launch_one<1, 1, WM, WN>(grid, s, a); break;
+    case 5: launch_one<1, 2, WM, WN>(grid, s, a); break;
+    case 6: launch_one<2, 0, WM, WN>(grid, s, a); break;
+    case 7: launch_one<2, 1, WM, WN>(grid, s, a); break;
+    default: launch_one<2, 2, WM, WN>(grid, s, a); break;
   }
 }
 
@@ -195,18 +227,32 @@ int gemm(const mser_gemm_desc& d, hipStream_t s) {
   MSER_REQUIRE(d.M >= 0 && d.N >= 0 && d.K >= 0, "mser_gemm: negative size");
   if (d.M == 0 || d.N == 0) return 0;
   const int b1 = d.batch1 > 0 ? d.batch1 : 1, b2 = d.batch2 > 0 ? d.batch2 : 1;
-  int splitk = d.splitk > 0 ? d.splitk : 1;
-  MSER_REQUIRE(!(splitk > 1 && (d.flags & MSER_GEMM_RELU)), "mser_gemm: split-K cannot fuse ReLU");
+  MSER_REQUIRE(!(d.splitk > 1 && (d.flags & MSER_GEMM_RELU)), "mser_gemm: split-K cannot fuse ReLU");
+  // ---- tile configuration: C0 (64x64) when it fills the chip on its own, otherwise C1 (64x32, two k-slices per workgroup)
+  constexpr long FILL = 256;                         // one workgroup per CU
+  const long tiles0 = (long)cdiv(d.M, 64) * cdiv(d.N, 64) * b1 * b2;
+  const bool c1 = tiles0 * (d.splitk > 1 ? 4 : 1) < FILL + FILL / 2 || d.N <= 32;
+  const int TM = 64, TN = c1 ? 32 : 64, BKT = c1 ? 64 : 32;
+  const long tiles = (long)cdiv(d.M, TM) * cdiv(d.N, TN) * b1 * b2;
+  // ---- split-K: `splitk > 1` means "C is initialised, accumulate atomically"; the split itself is chosen here so that the grid
+  // is about two workgroups per CU while every workgroup still runs at least two k-tiles
+  int splitk = 1;
+  if (d.splitk > 1 && d.K > 0) {
+    long want = (2 * FILL + tiles - 1) / tiles;
+    const long most = cdiv(d.K, 2 * BKT);
+    if (want > most) want = most;
+    splitk = (int)(want < 1 ? 1 : want);
+  }
   GemmArgs a;
   a.A = d.A; a.B = d.B; a.C = d.C; a.M = d.M; a.N = d.N; a.K = d.K;
   a.sAm = d.sAm; a.sAk = d.sAk; a.sBk = d.sBk; a.sBn = d.sBn; a.ldc = d.ldc;
-  a.batch2 = b2; a.splitk = splitk;
+  a.batch2 = b2;
   int kchunk = cdiv(d.K > 0 ? d.K : 1, splitk);
-  kchunk = cdiv(kchunk, BK) * BK;
+  kchunk = cdiv(kchunk, BKT) * BKT;
   a.kchunk = kchunk;
   a.splitk = splitk = (d.K > 0) ? cdiv(d.K, kchunk) : 1;
   if (splitk == 1 && d.splitk > 1) {
-    // degenerate split: fall back to a read-modify-write accumulate (caller promised C is initialised)
+    // degenerate split: a read-modify-write accumulate (caller promised C is initialised)
     a.flags = d.flags | MSER_GEMM_ACCUM;
   } else {
     a.flags = d.flags;
@@ -214,7 +260,7 @@ int gemm(const mser_gemm_desc& d, hipStream_t s) {
   a.sA1 = d.sA1; a.sA2 = d.sA2; a.sB1 = d.sB1; a.sB2 = d.sB2; a.sC1 = d.sC1; a.sC2 = d.sC2;
   a.bias = d.bias; a.alpha_dev = d.alpha_dev; a.alpha = d.alpha;
   a.R1 = d.R1; a.R2 = d.R2; a.ldr1 = d.ldr1; a.ldr2 = d.ldr2; a.sR1 = d.sR1_1; a.sR2 = d.sR1_2;
-  dim3 grid(cdiv(d.N, BN), cdiv(d.M, BM), b1 * b2 * splitk);
+  dim3 grid(cdiv(d.N, TN), cdiv(d.M, TM), b1 * b2 * splitk);
   MSER_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "mser_gemm: grid too large (M=%d batch=%d)", d.M, b1 * b2);
   // vector (float4) staging needs: unit stride along the vector, every other stride % 4 == 0, a 16-byte aligned base, and
   // extents such that no vector straddles the valid range
@@ -226,11 +272,13 @@ int gemm(const mser_gemm_desc& d, hipStream_t s) {
   else if (d.sAm == 1 && m4(d.sAk) && m4(d.sA1) && m4(d.sA2) && al16(d.A) && m4(d.M)) amode = 1;
   if (d.sBk == 1 && m4(d.sBn) && m4(d.sB1) && m4(d.sB2) && al16(d.B) && kvec_ok) bmode = 0;
   else if (d.sBn == 1 && m4(d.sBk) && m4(d.sB1) && m4(d.sB2) && al16(d.B) && m4(d.N)) bmode = 1;
-  switch (amode) {
-    case 0: launch_b<0>(bmode, grid, s, a); break;
-    case 1: launch_b<1>(bmode, grid, s, a); break;
-    default: launch_b<2>(bmode, grid, s, a); break;
-  }
+  static const bool log_calls = getenv("MSER_GEMM_LOG") != nullptr;      // diagnostic: one line per call on stderr
+  if (log_calls)
+    fprintf(stderr, "[gemm] M %d N %d K %d b %d splitk %d modes %d%d flags %d sAm %ld sAk %ld sBk %ld sBn %ld ldc %ld bias %d R %d grid %u cfg %d\n",
+            d.M, d.N, d.K, b1 * b2, d.splitk, amode, bmode, d.flags, d.sAm, d.sAk, d.sBk, d.sBn, d.ldc, d.bias != nullptr,
+            (d.R1 != nullptr) + (d.R2 != nullptr), grid.x * grid.y * grid.z, c1 ? 1 : 0);
+  if (c1) launch_modes<2, 1>(amode, bmode, grid, s, a);
+  else launch_modes<2, 2>(amode, bmode, grid, s, a);
   return check_launch("mser_gemm");
 }
 

@@ -56,8 +56,14 @@ struct CellK {
 // Every counter sits on a 128-byte line of its own (SYNC_LINE words apart): arrivals (atomics) and polls of one chain never queue
 // behind another chain's at the memory side.  Measured: with all eight counters on one line a second direction cost +56 % per
 // forward step and +24 % per backward step although the two directions share no data.
-enum { SYNC_LINE = 32, SYNC_SPK_FWD = 0, SYNC_LSTHM_FWD = 2 * SYNC_LINE, SYNC_LSTHM_BWD = 4 * SYNC_LINE, SYNC_SPK_BWD = 6 * SYNC_LINE,
-       SYNC_ABORT = 8 * SYNC_LINE, SYNC_STAMPS = 9 * SYNC_LINE, SYNC_WORDS = 11 * SYNC_LINE };
+// A counter is kept in SYNC_REP replicas (one line each): an arrival adds to every replica with ONE wave instruction (SYNC_REP
+// active lanes), a waiting workgroup polls only replica (workgroup id % SYNC_REP).
+#ifndef MSER_SYNC_REP
+#define MSER_SYNC_REP 8
+#endif
+enum { SYNC_LINE = 32, SYNC_REP = MSER_SYNC_REP, SYNC_DIR = SYNC_REP * SYNC_LINE, SYNC_SPK_FWD = 0, SYNC_LSTHM_FWD = 2 * SYNC_DIR,
+       SYNC_LSTHM_BWD = 4 * SYNC_DIR, SYNC_SPK_BWD = 6 * SYNC_DIR, SYNC_ABORT = 8 * SYNC_DIR, SYNC_STAMPS = SYNC_ABORT + SYNC_LINE,
+       SYNC_WORDS = SYNC_STAMPS + 2 * SYNC_LINE };
 
 
 // ---- optional per-kernel timing with HIP events (bench.py's live roofline measurement; off by default) ----------------------
@@ -177,12 +183,14 @@ constexpr unsigned SPIN_LIMIT = 1u << 22;
 __device__ __forceinline__ void barrier_arrive(unsigned* cnt) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its write-through stores
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add((gu32*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x < SYNC_REP) __hip_atomic_fetch_add((gu32*)cnt + threadIdx.x * SYNC_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ unsigned sync_replica() { return ((blockIdx.x + blockIdx.y + blockIdx.z) % SYNC_REP) * SYNC_LINE; }
 __device__ __forceinline__ bool barrier_wait(const unsigned* cnt, unsigned* abortw, unsigned target, int* lds_ok) {
   if (threadIdx.x == 0) {
     int ok = 1;
     unsigned spins = 0;
+    cnt += sync_replica();
     while (__hip_atomic_load((const gu32*)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
       if ((++spins & 255u) == 0u) {
@@ -206,10 +214,13 @@ __device__ __forceinline__ bool dir_barrier(unsigned* cnt, unsigned* abortw, uns
                                             const unsigned* cnt2 = nullptr, unsigned target2 = 0, bool wait = true) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its write-through stores
   __syncthreads();
+  if (cnt && threadIdx.x < SYNC_REP) __hip_atomic_fetch_add((gu32*)cnt + threadIdx.x * SYNC_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x == 0) {
-    if (cnt) __hip_atomic_fetch_add((gu32*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int ok = 1;
     unsigned spins = 0;
+    const unsigned rep = sync_replica();
+    if (cnt) cnt += rep;
+    if (cnt2) cnt2 += rep;
     while (wait) {
       const bool a = !cnt || __hip_atomic_load((const gu32*)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
       const bool b = !cnt2 || __hip_atomic_load((const gu32*)cnt2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target2;
@@ -488,7 +499,7 @@ __device__ __forceinline__ void spk_fwd_role(const CellK& P, const Role R, float
   for (int t = 0; t < P.T; ++t) {
     spk_fwd_body<true, NP>(P, D, ws, t, c, u0, mb, R.x == 0, bpre, red, tile);
     // the counter also tells the concurrently running LSTHM kernel that h_q[t] is published: arrive after the last step too
-    if (!dir_barrier(P.sync + SYNC_SPK_FWD + dir * SYNC_LINE, P.sync + SYNC_ABORT, nwg * (unsigned)(t + 1), lds_ok, nullptr, 0, t + 1 < P.T)) return;
+    if (!dir_barrier(P.sync + SYNC_SPK_FWD + dir * SYNC_DIR, P.sync + SYNC_ABORT, nwg * (unsigned)(t + 1), lds_ok, nullptr, 0, t + 1 < P.T)) return;
     STAMP_ACC(3);
   }
   STAMP_DUMP(P, 16, R.x == 0 && R.y == 0 && R.z == 0);
@@ -654,8 +665,8 @@ __device__ __forceinline__ void lsthm_fwd_role(const CellK& P, const Role R, flo
   float bpre[NP][8];
   preload_b<NP>(3 * P.H, LsthmFwdB{D, m, u0, P.H}, bpre);
   att_prepare(D, P.H, att, red);
-  unsigned* cnt = P.sync + SYNC_LSTHM_FWD + dir * SYNC_LINE;
-  const unsigned* spk = P.sync + SYNC_SPK_FWD + dir * SYNC_LINE;
+  unsigned* cnt = P.sync + SYNC_LSTHM_FWD + dir * SYNC_DIR;
+  const unsigned* spk = P.sync + SYNC_SPK_FWD + dir * SYNC_DIR;
   unsigned nbar = 0;
   if (!dir_barrier(nullptr, P.sync + SYNC_ABORT, 0, lds_ok, spk, nwg_spk)) return;      // h_q[0] published
   STAMP_INIT();
@@ -924,7 +935,7 @@ __device__ __forceinline__ void lsthm_bwd_role(const CellK& P, const Role R, flo
   }
   att_prepare(D, H, att, red);
   unsigned nbar = 0;
-  unsigned* cnt = P.sync + SYNC_LSTHM_BWD + dir * SYNC_LINE;
+  unsigned* cnt = P.sync + SYNC_LSTHM_BWD + dir * SYNC_DIR;
   STAMP_INIT();
   RowPre pre = lsthm_bwd_row_prefetch(P, D, P.T - 1, w < P.B ? w : 0);
   for (int t = P.T - 1; t >= 0; --t) {
@@ -1129,8 +1140,8 @@ __device__ __forceinline__ void spk_bwd_role(const CellK& P, const Role R, float
   const unsigned nwg = R.gx * R.gy * P.nmb;
   float bpre[NP][8];
   preload_b<NP>(4 * P.H, LsthmBwdB{(p & 1) ? D.Whh[p >> 1] : D.Wih[p >> 1], n0, P.H}, bpre);
-  unsigned* cnt = P.sync + SYNC_SPK_BWD + dir * SYNC_LINE;
-  const unsigned* lcnt = P.sync + SYNC_LSTHM_BWD + dir * SYNC_LINE;
+  unsigned* cnt = P.sync + SYNC_SPK_BWD + dir * SYNC_DIR;
+  const unsigned* lcnt = P.sync + SYNC_LSTHM_BWD + dir * SYNC_DIR;
   unsigned nbar = 0;
   if (!dir_barrier(nullptr, P.sync + SYNC_ABORT, 0, lds_ok, lcnt, 2u * nwg_l)) return;          // dHQ[T-1] complete
   STAMP_INIT();
@@ -1560,7 +1571,7 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       if (persist && k.rev)    // rows at and beyond len_b receive no gradient from the reversed direction
         MSER_CHECK_HIP(hipMemsetAsync(k.dxc, 0, 2 * (size_t)TB * D * sizeof(float), s));
     }
-    MSER_CHECK_HIP(hipMemsetAsync(h.sync + SYNC_LSTHM_BWD, 0, 4 * SYNC_LINE * sizeof(unsigned), s));
+    MSER_CHECK_HIP(hipMemsetAsync(h.sync + SYNC_LSTHM_BWD, 0, 4 * SYNC_DIR * sizeof(unsigned), s));
   }
   if (phases & MSER_PHASE_LSTHM_BWD) {
   // ---- LSTHM chain, reverse time
@@ -1768,8 +1779,8 @@ int mser_marn_cell_status(const mser_cell_desc* d, mser_stream_t stream) {
 #endif
   if (words[SYNC_ABORT] != 0) {
     set_error("marn_cell: a persistent kernel gave up waiting at an inter-workgroup barrier (counters: spk_fwd %u/%u lsthm_fwd %u/%u "
-              "lsthm_bwd %u/%u spk_bwd %u/%u)", words[SYNC_SPK_FWD], words[SYNC_SPK_FWD + SYNC_LINE], words[SYNC_LSTHM_FWD], words[SYNC_LSTHM_FWD + SYNC_LINE], words[SYNC_LSTHM_BWD],
-              words[SYNC_LSTHM_BWD + SYNC_LINE], words[SYNC_SPK_BWD], words[SYNC_SPK_BWD + SYNC_LINE]);
+              "lsthm_bwd %u/%u spk_bwd %u/%u)", words[SYNC_SPK_FWD], words[SYNC_SPK_FWD + SYNC_DIR], words[SYNC_LSTHM_FWD], words[SYNC_LSTHM_FWD + SYNC_DIR], words[SYNC_LSTHM_BWD],
+              words[SYNC_LSTHM_BWD + SYNC_DIR], words[SYNC_SPK_BWD], words[SYNC_SPK_BWD + SYNC_DIR]);
     return -2;
   }
   return 0;
