@@ -186,12 +186,17 @@ __device__ __forceinline__ void barrier_arrive(unsigned* cnt) {
   if (threadIdx.x < SYNC_REP) __hip_atomic_fetch_add((gu32*)cnt + threadIdx.x * SYNC_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ unsigned sync_replica() { return ((blockIdx.x + blockIdx.y + blockIdx.z) % SYNC_REP) * SYNC_LINE; }
-__device__ __forceinline__ bool barrier_wait(const unsigned* cnt, unsigned* abortw, unsigned target, int* lds_ok) {
+// One early look at this workgroup's replica (all lanes load the same word: uniform code, the value comes back while the
+// caller keeps computing); pass it to barrier_wait, which polls only if the count was not complete yet.
+__device__ __forceinline__ unsigned barrier_peek(const unsigned* cnt) {
+  return __hip_atomic_load((const gu32*)(cnt + sync_replica()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool barrier_wait(const unsigned* cnt, unsigned* abortw, unsigned target, int* lds_ok, unsigned seen = 0) {
   if (threadIdx.x == 0) {
     int ok = 1;
     unsigned spins = 0;
     cnt += sync_replica();
-    while (__hip_atomic_load((const gu32*)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    while (seen < target && __hip_atomic_load((const gu32*)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
       if ((++spins & 255u) == 0u) {
         if (spins > SPIN_LIMIT || __hip_atomic_load((const gu32*)abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
@@ -579,8 +584,12 @@ __device__ __forceinline__ void lsthm_gates_body(const CellK& P, const DirP& D, 
 
 // Row phase, one dialogue row b per call (NT threads): z[b,i] = sum_j softmax_j(c_l[i] * s_b * Wk[j]) c_a[j]  (:59-72, rank-1 form)
 // thread (i = tid % H, q = tid / H) covers keys j in [q*JC, (q+1)*JC).  scr: ca[H] pZ[NT] pN[NT] sh[16]
-template <bool PS, int JCT>       // JCT = keys per thread chunk when known at compile time (fully unrolled loops), 0 = runtime
-__device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, const WS& ws, int t, int b, const float* att, float* scr) {
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// `after_loads` runs right behind the row's own operand loads: loads issued there are YOUNGER than the row's, so the row phase
+// does not wait for them (vmcnt retires in order) -- used to fetch the next step's early-product operands under the exp2 work.
+template <bool PS, int JCT, class Hook = NoHook>       // JCT = keys per thread chunk when known at compile time (fully unrolled loops), 0 = runtime
+__device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, const WS& ws, int t, int b, const float* att, float* scr,
+                                             Hook after_loads = Hook()) {
   const int H = P.H, B = P.B, T = P.T;
   const int Q = NT / H, JC = JCT ? JCT : H / Q;
   float* ca = scr;
@@ -601,6 +610,7 @@ __device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, cons
   }
   const float cli = ldx<PS>(ws, c_l + i);
   const int tau = D.rev ? D.rev[(long)t * B + b] : t;
+  after_loads();
   sp = wave_sum(sp);
   if (lane == 0) sh[wave] = sp;
   __syncthreads();
@@ -633,6 +643,148 @@ __device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, cons
   __syncthreads();     // scratch is reused by the next row / phase
 }
 
+// ---- pipelined form of the forward step (persistent kernels only) --------------------------------------------------------------
+// gates[t] = pre[t] + [h_{t-1} | h_q[t]] [U | S]^T  +  z_{t-1} V^T.  Only the last term needs z: the first product ("early", K = 2H)
+// is known as soon as h_{t-1} is published.  Its operands are fetched at the start of the row phase and its MFMA chain runs in the
+// SHADOW OF THE BARRIER that ends the row phase (arrive -> MFMAs -> wait): ~1 us in which the workgroup would only poll.  The gates
+// phase then only adds the z product ("late", K = H).  The k range of both products is split over the 8 waves; each wave keeps
+// ONE accumulator across the barrier (no LDS round trip in between) and the 8 partials are reduced once.
+// (Measured alternatives: the early chain interleaved with the exp2 loop of the row phase in one wave, or on four dedicated
+// waves next to four exp2 waves, did not overlap on this hardware: 3.2 / 4.1 us for the row phase instead of 1.6.)
+// wave w, pass p < NPE: early k = w*16*NPE + 16p + half*8 (k < H: U / h, else S / h_q);  pass p >= NPE: late k = w*16*NPL + ...
+template <int NP>
+struct FwdSplit { static constexpr int NPE = 2 * NP / 3, NPL = NP / 3; };
+
+template <int NP>
+__device__ __forceinline__ void lsthm_preload_b_split(const DirP& D, int m, int u0, int H, float (*bpre)[8]) {
+  constexpr int NPE = FwdSplit<NP>::NPE, NPL = FwdSplit<NP>::NPL;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 31, half = lane >> 5;
+  const long wrow = (long)(n >> 3) * H + u0 + (n & 7);
+#pragma unroll
+  for (int p = 0; p < NPE; ++p) {
+    const int k = wave * 16 * NPE + 16 * p + half * 8;
+    load8((k < H ? D.U[m] + wrow * H + k : D.S[m] + wrow * H + (k - H)), bpre[p]);
+  }
+#pragma unroll
+  for (int p = 0; p < NPL; ++p) load8(D.V[m] + wrow * H + wave * 16 * NPL + 16 * p + half * 8, bpre[NPE + p]);
+}
+// A fragments of the early product for step t (rows = dialogues of block mb): h_m[t-1] (= hz[t], stream m) and h_q[t]
+template <int NP>
+__device__ __forceinline__ void lsthm_early_aload(const CellK& P, const DirP& D, const WS& ws, int t, int m, int mb, float (*a)[8]) {
+  constexpr int NPE = FwdSplit<NP>::NPE;
+  const int H = P.H, B = P.B;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int b = mb * 32 + r;
+  const int bc = b < B ? b : B - 1;           // clamped row, zeroed below (no load inside a branch)
+#pragma unroll
+  for (int p = 0; p < NPE; ++p) {
+    const int k = wave * 16 * NPE + 16 * p + half * 8;
+    const float* src = k < H ? D.hz + ((long)t * B + bc) * 3 * H + m * H + k : D.HQ + ((long)t * B + bc) * H + (k - H);
+    load8x<true>(ws, src, a[p]);
+  }
+  if (b >= B) {
+#pragma unroll
+    for (int p = 0; p < NPE; ++p) zero8(a[p]);
+  }
+}
+// PART 0 / 1: first / second half of the early chain (a poll of the barrier counter is issued in between)
+template <int NP, int PART>
+__device__ __forceinline__ f32x16 lsthm_early_mm(const float (*a)[8], const float (*bpre)[8], f32x16 acc) {
+  constexpr int NPE = FwdSplit<NP>::NPE;
+#pragma unroll
+  for (int p = PART * NPE / 2; p < (PART + 1) * NPE / 2; ++p)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][j], bpre[p][j], acc, 0, 0, 0);
+  return acc;
+}
+// Epilogue operands of step t that do not depend on the chain (pre-activation row + biases): fetched in the barrier shadow too.
+struct GatePre { float pre4[4]; int tau; };
+__device__ __forceinline__ GatePre lsthm_gate_prefetch(const CellK& P, const DirP& D, int t, int m, int u0, int mb) {
+  GatePre g;
+  g.pre4[0] = g.pre4[1] = g.pre4[2] = g.pre4[3] = 0.f;
+  g.tau = -1;
+  const int tid = threadIdx.x;
+  const int H = P.H, B = P.B, T = P.T;
+  if (tid < 256) {
+    const int b = mb * 32 + (tid >> 3), u = u0 + (tid & 7);
+    if (b < B) {
+      const float* pr = D.pre + ((long)m * T * B + (long)t * B + b) * 4 * H + u;
+#pragma unroll
+      for (int gt = 0; gt < 4; ++gt) g.pre4[gt] = pr[gt * H] + D.Ub[m][gt * H + u] + D.Vb[m][gt * H + u] + D.Sb[m][gt * H + u];
+      g.tau = D.rev ? D.rev[(long)t * B + b] : t;
+    }
+  }
+  return g;
+}
+
+// Gates phase of step t: acc (early product, in registers) += z_{t-1} V^T, cross-wave reduction, LSTM epilogue.
+// c_state: this thread's cell state c_{t-1}[b][u] (the same thread owns the same (b, u) every step: it never leaves the register).
+template <int NP>
+__device__ __forceinline__ void lsthm_gates_late(const CellK& P, const DirP& D, const WS& ws, int t, int m, int u0, int mb,
+                                                 const float (*bpre)[8], f32x16 acc, const GatePre& gp, float& c_state, float* red,
+                                                 float* tile) {
+  constexpr int NPE = FwdSplit<NP>::NPE, NPL = FwdSplit<NP>::NPL;
+  const int H = P.H, B = P.B, T = P.T;
+  float* hz_new = D.hz + (long)(t + 1) * B * 3 * H;
+  float* c_new = D.cstate + ((long)m * (T + 1) + t + 1) * B * H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  // late A fragments: z_{t-1} rows (published by the row phase of the previous step)
+  float a[NPL][8];
+  {
+    const int b = mb * 32 + r;
+    const int bc = b < B ? b : B - 1;
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+      load8x<true>(ws, D.hz + ((long)t * B + bc) * 3 * H + 2 * H + wave * 16 * NPL + 16 * p + half * 8, a[p]);
+    if (b >= B) {
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) zero8(a[p]);
+    }
+  }
+  STAMP_ACC(0);
+#pragma unroll
+  for (int p = 0; p < NPL; ++p)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][j], bpre[NPE + p][j], acc, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
+    red[wave * 1024 + row * 32 + r] = acc[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 1024 / NT; ++e) {
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) sum += red[w * 1024 + tid + e * NT];
+    tile[tid + e * NT] = sum;
+  }
+  __syncthreads();
+  STAMP_ACC(1);
+  if (tid < 256) {
+    const int rr = tid >> 3, uu = tid & 7;
+    const int b = mb * 32 + rr, u = u0 + uu;
+    if (b < B) {
+      const float gf = sigmoidf_(tile[rr * 32 + 0 + uu] + gp.pre4[0]);
+      const float gi = sigmoidf_(tile[rr * 32 + 8 + uu] + gp.pre4[1]);
+      const float go = sigmoidf_(tile[rr * 32 + 16 + uu] + gp.pre4[2]);
+      const float gc = tanhf(tile[rr * 32 + 24 + uu] + gp.pre4[3]);
+      const float cn = gf * c_state + gi * gc;
+      const float hn = tanhf(cn) * go;
+      c_state = cn;
+      stx<true>(ws, c_new + (long)b * H + u, cn);
+      stx<true>(ws, hz_new + (long)b * 3 * H + m * H + u, hn);
+      float* g = D.gates + ((long)m * T * B + (long)t * B + b) * 4 * H + u;
+      g[0] = gf; g[H] = gi; g[2 * H] = go; g[3 * H] = gc;
+      if (gp.tau >= 0) D.out[((long)gp.tau * B + b) * P.ldo + m * H + u] = hn;
+    }
+  }
+  STAMP_ACC(2);
+}
+
 // per-step launches
 __global__ __launch_bounds__(NT) void lsthm_fwd_gates(CellK P, int t) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -663,21 +815,41 @@ __device__ __forceinline__ void lsthm_fwd_role(const CellK& P, const Role R, flo
   const unsigned nwg_spk = nwg;                                          // the speaker chain uses the same logical grid
   const int w = (mb * R.gy + R.y) * R.gx + R.x;    // linear workgroup index inside the direction
   float bpre[NP][8];
-  preload_b<NP>(3 * P.H, LsthmFwdB{D, m, u0, P.H}, bpre);
+  lsthm_preload_b_split<NP>(D, m, u0, P.H, bpre);
   att_prepare(D, P.H, att, red);
   unsigned* cnt = P.sync + SYNC_LSTHM_FWD + dir * SYNC_DIR;
   const unsigned* spk = P.sync + SYNC_SPK_FWD + dir * SYNC_DIR;
   unsigned nbar = 0;
   if (!dir_barrier(nullptr, P.sync + SYNC_ABORT, 0, lds_ok, spk, nwg_spk)) return;      // h_q[0] published
   STAMP_INIT();
+  constexpr int JCT = (128 * NP / 3) * (128 * NP / 3) / NT;      // NP = 3H/128, keys per thread = H*H/NT
+  float a[FwdSplit<NP>::NPE][8];
+  lsthm_early_aload<NP>(P, D, ws, 0, m, mb, a);                     // h_{-1} = 0 (hz[0] is zeroed), h_q[0]
+  f32x16 acc = lsthm_early_mm<NP, 1>(a, bpre, lsthm_early_mm<NP, 0>(a, bpre, f32x16{0}));
+  GatePre gp = lsthm_gate_prefetch(P, D, 0, m, u0, mb);
+  float c_state = 0.f;                                              // c_{-1} = 0
   for (int t = 0; t < P.T; ++t) {
-    lsthm_gates_body<true, NP, true>(P, D, ws, t, m, u0, mb, bpre, red, tile);   // stamps 0 (loads) 1 (mm) 2 (epilogue)
-    if (!dir_barrier(cnt, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
+    lsthm_gates_late<NP>(P, D, ws, t, m, u0, mb, bpre, acc, gp, c_state, red, tile);   // stamps 0 (loads) 1 (mm) 2 (epilogue)
+    const bool more = t + 1 < P.T;
+    // h_t is published behind this barrier; the early product of step t+1 also needs h_q[t+1] from the speaker chain
+    if (!dir_barrier(cnt, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok, more ? spk : nullptr, nwg_spk * (unsigned)(t + 2))) return;
     STAMP_ACC(3);
-    for (int b = w; b < P.B; b += (int)nwg) lsthm_z_body<true, (128 * NP / 3) * (128 * NP / 3) / NT>(P, D, ws, t, b, att, red);   // NP = 3H/128, JC = H*H/NT
+    // operands of the next step's early product: requested behind the first row's own loads, in flight during the row phase
+    bool fetched = !more;
+    auto fetch = [&]() { if (!fetched) { lsthm_early_aload<NP>(P, D, ws, t + 1, m, mb, a); fetched = true; } };
+    for (int b = w; b < P.B; b += (int)nwg) lsthm_z_body<true, JCT>(P, D, ws, t, b, att, red, fetch);
+    fetch();                                                        // a workgroup that owns no row
     STAMP_ACC(4);
-    if (t + 1 == P.T) break;
-    if (!dir_barrier(cnt, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok, spk, nwg_spk * (unsigned)(t + 2))) return;
+    if (!more) break;
+    // split-phase barrier: the early MFMA chain, the next step's pre-activation fetch and the first poll of the counter all run
+    // while the hand-off is in flight
+    barrier_arrive(cnt);
+    ++nbar;
+    gp = lsthm_gate_prefetch(P, D, t + 1, m, u0, mb);
+    acc = lsthm_early_mm<NP, 0>(a, bpre, f32x16{0});
+    const unsigned seen = barrier_peek(cnt);
+    acc = lsthm_early_mm<NP, 1>(a, bpre, acc);
+    if (!barrier_wait(cnt, P.sync + SYNC_ABORT, nwg * nbar, lds_ok, seen)) return;
     STAMP_ACC(5);
   }
   STAMP_DUMP(P, 24, R.x == 3 && R.y == 1 && R.z == 0);
