@@ -191,12 +191,19 @@ __device__ __forceinline__ unsigned sync_replica() { return ((blockIdx.x + block
 __device__ __forceinline__ unsigned barrier_peek(const unsigned* cnt) {
   return __hip_atomic_load((const gu32*)(cnt + sync_replica()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ bool barrier_wait(const unsigned* cnt, unsigned* abortw, unsigned target, int* lds_ok, unsigned seen = 0) {
+__device__ __forceinline__ bool barrier_wait(const unsigned* cnt, unsigned* abortw, unsigned target, int* lds_ok, unsigned seen = 0,
+                                             const unsigned* cnt2 = nullptr, unsigned target2 = 0) {
   if (threadIdx.x == 0) {
     int ok = 1;
     unsigned spins = 0;
-    cnt += sync_replica();
-    while (seen < target && __hip_atomic_load((const gu32*)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    const unsigned rep = sync_replica();
+    cnt += rep;
+    if (cnt2) cnt2 += rep;
+    bool a = seen >= target, b = !cnt2;
+    while (true) {
+      if (!a) a = __hip_atomic_load((const gu32*)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
+      if (!b) b = __hip_atomic_load((const gu32*)cnt2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target2;
+      if (a && b) break;
       __builtin_amdgcn_s_sleep(1);
       if ((++spins & 255u) == 0u) {
         if (spins > SPIN_LIMIT || __hip_atomic_load((const gu32*)abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
@@ -662,15 +669,16 @@ __device__ __forceinline__ void lsthm_preload_b_split(const DirP& D, int m, int 
   const int n = lane & 31, half = lane >> 5;
   const long wrow = (long)(n >> 3) * H + u0 + (n & 7);
 #pragma unroll
-  for (int p = 0; p < NPE; ++p) {
-    const int k = wave * 16 * NPE + 16 * p + half * 8;
-    load8((k < H ? D.U[m] + wrow * H + k : D.S[m] + wrow * H + (k - H)), bpre[p]);
+  for (int p = 0; p < NPE; ++p) {      // passes [0, NPE/2): U (h part), [NPE/2, NPE): S (h_q part); both cover k = 0..H-1 over the waves
+    const int k = wave * 8 * NPE + 16 * (p % (NPE / 2)) + half * 8;
+    load8((p < NPE / 2 ? D.U[m] : D.S[m]) + wrow * H + k, bpre[p]);
   }
 #pragma unroll
   for (int p = 0; p < NPL; ++p) load8(D.V[m] + wrow * H + wave * 16 * NPL + 16 * p + half * 8, bpre[NPE + p]);
 }
-// A fragments of the early product for step t (rows = dialogues of block mb): h_m[t-1] (= hz[t], stream m) and h_q[t]
-template <int NP>
+// A fragments of the early product for step t (rows = dialogues of block mb).  PART 0: h_m[t-1] (= hz[t], stream m) into passes
+// [0, NPE/2); PART 1: h_q[t] into passes [NPE/2, NPE).
+template <int NP, int PART>
 __device__ __forceinline__ void lsthm_early_aload(const CellK& P, const DirP& D, const WS& ws, int t, int m, int mb, float (*a)[8]) {
   constexpr int NPE = FwdSplit<NP>::NPE;
   const int H = P.H, B = P.B;
@@ -679,17 +687,17 @@ __device__ __forceinline__ void lsthm_early_aload(const CellK& P, const DirP& D,
   const int b = mb * 32 + r;
   const int bc = b < B ? b : B - 1;           // clamped row, zeroed below (no load inside a branch)
 #pragma unroll
-  for (int p = 0; p < NPE; ++p) {
-    const int k = wave * 16 * NPE + 16 * p + half * 8;
-    const float* src = k < H ? D.hz + ((long)t * B + bc) * 3 * H + m * H + k : D.HQ + ((long)t * B + bc) * H + (k - H);
-    load8x<true>(ws, src, a[p]);
+  for (int p = 0; p < NPE / 2; ++p) {
+    const int k = wave * 8 * NPE + 16 * p + half * 8;
+    const float* src = PART == 0 ? D.hz + ((long)t * B + bc) * 3 * H + m * H + k : D.HQ + ((long)t * B + bc) * H + k;
+    load8x<true>(ws, src, a[PART * NPE / 2 + p]);
   }
   if (b >= B) {
 #pragma unroll
-    for (int p = 0; p < NPE; ++p) zero8(a[p]);
+    for (int p = 0; p < NPE / 2; ++p) zero8(a[PART * NPE / 2 + p]);
   }
 }
-// PART 0 / 1: first / second half of the early chain (a poll of the barrier counter is issued in between)
+// PART 0 / 1: h part / h_q part of the early chain
 template <int NP, int PART>
 __device__ __forceinline__ f32x16 lsthm_early_mm(const float (*a)[8], const float (*bpre)[8], f32x16 acc) {
   constexpr int NPE = FwdSplit<NP>::NPE;
@@ -820,36 +828,41 @@ __device__ __forceinline__ void lsthm_fwd_role(const CellK& P, const Role R, flo
   unsigned* cnt = P.sync + SYNC_LSTHM_FWD + dir * SYNC_DIR;
   const unsigned* spk = P.sync + SYNC_SPK_FWD + dir * SYNC_DIR;
   unsigned nbar = 0;
-  if (!dir_barrier(nullptr, P.sync + SYNC_ABORT, 0, lds_ok, spk, nwg_spk)) return;      // h_q[0] published
+  // h_q[0] and h_q[1] published (the speaker chain needs only qmask and normally runs far ahead)
+  if (!dir_barrier(nullptr, P.sync + SYNC_ABORT, 0, lds_ok, spk, nwg_spk * (P.T > 1 ? 2u : 1u))) return;
   STAMP_INIT();
   constexpr int JCT = (128 * NP / 3) * (128 * NP / 3) / NT;      // NP = 3H/128, keys per thread = H*H/NT
   float a[FwdSplit<NP>::NPE][8];
-  lsthm_early_aload<NP>(P, D, ws, 0, m, mb, a);                     // h_{-1} = 0 (hz[0] is zeroed), h_q[0]
+  lsthm_early_aload<NP, 0>(P, D, ws, 0, m, mb, a);                  // h_{-1} = 0 (hz[0] is zeroed)
+  lsthm_early_aload<NP, 1>(P, D, ws, 0, m, mb, a);                  // h_q[0]
   f32x16 acc = lsthm_early_mm<NP, 1>(a, bpre, lsthm_early_mm<NP, 0>(a, bpre, f32x16{0}));
   GatePre gp = lsthm_gate_prefetch(P, D, 0, m, u0, mb);
   float c_state = 0.f;                                              // c_{-1} = 0
   for (int t = 0; t < P.T; ++t) {
-    lsthm_gates_late<NP>(P, D, ws, t, m, u0, mb, bpre, acc, gp, c_state, red, tile);   // stamps 0 (loads) 1 (mm) 2 (epilogue)
     const bool more = t + 1 < P.T;
-    // h_t is published behind this barrier; the early product of step t+1 also needs h_q[t+1] from the speaker chain
-    if (!dir_barrier(cnt, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok, more ? spk : nullptr, nwg_spk * (unsigned)(t + 2))) return;
+    if (more) lsthm_early_aload<NP, 1>(P, D, ws, t + 1, m, mb, a);  // h_q[t+1]: known to be published since the previous barrier
+    lsthm_gates_late<NP>(P, D, ws, t, m, u0, mb, bpre, acc, gp, c_state, red, tile);   // stamps 0 (loads) 1 (mm) 2 (epilogue)
+    // split-phase barriers: MFMA chains whose operands are already in registers run while the hand-off is in flight.
+    // Behind this one h_t is published; in its shadow: the h_q part of the next step's early product.
+    barrier_arrive(cnt);
+    ++nbar;
+    acc = lsthm_early_mm<NP, 1>(a, bpre, f32x16{0});
+    if (!barrier_wait(cnt, P.sync + SYNC_ABORT, nwg * nbar, lds_ok)) return;
     STAMP_ACC(3);
-    // operands of the next step's early product: requested behind the first row's own loads, in flight during the row phase
+    // h part of the next step's early product: requested behind the first row's own loads, in flight during the row phase
     bool fetched = !more;
-    auto fetch = [&]() { if (!fetched) { lsthm_early_aload<NP>(P, D, ws, t + 1, m, mb, a); fetched = true; } };
+    auto fetch = [&]() { if (!fetched) { lsthm_early_aload<NP, 0>(P, D, ws, t + 1, m, mb, a); fetched = true; } };
     for (int b = w; b < P.B; b += (int)nwg) lsthm_z_body<true, JCT>(P, D, ws, t, b, att, red, fetch);
     fetch();                                                        // a workgroup that owns no row
     STAMP_ACC(4);
     if (!more) break;
-    // split-phase barrier: the early MFMA chain, the next step's pre-activation fetch and the first poll of the counter all run
-    // while the hand-off is in flight
+    // behind this one z_t is published; in its shadow: the h part of the early product and the pre-activation fetch.  The wait
+    // also covers h_q[t+2] of the speaker chain (fetched at the top of the next iteration).
     barrier_arrive(cnt);
     ++nbar;
     gp = lsthm_gate_prefetch(P, D, t + 1, m, u0, mb);
-    acc = lsthm_early_mm<NP, 0>(a, bpre, f32x16{0});
-    const unsigned seen = barrier_peek(cnt);
-    acc = lsthm_early_mm<NP, 1>(a, bpre, acc);
-    if (!barrier_wait(cnt, P.sync + SYNC_ABORT, nwg * nbar, lds_ok, seen)) return;
+    acc = lsthm_early_mm<NP, 0>(a, bpre, acc);
+    if (!barrier_wait(cnt, P.sync + SYNC_ABORT, nwg * nbar, lds_ok, 0, t + 2 < P.T ? spk : nullptr, nwg_spk * (unsigned)(t + 3))) return;
     STAMP_ACC(5);
   }
   STAMP_DUMP(P, 24, R.x == 3 && R.y == 1 && R.z == 0);
