@@ -906,30 +906,21 @@ __device__ __forceinline__ RowPre lsthm_bwd_row_prefetch(const CellK& P, const D
   return r;
 }
 
-template <bool PS, int JCT>
-__device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D, const WS& ws, int t, int b, const float* att, float* scr,
-                                                   const RowPre& pre) {
-  const int H = P.H, B = P.B, T = P.T;
+// The row step in two halves.  part1 needs only saved forward state (softmax statistics of pass 1): in the persistent kernel it
+// runs in the SHADOW OF THE BARRIER that publishes the carries of step t+1.  part2 needs those carries (dz, dh).
+struct RowMid { float s, u, Z, N2, N3; };
+
+template <int JCT>
+__device__ __forceinline__ RowMid lsthm_bwd_row_part1(const CellK& P, const float* att, float* scr, const RowPre& pre) {
+  const int H = P.H;
   const int Q = NT / H, JC = JCT ? JCT : H / Q;
   float* ca = scr;           float* cl = ca + H;   float* cw = cl + H;   float* coef = cw + H;
   float* p0 = coef + 8 * H;  float* p1 = p0 + NT;  float* p2 = p1 + NT;  float* sh = p2 + NT;
   const float* wk = att;
   const float* wq = att + H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long rowt = (long)t * B + b;
-  const bool last = (t == T - 1);
-  const float* dA = D.dA + (long)b * H;          // [4][B][H]: U_l, V_l, U_a, V_a products of step t+1
-  const long SA = (long)B * H;
   const float rsH = 1.0f / sqrtf((float)H);
   const int i = tid & (H - 1), q = tid / H;
-
-  // the only operands that come from other workgroups of this launch: the four carry products of step t+1
-  float dz_in = pre.dz_out, zi = pre.zi, dh2[2] = {pre.dh_out[0], pre.dh_out[1]}, dhq = pre.dhq;
-  if (q == 0 && !last) {
-    dz_in += ldx<PS>(ws, dA + 1 * SA + i) + ldx<PS>(ws, dA + 3 * SA + i);
-    dh2[0] += ldx<PS>(ws, dA + 0 * SA + i);
-    dh2[1] += ldx<PS>(ws, dA + 2 * SA + i);
-  }
   float sp = 0.f;
   if (tid < H) {
     const float cv = pre.cav, w = wk[tid];
@@ -940,13 +931,15 @@ __device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D
   if (lane == 0) sh[wave] = sp;
   __syncthreads();
   STAMP_ACC(4);
+  RowMid r;
   float s = 0.f;
 #pragma unroll
   for (int w = 0; w < NW; ++w) s += sh[w];
   s *= rsH;
-
+  r.s = s;
   // ---- pass 1: per output unit i, sums over the keys j of chunk q
   const float u = cl[i] * s;
+  r.u = u;
   const float mx = (u >= 0.f) ? u * att[2 * H] : u * att[2 * H + 1];
   const float u2 = u * LOG2E, m2 = mx * LOG2E;
   float Z = 0.f, N2 = 0.f, N3 = 0.f;
@@ -965,9 +958,45 @@ __device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D
   if (q > 0) { p0[tid] = Z; p1[tid] = N2; p2[tid] = N3; }
   __syncthreads();
   STAMP_ACC(5);
-  float du_cl = 0.f, dcl_att = 0.f;
   if (q == 0) {
     for (int qq = 1; qq < Q; ++qq) { Z += p0[qq * H + i]; N2 += p1[qq * H + i]; N3 += p2[qq * H + i]; }
+  }
+  r.Z = Z; r.N2 = N2; r.N3 = N3;
+  return r;
+}
+
+// carry[2]: the dc carry of this thread's unit, both streams (in: from step t+1, out: for step t-1).  The persistent kernel keeps it in
+// registers (the same thread owns the same (row, unit) every step); it is also written to dc_carry for the per-step launches.
+template <bool PS, int JCT>
+__device__ __forceinline__ void lsthm_bwd_row_part2(const CellK& P, const DirP& D, const WS& ws, int t, int b, const float* att, float* scr,
+                                                    const RowPre& pre, const RowMid& mid, float* carry) {
+  const int H = P.H, B = P.B, T = P.T;
+  const int Q = NT / H, JC = JCT ? JCT : H / Q;
+  float* ca = scr;           float* cl = ca + H;   float* cw = cl + H;   float* coef = cw + H;
+  float* p0 = coef + 8 * H;  float* p1 = p0 + NT;  float* p2 = p1 + NT;  float* sh = p2 + NT;
+  const float* wk = att;
+  const float* wq = att + H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long rowt = (long)t * B + b;
+  const bool last = (t == T - 1);
+  const float* dA = D.dA + (long)b * H;          // [4][B][H]: U_l, V_l, U_a, V_a products of step t+1
+  const long SA = (long)B * H;
+  const float rsH = 1.0f / sqrtf((float)H);
+  const int i = tid & (H - 1), q = tid / H;
+  const float s = mid.s, u = mid.u;
+  const float mx = (u >= 0.f) ? u * att[2 * H] : u * att[2 * H + 1];
+  const float u2 = u * LOG2E, m2 = mx * LOG2E;
+
+  // the only operands that come from other workgroups of this launch: the four carry products of step t+1
+  float dz_in = pre.dz_out, zi = pre.zi, dh2[2] = {pre.dh_out[0], pre.dh_out[1]}, dhq = pre.dhq;
+  if (q == 0 && !last) {
+    dz_in += ldx<PS>(ws, dA + 1 * SA + i) + ldx<PS>(ws, dA + 3 * SA + i);
+    dh2[0] += ldx<PS>(ws, dA + 0 * SA + i);
+    dh2[1] += ldx<PS>(ws, dA + 2 * SA + i);
+  }
+  float du_cl = 0.f, dcl_att = 0.f;
+  if (q == 0) {
+    const float Z = mid.Z, N2 = mid.N2, N3 = mid.N3;
     const float du = dz_in * (N2 - zi * N3) / Z;
     const float a = dz_in / Z;
     float* cf = coef + 8 * i;
@@ -1014,17 +1043,26 @@ __device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D
       const float dh = dh2[m];
       const float cc = m ? pre.cav : pre.clv;
       const float tc = tanhf(cc);
-      const float dc = pre.carry[m] + dh * go * (1.f - tc * tc) + (m ? dca_att : dcl_att);
+      const float dc = carry[m] + dh * go * (1.f - tc * tc) + (m ? dca_att : dcl_att);
       float* dg = D.dgates + ((long)m * T * B + rowt) * 4 * H + i;
       stx<PS>(ws, dg, dc * pre.cprev[m] * gf * (1.f - gf));
       stx<PS>(ws, dg + H, dc * gc * gi * (1.f - gi));
       stx<PS>(ws, dg + 2 * H, dh * tc * go * (1.f - go));
       stx<PS>(ws, dg + 3 * H, dc * gi * (1.f - gc * gc));
+      carry[m] = dc * gf;
       D.dc_carry[(long)m * SA + (long)b * H + i] = dc * gf;
     }
     stx<PS>(ws, D.dHQ + rowt * H + i, dhq);
   }
   __syncthreads();     // scratch is reused by the next row / phase
+}
+
+template <bool PS, int JCT>
+__device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D, const WS& ws, int t, int b, const float* att, float* scr,
+                                                   const RowPre& pre) {
+  const RowMid mid = lsthm_bwd_row_part1<JCT>(P, att, scr, pre);
+  float carry[2] = {pre.carry[0], pre.carry[1]};
+  lsthm_bwd_row_part2<PS, JCT>(P, D, ws, t, b, att, scr, pre, mid, carry);
 }
 
 // Matvec phase, role (product p, output slice n0..n0+31, row block mb):
@@ -1122,22 +1160,31 @@ __device__ __forceinline__ void lsthm_bwd_role(const CellK& P, const Role R, flo
   unsigned nbar = 0;
   unsigned* cnt = P.sync + SYNC_LSTHM_BWD + dir * SYNC_DIR;
   STAMP_INIT();
-  RowPre pre = lsthm_bwd_row_prefetch(P, D, P.T - 1, w < P.B ? w : 0);
+  constexpr int JCB = 2 * NP * NP;                         // NP = H/32, keys per thread = H*H/NT
+  const bool has_row = w < P.B;
+  // saved-state operands are fetched TWO steps ahead (a whole step for the loads to land); the dc carry stays in registers
+  const int rowb = has_row ? w : 0;
+  RowPre pre = lsthm_bwd_row_prefetch(P, D, P.T - 1, rowb);
+  RowPre pre_n = lsthm_bwd_row_prefetch(P, D, P.T > 1 ? P.T - 2 : 0, rowb);
+  RowMid mid = lsthm_bwd_row_part1<JCB>(P, att, red, pre);
+  float carry[2] = {0.f, 0.f};
   for (int t = P.T - 1; t >= 0; --t) {
-    for (int b = w; b < P.B; b += (int)nwg) {           // NP = H/32, JC = H*H/NT = 2 NP^2
-      if (b != w) pre = lsthm_bwd_row_prefetch(P, D, t, b);
-      lsthm_bwd_row_body<true, 2 * NP * NP>(P, D, ws, t, b, att, red, pre);
-    }
+    if (has_row) lsthm_bwd_row_part2<true, JCB>(P, D, ws, t, w, att, red, pre, mid, carry);
+    for (int b = w + (int)nwg; b < P.B; b += (int)nwg)
+      lsthm_bwd_row_body<true, JCB>(P, D, ws, t, b, att, red, lsthm_bwd_row_prefetch(P, D, t, b));
     STAMP_ACC(0);
     if (!dir_barrier(cnt, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
     STAMP_ACC(1);
     if (has_mat && (t > 0 || p >= 4)) lsthm_bwd_mat_body<true, NP>(P, D, ws, t, p, n0, mb, bpre, red, tile);   // t == 0: no carries needed
     STAMP_ACC(2);
-    // split-phase barrier: the saved-state operands of step t-1 are fetched while the hand-off is in flight
+    // split-phase barrier: while the carries are handed over, the half of step t-1's row work that needs only saved forward
+    // state (softmax statistics, pass 1) is computed and the saved state of step t-2 is requested
     barrier_arrive(cnt);
     ++nbar;
     if (t > 0) {
-      pre = lsthm_bwd_row_prefetch(P, D, t - 1, w < P.B ? w : 0);
+      pre = pre_n;
+      if (t > 1) pre_n = lsthm_bwd_row_prefetch(P, D, t - 2, rowb);
+      mid = lsthm_bwd_row_part1<JCB>(P, att, red, pre);
       if (!barrier_wait(cnt, P.sync + SYNC_ABORT, nwg * nbar, lds_ok)) return;
     }
     STAMP_ACC(3);
