@@ -70,6 +70,22 @@ def lsthm_step_bytes(backward):
                 + 2 * 2 * B * 4 * H + 4 * B * H + B * H + 2 * B * H)
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE
+    rocprofv3 passes over this same command, FETCH_SIZE doubled per the gfx950 correction).  PMC collection serialises kernels,
+    so it cannot run inside the timed region; None when no summary names the kernel."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+        try:
+            ks = json.load(open(f))["kernels"]
+        except (OSError, ValueError, KeyError):
+            continue
+        for name, v in ks.items():
+            if kernel + "<" in name or kernel + "(" in name:
+                return v["traffic_bytes_per_launch"]
+    return None
+
+
 def cpu_baseline(steps=3):
     from oracle import ref_cpu as O
     # the GPU box hands a 1-GPU job a 16-core CPU share (cgroup), while os.cpu_count() reports the whole host
@@ -228,13 +244,15 @@ def main():
             by = lsthm_step_bytes(backward) * steps_per_launch
             ach = by / (us * 1e-6) / 1e9
             return dict(bound="hbm", kernel=name, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, bytes_per_launch=by, avg_launch_us=round(us, 2),
+                        frac=round(ach / HBM_PEAK_GBS, 4), traffic=pmc_traffic(name), bytes_per_launch=by, avg_launch_us=round(us, 2),
                         launches_timed=launches, steps_per_launch=steps_per_launch,
                         note="dependency-latency bound recurrence (2 inter-workgroup hand-offs per time step); weights are "
                              "register-resident, so real HBM traffic is far below this streaming model")
         us_b, n_b = timed(4)     # MSER_PROF_LSTHM_BWD_ROW: brackets lsthm_bwd_persist (or each lsthm_bwd_row launch)
         us_f, n_f = timed(2)     # MSER_PROF_LSTHM_FWD_GATES: brackets lsthm_fwd_persist (or each lsthm_fwd_gates launch)
-        roofline = entry("lsthm_bwd_persist" if us_b > 200 else "lsthm_bwd_row", us_b, n_b, True)
+        # kernel = the symbol rocprofv3 reports (profiles/*_kernel_stats.csv): the BPTT launch is cell_bwd_fused (LSTHM BPTT with the
+        # speaker BPTT riding in the same grid), the forward chain is lsthm_fwd_persist (eager) / cell_fwd_fused (under capture)
+        roofline = entry("cell_bwd_fused" if us_b > 200 else "lsthm_bwd_row", us_b, n_b, True)
         roofline["lsthm_forward"] = entry("lsthm_fwd_persist" if us_f > 200 else "lsthm_fwd_gates", us_f, n_f, False)
 
     log("roofline pass done")
