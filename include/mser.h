@@ -93,6 +93,53 @@ int mser_scale_acc_dot(float* acc, int64_t ldacc, const float* t, int64_t ldt, c
                        const float* s_dev, float* ds, int64_t rows, int32_t D, mser_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * EncoderLayer (model/encoder.py:116-133: MultiHeadAttention :7-60, ScaledDotProductAttention :63-86,
+ * PositionwiseFeedForward :89-113) as one call: forward = projection GEMM + one attention launch per
+ * (dialogue, head) + one row-tiled launch (fc, residual, LayerNorm, FFN, residual, LayerNorm);
+ * backward = row-tiled launch + attention launch + input-gradient GEMM (MSER_ENC_BWD_ACT) and the four
+ * weight-gradient GEMMs (MSER_ENC_BWD_WGRAD, any stream, any time after ACT).
+ * Dropout sites (:54,:83,:106) are identities (eval mode / p = 0).  Rows: row(b, l) = b*sb + l*sl.
+ * The caller owns every buffer; `mser_encoder_layer_supported` tells whether the fused kernels cover the
+ * shape (L <= 128, d_k == d_v <= 64 and % 8 == 0, D <= 128, ...); otherwise compose the layer from mser_gemm + row kernels.
+ * ------------------------------------------------------------------------------------------------ */
+enum { MSER_ENC_BWD_ACT = 1, MSER_ENC_BWD_WGRAD = 2 };
+
+typedef struct mser_encoder_desc {
+  int32_t nb, nl;              /* dialogues, positions */
+  int64_t sb, sl;              /* row(b, l) = b*sb + l*sl */
+  int32_t D, nh, dk, dv, dff;  /* d_model, heads, d_k, d_v, d_inner */
+  float eps;                   /* LayerNorm eps (1e-6, :24,:97) */
+  const float* x;              /* [rows, D] contiguous layer input */
+  const uint8_t* mask;         /* [nb, nh, L, L] 0 = masked_fill(-1e9) (:75-77) or NULL */
+  /* parameters */
+  const float* w_qs; const float* w_ks; const float* w_vs;   /* [nh*dk, D] */
+  const float* fc;                                           /* [D, nh*dv] */
+  const float* ln1_g; const float* ln1_b;                    /* slf_attn.layer_norm */
+  const float* w1; const float* b1;                          /* [dff, D], [dff] */
+  const float* w2; const float* b2;                          /* [D, dff], [D] */
+  const float* ln2_g; const float* ln2_b;                    /* pos_ffn.layer_norm */
+  /* saved by the forward for the backward (caller-allocated) */
+  float* qkv;                  /* [rows, 2*nh*dk + nh*dv]  q | k | v */
+  float* P;                    /* [nb, nh, L, L] attention (the module's second return value) */
+  float* O;                    /* [rows, nh*dv] */
+  float* y1; float* mean1; float* rstd1;    /* pre-norm sum and statistics of LayerNorm 1 */
+  float* e1;                   /* [rows, D] MultiHeadAttention output */
+  float* hdn;                  /* [rows, dff] relu(w_1 e1) */
+  float* y2; float* mean2; float* rstd2;
+  float* out;                  /* [rows, D] */
+  /* backward only */
+  const float* dout;           /* [rows, D] */
+  float* dy2; float* dh; float* dy1; float* dO; float* dqkv;   /* scratch the weight-gradient phase reads */
+  float* dx;                   /* [rows, D] gradient of the layer input (written) */
+  float* g_w_qs; float* g_w_ks; float* g_w_vs; float* g_fc; float* g_ln1_g; float* g_ln1_b;   /* ACCUMULATED */
+  float* g_w1; float* g_b1; float* g_w2; float* g_b2; float* g_ln2_g; float* g_ln2_b;
+} mser_encoder_desc;
+
+int mser_encoder_layer_supported(const mser_encoder_desc* d);
+int mser_encoder_layer_fwd(const mser_encoder_desc* d, mser_stream_t stream);
+int mser_encoder_layer_bwd(const mser_encoder_desc* d, int32_t phases, mser_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Sequence bookkeeping (model/lsthm_sps.py:396-409 _reverse_seq; :177 argmax; :238-259 _select_parties).
  * ------------------------------------------------------------------------------------------------ */
 /* lens[b] = sum_t umask[b,t];  rev[t,b] = lens[b]-1-t if t < lens[b] else -1   (rev is int32 [L,B]) */

@@ -1,0 +1,708 @@
+// One post-LN Transformer encoder layer (reference model/encoder.py:116-133 = MultiHeadAttention :7-60 +
+// ScaledDotProductAttention :63-86 + PositionwiseFeedForward :89-113) as THREE launches forward and THREE on the
+// activation-gradient chain backward, instead of 9 / 25 generic launches:
+//
+//   forward : qkv = e0 Wqkv^T (gemm.hip)  ->  attn_fwd_kernel   (one workgroup per (dialogue, head): S = q k^T / sqrt(dk),
+//             softmax, O = P v; q/k/v/S live in LDS, P is written once for the backward)
+//                                         ->  post_fwd_kernel   (32 rows per workgroup: fc + residual + LayerNorm + FFN +
+//             residual + LayerNorm; every intermediate stays in LDS, only the tensors the backward needs are written)
+//   backward: post_bwd_kernel (LayerNorm, FFN, LayerNorm, fc backward for 32 rows; bias / LayerNorm parameter gradients by
+//             one float atomic per column per workgroup)  ->  attn_bwd_kernel (per (dialogue, head): dV, dP, dS, dQ, dK with P/dS
+//             and the head's q, k, v, dO in LDS)  ->  de0 = dqkv Wqkv + dy1 (gemm.hip);
+//             weight gradients (four split-K GEMMs) are a separate phase so the caller can park them on a side stream.
+//
+// Why this shape: at the reference sizes (D = 100, 8 heads x 40, d_inner = 40, L <= 128) every product of the layer is far too
+// small to fill the chip as a launch of its own (8-30 us each, mostly fixed cost); what bounds the layer is the NUMBER of
+// dependent launches on the critical path, not HBM bytes or MFMA rate.  All arithmetic is fp32 on v_mfma_f32_32x32x2_f32
+// (bit-exact fmaf chains), as everywhere on this path (parity gate 1e-4 on the log-probs).
+//
+// Operand conventions of the 32x32x2 MFMA used below: lane l supplies A[row = l & 31][k = l >> 5] and B[k = l >> 5][col = l & 31];
+// a "chunk" is 8 consecutive k: lane (r, half) holds k = 8c + 4 half + {0..3} as one float4 and issues 4 MFMAs.
+// Accumulator register i of lane l is C[row = (i & 3) + 8 (i >> 2) + 4 (l >> 5)][col = l & 31].
+#include "common.h"
+#include "../../include/mser.h"
+#include <cmath>
+#include <cstring>
+
+namespace mser {
+
+int gemm(const mser_gemm_desc& d, hipStream_t s);   // gemm.hip
+
+namespace {
+
+constexpr int ET = 512, EW = 8;           // threads / waves per workgroup
+constexpr int RT = 32;                    // rows per workgroup of the row-tiled kernels
+
+__device__ __forceinline__ f32x16 mfma4(const float4& a, const float4& b, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ int acc_row(int i, int half) { return (i & 3) + 8 * (i >> 2) + 4 * half; }
+
+// ================================================================================================ attention core
+struct AttnArgs {
+  const float* q; const float* k; const float* v;     // row views [rows, ld]; head h occupies columns h*dk .. h*dk+dk-1
+  long ldq, ldk, ldv;
+  float* o; long ldo;                                  // forward output / saved O (backward: delta = <dO, O>)
+  float* P;                                            // [nb, nh, L, L]
+  const unsigned char* mask;                           // [nb, nh, L, L], 0 = masked (logit := fill) or null
+  const float* dO; long lddo;
+  float* dq; float* dk_; float* dv; long lddq, lddk, lddv;
+  int nb, nh, L, dk;
+  long sb, sl;                                         // row of (dialogue b, position l) = b*sb + l*sl
+  float scale, fill;
+};
+
+__device__ __forceinline__ void stage_head(const float* src, long ld, int col0, int b, const AttnArgs& a, int LP, int SD, float* dst) {
+  const int vpr = a.dk >> 2;
+  for (int e = threadIdx.x; e < LP * vpr; e += ET) {
+    const int l = e / vpr, c4 = (e - l * vpr) << 2;
+    float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (l < a.L) v4 = *reinterpret_cast<const float4*>(src + ((long)b * a.sb + (long)l * a.sl) * ld + col0 + c4);
+    *reinterpret_cast<float4*>(dst + l * SD + c4) = v4;
+  }
+}
+
+// C[32 x 32] (+)= A-rows (float4 along k) x B-rows (float4 along k): both operands row-major in LDS with k contiguous
+__device__ __forceinline__ f32x16 tile_rr(const float* Arow, const float* Brow, int K, f32x16 acc) {
+  for (int kc = 0; kc < K; kc += 8)
+    acc = mfma4(*reinterpret_cast<const float4*>(Arow + kc), *reinterpret_cast<const float4*>(Brow + kc), acc);
+  return acc;
+}
+// A-rows (float4 along k) x B stored [k][n] (n = this lane's column, stride ldb along k); ok = column valid
+__device__ __forceinline__ f32x16 tile_rc(const float* Arow, const float* Bcol, int ldb, int K, bool ok, f32x16 acc) {
+  for (int kc = 0; kc < K; kc += 8) {
+    float4 b;
+    b.x = Bcol[(kc + 0) * ldb]; b.y = Bcol[(kc + 1) * ldb]; b.z = Bcol[(kc + 2) * ldb]; b.w = Bcol[(kc + 3) * ldb];
+    if (!ok) b = make_float4(0.f, 0.f, 0.f, 0.f);
+    acc = mfma4(*reinterpret_cast<const float4*>(Arow + kc), b, acc);
+  }
+  return acc;
+}
+// A stored [k][m] (m = this lane's row, stride lda along k) x B stored [k][n]
+__device__ __forceinline__ f32x16 tile_cc(const float* Acol, int lda, const float* Bcol, int ldb, int K, bool ok, f32x16 acc) {
+  for (int kc = 0; kc < K; kc += 8) {
+    float4 a, b;
+    a.x = Acol[(kc + 0) * lda]; a.y = Acol[(kc + 1) * lda]; a.z = Acol[(kc + 2) * lda]; a.w = Acol[(kc + 3) * lda];
+    b.x = Bcol[(kc + 0) * ldb]; b.y = Bcol[(kc + 1) * ldb]; b.z = Bcol[(kc + 2) * ldb]; b.w = Bcol[(kc + 3) * ldb];
+    if (!ok) b = make_float4(0.f, 0.f, 0.f, 0.f);
+    acc = mfma4(a, b, acc);
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(ET) void attn_fwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int L = a.L, LP = (L + 31) & ~31, dk = a.dk, SD = dk + 4, SS = LP + 4;
+  float* qs = sm;
+  float* ks = qs + LP * SD;
+  float* vs = ks + LP * SD;
+  float* S = vs + LP * SD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
+  stage_head(a.q, a.ldq, h * dk, b, a, LP, SD, qs);
+  stage_head(a.k, a.ldk, h * dk, b, a, LP, SD, ks);
+  stage_head(a.v, a.ldv, h * dk, b, a, LP, SD, vs);
+  __syncthreads();
+  const int nt = LP >> 5;
+  const long pbase = ((long)b * a.nh + h) * L * L;
+  // ---- S = scale * q k^T (+ mask), key padding -> -inf
+  for (int t = wave; t < nt * nt; t += EW) {
+    const int ti = t / nt, tj = t - ti * nt;
+    f32x16 acc = {0};
+    acc = tile_rr(qs + (ti * 32 + r) * SD + half * 4, ks + (tj * 32 + r) * SD + half * 4, dk, acc);
+    const int col = tj * 32 + r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = ti * 32 + acc_row(i, half);
+      float s = acc[i] * a.scale;
+      if (a.mask && row < L && col < L && a.mask[pbase + (long)row * L + col] == 0) s = a.fill;
+      if (col >= L) s = -INFINITY;
+      S[row * SS + col] = s;
+    }
+  }
+  __syncthreads();
+  // ---- row softmax (one wave per row, two columns per lane); padded query rows become zero rows
+  for (int row = wave; row < LP; row += EW) {
+    float* Sr = S + row * SS;
+    const bool has1 = lane + 64 < LP;
+    if (row >= L) {
+      if (lane < LP) Sr[lane] = 0.f;
+      if (has1) Sr[lane + 64] = 0.f;
+      continue;
+    }
+    const float v0 = lane < LP ? Sr[lane] : -INFINITY, v1 = has1 ? Sr[lane + 64] : -INFINITY;
+    const float m = wave_max(fmaxf(v0, v1));
+    const float e0 = expf(v0 - m), e1 = expf(v1 - m);
+    const float inv = 1.0f / wave_sum(e0 + e1);
+    const float p0 = e0 * inv, p1 = e1 * inv;
+    if (lane < LP) Sr[lane] = p0;
+    if (has1) Sr[lane + 64] = p1;
+    if (a.P) {
+      if (lane < L) a.P[pbase + (long)row * L + lane] = p0;
+      if (lane + 64 < L) a.P[pbase + (long)row * L + lane + 64] = p1;
+    }
+  }
+  __syncthreads();
+  // ---- O = P v
+  const int ntn = (dk + 31) >> 5;
+  for (int t = wave; t < nt * ntn; t += EW) {
+    const int ti = t / ntn, tn = t - ti * ntn;
+    const int col = tn * 32 + r;
+    const bool cok = col < dk;
+    f32x16 acc = {0};
+    acc = tile_rc(S + (ti * 32 + r) * SS + half * 4, vs + (half * 4) * SD + (cok ? col : 0), SD, LP, cok, acc);
+    if (cok) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = ti * 32 + acc_row(i, half);
+        if (row < L) a.o[((long)b * a.sb + (long)row * a.sl) * a.ldo + h * dk + col] = acc[i];
+      }
+    }
+  }
+}
+
+// Backward of the core for one (dialogue, head):  dV = P^T dO,  dP = dO V^T,  dS = scale * P o (dP - delta),
+// delta_i = <dO_i, O_i> (= sum_j P_ij dP_ij),  dQ = dS K,  dK = dS^T Q.
+__global__ __launch_bounds__(ET) void attn_bwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int L = a.L, LP = (L + 31) & ~31, dk = a.dk, SD = dk + 4, SS = LP + 4;
+  float* Pb = sm;                       // P, then dS in place
+  float* s0 = Pb + LP * SS;             // dO, then Q
+  float* s1 = s0 + LP * SD;             // V, then K
+  float* delta = s1 + LP * SD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
+  const long pbase = ((long)b * a.nh + h) * L * L;
+  for (int e = tid; e < LP * LP; e += ET) {
+    const int row = e / LP, col = e - row * LP;
+    Pb[row * SS + col] = (row < L && col < L) ? a.P[pbase + (long)row * L + col] : 0.f;
+  }
+  stage_head(a.dO, a.lddo, h * dk, b, a, LP, SD, s0);
+  stage_head(a.v, a.ldv, h * dk, b, a, LP, SD, s1);
+  for (int row = wave; row < LP; row += EW) {
+    float d = 0.f;
+    if (row < L && lane < dk) {
+      const long g = (long)b * a.sb + (long)row * a.sl;
+      d = a.dO[g * a.lddo + h * dk + lane] * a.o[g * a.ldo + h * dk + lane];
+    }
+    d = wave_sum(d);
+    if (lane == 0) delta[row] = d;
+  }
+  __syncthreads();
+  const int nt = LP >> 5, ntn = (dk + 31) >> 5;
+  // ---- dV = P^T dO
+  for (int t = wave; t < nt * ntn; t += EW) {
+    const int ti = t / ntn, tn = t - ti * ntn;
+    const int col = tn * 32 + r;
+    const bool cok = col < dk;
+    f32x16 acc = {0};
+    acc = tile_cc(Pb + (half * 4) * SS + ti * 32 + r, SS, s0 + (half * 4) * SD + (cok ? col : 0), SD, LP, cok, acc);
+    if (cok) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = ti * 32 + acc_row(i, half);
+        if (row < L) a.dv[((long)b * a.sb + (long)row * a.sl) * a.lddv + h * dk + col] = acc[i];
+      }
+    }
+  }
+  // ---- dP tiles stay in registers (at most two per wave: LP <= 128)
+  f32x16 dp[2];
+  dp[0] = f32x16{0}; dp[1] = f32x16{0};
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int t = wave + u * EW;
+    if (t < nt * nt) {
+      const int ti = t / nt, tj = t - ti * nt;
+      dp[u] = tile_rr(s0 + (ti * 32 + r) * SD + half * 4, s1 + (tj * 32 + r) * SD + half * 4, dk, dp[u]);
+    }
+  }
+  __syncthreads();                      // every wave is done with P (as P^T), dO and V
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int t = wave + u * EW;
+    if (t < nt * nt) {
+      const int ti = t / nt, tj = t - ti * nt;
+      const int col = tj * 32 + r;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = ti * 32 + acc_row(i, half);
+        float* p = Pb + row * SS + col;
+        *p = a.scale * *p * (dp[u][i] - delta[row]);
+      }
+    }
+  }
+  stage_head(a.q, a.ldq, h * dk, b, a, LP, SD, s0);
+  stage_head(a.k, a.ldk, h * dk, b, a, LP, SD, s1);
+  __syncthreads();
+  // ---- dQ = dS K ;  dK = dS^T Q
+  for (int t = wave; t < nt * ntn; t += EW) {
+    const int ti = t / ntn, tn = t - ti * ntn;
+    const int col = tn * 32 + r;
+    const bool cok = col < dk;
+    f32x16 acc = {0};
+    acc = tile_rc(Pb + (ti * 32 + r) * SS + half * 4, s1 + (half * 4) * SD + (cok ? col : 0), SD, LP, cok, acc);
+    f32x16 acc2 = {0};
+    acc2 = tile_cc(Pb + (half * 4) * SS + ti * 32 + r, SS, s0 + (half * 4) * SD + (cok ? col : 0), SD, LP, cok, acc2);
+    if (cok) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = ti * 32 + acc_row(i, half);
+        if (row < L) {
+          const long g = (long)b * a.sb + (long)row * a.sl;
+          a.dq[g * a.lddq + h * dk + col] = acc[i];
+          a.dk_[g * a.lddk + h * dk + col] = acc2[i];
+        }
+      }
+    }
+  }
+}
+
+// ================================================================================================ row-tiled blocks
+// C[32 x N] = A[32 x K] B for one workgroup.  A lives in LDS (row stride lda, zero-padded to a multiple of 8 along k).
+//   BT = 0: B[n][k], k contiguous (y = x W^T with W = [N, K] row-major): one float4 per chunk and lane
+//   BT = 1: B[k][n], n contiguous (dx = dy W with W = [K, N] row-major): four coalesced dwords per chunk and lane
+// The column tiles (and, when there are fewer than 8 of them, k-slices of each) are spread over the 8 waves; the partial
+// accumulators meet in `red` (8 x 32 x 33 floats) and emit(row, col, value) receives every finished element.
+// The B operand comes straight from global memory (the weights are a few hundred KB, L2-resident and shared by all
+// workgroups): loads run one pass (PASS chunks) ahead of the MFMAs, issued unconditionally from clamped addresses.
+constexpr int PASS = 8;
+constexpr int RED_LD = 33;
+
+template <int BT>
+__device__ __forceinline__ void load_pass(const float* Bg, long ldb, int nc, int K, int c, int c1, int half, float4* bv) {
+#pragma unroll
+  for (int j = 0; j < PASS; ++j) {
+    const int cc = min(c + j, c1 - 1);                  // clamped chunk (values of chunks >= c1 are never used)
+    const int k = cc * 8 + half * 4;
+    if (BT == 0) {
+      const int kk = min(k, K - 4);
+      bv[j] = *reinterpret_cast<const float4*>(Bg + (long)nc * ldb + kk);
+    } else {
+      bv[j].x = Bg[(long)min(k + 0, K - 1) * ldb + nc];
+      bv[j].y = Bg[(long)min(k + 1, K - 1) * ldb + nc];
+      bv[j].z = Bg[(long)min(k + 2, K - 1) * ldb + nc];
+      bv[j].w = Bg[(long)min(k + 3, K - 1) * ldb + nc];
+    }
+  }
+}
+__device__ __forceinline__ float4 mask_k(float4 v, int k, int K, bool nok) {
+  // zero the k positions past the end (the LDS A operand is zero there too, but never multiply by stray bits) and invalid columns
+  if (!nok || k >= K) v.x = 0.f;
+  if (!nok || k + 1 >= K) v.y = 0.f;
+  if (!nok || k + 2 >= K) v.z = 0.f;
+  if (!nok || k + 3 >= K) v.w = 0.f;
+  return v;
+}
+
+template <int BT, class Emit>
+__device__ __forceinline__ void wg_gemm32(const float* A, int lda, int K, const float* Bg, long ldb, int N, float* red, Emit emit) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
+  const int NT = (N + 31) >> 5, nch = (K + 7) >> 3;
+  for (int t0 = 0; t0 < NT; t0 += EW) {
+    const int ntg = min(EW, NT - t0);
+    const int KS = EW / ntg;                            // k-slices per column tile
+    const int tile = wave % ntg, slice = wave / ntg;
+    const int cps = (nch + KS - 1) / KS;
+    const int c0 = slice * cps, c1 = min(nch, c0 + cps);
+    f32x16 acc = {0};
+    if (slice < KS && c0 < c1) {
+      const int n = (t0 + tile) * 32 + r;
+      const bool nok = n < N;
+      const int nc = nok ? n : N - 1;
+      const float* Arow = A + r * lda + half * 4;
+      float4 bcur[PASS], bnext[PASS];
+      load_pass<BT>(Bg, ldb, nc, K, c0, c1, half, bcur);
+      for (int c = c0; c < c1; c += PASS) {
+        if (c + PASS < c1) load_pass<BT>(Bg, ldb, nc, K, c + PASS, c1, half, bnext);
+#pragma unroll
+        for (int j = 0; j < PASS; ++j) {
+          if (c + j < c1) {
+            const int k = (c + j) * 8 + half * 4;
+            acc = mfma4(*reinterpret_cast<const float4*>(Arow + (c + j) * 8), mask_k(bcur[j], k, K, nok), acc);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < PASS; ++j) bcur[j] = bnext[j];
+      }
+    }
+    float* my = red + wave * (32 * RED_LD);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) my[acc_row(i, half) * RED_LD + r] = acc[i];
+    __syncthreads();
+    for (int e = tid; e < ntg * 1024; e += ET) {
+      const int tl = e >> 10, rc = e & 1023, row = rc >> 5, col = rc & 31;
+      float s = 0.f;
+      for (int sl = 0; sl < KS; ++sl) s += red[(sl * ntg + tl) * (32 * RED_LD) + row * RED_LD + col];
+      const int n = (t0 + tl) * 32 + col;
+      if (n < N) emit(row, n, s);
+    }
+    __syncthreads();
+  }
+}
+
+struct PostArgs {
+  int rows, D, NO, F;
+  float eps;
+  // forward inputs / parameters
+  const float* O; const float* x;
+  const float* fc; const float* g1; const float* be1; const float* W1; const float* bb1; const float* W2; const float* bb2;
+  const float* g2; const float* be2;
+  // saved by the forward
+  float* y1; float* mean1; float* rstd1; float* e1; float* hdn; float* y2; float* mean2; float* rstd2; float* out;
+  // backward
+  const float* dout; float* dy2; float* dh; float* dy1; float* dO;
+  float* gg1; float* gbe1; float* gbb1; float* gbb2; float* gg2; float* gbe2;
+};
+
+__device__ __forceinline__ int pad8(int n) { return ((n + 7) & ~7) + 4; }   // LDS row stride: k padded to 8, +4 (= 4 * odd mod 32 for D=100,F=40,NO=320)
+
+// LayerNorm of the wave's rows of `ys` (+ residual / bias) -> normalised rows into `dst` (LDS, zero-padded) and global.
+// v(row, j) supplies the pre-norm value.
+template <class V>
+__device__ __forceinline__ void ln_rows(const PostArgs& p, long r0, int D, V v, const float* gamma, const float* beta, float* ysum,
+                                        float* mean, float* rstd, float* yout, float* dst, int ldd) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int rr = wave * (RT / EW); rr < (wave + 1) * (RT / EW); ++rr) {
+    const long row = r0 + rr;
+    const bool rok = row < p.rows;
+    float x0 = 0.f, x1 = 0.f;
+    if (rok && lane < D) x0 = v(rr, lane);
+    if (rok && lane + 64 < D) x1 = v(rr, lane + 64);
+    const float mu = wave_sum(x0 + x1) / D;
+    const float d0 = lane < D ? x0 - mu : 0.f, d1 = lane + 64 < D ? x1 - mu : 0.f;
+    const float rs = 1.0f / sqrtf(wave_sum(d0 * d0 + d1 * d1) / D + p.eps);
+    float o0 = 0.f, o1 = 0.f;
+    if (lane < D) o0 = d0 * rs * gamma[lane] + beta[lane];
+    if (lane + 64 < D) o1 = d1 * rs * gamma[lane + 64] + beta[lane + 64];
+    if (!rok) { o0 = 0.f; o1 = 0.f; }
+    if (dst) {
+      if (lane < ldd) dst[rr * ldd + lane] = lane < D ? o0 : 0.f;
+      if (lane + 64 < ldd) dst[rr * ldd + lane + 64] = lane + 64 < D ? o1 : 0.f;
+    }
+    if (rok) {
+      if (lane < D) { ysum[row * D + lane] = x0; yout[row * D + lane] = o0; }
+      if (lane + 64 < D) { ysum[row * D + lane + 64] = x1; yout[row * D + lane + 64] = o1; }
+      if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+  }
+}
+
+__global__ __launch_bounds__(ET) void post_fwd_kernel(PostArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int D = p.D, NO = p.NO, F = p.F;
+  const int NOP = pad8(NO), DP = pad8(D), FP = pad8(F);
+  float* red = sm;                          // 8 * 32 * 33
+  float* As = red + EW * 32 * RED_LD;       // [32][NOP]  attention output tile
+  float* ys = As + RT * NOP;                // [32][DP]   pre-norm sums
+  float* e1s = ys + RT * DP;                // [32][DP]
+  float* hs = e1s + RT * DP;                // [32][FP]
+  const int tid = threadIdx.x;
+  const long r0 = (long)blockIdx.x * RT;
+  {
+    const int vpr = NO >> 2, vpp = NOP >> 2;
+    for (int e = tid; e < RT * vpp; e += ET) {
+      const int rr = e / vpp, c4 = (e - rr * vpp) << 2;
+      float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r0 + rr < p.rows && c4 < vpr * 4) v4 = *reinterpret_cast<const float4*>(p.O + (r0 + rr) * NO + c4);
+      *reinterpret_cast<float4*>(As + rr * NOP + c4) = v4;
+    }
+  }
+  __syncthreads();
+  // t = O fc^T
+  wg_gemm32<0>(As, NOP, NO, p.fc, NO, D, red, [&](int row, int n, float s) { ys[row * DP + n] = s; });
+  // y1 = t + e0 ; e1 = LayerNorm(y1)
+  ln_rows(p, r0, D, [&](int rr, int j) { return ys[rr * DP + j] + p.x[(r0 + rr) * D + j]; }, p.g1, p.be1, p.y1, p.mean1, p.rstd1,
+          p.e1, e1s, DP);
+  __syncthreads();
+  // hdn = relu(e1 W1^T + b1)
+  for (int e = tid; e < RT * (FP - F); e += ET) hs[(e / (FP - F)) * FP + F + e % (FP - F)] = 0.f;
+  wg_gemm32<0>(e1s, DP, D, p.W1, D, F, red, [&](int row, int n, float s) {
+    const float hv = fmaxf(s + p.bb1[n], 0.f);
+    hs[row * FP + n] = hv;
+    if (r0 + row < p.rows) p.hdn[(r0 + row) * F + n] = hv;
+  });
+  // t2 = hdn W2^T + b2 ; y2 = t2 + e1 ; out = LayerNorm(y2)
+  wg_gemm32<0>(hs, FP, F, p.W2, F, D, red, [&](int row, int n, float s) { ys[row * DP + n] = s + p.bb2[n] + e1s[row * DP + n]; });
+  ln_rows(p, r0, D, [&](int rr, int j) { return ys[rr * DP + j]; }, p.g2, p.be2, p.y2, p.mean2, p.rstd2, p.out, nullptr, 0);
+}
+
+// LayerNorm backward for the wave's rows: dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma.
+// dyv(rr, j) supplies dy; results go to dst (LDS, zero-padded) and global dxg; per-column sums of dy*xhat / dy are left in
+// cs[wave][0/1][128] for the caller to reduce.
+template <class V>
+__device__ __forceinline__ void ln_bwd_rows(const PostArgs& p, long r0, int D, V dyv, const float* ysum, const float* mean,
+                                            const float* rstd, const float* gamma, float* dst, int ldd, float* dxg, float* cs) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ag0 = 0.f, ag1 = 0.f, ab0 = 0.f, ab1 = 0.f;
+  const float gm0 = lane < D ? gamma[lane] : 0.f, gm1 = lane + 64 < D ? gamma[lane + 64] : 0.f;
+  for (int rr = wave * (RT / EW); rr < (wave + 1) * (RT / EW); ++rr) {
+    const long row = r0 + rr;
+    const bool rok = row < p.rows;
+    float d0 = 0.f, d1 = 0.f, xh0 = 0.f, xh1 = 0.f, rs = 0.f;
+    if (rok) {
+      const float mu = mean[row];
+      rs = rstd[row];
+      if (lane < D) { d0 = dyv(rr, lane); xh0 = (ysum[row * D + lane] - mu) * rs; }
+      if (lane + 64 < D) { d1 = dyv(rr, lane + 64); xh1 = (ysum[row * D + lane + 64] - mu) * rs; }
+    }
+    const float g0 = d0 * gm0, g1 = d1 * gm1;
+    ag0 += d0 * xh0; ag1 += d1 * xh1; ab0 += d0; ab1 += d1;
+    const float s1 = wave_sum(g0 + g1) / D, s2 = wave_sum(g0 * xh0 + g1 * xh1) / D;
+    const float o0 = rs * (g0 - s1 - xh0 * s2), o1 = rs * (g1 - s1 - xh1 * s2);
+    if (lane < ldd) dst[rr * ldd + lane] = lane < D ? o0 : 0.f;
+    if (lane + 64 < ldd) dst[rr * ldd + lane + 64] = lane + 64 < D ? o1 : 0.f;
+    if (rok) {
+      if (lane < D) dxg[row * D + lane] = o0;
+      if (lane + 64 < D) dxg[row * D + lane + 64] = o1;
+    }
+  }
+  cs[(wave * 2 + 0) * 128 + lane] = ag0; cs[(wave * 2 + 0) * 128 + lane + 64] = ag1;
+  cs[(wave * 2 + 1) * 128 + lane] = ab0; cs[(wave * 2 + 1) * 128 + lane + 64] = ab1;
+}
+__device__ __forceinline__ void flush_cs(const float* cs, int D, float* gg, float* gb) {
+  const int tid = threadIdx.x;
+  if (tid < 2 * 128) {
+    const int which = tid >> 7, j = tid & 127;
+    if (j < D) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < EW; ++w) s += cs[(w * 2 + which) * 128 + j];
+      atomicAdd((which ? gb : gg) + j, s);
+    }
+  }
+}
+// out[j] += sum over the 32 tile rows of T[row][j]
+__device__ __forceinline__ void colsum_tile(const float* T, int ld, int n, float* out) {
+  for (int j = threadIdx.x; j < n; j += ET) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int rr = 0; rr < RT; ++rr) s += T[rr * ld + j];
+    atomicAdd(out + j, s);
+  }
+}
+
+__global__ __launch_bounds__(ET) void post_bwd_kernel(PostArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int D = p.D, NO = p.NO, F = p.F;
+  const int DP = pad8(D), FP = pad8(F);
+  float* red = sm;                          // 8 * 32 * 33
+  float* dys = red + EW * 32 * RED_LD;      // [32][DP]  dy2, later dy1
+  float* des = dys + RT * DP;               // [32][DP]  de1
+  float* dhs = des + RT * DP;               // [32][FP]
+  float* cs = dhs + RT * FP;                // [8][2][128]
+  const int tid = threadIdx.x;
+  const long r0 = (long)blockIdx.x * RT;
+  // ---- LayerNorm 2 backward -> dy2
+  ln_bwd_rows(p, r0, D, [&](int rr, int j) { return p.dout[(r0 + rr) * D + j]; }, p.y2, p.mean2, p.rstd2, p.g2, dys, DP, p.dy2, cs);
+  for (int e = tid; e < RT * (FP - F); e += ET) dhs[(e / (FP - F)) * FP + F + e % (FP - F)] = 0.f;
+  __syncthreads();
+  flush_cs(cs, D, p.gg2, p.gbe2);
+  colsum_tile(dys, DP, D, p.gbb2);
+  // ---- dh = (dy2 W2) o (hdn > 0)
+  wg_gemm32<1>(dys, DP, D, p.W2, F, F, red, [&](int row, int n, float s) {
+    const bool rok = r0 + row < p.rows;
+    const float v = (rok && p.hdn[(r0 + row) * F + n] > 0.f) ? s : 0.f;
+    dhs[row * FP + n] = v;
+    if (rok) p.dh[(r0 + row) * F + n] = v;
+  });
+  colsum_tile(dhs, FP, F, p.gbb1);
+  // ---- de1 = dh W1 + dy2
+  wg_gemm32<1>(dhs, FP, F, p.W1, D, D, red, [&](int row, int n, float s) { des[row * DP + n] = s + dys[row * DP + n]; });
+  // ---- LayerNorm 1 backward -> dy1 (overwrites the dy2 tile)
+  ln_bwd_rows(p, r0, D, [&](int rr, int j) { return des[rr * DP + j]; }, p.y1, p.mean1, p.rstd1, p.g1, dys, DP, p.dy1, cs);
+  __syncthreads();
+  flush_cs(cs, D, p.gg1, p.gbe1);
+  // ---- dO = dy1 fc
+  wg_gemm32<1>(dys, DP, D, p.fc, NO, NO, red, [&](int row, int n, float s) {
+    if (r0 + row < p.rows) p.dO[(r0 + row) * NO + n] = s;
+  });
+}
+
+size_t attn_lds_bytes(int L, int dk, bool bwd) {
+  const size_t LP = (size_t)((L + 31) & ~31), SD = dk + 4, SS = LP + 4;
+  return (bwd ? LP * SS + 2 * LP * SD + LP : 3 * LP * SD + LP * SS) * sizeof(float);
+}
+size_t post_lds_bytes(int D, int NO, int F, bool bwd) {
+  const size_t DP = ((D + 7) & ~7) + 4, FP = ((F + 7) & ~7) + 4, NOP = ((NO + 7) & ~7) + 4;
+  const size_t red = EW * 32 * RED_LD;
+  return (bwd ? red + 2 * RT * DP + RT * FP + EW * 2 * 128 : red + RT * NOP + 2 * RT * DP + RT * FP) * sizeof(float);
+}
+constexpr size_t LDS_MAX = 160 * 1024;
+
+int allow(const void* kernel, size_t bytes) {
+  if (bytes > 64 * 1024) MSER_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return 0;
+}
+bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+static const char* enc_unsupported(const mser_encoder_desc& d) {
+  if (d.nb <= 0 || d.nl <= 0 || d.D <= 0) return "empty shape";
+  if (d.nl > 128) return "sequence longer than 128 (the S tile of one head must fit LDS)";
+  if (d.dk != d.dv) return "d_k != d_v";
+  if (d.dk % 8 || d.dk > 64) return "head width must be a multiple of 8 and <= 64";
+  if (d.D % 4 || d.D > 128) return "model width must be a multiple of 4 and <= 128";
+  if (d.dff % 4 || d.dff > 128) return "FFN width must be a multiple of 4 and <= 128";
+  if (d.nh * d.dk > 1024) return "n_head * d_k > 1024";
+  if (attn_lds_bytes(d.nl, d.dk, false) > LDS_MAX || attn_lds_bytes(d.nl, d.dk, true) > LDS_MAX) return "attention tile exceeds LDS";
+  if (post_lds_bytes(d.D, d.nh * d.dv, d.dff, false) > LDS_MAX) return "row tile exceeds LDS";
+  return nullptr;
+}
+
+static int enc_validate(const mser_encoder_desc& d, bool bwd) {
+  const char* why = enc_unsupported(d);
+  MSER_REQUIRE(!why, "mser_encoder_layer: unsupported configuration: %s", why ? why : "");
+  MSER_REQUIRE(d.x && d.w_qs && d.w_ks && d.w_vs && d.fc && d.ln1_g && d.ln1_b && d.w1 && d.b1 && d.w2 && d.b2 && d.ln2_g && d.ln2_b,
+               "mser_encoder_layer: null parameter / input");
+  MSER_REQUIRE(d.qkv && d.P && d.O && d.y1 && d.mean1 && d.rstd1 && d.e1 && d.hdn && d.y2 && d.mean2 && d.rstd2 && d.out,
+               "mser_encoder_layer: null saved-tensor / output buffer");
+  MSER_REQUIRE(al16(d.x) && al16(d.qkv) && al16(d.O) && al16(d.fc) && al16(d.w1) && al16(d.w2) && al16(d.w_qs) && al16(d.w_ks) && al16(d.w_vs),
+               "mser_encoder_layer: buffers must be 16-byte aligned");
+  if (bwd) {
+    MSER_REQUIRE(d.dout && d.dy2 && d.dh && d.dy1 && d.dO && d.dqkv && d.dx, "mser_encoder_layer_bwd: null gradient buffer");
+    MSER_REQUIRE(al16(d.dO) && al16(d.dqkv), "mser_encoder_layer_bwd: buffers must be 16-byte aligned");
+  }
+  return 0;
+}
+
+static AttnArgs attn_args(const mser_encoder_desc& d) {
+  AttnArgs a;
+  const int nq = d.nh * d.dk;
+  a.q = d.qkv; a.k = d.qkv + nq; a.v = d.qkv + 2 * nq;
+  a.ldq = a.ldk = a.ldv = 3L * nq;
+  a.o = d.O; a.ldo = nq;
+  a.P = d.P; a.mask = d.mask;
+  a.dO = d.dO; a.lddo = nq;
+  a.dq = d.dqkv; a.dk_ = d.dqkv ? d.dqkv + nq : nullptr; a.dv = d.dqkv ? d.dqkv + 2 * nq : nullptr;
+  a.lddq = a.lddk = a.lddv = 3L * nq;
+  a.nb = d.nb; a.nh = d.nh; a.L = d.nl; a.dk = d.dk;
+  a.sb = d.sb; a.sl = d.sl;
+  a.scale = 1.0f / sqrtf((float)d.dk); a.fill = -1e9f;
+  return a;
+}
+static PostArgs post_args(const mser_encoder_desc& d) {
+  PostArgs p;
+  p.rows = d.nb * d.nl; p.D = d.D; p.NO = d.nh * d.dv; p.F = d.dff; p.eps = d.eps;
+  p.O = d.O; p.x = d.x; p.fc = d.fc; p.g1 = d.ln1_g; p.be1 = d.ln1_b; p.W1 = d.w1; p.bb1 = d.b1; p.W2 = d.w2; p.bb2 = d.b2;
+  p.g2 = d.ln2_g; p.be2 = d.ln2_b;
+  p.y1 = d.y1; p.mean1 = d.mean1; p.rstd1 = d.rstd1; p.e1 = d.e1; p.hdn = d.hdn; p.y2 = d.y2; p.mean2 = d.mean2; p.rstd2 = d.rstd2;
+  p.out = d.out;
+  p.dout = d.dout; p.dy2 = d.dy2; p.dh = d.dh; p.dy1 = d.dy1; p.dO = d.dO;
+  p.gg1 = d.g_ln1_g; p.gbe1 = d.g_ln1_b; p.gbb1 = d.g_b1; p.gbb2 = d.g_b2; p.gg2 = d.g_ln2_g; p.gbe2 = d.g_ln2_b;
+  return p;
+}
+// w_qs, w_ks, w_vs back to back (the flat parameter buffer lays them out that way) -> one N = 3*nh*dk projection
+static bool qkv_adjacent(const float* a, const float* b, const float* c, long n) { return b == a + n && c == b + n; }
+
+static mser_gemm_desc gd0() {
+  mser_gemm_desc g;
+  memset(&g, 0, sizeof g);
+  g.batch1 = g.batch2 = 1; g.alpha = 1.0f; g.splitk = 1;
+  return g;
+}
+
+int encoder_layer_fwd(const mser_encoder_desc& d, hipStream_t s) {
+  MSER_TRY(enc_validate(d, false));
+  const int rows = d.nb * d.nl, nq = d.nh * d.dk, D = d.D;
+  // ---- q | k | v = e0 [Wq; Wk; Wv]^T
+  mser_gemm_desc g = gd0();
+  g.A = d.x; g.sAm = D; g.sAk = 1; g.M = rows; g.K = D; g.sBk = 1; g.sBn = D; g.ldc = 3L * nq;
+  if (qkv_adjacent(d.w_qs, d.w_ks, d.w_vs, (long)nq * D)) {
+    g.B = d.w_qs; g.C = d.qkv; g.N = 3 * nq;
+    MSER_TRY(gemm(g, s));
+  } else {
+    const float* w[3] = {d.w_qs, d.w_ks, d.w_vs};
+    for (int i = 0; i < 3; ++i) {
+      g.B = w[i]; g.C = d.qkv + i * nq; g.N = nq;
+      MSER_TRY(gemm(g, s));
+    }
+  }
+  const AttnArgs a = attn_args(d);
+  const size_t lds_a = attn_lds_bytes(d.nl, d.dk, false);
+  MSER_TRY(allow((const void*)attn_fwd_kernel, lds_a));
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(d.nh, d.nb), dim3(ET), lds_a, s, a);
+  MSER_TRY(check_launch("attn_fwd_kernel"));
+  const PostArgs p = post_args(d);
+  const size_t lds_p = post_lds_bytes(d.D, nq, d.dff, false);
+  MSER_TRY(allow((const void*)post_fwd_kernel, lds_p));
+  hipLaunchKernelGGL(post_fwd_kernel, dim3(cdiv(rows, RT)), dim3(ET), lds_p, s, p);
+  return check_launch("post_fwd_kernel");
+}
+
+int encoder_layer_bwd(const mser_encoder_desc& d, int phases, hipStream_t s) {
+  MSER_TRY(enc_validate(d, true));
+  const int rows = d.nb * d.nl, nq = d.nh * d.dk, D = d.D, F = d.dff;
+  const bool adj = qkv_adjacent(d.w_qs, d.w_ks, d.w_vs, (long)nq * D);
+  if (phases & MSER_ENC_BWD_ACT) {
+    MSER_REQUIRE(d.g_ln1_g && d.g_ln1_b && d.g_b1 && d.g_b2 && d.g_ln2_g && d.g_ln2_b, "mser_encoder_layer_bwd: null bias / LayerNorm gradient");
+    const PostArgs p = post_args(d);
+    const size_t lds_p = post_lds_bytes(d.D, nq, d.dff, true);
+    MSER_TRY(allow((const void*)post_bwd_kernel, lds_p));
+    hipLaunchKernelGGL(post_bwd_kernel, dim3(cdiv(rows, RT)), dim3(ET), lds_p, s, p);
+    MSER_TRY(check_launch("post_bwd_kernel"));
+    const AttnArgs a = attn_args(d);
+    const size_t lds_a = attn_lds_bytes(d.nl, d.dk, true);
+    MSER_TRY(allow((const void*)attn_bwd_kernel, lds_a));
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(d.nh, d.nb), dim3(ET), lds_a, s, a);
+    MSER_TRY(check_launch("attn_bwd_kernel"));
+    // de0 = dy1 (residual) + dq Wq + dk Wk + dv Wv
+    mser_gemm_desc g = gd0();
+    g.C = d.dx; g.ldc = D; g.M = rows; g.N = D; g.sAk = 1; g.sBn = 1; g.sBk = D;
+    g.R1 = d.dy1; g.ldr1 = D;
+    if (adj) {
+      g.A = d.dqkv; g.sAm = 3L * nq; g.K = 3 * nq; g.B = d.w_qs;
+      MSER_TRY(gemm(g, s));
+    } else {
+      const float* w[3] = {d.w_qs, d.w_ks, d.w_vs};
+      for (int i = 0; i < 3; ++i) {
+        g.A = d.dqkv + i * nq; g.sAm = 3L * nq; g.K = nq; g.B = w[i];
+        if (i > 0) { g.R1 = nullptr; g.flags = MSER_GEMM_ACCUM; }
+        MSER_TRY(gemm(g, s));
+      }
+    }
+  }
+  if (phases & MSER_ENC_BWD_WGRAD) {
+    MSER_REQUIRE(d.g_w_qs && d.g_w_ks && d.g_w_vs && d.g_fc && d.g_w1 && d.g_w2, "mser_encoder_layer_bwd: null weight gradient");
+    // dW[N, K] += dY^T X : A = dY^T (m contiguous), B = X (n contiguous), reduction over the rows, split-K float atomics
+    auto wgrad = [&](const float* dY, long lddy, int N, const float* X, long ldx, int K, float* dW) -> int {
+      mser_gemm_desc g = gd0();
+      g.A = dY; g.sAm = 1; g.sAk = lddy; g.B = X; g.sBk = ldx; g.sBn = 1; g.C = dW; g.ldc = K; g.M = N; g.N = K; g.K = rows;
+      g.splitk = 16;
+      return gemm(g, s);
+    };
+    if (adj && qkv_adjacent(d.g_w_qs, d.g_w_ks, d.g_w_vs, (long)nq * D)) {
+      MSER_TRY(wgrad(d.dqkv, 3L * nq, 3 * nq, d.x, D, D, d.g_w_qs));
+    } else {
+      float* gw[3] = {d.g_w_qs, d.g_w_ks, d.g_w_vs};
+      for (int i = 0; i < 3; ++i) MSER_TRY(wgrad(d.dqkv + i * nq, 3L * nq, nq, d.x, D, D, gw[i]));
+    }
+    MSER_TRY(wgrad(d.dy1, D, D, d.O, nq, nq, d.g_fc));
+    MSER_TRY(wgrad(d.dh, F, F, d.e1, D, D, d.g_w1));
+    MSER_TRY(wgrad(d.dy2, D, D, d.hdn, F, F, d.g_w2));
+  }
+  return 0;
+}
+
+}  // namespace mser
+
+extern "C" {
+
+int mser_encoder_layer_supported(const mser_encoder_desc* d) {
+  if (!d) return 0;
+  return mser::enc_unsupported(*d) == nullptr ? 1 : 0;
+}
+int mser_encoder_layer_fwd(const mser_encoder_desc* d, mser_stream_t stream) {
+  if (!d) { mser::set_error("mser_encoder_layer_fwd: null descriptor"); return -1; }
+  return mser::encoder_layer_fwd(*d, (hipStream_t)stream);
+}
+int mser_encoder_layer_bwd(const mser_encoder_desc* d, int32_t phases, mser_stream_t stream) {
+  if (!d) { mser::set_error("mser_encoder_layer_bwd: null descriptor"); return -1; }
+  return mser::encoder_layer_bwd(*d, phases, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -187,7 +187,7 @@ class EncoderLayer(nn.Module):
                 x2 = x.contiguous().view(B * L, D)
                 m = _mask_u8(slf_attn_mask.unsqueeze(1) if slf_attn_mask is not None else None, B, nh, L, L)
                 out, c = F_.encoder_layer_fwd(x2, None, P, Layout.batch_major(B, L), nh, dk, dv, mask=m)
-                return (out.view(B, L, D), c[0].P), (c, P)
+                return (out.view(B, L, D), F_.encoder_attention(c)), (c, P)
 
             @staticmethod
             def bwd(saved, tensors, dout, dattn):

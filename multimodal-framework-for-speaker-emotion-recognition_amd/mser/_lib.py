@@ -53,6 +53,26 @@ class CellDesc(C.Structure):
     ]
 
 
+class EncoderDesc(C.Structure):
+    """mser_encoder_desc (include/mser.h): one EncoderLayer, forward inputs / parameters / saved tensors / backward buffers."""
+    _fields_ = [
+        ("nb", C.c_int32), ("nl", C.c_int32), ("sb", C.c_int64), ("sl", C.c_int64),
+        ("D", C.c_int32), ("nh", C.c_int32), ("dk", C.c_int32), ("dv", C.c_int32), ("dff", C.c_int32), ("eps", C.c_float),
+        ("x", C.c_void_p), ("mask", C.c_void_p),
+        ("w_qs", C.c_void_p), ("w_ks", C.c_void_p), ("w_vs", C.c_void_p), ("fc", C.c_void_p),
+        ("ln1_g", C.c_void_p), ("ln1_b", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p),
+        ("w2", C.c_void_p), ("b2", C.c_void_p), ("ln2_g", C.c_void_p), ("ln2_b", C.c_void_p),
+        ("qkv", C.c_void_p), ("P", C.c_void_p), ("O", C.c_void_p),
+        ("y1", C.c_void_p), ("mean1", C.c_void_p), ("rstd1", C.c_void_p), ("e1", C.c_void_p), ("hdn", C.c_void_p),
+        ("y2", C.c_void_p), ("mean2", C.c_void_p), ("rstd2", C.c_void_p), ("out", C.c_void_p),
+        ("dout", C.c_void_p), ("dy2", C.c_void_p), ("dh", C.c_void_p), ("dy1", C.c_void_p), ("dO", C.c_void_p),
+        ("dqkv", C.c_void_p), ("dx", C.c_void_p),
+        ("g_w_qs", C.c_void_p), ("g_w_ks", C.c_void_p), ("g_w_vs", C.c_void_p), ("g_fc", C.c_void_p),
+        ("g_ln1_g", C.c_void_p), ("g_ln1_b", C.c_void_p), ("g_w1", C.c_void_p), ("g_b1", C.c_void_p),
+        ("g_w2", C.c_void_p), ("g_b2", C.c_void_p), ("g_ln2_g", C.c_void_p), ("g_ln2_b", C.c_void_p),
+    ]
+
+
 MSER_GEMM_RELU = 1
 MSER_GEMM_ACCUM = 2
 
@@ -71,6 +91,9 @@ SIGNATURES = {
     "mser_relu_bwd": (C.c_int, [_vp, _vp, _i64, _vp]),
     "mser_add_rows": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
     "mser_scale_acc_dot": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _vp]),
+    "mser_encoder_layer_supported": (C.c_int, [C.POINTER(EncoderDesc)]),
+    "mser_encoder_layer_fwd": (C.c_int, [C.POINTER(EncoderDesc), _vp]),
+    "mser_encoder_layer_bwd": (C.c_int, [C.POINTER(EncoderDesc), _i32, _vp]),
     "mser_build_reverse_index": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "mser_reverse_by_length": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "mser_build_slot_tables": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),

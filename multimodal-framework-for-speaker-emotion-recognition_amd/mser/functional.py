@@ -240,16 +240,74 @@ def _sub(P: Getter, prefix: str) -> Getter:
     return lambda n: P(prefix + n)
 
 
+# The fused EncoderLayer (csrc/encoder.hip: 3 launches forward, 3 on the backward's activation chain) is used whenever the
+# shape fits its LDS tiles; FUSED_ENCODER = False forces the composed path (generic GEMM + row kernels), which stays as the
+# general fallback (L > 128, other head widths) and as the cross-check in tests/test_gpu_ops.py.
+FUSED_ENCODER = True
+
+_ENC_PARAMS = (("w_qs", "slf_attn.w_qs.weight"), ("w_ks", "slf_attn.w_ks.weight"), ("w_vs", "slf_attn.w_vs.weight"),
+               ("fc", "slf_attn.fc.weight"), ("ln1_g", "slf_attn.layer_norm.weight"), ("ln1_b", "slf_attn.layer_norm.bias"),
+               ("w1", "pos_ffn.w_1.weight"), ("b1", "pos_ffn.w_1.bias"), ("w2", "pos_ffn.w_2.weight"), ("b2", "pos_ffn.w_2.bias"),
+               ("ln2_g", "pos_ffn.layer_norm.weight"), ("ln2_b", "pos_ffn.layer_norm.bias"))
+
+
+@dataclass
+class EncFusedCtx:
+    desc: object = None
+    keep: tuple = ()
+    P: Tensor = None          # attention [nb, nh, L, L] (the module's second return value)
+    rows: int = 0
+    D: int = 0
+
+
+def _encoder_desc(e0: Tensor, P: Getter, lay: Layout, nh: int, dk: int, dv: int, mask: Optional[Tensor]):
+    from . import _lib as L_
+    d = L_.EncoderDesc()
+    d.nb, d.nl, d.sb, d.sl = lay.nb, lay.nl, lay.sb, lay.sl
+    d.D, d.nh, d.dk, d.dv = e0.shape[1], nh, dk, dv
+    d.dff = P("pos_ffn.w_1.weight").shape[0]
+    d.eps = 1e-6
+    d.x = e0.data_ptr()
+    d.mask = mask.data_ptr() if mask is not None else None
+    for f, n in _ENC_PARAMS:
+        t = P(n)
+        if not t.is_contiguous():
+            return None
+        setattr(d, f, t.data_ptr())
+    return d
+
+
+def encoder_attention(c) -> Tensor:
+    """The attention tensor [nb, nh, L, L] of an encoder_layer_fwd context (either path)."""
+    return c.P if isinstance(c, EncFusedCtx) else c[0].P
+
+
 def encoder_layer_fwd(x: Tensor, x2: Optional[Tensor], P: Getter, lay: Layout, nh: int, dk: int, dv: int,
                       mask: Optional[Tensor] = None, out: Optional[Tensor] = None):
     """EncoderLayer.forward on input (x + x2) -- reference model/encoder.py:130-133; x2 carries the residual of the model's
-    second pass (model/lsthm_sps.py:357-358).  Returns (out [rows,D], (mha_ctx, ffn_ctx))."""
+    second pass (model/lsthm_sps.py:357-358).  Returns (out [rows,D], ctx)."""
     rows, D = x.shape
     if x2 is None and x.stride(0) == D:
         e0 = x
     else:
         e0 = _empty(rows, D, like=x)
         ops.add_rows(e0, x, x2)
+    if FUSED_ENCODER:
+        d = _encoder_desc(e0, P, lay, nh, dk, dv, mask)
+        if d is not None and ops.encoder_layer_supported(d):
+            nq, F = nh * dk, d.dff
+            if out is None:
+                out = _empty(rows, D, like=x)
+            qkv = _empty(rows, 2 * nq + nh * dv, like=x)
+            Pm = _empty(lay.nb, nh, lay.nl, lay.nl, like=x)
+            O = _empty(rows, nh * dv, like=x)
+            y1, e1, y2 = _empty(rows, D, like=x), _empty(rows, D, like=x), _empty(rows, D, like=x)
+            hdn = _empty(rows, F, like=x)
+            st = _empty(4, rows, like=x)
+            d.qkv, d.P, d.O, d.y1, d.e1, d.hdn, d.y2, d.out = (t.data_ptr() for t in (qkv, Pm, O, y1, e1, hdn, y2, out))
+            d.mean1, d.rstd1, d.mean2, d.rstd2 = (st[i].data_ptr() for i in range(4))
+            ops.encoder_layer_fwd(d)
+            return out, EncFusedCtx(desc=d, keep=(e0, mask, qkv, Pm, O, y1, e1, hdn, y2, st, out), P=Pm, rows=rows, D=D)
     e1, cm = mha_fwd(e0, e0, e0, _sub(P, "slf_attn."), lay, lay, nh, dk, dv, mask=mask)
     out, cf = ffn_fwd(e1, _sub(P, "pos_ffn."), out=out)
     return out, (cm, cf)
@@ -257,6 +315,22 @@ def encoder_layer_fwd(x: Tensor, x2: Optional[Tensor], P: Getter, lay: Layout, n
 
 def encoder_layer_bwd(c, dout: Tensor, P: Getter, G: Getter) -> Tensor:
     """Returns d(x + x2) [rows, D]; parameter gradients are accumulated into G(name)."""
+    if isinstance(c, EncFusedCtx):
+        d, rows, D = c.desc, c.rows, c.D
+        nq3, F = 3 * d.nh * d.dk, d.dff
+        dout = dout if dout.is_contiguous() else dout.contiguous()
+        dx = _empty(rows, D, like=dout)
+        dy2, dy1 = _empty(rows, D, like=dout), _empty(rows, D, like=dout)
+        dh, dO, dqkv = _empty(rows, F, like=dout), _empty(rows, d.nh * d.dv, like=dout), _empty(rows, nq3, like=dout)
+        d.dout, d.dx, d.dy2, d.dy1, d.dh, d.dO, d.dqkv = (t.data_ptr() for t in (dout, dx, dy2, dy1, dh, dO, dqkv))
+        for f, n in _ENC_PARAMS:
+            g = G(n)
+            if g is None or not g.is_contiguous():
+                raise RuntimeError(f"encoder_layer_bwd: gradient buffer for {n} missing or not contiguous")
+            setattr(d, "g_" + f, g.data_ptr())
+        ops.encoder_layer_bwd(d, ops.ENC_BWD_ACT)
+        ops.encoder_layer_bwd(d, ops.ENC_BWD_WGRAD, deferred=(dout, dx, dy2, dy1, dh, dO, dqkv) + tuple(c.keep))
+        return dx
     cm, cf = c
     de1 = ffn_bwd(cf, dout, _sub(P, "pos_ffn."), _sub(G, "pos_ffn."))
     de0 = torch.empty_like(de1)

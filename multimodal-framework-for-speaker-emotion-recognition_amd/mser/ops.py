@@ -224,6 +224,27 @@ def scale_acc_dot(acc: Tensor, t: Tensor, x: Optional[Tensor], s_dev: Optional[T
                                         rows, D, _stream()), "scale_acc_dot")
 
 
+ENC_BWD_ACT, ENC_BWD_WGRAD = 1, 2
+
+
+def encoder_layer_supported(desc: L.EncoderDesc) -> bool:
+    return bool(_lib().mser_encoder_layer_supported(C.byref(desc)))
+
+
+def encoder_layer_fwd(desc: L.EncoderDesc) -> None:
+    L.check(_lib().mser_encoder_layer_fwd(C.byref(desc), _stream()), "encoder_layer_fwd")
+
+
+def encoder_layer_bwd(desc: L.EncoderDesc, phases: int, deferred: Optional[tuple] = None) -> None:
+    """phases = ENC_BWD_ACT (activation-gradient chain) and / or ENC_BWD_WGRAD (weight-gradient GEMMs).  With ``deferred``
+    (the tensors the weight-gradient phase reads) the call goes to the wgrad side stream when a wgrad_scope is active."""
+    if deferred is not None:
+        with _deferred(*deferred):
+            L.check(_lib().mser_encoder_layer_bwd(C.byref(desc), phases, _stream()), "encoder_layer_bwd")
+    else:
+        L.check(_lib().mser_encoder_layer_bwd(C.byref(desc), phases, _stream()), "encoder_layer_bwd")
+
+
 def build_reverse_index(umask: Tensor, lens: Tensor, rev: Tensor) -> None:
     B, Ln = umask.shape
     L.check(_lib().mser_build_reverse_index(_p(umask), B, Ln, _p(lens), _p(rev), _stream()), "build_reverse_index")
