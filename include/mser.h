@@ -58,6 +58,10 @@ typedef struct mser_gemm_desc {
 } mser_gemm_desc;
 
 int mser_gemm(const mser_gemm_desc* d, mser_stream_t stream);
+/* n independent products in as few launches as their load-mode / tile classes allow (one for the weight gradients of a
+ * training step: dW = dY^T X of every nn.Linear on the path -- what autograd computes per module, model_trainer.py:113).
+ * Results are identical to n mser_gemm calls up to the order of the split-K float atomics. */
+int mser_gemm_grouped(const mser_gemm_desc* d, int32_t n, mser_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row kernels.

@@ -27,6 +27,7 @@
 namespace mser {
 
 int gemm(const mser_gemm_desc& d, hipStream_t s);   // gemm.hip
+int gemm_group(const mser_gemm_desc* d, int n, hipStream_t s);
 
 namespace {
 
@@ -669,11 +670,14 @@ int encoder_layer_bwd(const mser_encoder_desc& d, int phases, hipStream_t s) {
   if (phases & MSER_ENC_BWD_WGRAD) {
     MSER_REQUIRE(d.g_w_qs && d.g_w_ks && d.g_w_vs && d.g_fc && d.g_w1 && d.g_w2, "mser_encoder_layer_bwd: null weight gradient");
     // dW[N, K] += dY^T X : A = dY^T (m contiguous), B = X (n contiguous), reduction over the rows, split-K float atomics
+    mser_gemm_desc wg[6];
+    int nwg = 0;
     auto wgrad = [&](const float* dY, long lddy, int N, const float* X, long ldx, int K, float* dW) -> int {
       mser_gemm_desc g = gd0();
       g.A = dY; g.sAm = 1; g.sAk = lddy; g.B = X; g.sBk = ldx; g.sBn = 1; g.C = dW; g.ldc = K; g.M = N; g.N = K; g.K = rows;
       g.splitk = 16;
-      return gemm(g, s);
+      wg[nwg++] = g;
+      return 0;
     };
     if (adj && qkv_adjacent(d.g_w_qs, d.g_w_ks, d.g_w_vs, (long)nq * D)) {
       MSER_TRY(wgrad(d.dqkv, 3L * nq, 3 * nq, d.x, D, D, d.g_w_qs));
@@ -684,6 +688,7 @@ int encoder_layer_bwd(const mser_encoder_desc& d, int phases, hipStream_t s) {
     MSER_TRY(wgrad(d.dy1, D, D, d.O, nq, nq, d.g_fc));
     MSER_TRY(wgrad(d.dh, F, F, d.e1, D, D, d.g_w1));
     MSER_TRY(wgrad(d.dy2, D, D, d.hdn, F, F, d.g_w2));
+    MSER_TRY(gemm_group(wg, nwg, s));        // one grouped launch for the layer's weight gradients
   }
   return 0;
 }

@@ -21,6 +21,7 @@
 // head-interleaved product of the forward and backward pass goes through this one kernel.
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 #include "common.h"
 #include "../../include/mser.h"
 
@@ -103,7 +104,7 @@ struct TileLoader {
 
 // WM x WN waves side by side, KS = 4 / (WM * WN) k-slices of every BK tile (one per remaining wave).
 template <int AMODE, int BMODE, int WM, int WN>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int bz) {
   constexpr int KS = 4 / (WM * WN), TM = 32 * WM, TN = 32 * WN, BKT = 32 * KS;
   using LA = TileLoader<AMODE, TM, BKT>;
   using LB = TileLoader<BMODE, TN, BKT>;
@@ -116,8 +117,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int lane = tid & 63, wave = tid >> 6;
   const int kh = wave / (WM * WN), wt = wave % (WM * WN);
   const int wr = wt / WN, wc = wt % WN;
-  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-  int z = blockIdx.z;
+  const int m0 = by * TM, n0 = bx * TN;
+  int z = bz;
   const int ks = z % g.splitk; z /= g.splitk;
   const int z2 = z % g.batch2, z1 = z / g.batch2;
   const int kbeg = ks * g.kchunk;
@@ -203,6 +204,36 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
 }
 
+template <int AMODE, int BMODE, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  gemm_body<AMODE, BMODE, WM, WN>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Grouped launch: up to MAXG independent products (same load modes and tile configuration) share ONE grid.  The many small
+// weight-gradient products of a training step (M, N <= 1280, K = B*L rows) are each far too small to fill the chip and cost a
+// launch apiece; as one grid they fill it together, which also lets every member use a SMALLER split-K (fewer float atomics).
+// Workgroup -> (member, tile) through a prefix table in the kernel arguments (uniform scalar search).
+constexpr int MAXG = 16;
+struct GroupArgs {
+  int n;
+  int start[MAXG + 1];
+  int gx[MAXG], gy[MAXG];
+  GemmArgs a[MAXG];
+};
+static_assert(sizeof(GroupArgs) <= 4096, "kernel arguments are limited to 4 KB");
+
+template <int AMODE, int BMODE, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_group_kernel(GroupArgs G) {
+  const int w = blockIdx.x;
+  int p = 0;
+#pragma unroll 1
+  while (p + 1 < G.n && w >= G.start[p + 1]) ++p;
+  const int local = w - G.start[p];
+  const int gx = G.gx[p], gy = G.gy[p];
+  const int bx = local % gx, t = local / gx;
+  gemm_body<AMODE, BMODE, WM, WN>(G.a[p], bx, t % gy, t / gy);
+}
+
 template <int AM, int BM_, int WM, int WN>
 static void launch_one(dim3 grid, hipStream_t s, const GemmArgs& a) {
   hipLaunchKernelGGL((gemm_kernel<AM, BM_, WM, WN>), grid, dim3(256), 0, s, a);
@@ -222,28 +253,37 @@ static void launch_modes(int amode, int bmode, dim3 grid, hipStream_t s, const G
   }
 }
 
-int gemm(const mser_gemm_desc& d, hipStream_t s) {
+struct Plan {
+  GemmArgs a;
+  dim3 grid;
+  int amode, bmode;
+  bool c1;
+};
+
+// group_tiles = 64x64 tiles of all the products that will share the launch (0: this product alone)
+static int plan(const mser_gemm_desc& d, long group_tiles, Plan& P) {
   MSER_REQUIRE(d.A && d.B && d.C, "mser_gemm: null operand");
   MSER_REQUIRE(d.M >= 0 && d.N >= 0 && d.K >= 0, "mser_gemm: negative size");
-  if (d.M == 0 || d.N == 0) return 0;
   const int b1 = d.batch1 > 0 ? d.batch1 : 1, b2 = d.batch2 > 0 ? d.batch2 : 1;
   MSER_REQUIRE(!(d.splitk > 1 && (d.flags & MSER_GEMM_RELU)), "mser_gemm: split-K cannot fuse ReLU");
   // ---- tile configuration: C0 (64x64) when it fills the chip on its own, otherwise C1 (64x32, two k-slices per workgroup)
   constexpr long FILL = 256;                         // one workgroup per CU
   const long tiles0 = (long)cdiv(d.M, 64) * cdiv(d.N, 64) * b1 * b2;
-  const bool c1 = tiles0 * (d.splitk > 1 ? 4 : 1) < FILL + FILL / 2 || d.N <= 32;
+  const long fill0 = group_tiles > 0 ? group_tiles : tiles0;
+  const bool c1 = fill0 * (d.splitk > 1 ? 4 : 1) < FILL + FILL / 2 || d.N <= 32;
   const int TM = 64, TN = c1 ? 32 : 64, BKT = c1 ? 64 : 32;
   const long tiles = (long)cdiv(d.M, TM) * cdiv(d.N, TN) * b1 * b2;
   // ---- split-K: `splitk > 1` means "C is initialised, accumulate atomically"; the split itself is chosen here so that the grid
-  // is about two workgroups per CU while every workgroup still runs at least two k-tiles
+  // (of the whole group) is about two workgroups per CU while every workgroup still runs at least two k-tiles
   int splitk = 1;
   if (d.splitk > 1 && d.K > 0) {
-    long want = (2 * FILL + tiles - 1) / tiles;
+    const long all = group_tiles > 0 ? group_tiles * (c1 ? 2 : 1) : tiles;
+    long want = (2 * FILL + all - 1) / all;
     const long most = cdiv(d.K, 2 * BKT);
     if (want > most) want = most;
     splitk = (int)(want < 1 ? 1 : want);
   }
-  GemmArgs a;
+  GemmArgs& a = P.a;
   a.A = d.A; a.B = d.B; a.C = d.C; a.M = d.M; a.N = d.N; a.K = d.K;
   a.sAm = d.sAm; a.sAk = d.sAk; a.sBk = d.sBk; a.sBn = d.sBn; a.ldc = d.ldc;
   a.batch2 = b2;
@@ -260,8 +300,8 @@ int gemm(const mser_gemm_desc& d, hipStream_t s) {
   a.sA1 = d.sA1; a.sA2 = d.sA2; a.sB1 = d.sB1; a.sB2 = d.sB2; a.sC1 = d.sC1; a.sC2 = d.sC2;
   a.bias = d.bias; a.alpha_dev = d.alpha_dev; a.alpha = d.alpha;
   a.R1 = d.R1; a.R2 = d.R2; a.ldr1 = d.ldr1; a.ldr2 = d.ldr2; a.sR1 = d.sR1_1; a.sR2 = d.sR1_2;
-  dim3 grid(cdiv(d.N, TN), cdiv(d.M, TM), b1 * b2 * splitk);
-  MSER_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "mser_gemm: grid too large (M=%d batch=%d)", d.M, b1 * b2);
+  P.grid = dim3(cdiv(d.N, TN), cdiv(d.M, TM), b1 * b2 * splitk);
+  MSER_REQUIRE(P.grid.y <= 65535 && P.grid.z <= 65535, "mser_gemm: grid too large (M=%d batch=%d)", d.M, b1 * b2);
   // vector (float4) staging needs: unit stride along the vector, every other stride % 4 == 0, a 16-byte aligned base, and
   // extents such that no vector straddles the valid range
   auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
@@ -272,17 +312,88 @@ int gemm(const mser_gemm_desc& d, hipStream_t s) {
   else if (d.sAm == 1 && m4(d.sAk) && m4(d.sA1) && m4(d.sA2) && al16(d.A) && m4(d.M)) amode = 1;
   if (d.sBk == 1 && m4(d.sBn) && m4(d.sB1) && m4(d.sB2) && al16(d.B) && kvec_ok) bmode = 0;
   else if (d.sBn == 1 && m4(d.sBk) && m4(d.sB1) && m4(d.sB2) && al16(d.B) && m4(d.N)) bmode = 1;
+  P.amode = amode; P.bmode = bmode; P.c1 = c1;
   static const bool log_calls = getenv("MSER_GEMM_LOG") != nullptr;      // diagnostic: one line per call on stderr
   if (log_calls)
-    fprintf(stderr, "[gemm] M %d N %d K %d b %d splitk %d modes %d%d flags %d sAm %ld sAk %ld sBk %ld sBn %ld ldc %ld bias %d R %d grid %u cfg %d\n",
+    fprintf(stderr, "[gemm] M %d N %d K %d b %d splitk %d modes %d%d flags %d sAm %ld sAk %ld sBk %ld sBn %ld ldc %ld bias %d R %d grid %u cfg %d grp %ld\n",
             d.M, d.N, d.K, b1 * b2, d.splitk, amode, bmode, d.flags, d.sAm, d.sAk, d.sBk, d.sBn, d.ldc, d.bias != nullptr,
-            (d.R1 != nullptr) + (d.R2 != nullptr), grid.x * grid.y * grid.z, c1 ? 1 : 0);
-  if (c1) launch_modes<2, 1>(amode, bmode, grid, s, a);
-  else launch_modes<2, 2>(amode, bmode, grid, s, a);
+            (d.R1 != nullptr) + (d.R2 != nullptr), P.grid.x * P.grid.y * P.grid.z, c1 ? 1 : 0, group_tiles);
+  return 0;
+}
+
+int gemm(const mser_gemm_desc& d, hipStream_t s) {
+  if (d.M == 0 || d.N == 0) {
+    MSER_REQUIRE(d.M >= 0 && d.N >= 0, "mser_gemm: negative size");
+    return 0;
+  }
+  Plan P;
+  MSER_TRY(plan(d, 0, P));
+  if (P.c1) launch_modes<2, 1>(P.amode, P.bmode, P.grid, s, P.a);
+  else launch_modes<2, 2>(P.amode, P.bmode, P.grid, s, P.a);
   return check_launch("mser_gemm");
 }
 
+template <int WM, int WN>
+static void launch_group_modes(int amode, int bmode, unsigned grid, hipStream_t s, const GroupArgs& G) {
+#define MSER_GRP(AM, BM_) hipLaunchKernelGGL((gemm_group_kernel<AM, BM_, WM, WN>), dim3(grid), dim3(256), 0, s, G)
+  switch (amode * 3 + bmode) {
+    case 0: MSER_GRP(0, 0); break;
+    case 1: MSER_GRP(0, 1); break;
+    case 2: MSER_GRP(0, 2); break;
+    case 3: MSER_GRP(1, 0); break;
+    case 4: MSER_GRP(1, 1); break;
+    case 5: MSER_GRP(1, 2); break;
+    case 6: MSER_GRP(2, 0); break;
+    case 7: MSER_GRP(2, 1); break;
+    default: MSER_GRP(2, 2); break;
+  }
+#undef MSER_GRP
+}
+
+// n independent products in as few launches as their (load mode, tile configuration) classes allow.
+int gemm_group(const mser_gemm_desc* d, int n, hipStream_t s) {
+  MSER_REQUIRE(n >= 0 && (d || n == 0), "mser_gemm_grouped: null descriptor array");
+  if (n == 0) return 0;
+  if (n == 1) return gemm(d[0], s);
+  long group_tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    MSER_REQUIRE(d[i].M >= 0 && d[i].N >= 0, "mser_gemm_grouped: negative size");
+    group_tiles += (long)cdiv(d[i].M, 64) * cdiv(d[i].N, 64) * (d[i].batch1 > 0 ? d[i].batch1 : 1) * (d[i].batch2 > 0 ? d[i].batch2 : 1);
+  }
+  std::vector<Plan> plans(n);
+  std::vector<char> done(n, 0);
+  for (int i = 0; i < n; ++i) {
+    if (d[i].M == 0 || d[i].N == 0) { done[i] = 1; continue; }
+    MSER_TRY(plan(d[i], group_tiles, plans[i]));
+  }
+  for (int i = 0; i < n; ++i) {
+    if (done[i]) continue;
+    GroupArgs G;
+    G.n = 0;
+    G.start[0] = 0;
+    const Plan& lead = plans[i];
+    for (int j = i; j < n && G.n < MAXG; ++j) {
+      if (done[j]) continue;
+      const Plan& q = plans[j];
+      if (q.amode != lead.amode || q.bmode != lead.bmode || q.c1 != lead.c1) continue;
+      G.a[G.n] = q.a;
+      G.gx[G.n] = q.grid.x; G.gy[G.n] = q.grid.y;
+      G.start[G.n + 1] = G.start[G.n] + (int)(q.grid.x * q.grid.y * q.grid.z);
+      ++G.n;
+      done[j] = 1;
+    }
+    if (lead.c1) launch_group_modes<2, 1>(lead.amode, lead.bmode, (unsigned)G.start[G.n], s, G);
+    else launch_group_modes<2, 2>(lead.amode, lead.bmode, (unsigned)G.start[G.n], s, G);
+    MSER_TRY(check_launch("mser_gemm_grouped"));
+  }
+  return 0;
+}
+
 }  // namespace mser
+
+extern "C" int mser_gemm_grouped(const mser_gemm_desc* d, int32_t n, mser_stream_t stream) {
+  return mser::gemm_group(d, n, (hipStream_t)stream);
+}
 
 extern "C" int mser_gemm(const mser_gemm_desc* d, mser_stream_t stream) {
   if (!d) { mser::set_error("mser_gemm: null descriptor"); return -1; }

@@ -19,10 +19,12 @@
 #include "common.h"
 #include "../../include/mser.h"
 #include <cstring>
+#include <vector>
 
 namespace mser {
 
 int gemm(const mser_gemm_desc& d, hipStream_t s);   // gemm.hip
+int gemm_group(const mser_gemm_desc* d, int n, hipStream_t s);
 
 struct DirP {
   // parameters
@@ -1835,7 +1837,9 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   MSER_TRY(check_launch("lsthm_bwd"));
   }
   // ---- deferred (non-recurrent) GEMMs of the LSTHM streams.  DX: what the rest of the backward waits for (dHQ for the speaker
-  // chain, dx_l / dx_a for the encoders).  WGRAD: parameter gradients only -- nothing downstream reads them in this step.
+  // chain, dx_l / dx_a for the encoders).  WGRAD: parameter gradients only -- nothing downstream reads them in this step; all
+  // of them (4 per stream and direction) go out as ONE grouped launch.
+  std::vector<mser_gemm_desc> wg;
   for (int i = 0; i < d.ndir; ++i) {
     DirP& k = K.d[i];
     const mser_cell_params& G = d.dir[i].g;
@@ -1870,16 +1874,16 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
         // dW_m += dg^T xdir ; dS_m += dg^T HQ ; dU_m += dg^T h_prev ; dV_m += dg^T z_prev
         g = gd(dg, 1, 4 * H, xs[m], lds[m], 1, G.lsthm_W[m], D, 4 * H, D, (int)TB);
         g.splitk = SPLITK;
-        MSER_TRY(gemm(g, s));
+        wg.push_back(g);
         g = gd(dg, 1, 4 * H, k.HQ, H, 1, G.lsthm_S[m], H, 4 * H, H, (int)TB);
         g.splitk = SPLITK;
-        MSER_TRY(gemm(g, s));
+        wg.push_back(g);
         g = gd(dg, 1, 4 * H, k.hz + m * H, 3 * H, 1, G.lsthm_U[m], H, 4 * H, H, (int)TB);
         g.splitk = SPLITK;
-        MSER_TRY(gemm(g, s));
+        wg.push_back(g);
         g = gd(dg, 1, 4 * H, k.hz + 2 * H, 3 * H, 1, G.lsthm_V[m], H, 4 * H, H, (int)TB);
         g.splitk = SPLITK;
-        MSER_TRY(gemm(g, s));
+        wg.push_back(g);
         MSER_TRY(colsum4(dg, TB, 4 * H, 4 * H, G.lsthm_Wb[m], G.lsthm_Ub[m], G.lsthm_Vb[m], G.lsthm_Sb[m], s));
       }
     }
@@ -1888,6 +1892,8 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       MSER_TRY(colsum4(k.attacc + H, B, H, 2 * H, G.att_Wk, nullptr, nullptr, nullptr, s));
     }
   }
+  MSER_TRY(gemm_group(wg.data(), (int)wg.size(), s));
+  wg.clear();
   if (!(phases & MSER_PHASE_SPEAKER_BWD)) return 0;
   // ---- speaker chain, reverse time
   const size_t spk_lds = mm_lds + 32 * (4 * (size_t)H + 4) * sizeof(float);
@@ -1907,14 +1913,14 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       const float* dsg = k.dsg + (long)c * TB * 4 * H;
       mser_gemm_desc g = gd(dsg, 1, 4 * H, k.qsel + (long)c * TB * H, H, 1, G.q_Wih[c], H, 4 * H, H, (int)TB);
       g.splitk = SPLITK;
-      MSER_TRY(gemm(g, s));
+      wg.push_back(g);
       g = gd(dsg, 1, 4 * H, k.hq_state + (long)c * (T + 1) * SB, H, 1, G.q_Whh[c], H, 4 * H, H, (int)TB);
       g.splitk = SPLITK;
-      MSER_TRY(gemm(g, s));
+      wg.push_back(g);
       MSER_TRY(colsum4(dsg, TB, 4 * H, 4 * H, G.q_bih[c], G.q_bhh[c], nullptr, nullptr, s));
     }
   }
-  return 0;
+  return gemm_group(wg.data(), (int)wg.size(), s);
 }
 
 // ================================================================================================ module-level single steps

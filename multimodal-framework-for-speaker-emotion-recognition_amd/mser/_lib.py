@@ -83,6 +83,7 @@ SIGNATURES = {
     "mser_version": (C.c_int, []),
     "mser_last_error": (C.c_char_p, []),
     "mser_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "mser_gemm_grouped": (C.c_int, [C.POINTER(GemmDesc), _i32, _vp]),
     "mser_softmax_rows": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _i32, _f32, _vp]),
     "mser_softmax_bwd_rows": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp]),
     "mser_add_layernorm_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),

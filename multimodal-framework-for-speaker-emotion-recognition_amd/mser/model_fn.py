@@ -209,7 +209,9 @@ def marn1_backward(c: ModelCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: Opt
     # The side stream costs the host an event record + wait per call (~25 us): worth it only when launches are captured into a
     # hipGraph (no host cost at replay); in eager mode the host would become the bottleneck.
     wstream = _Streams.get(dev)[4] if (use_streams and torch.cuda.is_current_stream_capturing()) else None
-    with ops.wgrad_scope(wstream):        # parameter gradients run on their own stream, off the activation-gradient chain
+    # parameter gradients: bias / LayerNorm sums on their own stream (under capture), the weight-gradient GEMMs of the head, the
+    # sequence-level attention modules and linear_in as ONE grouped launch at the end of the backward
+    with ops.wgrad_scope(wstream, batch=True):
         _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams)
 
 

@@ -22,25 +22,37 @@ Tensor = torch.Tensor
 # ``wgrad_scope`` every grad_weight / colsum_acc is enqueued on a dedicated side stream behind an event recorded at the call
 # site, so the activation-gradient chain (the critical path) never waits for them.  Operands are kept alive until the scope
 # joins; callers must not modify an operand in place after handing it over (functional.py is written accordingly).
-_WG = {"stream": None, "keep": []}
+# With ``batch=True`` the weight-gradient GEMMs issued through ``grad_weight`` are not launched one by one: their descriptors
+# are collected and go out as ONE grouped launch (mser_gemm_grouped) when the scope closes, on the stream that is current
+# there -- the caller closes the scope after every producer stream has been joined.
+_WG = {"stream": None, "keep": [], "batch": None}
 
 
 class wgrad_scope:
-    def __init__(self, stream):
+    def __init__(self, stream, batch: bool = False):
         self.stream = stream
+        self.batch = batch
 
     def __enter__(self):
         _WG["stream"] = self.stream
         _WG["keep"] = []
+        _WG["batch"] = [] if self.batch else None
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
         return self
 
     def __exit__(self, *exc):
-        if self.stream is not None:
-            torch.cuda.current_stream().wait_stream(self.stream)
-        _WG["stream"] = None
-        _WG["keep"] = []
+        try:
+            if self.stream is not None:
+                torch.cuda.current_stream().wait_stream(self.stream)
+            descs = _WG["batch"]
+            if descs and exc[0] is None:
+                arr = (L.GemmDesc * len(descs))(*descs)
+                L.check(_lib().mser_gemm_grouped(arr, len(descs), _stream()), "mser_gemm_grouped")
+        finally:
+            _WG["stream"] = None
+            _WG["keep"] = []
+            _WG["batch"] = None
         return False
 
 
@@ -170,6 +182,23 @@ def grad_weight(dy: Tensor, x: Tensor, dW: Tensor, transposed: bool = False, alp
                 splitk: int = 16) -> None:
     """dW += dy^T x (nn.Linear weight [N,K]) or, transposed, dW += x^T dy (matmul weight [K,N]); split-K float atomics."""
     rows = dy.shape[0]
+    batch = _WG["batch"]
+    if batch is not None:
+        d = L.GemmDesc()
+        if not transposed:
+            N, K = dy.shape[1], x.shape[1]
+            d.A, d.B, d.M, d.N, d.sAm, d.sAk, d.sBk, d.sBn = dy.data_ptr(), x.data_ptr(), N, K, 1, _ld(dy), _ld(x), 1
+        else:
+            K, N = x.shape[1], dy.shape[1]
+            d.A, d.B, d.M, d.N, d.sAm, d.sAk, d.sBk, d.sBn = x.data_ptr(), dy.data_ptr(), K, N, 1, _ld(x), _ld(dy), 1
+        d.C, d.K, d.ldc = dW.data_ptr(), rows, dW.stride(0)
+        d.batch1 = d.batch2 = 1
+        d.alpha = 1.0
+        d.alpha_dev = alpha_dev.data_ptr() if alpha_dev is not None else None
+        d.splitk = splitk
+        batch.append(d)
+        _WG["keep"].append((dy, x, dW, alpha_dev))
+        return
     with _deferred(dy, x):
         if not transposed:
             N, K = dy.shape[1], x.shape[1]
