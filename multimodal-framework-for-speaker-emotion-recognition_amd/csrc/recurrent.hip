@@ -45,6 +45,9 @@ struct DirP {
   float *dgates, *dc_carry, *dA, *attacc, *dHQ, *dHQp;   // dHQp[2][T][B][H]: dgates_m @ S_m per step (pipelined mode)
   float *dsg, *Xb, *dhprev, *dcprev;   // Xb[2][B][H]: grad wrt q_{t-1}[b, party_t[b]], ping-pong by step parity
   float* mnext;                        // [T][B]: qmask_t[r][party_{t+1}[r]] (0 at the last step)
+  // in-kernel weight-gradient roles (cell_bwd_fused): LSTHM input rows in direction time order and the gradient tensors
+  const float* xw[2]; long ldxw[2];
+  float *gW[2], *gU[2], *gV[2], *gS[2], *gWih[2], *gWhh[2];
 };
 
 struct CellK {
@@ -53,6 +56,7 @@ struct CellK {
   void* wsbase;        // the cell workspace: one buffer descriptor spans it (sc1 hand-off accesses)
   unsigned wsbytes;
   unsigned* sync;      // persistent-kernel counters: [SYNC_*] words, zeroed by a memset node before every launch
+  int wgrad_wgs;       // cell_bwd_fused: workgroups that accumulate the weight gradients while the BPTT chains run (0: none)
   DirP d[2];
 };
 // Every counter sits on a 128-byte line of its own (SYNC_LINE words apart): arrivals (atomics) and polls of one chain never queue
@@ -209,6 +213,29 @@ __device__ __forceinline__ bool barrier_wait(const unsigned* cnt, unsigned* abor
       __builtin_amdgcn_s_sleep(1);
       if ((++spins & 255u) == 0u) {
         if (spins > SPIN_LIMIT || __hip_atomic_load((const gu32*)abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          ok = 0;
+          break;
+        }
+      }
+    }
+    if (!ok) __hip_atomic_store((gu32*)abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *lds_ok = ok;
+  }
+  __syncthreads();
+  return *lds_ok != 0;
+}
+
+// Wait of a workgroup that is NOT on the critical chain (weight-gradient roles following a chain's step counter): long sleeps
+// between polls, so that its polls do not queue in front of the chain's own arrivals and polls on the counter line.
+__device__ __forceinline__ bool lazy_wait(const unsigned* cnt, unsigned* abortw, unsigned target, int* lds_ok) {
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    unsigned spins = 0;
+    cnt += sync_replica();
+    while (__hip_atomic_load((const gu32*)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(48);
+      if ((++spins & 15u) == 0u) {
+        if (spins > (SPIN_LIMIT >> 3) || __hip_atomic_load((const gu32*)abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
           ok = 0;
           break;
         }
@@ -1323,7 +1350,7 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, cons
         if (Nc == 0) st4x<PS>(ws, dhprev_c + (long)slot * H + u, make_float4(dhp[0], dhp[1], dhp[2], dhp[3]));
         float* o = dsg_g + (long)slot * 4 * H + u;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(o + k * H) = make_float4(d4[k][0], d4[k][1], d4[k][2], d4[k][3]);
+        for (int k = 0; k < 4; ++k) st4x<PS>(ws, o + k * H, make_float4(d4[k][0], d4[k][1], d4[k][2], d4[k][3]));   // read by the wgrad roles
       }
       float* l = dsg_s + rr * LDS_LD + u;
 #pragma unroll
@@ -1382,7 +1409,10 @@ __device__ __forceinline__ void spk_bwd_role(const CellK& P, const Role R, float
   for (int t = P.T - 1; t >= 0; --t) {
     spk_bwd_body<true, NP, true>(P, D, ws, t, p, n0, mb, (int)((p & 1) * R.gx + R.x), bpre, red, tile, dsg_s);
     STAMP_ACC(2);
-    if (t == 0) break;
+    if (t == 0) {              // no consumer inside the chain, but the weight-gradient roles wait for dsg[0]: arrive only
+      barrier_arrive(cnt);
+      break;
+    }
     if (!dir_barrier(cnt, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok, lcnt, 2u * nwg_l * (unsigned)(P.T - t + 1))) return;
     STAMP_ACC(3);
   }
@@ -1426,20 +1456,136 @@ __global__ __launch_bounds__(NT) void lsthm_fwd_persist(CellK P) {
   lsthm_fwd_role<NP>(P, Role{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, smem, ws);
 }
 
+// ================================================================================================ weight gradients inside the BPTT launch
+// dW_m += dgates_m^T x, dS_m += dgates_m^T h_q, dU_m += dgates_m^T h_prev, dV_m += dgates_m^T z_prev and, for the two speaker cells,
+// dW_ih += dsg^T q_sel, dW_hh += dsg^T h_q_prev are reductions over all T*B rows: 12.4 GFLOP of exact-fp32 MFMA work that, run
+// after the chains, is MFMA-bound (~100-270 us) on a chip that sat 60 % idle for the 1.5 ms of the BPTT.  These roles run beside
+// the chains in the same launch (one residency guarantee): every wave owns FOUR 32x32 output tiles for the whole launch
+// (accumulators in registers, no split-K, no atomics: one deterministic read-modify-write per element at the end) and follows the
+// producing chain through its step counter, two time steps per poll.  The gate gradients are read with the same write-through /
+// L1-bypassing hand-off form as inside the chains.
+//   LSTHM tiles : (dir, stream m, row tile mt of the 4H gate rows, 16 column tiles = W | S | U | V segments)  -> 4 waves per mt
+//   speaker     : (dir, cell c,   row tile mt,                     8 column tiles = W_ih | W_hh)            -> 2 waves per mt
+constexpr int WG_CH = 2;        // time steps per poll
+struct WgSeg { const float* base; long ld; int width; float* g; long ldg; };
+
+template <bool SPK>
+__device__ __forceinline__ void wgrad_role(const CellK& P, int id, const WS& ws, unsigned nwg_src, float* smem) {
+  const int H = P.H, B = P.B, T = P.T;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the segment (and its buffer descriptor) is per wave
+  int* lds_ok = (int*)smem;
+  const int MT = 4 * H / 32;
+  // ---- decode (workgroup, wave) -> (dir, m or c, row tile, first of 4 column tiles)
+  const int wpm = SPK ? 2 : 4;                    // waves per row tile
+  const int mpw = NW / wpm;                       // row tiles per workgroup
+  const int unit = id / (MT / mpw);               // (dir, m/c)
+  const int dir = unit >> 1, mc = unit & 1;
+  const int mt = (id % (MT / mpw)) * mpw + wave / wpm;
+  const int nt0 = (wave % wpm) * 4;
+  const DirP& D = P.d[dir];
+  const long TB = (long)T * B, SB = (long)B * H;
+  const float* A = (SPK ? D.dsg : D.dgates) + (long)mc * TB * 4 * H + mt * 32 + r;
+  // column segment of tile nt (compile-time unrolled selects: no runtime-indexed local arrays, they would live in scratch)
+  const int tps = H / 32;                         // column tiles per segment (the W segment is padded to the same count)
+  auto segment = [&](int nt) -> WgSeg {
+    const int sg = nt / tps;
+    if (SPK) {
+      if (sg == 0) return WgSeg{D.qsel + (long)mc * TB * H, H, H, D.gWih[mc], H};
+      return WgSeg{D.hq_state + (long)mc * (T + 1) * SB, H, H, D.gWhh[mc], H};
+    }
+    if (sg == 0) return WgSeg{D.xw[mc], D.ldxw[mc], P.D, D.gW[mc], P.D};
+    if (sg == 1) return WgSeg{D.HQ, H, H, D.gS[mc], H};
+    if (sg == 2) return WgSeg{D.hz + mc * H, 3L * H, H, D.gU[mc], H};
+    return WgSeg{D.hz + 2 * H, 3L * H, H, D.gV[mc], H};
+  };
+  // the four tiles of a wave lie in ONE segment (tps == 4 and nt0 is a multiple of 4)
+  const WgSeg sg0 = segment(nt0);
+  // B rows through one buffer descriptor per wave with 32-bit byte offsets (64-bit per-load addresses would push the role past
+  // the register budget the chain roles are compiled for)
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)sg0.base, 0, 0x7ffffffc, 0x00020000);
+  bool ok[4];
+  int coff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = ((nt0 + j) % tps) * 32 + r;
+    ok[j] = col < sg0.width;
+    coff[j] = (ok[j] ? col : 0) * 4;
+  }
+  const int ldb4 = (int)sg0.ld * 4;
+  const int aoff = (int)((const char*)A - ws.base);
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = f32x16{0};
+  const unsigned* cnt = P.sync + (SPK ? SYNC_SPK_BWD : SYNC_LSTHM_BWD) + dir * SYNC_DIR;
+  for (int t_hi = T - 1; t_hi >= 0; t_hi -= WG_CH) {
+    const int t_lo = t_hi - WG_CH + 1 > 0 ? t_hi - WG_CH + 1 : 0;
+    // dgates[t] is complete behind the row-phase barrier of step t (barrier 2(T-1-t)+1 of the LSTHM chain); dsg[t] behind
+    // barrier T-t of the speaker chain
+    const unsigned target = SPK ? nwg_src * (unsigned)(T - t_lo) : nwg_src * (2u * (unsigned)(T - 1 - t_lo) + 1u);
+    if (!lazy_wait(cnt, P.sync + SYNC_ABORT, target, lds_ok)) return;
+#ifdef MSER_WGRAD_EXPERIMENT_SKIP       // diagnostic build only: follow the counters, do no work
+    continue;
+#endif
+    for (int t = t_hi; t >= t_lo; --t) {
+      for (int k0 = 0; k0 < B; k0 += 8) {
+        // MFMA j of this group consumes rows k0 + 2j + half; rows >= B read row B-1 and are zeroed (no load inside a branch).
+        // Groups of 4 MFMAs per tile keep the role under the 128 VGPRs the chain roles are compiled for.
+        float a[4], b[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = k0 + 2 * j + half;
+          const int row = t * B + (k < B ? k : B - 1);
+          a[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ws.r, aoff + row * 16 * H, 0, AUX_SC1));
+          const int roff = row * ldb4;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) b[q][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, roff + coff[q], 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool kok = k0 + 2 * j + half < B;
+          const float av = kok ? a[j] : 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, ok[q] ? b[q][j] : 0.f, acc[q], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- accumulate into the gradient tensors (each element has exactly one owner in the launch)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int col = ((nt0 + q) % tps) * 32 + r;
+    if (!ok[q]) continue;
+    float* g = sg0.g + col;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+      g[(long)row * sg0.ldg] += acc[q][i];
+    }
+  }
+}
+
 template <int NPL, int NPS>
 __global__ __launch_bounds__(NT) void cell_bwd_fused(CellK P, unsigned bwd_nwg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const WS ws = make_ws(P.wsbase, P.wsbytes);
   const int n_l = (int)bwd_nwg * P.ndir;
+  const int gx = P.H / 32, gy = 4;
+  const int n_s = gx * gy * P.nmb * P.ndir;
   int id = blockIdx.x;
   if (id < n_l) {
     const Role R{id % (int)bwd_nwg, 0, id / (int)bwd_nwg, (int)bwd_nwg, 1};
     lsthm_bwd_role<NPL>(P, R, smem, ws);
-  } else {
+  } else if (id < n_l + n_s) {
     id -= n_l;
-    const int gx = P.H / 32, gy = 4;
     const Role R{id % gx, (id / gx) % gy, id / (gx * gy), gx, gy};
     spk_bwd_role<NPS>(P, R, smem, ws, bwd_nwg);
+  } else {
+    id -= n_l + n_s;
+    // LSTHM weight gradients first ((4H/32)/2 workgroups per (dir, stream)), then the speaker cells ((4H/32)/4 per (dir, cell))
+    const int n_wl = P.ndir * 2 * (4 * P.H / 32) / 2;
+    if (id < n_wl) wgrad_role<false>(P, id, ws, bwd_nwg, smem);
+    else wgrad_role<true>(P, id - n_wl, ws, (unsigned)(gx * gy * P.nmb), smem);
   }
 }
 
@@ -1653,6 +1799,7 @@ static size_t row_lds_bytes(int H) { return ((size_t)RED_FLOATS + 2 * (size_t)H 
 
 // ---- launch mode ---------------------------------------------------------------------------------------------------------
 static int g_opt_persistent = 1;      // MSER_OPT_PERSISTENT
+static int g_opt_wgrad_inkernel = 1;  // MSER_OPT_WGRAD_INKERNEL
 static int g_num_cus = 0;
 constexpr size_t PERSIST_MIN_LDS = 84 * 1024;     // > half of the 160 KiB LDS: at most ONE persistent workgroup per CU
 
@@ -1797,6 +1944,28 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   const bool persist = persist_ok(H, ((long)bwd_nwg + spk_wgs) * d.ndir);
   const size_t p_lds = persist_lds(mm_lds + (2 * (size_t)H + 16) * sizeof(float) + 64);
   const int SPLITK = 16;
+  // Weight gradients inside the fused BPTT launch (wgrad_role): needs the persistent launch, the H = 128 tiling (16 / 8 column
+  // tiles per row tile), D <= H, every gradient tensor present and room for its workgroups beside the chains.
+  const int wgrad_wgs = d.ndir * 2 * ((4 * H / 32) / 2 + (4 * H / 32) / 4);
+  bool wgrad_in = persist && H == 128 && D <= H && ((long)bwd_nwg + spk_wgs) * d.ndir + wgrad_wgs <= num_cus() && g_opt_wgrad_inkernel;
+  for (int i = 0; i < d.ndir && wgrad_in; ++i) {
+    const mser_cell_params& G = d.dir[i].g;
+    for (int m = 0; m < 2; ++m)
+      wgrad_in = wgrad_in && G.lsthm_W[m] && G.lsthm_U[m] && G.lsthm_V[m] && G.lsthm_S[m] && G.q_Wih[m] && G.q_Whh[m];
+  }
+  K.wgrad_wgs = wgrad_in ? wgrad_wgs : 0;
+  if (wgrad_in) {
+    for (int i = 0; i < d.ndir; ++i) {
+      DirP& k = K.d[i];
+      const mser_cell_params& G = d.dir[i].g;
+      k.xw[0] = k.rev ? h.xrev[0] : d.x_l; k.xw[1] = k.rev ? h.xrev[1] : d.x_a;
+      k.ldxw[0] = k.rev ? D : d.ldxl; k.ldxw[1] = k.rev ? D : d.ldxa;
+      for (int m = 0; m < 2; ++m) {
+        k.gW[m] = G.lsthm_W[m]; k.gU[m] = G.lsthm_U[m]; k.gV[m] = G.lsthm_V[m]; k.gS[m] = G.lsthm_S[m];
+        k.gWih[m] = G.q_Wih[m]; k.gWhh[m] = G.q_Whh[m];
+      }
+    }
+  }
   if (phases & MSER_PHASE_BWD_PREP) {
     for (int i = 0; i < d.ndir; ++i) {
       DirP& k = K.d[i];
@@ -1812,7 +1981,7 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   if (persist) {
     // ONE launch for both BPTT chains: bwd_nwg*ndir LSTHM workgroups + spk_wgs*ndir speaker workgroups
     const size_t f_lds = persist_lds(mm_lds + 32 * (4 * (size_t)H + 4) * sizeof(float) + 64);
-    const unsigned grid = (unsigned)(((long)bwd_nwg + spk_wgs) * d.ndir);
+    const unsigned grid = (unsigned)(((long)bwd_nwg + spk_wgs) * d.ndir + K.wgrad_wgs);
     ProfScope ps(MSER_PROF_LSTHM_BWD_ROW, s);
     if (H == 128) {
       MSER_TRY(allow_lds((const void*)cell_bwd_fused<4, 4>, f_lds));
@@ -1871,7 +2040,11 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
         }
       }
       if ((phases & MSER_PHASE_LSTHM_WGRAD) && G.lsthm_W[m]) {
-        // dW_m += dg^T xdir ; dS_m += dg^T HQ ; dU_m += dg^T h_prev ; dV_m += dg^T z_prev
+        // dW_m += dg^T xdir ; dS_m += dg^T HQ ; dU_m += dg^T h_prev ; dV_m += dg^T z_prev  (unless the BPTT launch did them)
+        if (wgrad_in) {
+          MSER_TRY(colsum4(dg, TB, 4 * H, 4 * H, G.lsthm_Wb[m], G.lsthm_Ub[m], G.lsthm_Vb[m], G.lsthm_Sb[m], s));
+          continue;
+        }
         g = gd(dg, 1, 4 * H, xs[m], lds[m], 1, G.lsthm_W[m], D, 4 * H, D, (int)TB);
         g.splitk = SPLITK;
         wg.push_back(g);
@@ -1911,6 +2084,10 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
     if (!G.q_Wih[0]) continue;
     for (int c = 0; c < 2; ++c) {
       const float* dsg = k.dsg + (long)c * TB * 4 * H;
+      if (wgrad_in) {
+        MSER_TRY(colsum4(dsg, TB, 4 * H, 4 * H, G.q_bih[c], G.q_bhh[c], nullptr, nullptr, s));
+        continue;
+      }
       mser_gemm_desc g = gd(dsg, 1, 4 * H, k.qsel + (long)c * TB * H, H, 1, G.q_Wih[c], H, 4 * H, H, (int)TB);
       g.splitk = SPLITK;
       wg.push_back(g);
@@ -1994,6 +2171,7 @@ extern "C" {
 int mser_set_option(int32_t key, int32_t value) {
   switch (key) {
     case MSER_OPT_PERSISTENT: g_opt_persistent = value ? 1 : 0; return 0;
+    case MSER_OPT_WGRAD_INKERNEL: g_opt_wgrad_inkernel = value ? 1 : 0; return 0;
     default: set_error("mser_set_option: unknown key %d", key); return -1;
   }
 }

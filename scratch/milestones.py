@@ -26,20 +26,26 @@ def patched(desc, phases):
 ops.marn_cell_run = patched
 import mser.model_fn as mf
 mf.ops.marn_cell_run = patched
-for _ in range(5):
-    tr.train_step(x, qmask, umask, label)
-torch.cuda.synchronize()
-res = []
-allm = []
-for it in range(12):          # no host sync inside the loop: the host runs ahead of the GPU exactly as in bench.py
-    marks.clear()
-    s = torch.cuda.Event(enable_timing=True); s.record()
-    tr.train_step(x, qmask, umask, label)
-    e = torch.cuda.Event(enable_timing=True); e.record()
-    allm.append((s, list(marks), e))
-torch.cuda.synchronize()
-for s, mk, e in allm[2:]:
-    (n1, a0, a1), (n2, b0, b1) = mk
-    res.append([s.elapsed_time(a0), a0.elapsed_time(a1), a1.elapsed_time(b0), b0.elapsed_time(b1), b1.elapsed_time(e), s.elapsed_time(e)])
-r = np.median(np.array(res), axis=0) * 1e3
-print("us: pre-chain %.0f | chain fwd %.0f | head+loss+head-bwd %.0f | chain bwd %.0f | post-chain %.0f | total %.0f" % tuple(r))
+def run_config(tag):
+    for _ in range(5):
+        tr.train_step(x, qmask, umask, label)
+    torch.cuda.synchronize()
+    res, allm = [], []
+    for it in range(12):          # no host sync inside the loop: the host runs ahead of the GPU exactly as in bench.py
+        marks.clear()
+        s = torch.cuda.Event(enable_timing=True); s.record()
+        tr.train_step(x, qmask, umask, label)
+        e = torch.cuda.Event(enable_timing=True); e.record()
+        allm.append((s, list(marks), e))
+    torch.cuda.synchronize()
+    for s, mk, e in allm[2:]:
+        (n1, a0, a1), (n2, b0, b1) = mk
+        res.append([s.elapsed_time(a0), a0.elapsed_time(a1), a1.elapsed_time(b0), b0.elapsed_time(b1), b1.elapsed_time(e), s.elapsed_time(e)])
+    r = np.median(np.array(res), axis=0) * 1e3
+    print(tag, "us: pre-chain %.0f | chain fwd %.0f | head+loss+head-bwd %.0f | chain bwd %.0f | post-chain %.0f | total %.0f" % tuple(r))
+
+
+for rep in range(2):
+    for v in (0, 1):
+        ops.set_option(ops.MSER_OPT_WGRAD_INKERNEL, v)
+        run_config("wgrad_inkernel=%d" % v)
