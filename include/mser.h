@@ -142,6 +142,9 @@ typedef struct mser_encoder_desc {
 int mser_encoder_layer_supported(const mser_encoder_desc* d);
 int mser_encoder_layer_fwd(const mser_encoder_desc* d, mser_stream_t stream);
 int mser_encoder_layer_bwd(const mser_encoder_desc* d, int32_t phases, mser_stream_t stream);
+/* The MSER_ENC_BWD_WGRAD products as descriptors (at most 6) for a caller that batches them with other weight gradients
+ * into one mser_gemm_grouped launch; returns the number written (< 0: error).  Valid once MSER_ENC_BWD_ACT is enqueued. */
+int mser_encoder_layer_wgrad_descs(const mser_encoder_desc* d, mser_gemm_desc* out, int32_t cap);
 
 /* ------------------------------------------------------------------------------------------------
  * Sequence bookkeeping (model/lsthm_sps.py:396-409 _reverse_seq; :177 argmax; :238-259 _select_parties).
@@ -191,6 +194,10 @@ typedef struct mser_cell_desc {
   mser_cell_dir dir[2];
   void* workspace;             /* mser_marn_cell_workspace_bytes(); holds everything saved for the backward */
   size_t workspace_bytes;
+  /* optional (may be NULL): further contiguous [T*B, D] addends that MSER_PHASE_LSTHM_BWD_DX folds into dx_l / dx_a in the same
+   * launch that adds the cell's own input gradients (the caller's partial sums from other branches of the backward graph) */
+  const float* dx_l_add[2];
+  const float* dx_a_add[2];
 } mser_cell_desc;
 
 size_t mser_marn_cell_workspace_bytes(int32_t T, int32_t B, int32_t D, int32_t H, int32_t ndir);
@@ -247,6 +254,19 @@ int mser_masked_nll_fwd(const float* pred, const int64_t* target, const float* m
 /* dpred[r,c] = -(*gscale_dev) * mask[r] / sum(mask) * (c == target[r]) */
 int mser_masked_nll_bwd(const int64_t* target, const float* mask, const float* loss_out, const float* gscale_dev,
                         float* dpred, int64_t rows, int32_t C, mser_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The steps either side of the model in the trainer's loops.
+ * ------------------------------------------------------------------------------------------------ */
+/* Batch ingest (model_trainer.py:104-105, :138-139): x[r, :d_r] = (((r1+r2)+r3)+r4)/4, x[r, d_r:d_r+d_a] = acouf[r, :]; all
+ * inputs contiguous [rows, d_r] / [rows, d_a], x contiguous [rows, d_r+d_a].  Bit-identical to the reference expression. */
+int mser_ingest_features(const float* r1, const float* r2, const float* r3, const float* r4, const float* acouf, float* x,
+                         int64_t rows, int32_t d_r, int32_t d_a, mser_stream_t stream);
+/* Evaluation bookkeeping (model_trainer.py:142-156): pred[r] = argmax_c lp[r, c] (first maximum) and
+ * conf[label[r]*C + pred[r]] += mask[r] (float64, accumulated across calls; the caller zeroes it).  accuracy_score and the
+ * weighted f1_score with sample_weight = mask are functions of this C x C matrix.  pred_out (int64 [rows]) may be NULL. */
+int mser_confusion_update(const float* lp, const int64_t* label, const float* mask, int64_t rows, int32_t C, double* conf,
+                          int64_t* pred_out, mser_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser over the flat parameter buffer: torch.optim.Adam(lr, weight_decay=wd) (model_trainer.py:82).

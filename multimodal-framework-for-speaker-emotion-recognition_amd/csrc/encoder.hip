@@ -635,6 +635,33 @@ int encoder_layer_fwd(const mser_encoder_desc& d, hipStream_t s) {
   return check_launch("post_fwd_kernel");
 }
 
+// The layer's weight-gradient products dW[N, K] += dY^T X (A = dY^T, m contiguous; B = X, n contiguous; reduction over the rows,
+// split-K float atomics) as descriptors: launched here as one group, or handed to the caller who batches them with the rest of
+// the model's weight gradients (mser_gemm_grouped).  Valid once the MSER_ENC_BWD_ACT phase has been enqueued.
+int encoder_layer_wgrad_descs(const mser_encoder_desc& d, mser_gemm_desc* out, int cap) {
+  MSER_TRY(enc_validate(d, true));
+  MSER_REQUIRE(d.g_w_qs && d.g_w_ks && d.g_w_vs && d.g_fc && d.g_w1 && d.g_w2, "mser_encoder_layer_bwd: null weight gradient");
+  MSER_REQUIRE(out && cap >= 6, "mser_encoder_layer_wgrad_descs: need room for 6 descriptors");
+  const int rows = d.nb * d.nl, nq = d.nh * d.dk, D = d.D, F = d.dff;
+  int n = 0;
+  auto wgrad = [&](const float* dY, long lddy, int N, const float* X, long ldx, int K, float* dW) {
+    mser_gemm_desc g = gd0();
+    g.A = dY; g.sAm = 1; g.sAk = lddy; g.B = X; g.sBk = ldx; g.sBn = 1; g.C = dW; g.ldc = K; g.M = N; g.N = K; g.K = rows;
+    g.splitk = 16;
+    out[n++] = g;
+  };
+  if (qkv_adjacent(d.w_qs, d.w_ks, d.w_vs, (long)nq * D) && qkv_adjacent(d.g_w_qs, d.g_w_ks, d.g_w_vs, (long)nq * D)) {
+    wgrad(d.dqkv, 3L * nq, 3 * nq, d.x, D, D, d.g_w_qs);
+  } else {
+    float* gw[3] = {d.g_w_qs, d.g_w_ks, d.g_w_vs};
+    for (int i = 0; i < 3; ++i) wgrad(d.dqkv + i * nq, 3L * nq, nq, d.x, D, D, gw[i]);
+  }
+  wgrad(d.dy1, D, D, d.O, nq, nq, d.g_fc);
+  wgrad(d.dh, F, F, d.e1, D, D, d.g_w1);
+  wgrad(d.dy2, D, D, d.hdn, F, F, d.g_w2);
+  return n;
+}
+
 int encoder_layer_bwd(const mser_encoder_desc& d, int phases, hipStream_t s) {
   MSER_TRY(enc_validate(d, true));
   const int rows = d.nb * d.nl, nq = d.nh * d.dk, D = d.D, F = d.dff;
@@ -668,26 +695,9 @@ int encoder_layer_bwd(const mser_encoder_desc& d, int phases, hipStream_t s) {
     }
   }
   if (phases & MSER_ENC_BWD_WGRAD) {
-    MSER_REQUIRE(d.g_w_qs && d.g_w_ks && d.g_w_vs && d.g_fc && d.g_w1 && d.g_w2, "mser_encoder_layer_bwd: null weight gradient");
-    // dW[N, K] += dY^T X : A = dY^T (m contiguous), B = X (n contiguous), reduction over the rows, split-K float atomics
     mser_gemm_desc wg[6];
-    int nwg = 0;
-    auto wgrad = [&](const float* dY, long lddy, int N, const float* X, long ldx, int K, float* dW) -> int {
-      mser_gemm_desc g = gd0();
-      g.A = dY; g.sAm = 1; g.sAk = lddy; g.B = X; g.sBk = ldx; g.sBn = 1; g.C = dW; g.ldc = K; g.M = N; g.N = K; g.K = rows;
-      g.splitk = 16;
-      wg[nwg++] = g;
-      return 0;
-    };
-    if (adj && qkv_adjacent(d.g_w_qs, d.g_w_ks, d.g_w_vs, (long)nq * D)) {
-      MSER_TRY(wgrad(d.dqkv, 3L * nq, 3 * nq, d.x, D, D, d.g_w_qs));
-    } else {
-      float* gw[3] = {d.g_w_qs, d.g_w_ks, d.g_w_vs};
-      for (int i = 0; i < 3; ++i) MSER_TRY(wgrad(d.dqkv + i * nq, 3L * nq, nq, d.x, D, D, gw[i]));
-    }
-    MSER_TRY(wgrad(d.dy1, D, D, d.O, nq, nq, d.g_fc));
-    MSER_TRY(wgrad(d.dh, F, F, d.e1, D, D, d.g_w1));
-    MSER_TRY(wgrad(d.dy2, D, D, d.hdn, F, F, d.g_w2));
+    const int nwg = encoder_layer_wgrad_descs(d, wg, 6);
+    if (nwg < 0) return nwg;
     MSER_TRY(gemm_group(wg, nwg, s));        // one grouped launch for the layer's weight gradients
   }
   return 0;
@@ -704,6 +714,10 @@ int mser_encoder_layer_supported(const mser_encoder_desc* d) {
 int mser_encoder_layer_fwd(const mser_encoder_desc* d, mser_stream_t stream) {
   if (!d) { mser::set_error("mser_encoder_layer_fwd: null descriptor"); return -1; }
   return mser::encoder_layer_fwd(*d, (hipStream_t)stream);
+}
+int mser_encoder_layer_wgrad_descs(const mser_encoder_desc* d, mser_gemm_desc* out, int32_t cap) {
+  if (!d) { mser::set_error("mser_encoder_layer_wgrad_descs: null descriptor"); return -1; }
+  return mser::encoder_layer_wgrad_descs(*d, out, cap);
 }
 int mser_encoder_layer_bwd(const mser_encoder_desc* d, int32_t phases, mser_stream_t stream) {
   if (!d) { mser::set_error("mser_encoder_layer_bwd: null descriptor"); return -1; }

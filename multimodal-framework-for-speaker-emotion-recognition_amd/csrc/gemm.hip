@@ -27,6 +27,8 @@
 
 namespace mser {
 
+constexpr int GEMM_ATOMIC = 1 << 8;   // internal flag: accumulate with float atomics even without a split (grouped launches)
+
 struct GemmArgs {
   const float* A; const float* B; float* C;
   int M, N, K;
@@ -198,7 +200,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
       if (R2) v += R2[(long)m * g.ldr2 + n];
     }
     float* dst = C + (long)m * g.ldc + n;
-    if (g.splitk > 1) atomicAdd(dst, v);
+    if (g.splitk > 1 || (g.flags & GEMM_ATOMIC)) atomicAdd(dst, v);
     else if (g.flags & MSER_GEMM_ACCUM) *dst += v;
     else *dst = v;
   }
@@ -292,8 +294,9 @@ static int plan(const mser_gemm_desc& d, long group_tiles, Plan& P) {
   a.kchunk = kchunk;
   a.splitk = splitk = (d.K > 0) ? cdiv(d.K, kchunk) : 1;
   if (splitk == 1 && d.splitk > 1) {
-    // degenerate split: a read-modify-write accumulate (caller promised C is initialised)
-    a.flags = d.flags | MSER_GEMM_ACCUM;
+    // degenerate split: a read-modify-write accumulate (caller promised C is initialised).  Inside a group two members may
+    // accumulate into the SAME tensor (a layer applied twice shares its weight gradient): those must stay atomic.
+    a.flags = d.flags | (group_tiles > 0 ? GEMM_ATOMIC : MSER_GEMM_ACCUM);
   } else {
     a.flags = d.flags;
   }

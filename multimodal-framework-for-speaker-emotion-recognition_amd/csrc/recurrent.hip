@@ -1668,6 +1668,33 @@ static int colsum4(const float* X, long rows, int n, long ld, float* o0, float* 
   return check_launch("colsum4");
 }
 
+// dx_l / dx_a (contiguous [T*B, D]) += up to four contiguous addends each, both modalities in one launch (blockIdx.y):
+// the BPTT launch's dx products of the two directions and the caller's partial sums (sequence-level attention branches).
+struct SumArgs { float* out[2]; const float* src[2][4]; long n; };
+template <int VEC>
+__global__ void sum_into_kernel(SumArgs a) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  if (i >= a.n) return;
+  const int m = blockIdx.y;
+  if (VEC == 4) {
+    float4 v = *reinterpret_cast<const float4*>(a.out[m] + i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (a.src[m][k]) {
+        const float4 w = *reinterpret_cast<const float4*>(a.src[m][k] + i);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+      }
+    }
+    *reinterpret_cast<float4*>(a.out[m] + i) = v;
+  } else {
+    float v = a.out[m][i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (a.src[m][k]) v += a.src[m][k][i];
+    a.out[m][i] = v;
+  }
+}
+
 // ================================================================================================ host side
 struct Carver {
   char* base; size_t off;
@@ -2026,8 +2053,7 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
           MSER_TRY(gemm(g, s));
         }
         // dx (direction order) = dg W_m
-        if (persist) {       // produced inside the BPTT kernel at natural time rows: just add it
-          MSER_TRY(mser_add_rows(dxs[m], D, dxs[m], D, k.dxc + (long)m * TB * D, D, TB, D, s));
+        if (persist) {       // produced inside the BPTT kernel at natural time rows: summed below, both directions in one launch
         } else if (!k.rev) {
           g = gd(dg, 4 * H, 1, k.W[m], D, 1, dxs[m], D, (int)TB, D, 4 * H);
           g.flags = MSER_GEMM_ACCUM;
@@ -2064,6 +2090,27 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       MSER_TRY(colsum4(k.attacc, B, H, 2 * H, G.att_Wq, nullptr, nullptr, nullptr, s));
       MSER_TRY(colsum4(k.attacc + H, B, H, 2 * H, G.att_Wk, nullptr, nullptr, nullptr, s));
     }
+  }
+  if ((phases & MSER_PHASE_LSTHM_BWD_DX) && (persist || d.dx_l_add[0] || d.dx_l_add[1] || d.dx_a_add[0] || d.dx_a_add[1])) {
+    SumArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.out[0] = d.dx_l; sa.out[1] = d.dx_a;
+    sa.n = TB * D;
+    int n[2] = {0, 0};
+    for (int i = 0; i < d.ndir && persist; ++i)
+      for (int m = 0; m < 2; ++m) sa.src[m][n[m]++] = K.d[i].dxc + (long)m * TB * D;
+    for (int j = 0; j < 2; ++j) {
+      if (d.dx_l_add[j]) sa.src[0][n[0]++] = d.dx_l_add[j];
+      if (d.dx_a_add[j]) sa.src[1][n[1]++] = d.dx_a_add[j];
+    }
+    bool vec = (sa.n & 3) == 0;
+    for (int m = 0; m < 2; ++m) {
+      vec = vec && ((uintptr_t)sa.out[m] & 15) == 0;
+      for (int j = 0; j < 4; ++j) vec = vec && ((uintptr_t)sa.src[m][j] & 15) == 0;
+    }
+    if (vec) hipLaunchKernelGGL(sum_into_kernel<4>, dim3(cdiv(sa.n / 4, 256), 2), dim3(256), 0, s, sa);
+    else hipLaunchKernelGGL(sum_into_kernel<1>, dim3(cdiv(sa.n, 256), 2), dim3(256), 0, s, sa);
+    MSER_TRY(check_launch("sum_into"));
   }
   MSER_TRY(gemm_group(wg.data(), (int)wg.size(), s));
   wg.clear();

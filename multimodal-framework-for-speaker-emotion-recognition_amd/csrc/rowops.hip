@@ -172,6 +172,69 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dy, con
   }
 }
 
+// ---------------------------------------------------------------------------------------------- batch ingest / metrics
+// x[r, 0:dr] = (((r1 + r2) + r3) + r4) / 4 ;  x[r, dr:dr+da] = acouf[r, :]   (model_trainer.py:104-105: textf average + cat).
+// Same association order as the reference expression, so the result is bit-identical to the torch CPU evaluation.
+// HBM-bound: (4 dr + da) floats read and (dr + da) written per utterance; 16-byte accesses when every width is a multiple of 4.
+template <int VEC>
+__global__ __launch_bounds__(256) void ingest_kernel(const float* r1, const float* r2, const float* r3, const float* r4,
+                                                     const float* ac, float* x, long rows, int dr, int da) {
+  const int W = (dr + da) / VEC;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * W) return;
+  const long r = i / W;
+  const int j = (int)(i - r * W) * VEC;
+  float* dst = x + r * (dr + da) + j;
+  if (VEC == 4) {
+    float4 v;
+    if (j < dr) {
+      const long o = r * dr + j;
+      const float4 a = *reinterpret_cast<const float4*>(r1 + o), b = *reinterpret_cast<const float4*>(r2 + o);
+      const float4 c = *reinterpret_cast<const float4*>(r3 + o), d = *reinterpret_cast<const float4*>(r4 + o);
+      v.x = (((a.x + b.x) + c.x) + d.x) / 4.f; v.y = (((a.y + b.y) + c.y) + d.y) / 4.f;
+      v.z = (((a.z + b.z) + c.z) + d.z) / 4.f; v.w = (((a.w + b.w) + c.w) + d.w) / 4.f;
+    } else {
+      v = *reinterpret_cast<const float4*>(ac + r * da + (j - dr));
+    }
+    *reinterpret_cast<float4*>(dst) = v;
+  } else {
+    if (j < dr) {
+      const long o = r * dr + j;
+      *dst = (((r1[o] + r2[o]) + r3[o]) + r4[o]) / 4.f;
+    } else {
+      *dst = ac[r * da + (j - dr)];
+    }
+  }
+}
+
+// Confusion matrix of one evaluation batch (model_trainer.py:142-156): pred = argmax_c lp[r, c] (first maximum),
+// conf[label[r]][pred] += mask[r] in float64 (sklearn's sample_weight sums), pred_out[r] = pred (the res.csv column).
+// One thread per utterance row; C*C float64 partial sums per workgroup in LDS, one atomic per non-zero cell per workgroup.
+constexpr int CONF_MAXC = 16;
+__global__ __launch_bounds__(256) void confusion_kernel(const float* lp, const long* label, const float* mask, long rows, int C,
+                                                        double* conf, long* pred_out) {
+  __shared__ double part[CONF_MAXC * CONF_MAXC];
+  for (int i = threadIdx.x; i < C * C; i += blockDim.x) part[i] = 0.0;
+  __syncthreads();
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows) {
+    const float* p = lp + r * C;
+    int best = 0;
+    float bv = p[0];
+    for (int c = 1; c < C; ++c) {
+      const float v = p[c];
+      if (v > bv) { bv = v; best = c; }
+    }
+    if (pred_out) pred_out[r] = best;
+    const long y = label[r];
+    const float w = mask[r];
+    if (w != 0.f && y >= 0 && y < C) atomicAdd(&part[(int)y * C + best], (double)w);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * C; i += blockDim.x)
+    if (part[i] != 0.0) atomicAdd(&conf[i], part[i]);
+}
+
 // ---------------------------------------------------------------------------------------------- reductions
 // out[n] += sum_m X[m,n]; block = 256 threads covering 64 columns x 4 row-lanes, 64 rows per block.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* X, long rows, int n, long ld, float* out) {
@@ -469,6 +532,33 @@ int mser_add_rows(float* out, int64_t ldo, const float* a, int64_t lda, const fl
   hipLaunchKernelGGL(add_rows_kernel, dim3(cdiv(rows * D, 256)), dim3(256), 0, (hipStream_t)stream, out, (long)ldo, a, (long)lda,
                      b, (long)ldb, (long)rows, D);
   return check_launch("mser_add_rows");
+}
+
+int mser_ingest_features(const float* r1, const float* r2, const float* r3, const float* r4, const float* acouf, float* x,
+                         int64_t rows, int32_t d_r, int32_t d_a, mser_stream_t stream) {
+  MSER_REQUIRE(r1 && r2 && r3 && r4 && acouf && x, "mser_ingest_features: null pointer");
+  MSER_REQUIRE(d_r > 0 && d_a >= 0, "mser_ingest_features: bad widths d_r=%d d_a=%d", d_r, d_a);
+  if (rows <= 0) return 0;
+  auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  const bool vec = (d_r % 4 == 0) && (d_a % 4 == 0) && al(r1) && al(r2) && al(r3) && al(r4) && al(acouf) && al(x);
+  if (vec) {
+    const long n = rows * ((d_r + d_a) / 4);
+    hipLaunchKernelGGL(ingest_kernel<4>, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, r1, r2, r3, r4, acouf, x, (long)rows, d_r, d_a);
+  } else {
+    const long n = rows * (d_r + d_a);
+    hipLaunchKernelGGL(ingest_kernel<1>, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, r1, r2, r3, r4, acouf, x, (long)rows, d_r, d_a);
+  }
+  return check_launch("mser_ingest_features");
+}
+
+int mser_confusion_update(const float* lp, const int64_t* label, const float* mask, int64_t rows, int32_t C, double* conf,
+                          int64_t* pred_out, mser_stream_t stream) {
+  MSER_REQUIRE(lp && label && mask && conf, "mser_confusion_update: null pointer");
+  MSER_REQUIRE(C > 0 && C <= CONF_MAXC, "mser_confusion_update: C=%d unsupported (<= %d)", C, CONF_MAXC);
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(confusion_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, lp, (const long*)label, mask,
+                     (long)rows, C, conf, (long*)pred_out);
+  return check_launch("mser_confusion_update");
 }
 
 int mser_scale_acc_dot(float* acc, int64_t ldacc, const float* t, int64_t ldt, const float* x, int64_t ldx, const float* s_dev,

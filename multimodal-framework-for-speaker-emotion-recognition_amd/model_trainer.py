@@ -17,7 +17,9 @@ import torch.nn as nn
 
 from loss import MaskedLoss
 from models.lsthm_sps import MARN1_sps
+from mser import ops
 from mser.dist import FlatAllReduce
+from mser.metrics import accuracy_and_weighted_f1
 from mser.optim import FlatAdam, StepLR
 
 _OUT_OF_SCOPE = ("DialogueRNN", "MARN", "BiLSTM", "MARN1_newz", "MARN1_azs", "MARN1_mf", "MARN1_la", "MARN1_cf", "MARN1_sp",
@@ -56,9 +58,8 @@ class ModelTrainer(nn.Module):
         return r1, r2, r3, r4, acouf, qmask, umask, label
 
     def _features(self, r1, r2, r3, r4, acouf):
-        # batch prep stays in torch (SURVEY.md 8(f3) "next" row): textf = (r1+r2+r3+r4)/4 ; x = cat(textf, acouf)
-        textf = (r1 + r2 + r3 + r4) / 4
-        return torch.cat((textf, acouf), dim=-1)
+        # batch ingest (reference :104-105): textf = (r1+r2+r3+r4)/4 ; x = cat(textf, acouf) -- one HBM-bound launch
+        return ops.ingest_features(r1, r2, r3, r4, acouf)
 
     def forward_backward(self, x, qmask, umask, label):
         """zero_grad + forward + MaskedLoss + backward (graph-capturable: no host sync, no host-dependent scalars)."""
@@ -103,20 +104,27 @@ class ModelTrainer(nn.Module):
         avg_loss = round(float(num / den), 4)
         return lr, avg_loss
 
-    def eval_network(self, loader):
-        from sklearn.metrics import accuracy_score, f1_score
+    def eval_network(self, loader, return_predictions=False):
+        """Reference :127-168.  argmax, the mask-weighted confusion matrix and hence accuracy / weighted F1 are accumulated on
+        the device (one launch per batch, one C x C read-back per call) instead of copying every prediction to the host;
+        ``return_predictions=True`` additionally returns the (preds, labels, masks) columns the reference dumps to res.csv."""
         self.eval()
-        preds, labels, masks = [], [], []
+        n_classes = self.model.dims.n_classes
+        conf = torch.zeros(n_classes, n_classes, device=self.device, dtype=torch.float64)
+        cols = []
         with torch.no_grad():
             for _, data in enumerate(loader):
                 r1, r2, r3, r4, acouf, qmask, umask, label = self._unpack(data)
                 lp_, x_a, x_l = self.model(self._features(r1, r2, r3, r4, acouf), qmask, umask)
-                preds.append(torch.argmax(lp_, 1).cpu().numpy())
-                labels.append(label.view(-1).cpu().numpy())
-                masks.append(umask.view(-1).cpu().numpy())
-        preds, labels, masks = np.concatenate(preds), np.concatenate(labels), np.concatenate(masks)
-        avg_accuracy = round(accuracy_score(labels, preds, sample_weight=masks) * 100, 2)
-        avg_fscore = round(f1_score(labels, preds, sample_weight=masks, average='weighted') * 100, 2)
+                pred = torch.empty(lp_.shape[0], device=self.device, dtype=torch.int64) if return_predictions else None
+                ops.confusion_update(lp_, label.view(-1), umask.reshape(-1), conf, pred)
+                if return_predictions:
+                    cols.append((pred, label.view(-1), umask.reshape(-1)))
+        acc, wf1 = accuracy_and_weighted_f1(conf.cpu().numpy())
+        avg_accuracy, avg_fscore = round(acc * 100, 2), round(wf1 * 100, 2)
+        if return_predictions:
+            table = {k: np.concatenate([c[i].cpu().numpy() for c in cols]) for i, k in enumerate(("preds", "labels", "masks"))}
+            return avg_accuracy, avg_fscore, {}, table
         return avg_accuracy, avg_fscore, {}
 
     def save_parameters(self, path):

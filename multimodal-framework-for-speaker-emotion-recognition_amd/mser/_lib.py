@@ -50,6 +50,7 @@ class CellDesc(C.Structure):
         ("x_l", C.c_void_p), ("ldxl", C.c_int64), ("x_a", C.c_void_p), ("ldxa", C.c_int64),
         ("dx_l", C.c_void_p), ("dx_a", C.c_void_p), ("ldo", C.c_int64),
         ("dir", CellDir * 2), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("dx_l_add", _P2), ("dx_a_add", _P2),
     ]
 
 
@@ -95,6 +96,7 @@ SIGNATURES = {
     "mser_encoder_layer_supported": (C.c_int, [C.POINTER(EncoderDesc)]),
     "mser_encoder_layer_fwd": (C.c_int, [C.POINTER(EncoderDesc), _vp]),
     "mser_encoder_layer_bwd": (C.c_int, [C.POINTER(EncoderDesc), _i32, _vp]),
+    "mser_encoder_layer_wgrad_descs": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(GemmDesc), _i32]),
     "mser_build_reverse_index": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "mser_reverse_by_length": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "mser_build_slot_tables": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
@@ -109,6 +111,8 @@ SIGNATURES = {
     "mser_logsoftmax_tb_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mser_masked_nll_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "mser_masked_nll_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "mser_ingest_features": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "mser_confusion_update": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "mser_adam_flat": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
     "mser_adam_flat_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _f32, _vp, _f32, _vp]),
     "mser_dp_pack": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),

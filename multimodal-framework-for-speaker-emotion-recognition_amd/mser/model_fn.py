@@ -268,7 +268,9 @@ def _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams):
     for r, pre, sl in ((c.cell_dirs[0], "marn_cell_f.", slice(0, 4 * H)), (c.cell_dirs[1], "marn_cell_b.", slice(4 * H, 8 * H))):
         r["g"] = ops.cell_param_struct(_sub(G, pre))
         r["dout"] = dH[:, sl]
-    desc = ops.make_cell_desc(Ln, B, D, H, c.x_l, c.x_a, c.cell_dirs, 10 * H, c.cell_ws, dx_l=dx_l, dx_a=dx_a)
+    # the attention branches' partial input gradients are folded into dx_l / dx_a by the cell's BWD_DX phase (one launch)
+    desc = ops.make_cell_desc(Ln, B, D, H, c.x_l, c.x_a, c.cell_dirs, 10 * H, c.cell_ws, dx_l=dx_l, dx_a=dx_a,
+                              dx_l_add=(dxl_a, dxl_b), dx_a_add=(dxa_a, dxa_b))
     c.cell_desc = desc
     Pl, Pa, Gl, Ga = _sub(P, "encoder_l."), _sub(P, "encoder_a."), _sub(G, "encoder_l."), _sub(G, "encoder_a.")
     cur = torch.cuda.current_stream()
@@ -284,12 +286,6 @@ def _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams):
     def audio_branch():
         d2 = F_.encoder_layer_bwd(c.enc[3], dx_a, Pa, Ga)
         F_.encoder_layer_bwd(c.enc[2], d2, Pa, Ga)                 # input features need no gradient
-
-    def merge_dx():
-        ops.add_rows(dxl_a, dxl_a, dxl_b)
-        ops.add_rows(dx_l, dx_l, dxl_a)
-        ops.add_rows(dxa_a, dxa_a, dxa_b)
-        ops.add_rows(dx_a, dx_a, dxa_a)
 
     if side is not None:
         s_audio, s_spk, s_xa, s_xb = side[:4]
@@ -311,8 +307,7 @@ def _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams):
             xattn_b_bwd()
         cur.wait_stream(s_xa)
         cur.wait_stream(s_xb)
-        merge_dx()
-        ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD_DX)            # dx_l += dg W_l, dx_a += dg W_a (and dHQ when not pipelined)
+        ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD_DX)            # dx_l += dg W_l + attention branches, likewise dx_a
         s_audio.wait_stream(cur)
         s_xa.wait_stream(cur)
         if not c.pipelined:
@@ -330,7 +325,6 @@ def _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams):
         xattn_a_bwd()
         xattn_b_bwd()
         ops.marn_cell_run(desc, ops.PHASE_BWD_PREP | ops.PHASE_LSTHM_BWD)
-        merge_dx()
         ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD_DX | ops.PHASE_LSTHM_WGRAD | ops.PHASE_SPEAKER_BWD)
         text_branch()
         audio_branch()

@@ -267,6 +267,19 @@ def encoder_layer_fwd(desc: L.EncoderDesc) -> None:
 def encoder_layer_bwd(desc: L.EncoderDesc, phases: int, deferred: Optional[tuple] = None) -> None:
     """phases = ENC_BWD_ACT (activation-gradient chain) and / or ENC_BWD_WGRAD (weight-gradient GEMMs).  With ``deferred``
     (the tensors the weight-gradient phase reads) the call goes to the wgrad side stream when a wgrad_scope is active."""
+    batch = _WG["batch"]
+    if batch is not None and phases == ENC_BWD_WGRAD:
+        # hand the layer's weight-gradient products to the step's single grouped launch (wgrad_scope(batch=True))
+        arr = (L.GemmDesc * 6)()
+        n = _lib().mser_encoder_layer_wgrad_descs(C.byref(desc), arr, 6)
+        if n < 0:
+            L.check(n, "encoder_layer_wgrad_descs")
+        for i in range(n):
+            d = L.GemmDesc()
+            C.memmove(C.byref(d), C.byref(arr[i]), C.sizeof(L.GemmDesc))
+            batch.append(d)
+        _WG["keep"].append((desc,) + tuple(deferred or ()))
+        return
     if deferred is not None:
         with _deferred(*deferred):
             L.check(_lib().mser_encoder_layer_bwd(C.byref(desc), phases, _stream()), "encoder_layer_bwd")
@@ -307,6 +320,33 @@ def masked_nll_bwd(target: Tensor, mask: Tensor, loss_out: Tensor, gscale: Optio
     rows, Cn = dpred.shape
     L.check(_lib().mser_masked_nll_bwd(_p(target), _p(mask), _p(loss_out), _p(gscale), _p(dpred), rows, Cn, _stream()),
             "masked_nll_bwd")
+
+
+def ingest_features(r1: Tensor, r2: Tensor, r3: Tensor, r4: Tensor, acouf: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """x = cat((r1+r2+r3+r4)/4, acouf) along the last dim (reference model_trainer.py:104-105) in one launch."""
+    for t in (r1, r2, r3, r4, acouf):
+        _f32(t, "ingest_features")
+        if not t.is_cuda:
+            raise RuntimeError("mser ops need GPU tensors (the product path has no CPU fallback)")
+    if not (r1.shape == r2.shape == r3.shape == r4.shape) or r1.shape[:-1] != acouf.shape[:-1]:
+        raise RuntimeError(f"ingest_features: shape mismatch {tuple(r1.shape)} / {tuple(acouf.shape)}")
+    r1, r2, r3, r4, acouf = (t.contiguous() for t in (r1, r2, r3, r4, acouf))
+    d_r, d_a = r1.shape[-1], acouf.shape[-1]
+    rows = r1.numel() // d_r
+    if out is None:
+        out = torch.empty(*r1.shape[:-1], d_r + d_a, device=r1.device)
+    L.check(_lib().mser_ingest_features(_p(r1), _p(r2), _p(r3), _p(r4), _p(acouf), _p(out), rows, d_r, d_a, _stream()),
+            "ingest_features")
+    return out
+
+
+def confusion_update(lp: Tensor, label: Tensor, mask: Tensor, conf: Tensor, pred_out: Optional[Tensor] = None) -> None:
+    """conf[C, C] (float64, accumulated) += mask-weighted counts of (label, argmax lp); pred_out int64 [rows] optional."""
+    rows, Cn = lp.shape
+    if conf.dtype != torch.float64 or label.dtype != torch.int64:
+        raise RuntimeError("confusion_update: conf must be float64 and label int64")
+    L.check(_lib().mser_confusion_update(_p(lp.contiguous()), _p(label.contiguous()), _p(mask.contiguous()), rows, Cn, _p(conf),
+                                           _p(pred_out), _stream()), "confusion_update")
 
 
 def adam_flat(p: Tensor, g: Tensor, m: Tensor, v: Tensor, live: Optional[Tensor], step: int, lr: float, beta1: float = 0.9,
@@ -368,7 +408,8 @@ def cell_workspace_bytes(T: int, B: int, D: int, H: int, ndir: int) -> int:
 
 
 def make_cell_desc(T: int, B: int, D: int, H: int, x_l: Tensor, x_a: Tensor, dirs: Sequence[dict], ldo: int,
-                   workspace: Tensor, dx_l: Optional[Tensor] = None, dx_a: Optional[Tensor] = None) -> L.CellDesc:
+                   workspace: Tensor, dx_l: Optional[Tensor] = None, dx_a: Optional[Tensor] = None,
+                   dx_l_add: Sequence[Tensor] = (), dx_a_add: Sequence[Tensor] = ()) -> L.CellDesc:
     """dirs: list of dicts with keys p (CellParams), g (CellParams or None), qmask, rev (or None), out, dout (or None)."""
     d = L.CellDesc()
     d.T, d.B, d.D, d.H, d.ndir = T, B, D, H, len(dirs)
@@ -386,6 +427,14 @@ def make_cell_desc(T: int, B: int, D: int, H: int, x_l: Tensor, x_a: Tensor, dir
         d.dir[i].dout = _p(r.get("dout"))
     d.workspace = _p(workspace)
     d.workspace_bytes = workspace.numel() * workspace.element_size()
+    for i, t in enumerate(dx_l_add):       # contiguous [T*B, D] partial sums folded into dx_l / dx_a by PHASE_LSTHM_BWD_DX
+        if not t.is_contiguous():
+            raise RuntimeError("dx_l_add entries must be contiguous")
+        d.dx_l_add[i] = _p(t)
+    for i, t in enumerate(dx_a_add):
+        if not t.is_contiguous():
+            raise RuntimeError("dx_a_add entries must be contiguous")
+        d.dx_a_add[i] = _p(t)
     return d
 
 

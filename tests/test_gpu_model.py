@@ -247,3 +247,28 @@ def test_checkpoint_roundtrip(O, tmp_path):
     a.eval(); b.eval()
     with torch.no_grad():
         assert torch.equal(a.model(x, qmask, umask)[0], b.model(x, qmask, umask)[0])
+
+
+def test_eval_network_metrics_vs_sklearn(O):
+    """ModelTrainer.eval_network (reference model_trainer.py:127-168): on-device argmax + confusion matrix, metrics on the host,
+    against scikit-learn's accuracy_score / weighted f1_score (what the reference calls) on the oracle's log-probs."""
+    from sklearn.metrics import accuracy_score, f1_score
+    from model_trainer import ModelTrainer
+    tr = ModelTrainer(torch.device("cuda:0"), 1e-3, 1, 0.98, "MARN1_sps", "NLL", 6, "IEMOCAP", quiet=True)
+    P = O.seeded_params(seed=9)
+    load_params(tr.model, P)
+    B, L = 3, 9
+    batches, preds, labels, masks = [], [], [], []
+    for s in range(2):
+        x, qmask, umask, label = O.seeded_batch(B, L, d_r=1024, seed=70 + s, ragged=True)
+        r = x[:, :, :1024]
+        batches.append([r, r, r, r, torch.zeros(L, B, 4), x[:, :, 1024:], qmask, umask, label, ["v"] * B])
+        lp_ref, _, _ = O.marn1_sps_forward(P, x, qmask, umask, d_r=1024)
+        preds.append(lp_ref.argmax(1).numpy()); labels.append(label.view(-1).numpy()); masks.append(umask.reshape(-1).numpy())
+    preds, labels, masks = np.concatenate(preds), np.concatenate(labels), np.concatenate(masks)
+    acc, f1, extra, table = tr.eval_network(batches, return_predictions=True)
+    assert extra == {} and tr.eval_network(batches) == (acc, f1, {})
+    assert acc == round(accuracy_score(labels, preds, sample_weight=masks) * 100, 2)
+    assert f1 == round(f1_score(labels, preds, sample_weight=masks, average="weighted") * 100, 2)
+    sel = masks > 0
+    assert np.array_equal(table["preds"][sel], preds[sel]) and np.array_equal(table["labels"], labels) and np.array_equal(table["masks"], masks)

@@ -331,3 +331,33 @@ def test_gemm_grouped_matches_single_launches(env):
     for (N, K), out, ref in zip(specs, outs, refs):
         if N:
             assert float((out.cpu().double() - ref).abs().max()) < 3e-5 * max(1.0, float(ref.abs().max())), (N, K)
+
+
+@pytest.mark.parametrize("L,B,d_r,d_a", [(5, 3, 1024, 100), (7, 2, 30, 5), (128, 32, 768, 100)])
+def test_ingest_features_bit_exact(env, L, B, d_r, d_a):
+    """x = cat((r1+r2+r3+r4)/4, acouf) (reference model_trainer.py:104-105): bit-identical to the torch CPU expression."""
+    ops = env
+    rs = np.random.RandomState(2)
+    r = [torch.tensor(rs.standard_normal((L, B, d_r)).astype(np.float32)) for _ in range(4)]
+    ac = torch.tensor(rs.standard_normal((L, B, d_a)).astype(np.float32))
+    ref = torch.cat(((r[0] + r[1] + r[2] + r[3]) / 4, ac), dim=-1)
+    out = ops.ingest_features(*[t.cuda() for t in r], ac.cuda())
+    assert out.shape == ref.shape and torch.equal(out.cpu(), ref)
+
+
+def test_confusion_update_matches_numpy(env):
+    ops = env
+    from mser.metrics import confusion_matrix
+    rs = np.random.RandomState(4)
+    rows, C = 4099, 6
+    lp = torch.tensor(rs.standard_normal((rows, C)).astype(np.float32))
+    lp[5, 1] = lp[5, 3] = 9.0                            # tie -> first maximum, like torch.argmax on the host
+    label = torch.tensor(rs.randint(0, C, rows).astype(np.int64))
+    mask = torch.tensor((rs.rand(rows) > 0.25).astype(np.float32))
+    conf = torch.zeros(C, C, dtype=torch.float64, device="cuda")
+    pred = torch.empty(rows, dtype=torch.int64, device="cuda")
+    ops.confusion_update(lp.cuda(), label.cuda(), mask.cuda(), conf, pred)
+    ops.confusion_update(lp.cuda(), label.cuda(), mask.cuda(), conf, None)        # accumulates across calls
+    p_ref = lp.argmax(1)
+    assert torch.equal(pred.cpu(), p_ref) and int(pred[5]) == 1
+    assert np.array_equal(conf.cpu().numpy(), 2 * confusion_matrix(label.numpy(), p_ref.numpy(), mask.numpy(), C))

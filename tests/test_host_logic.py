@@ -116,3 +116,20 @@ def test_out_of_scope_models_are_refused_loudly():
     from model_trainer import ModelTrainer
     with pytest.raises(NotImplementedError):
         ModelTrainer("cpu", 1e-3, 1, 0.98, "DialogueRNN", "NLL", 6, "IEMOCAP", quiet=True)
+
+
+def test_metrics_from_confusion_match_sklearn():
+    """accuracy / weighted F1 from the mask-weighted confusion matrix (mser/metrics.py; the device accumulates the matrix)
+    vs the library calls of the reference (model_trainer.py:155-156), incl. a class that never occurs and zero-weight rows."""
+    from sklearn.metrics import accuracy_score, f1_score
+    from mser.metrics import accuracy_and_weighted_f1, confusion_matrix
+    rs = np.random.RandomState(5)
+    for C, n in ((6, 500), (6, 7), (3, 64)):
+        labels = rs.randint(0, C - 1, n)               # class C-1 never true
+        preds = rs.randint(0, C, n)
+        masks = (rs.rand(n) > 0.3).astype(np.float32)
+        masks[0] = 1.0
+        acc, wf1 = accuracy_and_weighted_f1(confusion_matrix(labels, preds, masks, C))
+        assert abs(acc - accuracy_score(labels, preds, sample_weight=masks)) < 1e-12
+        assert abs(wf1 - f1_score(labels, preds, sample_weight=masks, average="weighted")) < 1e-12
+    assert accuracy_and_weighted_f1(np.zeros((4, 4))) == (0.0, 0.0)
