@@ -305,6 +305,11 @@ def _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams):
             xattn_a_bwd()
         with torch.cuda.stream(s_xb):
             xattn_b_bwd()
+        # the weight gradients of the head and of the four attention modules are complete long before the BPTT chain is: their
+        # grouped launch goes out now, on a side stream, and runs on the CUs the chain leaves idle
+        with torch.cuda.stream(s_xa):
+            s_xa.wait_stream(s_xb)
+            ops.wgrad_scope.flush()
         cur.wait_stream(s_xa)
         cur.wait_stream(s_xb)
         ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD_DX)            # dx_l += dg W_l + attention branches, likewise dx_a

@@ -41,14 +41,22 @@ class wgrad_scope:
             self.stream.wait_stream(torch.cuda.current_stream())
         return self
 
+    @staticmethod
+    def flush():
+        """Launch the weight-gradient products collected so far as one group on the CURRENT stream (which must already be
+        ordered behind every producer of their operands); later grad_weight calls start a new batch."""
+        descs = _WG["batch"]
+        if descs:
+            arr = (L.GemmDesc * len(descs))(*descs)
+            L.check(_lib().mser_gemm_grouped(arr, len(descs), _stream()), "mser_gemm_grouped")
+            _WG["batch"] = []
+
     def __exit__(self, *exc):
         try:
             if self.stream is not None:
                 torch.cuda.current_stream().wait_stream(self.stream)
-            descs = _WG["batch"]
-            if descs and exc[0] is None:
-                arr = (L.GemmDesc * len(descs))(*descs)
-                L.check(_lib().mser_gemm_grouped(arr, len(descs), _stream()), "mser_gemm_grouped")
+            if exc[0] is None:
+                self.flush()
         finally:
             _WG["stream"] = None
             _WG["keep"] = []
