@@ -225,8 +225,10 @@ int mser_marn_cell_run(const mser_cell_desc* d, int32_t phases, mser_stream_t st
 /* MSER_OPT_WGRAD_INKERNEL = 1 (default): in persistent mode at H = 128 the weight gradients of the LSTHM streams and the speaker
  * cells (dW, dU, dV, dS, dW_ih, dW_hh) are accumulated by extra workgroups of the fused BPTT launch while the chains run
  * (registers, no atomics: deterministic); MSER_PHASE_LSTHM_WGRAD / SPEAKER_BWD then only add the bias sums.  The gradient
- * pointers of the descriptor must be the same in every phase of one backward pass.  0: grouped split-K GEMMs after the chains. */
-enum { MSER_OPT_PERSISTENT = 1, MSER_OPT_WGRAD_INKERNEL = 2 };
+ * pointers of the descriptor must be the same in every phase of one backward pass.  0: grouped split-K GEMMs after the chains.
+ * MSER_OPT_BPTT_KSPLIT = 1 (default): at H = 128 every matvec product of a BPTT step is reduced by two workgroups (K halves,
+ * the consumers add the partials) when the doubled grid still fits the chip. */
+enum { MSER_OPT_PERSISTENT = 1, MSER_OPT_WGRAD_INKERNEL = 2, MSER_OPT_BPTT_KSPLIT = 3 };
 int mser_set_option(int32_t key, int32_t value);
 /* Synchronises `stream` and reports whether a persistent kernel of the last fwd/bwd call on this workspace gave up at a
  * barrier (bounded spins; returns -2 and a message in that case).  Diagnostic; not needed on the hot path. */

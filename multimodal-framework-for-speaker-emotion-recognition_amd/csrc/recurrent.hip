@@ -57,6 +57,8 @@ struct CellK {
   unsigned wsbytes;
   unsigned* sync;      // persistent-kernel counters: [SYNC_*] words, zeroed by a memset node before every launch
   int wgrad_wgs;       // cell_bwd_fused: workgroups that accumulate the weight gradients while the BPTT chains run (0: none)
+  int ksplit;          // BPTT matvec phase: every product's K = 4H reduction is split over `ksplit` workgroups (1 or 2); the
+                       // partial results live in consecutive copies of dA / dHQp / dxc and the consumers add them
   DirP d[2];
 };
 // Every counter sits on a 128-byte line of its own (SYNC_LINE words apart): arrivals (atomics) and polls of one chain never queue
@@ -1022,6 +1024,11 @@ __device__ __forceinline__ void lsthm_bwd_row_part2(const CellK& P, const DirP& 
     dz_in += ldx<PS>(ws, dA + 1 * SA + i) + ldx<PS>(ws, dA + 3 * SA + i);
     dh2[0] += ldx<PS>(ws, dA + 0 * SA + i);
     dh2[1] += ldx<PS>(ws, dA + 2 * SA + i);
+    if (P.ksplit == 2) {       // second K-half of every carry product
+      dz_in += ldx<PS>(ws, dA + 5 * SA + i) + ldx<PS>(ws, dA + 7 * SA + i);
+      dh2[0] += ldx<PS>(ws, dA + 4 * SA + i);
+      dh2[1] += ldx<PS>(ws, dA + 6 * SA + i);
+    }
   }
   float du_cl = 0.f, dcl_att = 0.f;
   if (q == 0) {
@@ -1113,19 +1120,22 @@ struct LsthmBwdB {
   }
 };
 
+// kh / ksplit: this workgroup reduces over gate columns [kh * 4H/ksplit, (kh+1) * 4H/ksplit) and writes partial copy kh.
 template <bool PS, int NP>
 __device__ __forceinline__ void lsthm_bwd_mat_body(const CellK& P, const DirP& D, const WS& ws, int t, int p, int n0, int mb,
-                                                   const float (*bpre)[8], float* red, float* tile) {
+                                                   const float (*bpre)[8], float* red, float* tile, int kh = 0, int ksplit = 1) {
   const int m = p < 4 ? p >> 1 : (p - 4) & 1;
   const int H = P.H, B = P.B, T = P.T;
+  const int KH = 4 * H / ksplit, koff = kh * KH;
   const float* Wp = p >= 6 ? D.W[m] : (p >= 4 ? D.S[m] : ((p & 1) ? D.V[m] : D.U[m]));
-  const float* dg = D.dgates + ((long)m * T * B + (long)t * B) * 4 * H;
+  const float* dg = D.dgates + ((long)m * T * B + (long)t * B) * 4 * H + koff;
   auto aload = [&](int r, int k, float* a) {
     const int b = mb * 32 + r;
     if (b >= B) { zero8(a); return; }
     load8x<PS>(ws, dg + (long)b * 4 * H + k, a);
   };
-  wg_mm32<NP>(4 * H, aload, LsthmBwdB{Wp, n0, p >= 6 ? P.D : H, p >= 6 ? P.D : H}, bpre, red, tile);
+  const int ldw = p >= 6 ? P.D : H;
+  wg_mm32<NP>(KH, aload, LsthmBwdB{Wp + (long)koff * ldw, n0, ldw, ldw}, bpre, red, tile);
 #pragma unroll
   for (int e = 0; e < 1024 / NT; ++e) {
     const int idx = threadIdx.x + e * NT;
@@ -1134,9 +1144,9 @@ __device__ __forceinline__ void lsthm_bwd_mat_body(const CellK& P, const DirP& D
     if (b < B) {
       if (p >= 6) {              // dx of this direction at the natural time position (consumed after the launch: plain store)
         const int tau = D.rev ? D.rev[(long)t * B + b] : t;
-        if (tau >= 0 && n0 + n < P.D) D.dxc[((long)m * T * B + (long)tau * B + b) * P.D + n0 + n] = tile[idx];
+        if (tau >= 0 && n0 + n < P.D) D.dxc[(((long)kh * 2 + m) * T * B + (long)tau * B + b) * P.D + n0 + n] = tile[idx];
       } else {
-        float* dst = p < 4 ? D.dA + ((long)p * B + b) * H : D.dHQp + (((long)m * T + t) * B + b) * H;
+        float* dst = p < 4 ? D.dA + (((long)kh * 4 + p) * B + b) * H : D.dHQp + ((((long)kh * 2 + m) * T + t) * B + b) * H;
         stx<PS>(ws, dst + n0 + n, tile[idx]);
       }
     }
@@ -1161,8 +1171,9 @@ __global__ __launch_bounds__(NT) void lsthm_bwd_mat(CellK P, int t) {
 // persistent launch: grid (nwg, 1, ndir), nwg >= (H/32)*6*nmb.  Row phase: rows round-robin over all nwg workgroups;
 // matvec phase: the first (H/32)*6*nmb workgroups (4 carry products + 2 speaker-gradient products).  Two barriers per step;
 // the counter doubles as the "dHQ[t] is complete" signal for the concurrently running speaker BPTT (value 2*(T-t)*nwg).
-template <int NP>
+template <int NP, int KSPLIT = 1>
 __device__ __forceinline__ void lsthm_bwd_role(const CellK& P, const Role R, float* smem, const WS& ws) {
+  constexpr int NPM = NP / KSPLIT;                 // k-passes per wave of the (K-split) matvec products
   float* red = smem;
   float* tile = smem + RED_FLOATS;
   float* att = tile + 1024;
@@ -1174,16 +1185,18 @@ __device__ __forceinline__ void lsthm_bwd_role(const CellK& P, const Role R, flo
   const int w = R.x;
   // matvec roles: 6 products x H/32 slices (carries + speaker gradient), then 2 products x ceil(D/32) slices (dx = dgates W)
   const int nsl = H / 32, nslx = (P.D + 31) / 32;
-  const int per_mb = 6 * nsl + 2 * nslx;
+  const int per_kh = 6 * nsl + 2 * nslx;
+  const int per_mb = per_kh * KSPLIT;              // K-halves of one product sit per_kh workgroups apart
   const bool has_mat = w < per_mb * P.nmb;
-  const int mb = w / per_mb, wr = w % per_mb;
+  const int mb = w / per_mb, kh = (w % per_mb) / per_kh, wr = w % per_kh;
   const int p = wr < 6 * nsl ? wr / nsl : 6 + (wr - 6 * nsl) / nslx;
   const int n0 = (wr < 6 * nsl ? wr % nsl : (wr - 6 * nsl) % nslx) * 32;
-  float bpre[NP][8];
+  float bpre[NPM][8];
   if (has_mat) {
     const int m = p < 4 ? p >> 1 : (p - 4) & 1;
     const float* Wp = p >= 6 ? D.W[m] : (p >= 4 ? D.S[m] : ((p & 1) ? D.V[m] : D.U[m]));
-    preload_b<NP>(4 * H, LsthmBwdB{Wp, n0, p >= 6 ? P.D : H, p >= 6 ? P.D : H}, bpre);
+    const int ldw = p >= 6 ? P.D : H;
+    preload_b<NPM>(4 * H / KSPLIT, LsthmBwdB{Wp + (long)kh * (4 * H / KSPLIT) * ldw, n0, ldw, ldw}, bpre);
   }
   att_prepare(D, H, att, red);
   unsigned nbar = 0;
@@ -1204,7 +1217,7 @@ __device__ __forceinline__ void lsthm_bwd_role(const CellK& P, const Role R, flo
     STAMP_ACC(0);
     if (!dir_barrier(cnt, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
     STAMP_ACC(1);
-    if (has_mat && (t > 0 || p >= 4)) lsthm_bwd_mat_body<true, NP>(P, D, ws, t, p, n0, mb, bpre, red, tile);   // t == 0: no carries needed
+    if (has_mat && (t > 0 || p >= 4)) lsthm_bwd_mat_body<true, NPM>(P, D, ws, t, p, n0, mb, bpre, red, tile, kh, KSPLIT);   // t == 0: no carries needed
     STAMP_ACC(2);
     // split-phase barrier: while the carries are handed over, the half of step t-1's row work that needs only saved forward
     // state (softmax statistics, pass 1) is computed and the saved state of step t-2 is requested
@@ -1304,6 +1317,11 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, cons
             const float4 q1 = ld4x<PS>(ws, D.dHQp + (((long)0 * T + t) * B + r) * H + u);
             const float4 q2 = ld4x<PS>(ws, D.dHQp + (((long)1 * T + t) * B + r) * H + u);
             v_hq[ii] = make_float4(q0.x + q1.x + q2.x, q0.y + q1.y + q2.y, q0.z + q1.z + q2.z, q0.w + q1.w + q2.w);
+            if (P.ksplit == 2) {     // second K-half of the two speaker-gradient products
+              const float4 q3 = ld4x<PS>(ws, D.dHQp + (((long)2 * T + t) * B + r) * H + u);
+              const float4 q4 = ld4x<PS>(ws, D.dHQp + (((long)3 * T + t) * B + r) * H + u);
+              v_hq[ii].x += q3.x + q4.x; v_hq[ii].y += q3.y + q4.y; v_hq[ii].z += q3.z + q4.z; v_hq[ii].w += q3.w + q4.w;
+            }
           } else {
             v_hq[ii] = *reinterpret_cast<const float4*>(D.dHQ + ((long)t * B + r) * H + u);
           }
@@ -1565,7 +1583,7 @@ __device__ __forceinline__ void wgrad_role(const CellK& P, int id, const WS& ws,
   }
 }
 
-template <int NPL, int NPS>
+template <int NPL, int NPS, int KSPLIT = 1>
 __global__ __launch_bounds__(NT) void cell_bwd_fused(CellK P, unsigned bwd_nwg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const WS ws = make_ws(P.wsbase, P.wsbytes);
@@ -1575,7 +1593,7 @@ __global__ __launch_bounds__(NT) void cell_bwd_fused(CellK P, unsigned bwd_nwg) 
   int id = blockIdx.x;
   if (id < n_l) {
     const Role R{id % (int)bwd_nwg, 0, id / (int)bwd_nwg, (int)bwd_nwg, 1};
-    lsthm_bwd_role<NPL>(P, R, smem, ws);
+    lsthm_bwd_role<NPL, KSPLIT>(P, R, smem, ws);
   } else if (id < n_l + n_s) {
     id -= n_l;
     const Role R{id % gx, (id / gx) % gy, id / (gx * gy), gx, gy};
@@ -1670,7 +1688,7 @@ static int colsum4(const float* X, long rows, int n, long ld, float* o0, float* 
 
 // dx_l / dx_a (contiguous [T*B, D]) += up to four contiguous addends each, both modalities in one launch (blockIdx.y):
 // the BPTT launch's dx products of the two directions and the caller's partial sums (sequence-level attention branches).
-struct SumArgs { float* out[2]; const float* src[2][4]; long n; };
+struct SumArgs { float* out[2]; const float* src[2][6]; long n; };
 template <int VEC>
 __global__ void sum_into_kernel(SumArgs a) {
   const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
@@ -1679,7 +1697,7 @@ __global__ void sum_into_kernel(SumArgs a) {
   if (VEC == 4) {
     float4 v = *reinterpret_cast<const float4*>(a.out[m] + i);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 6; ++k) {
       if (a.src[m][k]) {
         const float4 w = *reinterpret_cast<const float4*>(a.src[m][k] + i);
         v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
@@ -1689,7 +1707,7 @@ __global__ void sum_into_kernel(SumArgs a) {
   } else {
     float v = a.out[m][i];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < 6; ++k)
       if (a.src[m][k]) v += a.src[m][k][i];
     a.out[m][i] = v;
   }
@@ -1722,11 +1740,11 @@ static void carve_dir(Carver& cv, DirP& d, int T, int B, int D, int H) {
   d.hz = cv.take<float>((T + 1) * (size_t)B * 3 * H);
   d.dgates = cv.take<float>(2 * TB * 4 * H);
   d.dc_carry = cv.take<float>(2 * SB);
-  d.dA = cv.take<float>(4 * SB);
+  d.dA = cv.take<float>(2 * 4 * SB);          // x2: K-split partial copies (CellK::ksplit)
   d.attacc = cv.take<float>((size_t)B * 2 * H);
   d.dHQ = cv.take<float>(TB * H);
-  d.dHQp = cv.take<float>(2 * TB * H);
-  d.dxc = cv.take<float>(2 * TB * D);
+  d.dHQp = cv.take<float>(2 * 2 * TB * H);
+  d.dxc = cv.take<float>(2 * 2 * TB * D);
   d.dsg = cv.take<float>(2 * TB * 4 * H);
   d.Xb = cv.take<float>(2 * SB);
   d.dhprev = cv.take<float>(2 * 2 * SB);
@@ -1745,6 +1763,7 @@ static size_t carve_all(char* base, const mser_cell_desc& d, CellHost* out) {
   Carver cv{base, 0};
   CellHost h;
   h.k.T = d.T; h.k.B = d.B; h.k.D = d.D; h.k.H = d.H; h.k.ndir = d.ndir; h.k.nmb = cdiv(d.B, 32); h.k.ldo = d.ldo;
+  h.k.wgrad_wgs = 0; h.k.ksplit = 1;
   h.sync = cv.take<unsigned>(SYNC_WORDS);
   h.k.sync = h.sync;
   h.k.wsbase = base;
@@ -1827,6 +1846,7 @@ static size_t row_lds_bytes(int H) { return ((size_t)RED_FLOATS + 2 * (size_t)H 
 // ---- launch mode ---------------------------------------------------------------------------------------------------------
 static int g_opt_persistent = 1;      // MSER_OPT_PERSISTENT
 static int g_opt_wgrad_inkernel = 1;  // MSER_OPT_WGRAD_INKERNEL
+static int g_opt_ksplit = 1;          // MSER_OPT_BPTT_KSPLIT
 static int g_num_cus = 0;
 constexpr size_t PERSIST_MIN_LDS = 84 * 1024;     // > half of the 160 KiB LDS: at most ONE persistent workgroup per CU
 
@@ -1965,7 +1985,12 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   const size_t mm_lds = (RED_FLOATS + 1024) * sizeof(float);
   const size_t row_lds = row_lds_bytes(H);
   const int spk_wgs = (H / 32) * 4 * K.nmb;                  // speaker BPTT: 4 products
-  const int mat_wgs = ((H / 32) * 6 + ((D + 31) / 32) * 2) * K.nmb;   // LSTHM BPTT matvec roles: 4 carries + 2 speaker-gradient + 2 dx products
+  const int mat_wgs1 = ((H / 32) * 6 + ((D + 31) / 32) * 2) * K.nmb;  // LSTHM BPTT matvec roles: 4 carries + 2 speaker-gradient + 2 dx products
+  // K-split of the matvec phase (the longest phase of a BPTT step, MFMA-paced: 8 waves x 32 MFMAs on 4 SIMDs): two workgroups per
+  // product halve it when the doubled grid still fits beside the speaker chain
+  const int ksplit = (g_opt_persistent && g_opt_ksplit && H == 128 && ((long)2 * mat_wgs1 + spk_wgs) * d.ndir <= num_cus()) ? 2 : 1;
+  K.ksplit = ksplit;
+  const int mat_wgs = mat_wgs1 * ksplit;
   const int bwd_nwg = mat_wgs > 32 ? mat_wgs : 32;           // row phase spreads the B rows over all of them
   // both BPTT kernels run concurrently (pipelined): all their workgroups must be co-resident
   const bool persist = persist_ok(H, ((long)bwd_nwg + spk_wgs) * d.ndir);
@@ -1999,7 +2024,7 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       MSER_CHECK_HIP(hipMemsetAsync(k.dc_carry, 0, 2 * SB * sizeof(float), s));
       MSER_CHECK_HIP(hipMemsetAsync(k.attacc, 0, (size_t)B * 2 * H * sizeof(float), s));
       if (persist && k.rev)    // rows at and beyond len_b receive no gradient from the reversed direction
-        MSER_CHECK_HIP(hipMemsetAsync(k.dxc, 0, 2 * (size_t)TB * D * sizeof(float), s));
+        MSER_CHECK_HIP(hipMemsetAsync(k.dxc, 0, (size_t)ksplit * 2 * TB * D * sizeof(float), s));
     }
     MSER_CHECK_HIP(hipMemsetAsync(h.sync + SYNC_LSTHM_BWD, 0, 4 * SYNC_DIR * sizeof(unsigned), s));
   }
@@ -2010,7 +2035,10 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
     const size_t f_lds = persist_lds(mm_lds + 32 * (4 * (size_t)H + 4) * sizeof(float) + 64);
     const unsigned grid = (unsigned)(((long)bwd_nwg + spk_wgs) * d.ndir + K.wgrad_wgs);
     ProfScope ps(MSER_PROF_LSTHM_BWD_ROW, s);
-    if (H == 128) {
+    if (H == 128 && ksplit == 2) {
+      MSER_TRY(allow_lds((const void*)cell_bwd_fused<4, 4, 2>, f_lds));
+      hipLaunchKernelGGL((cell_bwd_fused<4, 4, 2>), dim3(grid), dim3(NT), f_lds, s, K, (unsigned)bwd_nwg);
+    } else if (H == 128) {
       MSER_TRY(allow_lds((const void*)cell_bwd_fused<4, 4>, f_lds));
       hipLaunchKernelGGL((cell_bwd_fused<4, 4>), dim3(grid), dim3(NT), f_lds, s, K, (unsigned)bwd_nwg);
     } else {
@@ -2098,7 +2126,8 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
     sa.n = TB * D;
     int n[2] = {0, 0};
     for (int i = 0; i < d.ndir && persist; ++i)
-      for (int m = 0; m < 2; ++m) sa.src[m][n[m]++] = K.d[i].dxc + (long)m * TB * D;
+      for (int kh = 0; kh < ksplit; ++kh)
+        for (int m = 0; m < 2; ++m) sa.src[m][n[m]++] = K.d[i].dxc + ((long)kh * 2 + m) * TB * D;
     for (int j = 0; j < 2; ++j) {
       if (d.dx_l_add[j]) sa.src[0][n[0]++] = d.dx_l_add[j];
       if (d.dx_a_add[j]) sa.src[1][n[1]++] = d.dx_a_add[j];
@@ -2106,7 +2135,7 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
     bool vec = (sa.n & 3) == 0;
     for (int m = 0; m < 2; ++m) {
       vec = vec && ((uintptr_t)sa.out[m] & 15) == 0;
-      for (int j = 0; j < 4; ++j) vec = vec && ((uintptr_t)sa.src[m][j] & 15) == 0;
+      for (int j = 0; j < 6; ++j) vec = vec && ((uintptr_t)sa.src[m][j] & 15) == 0;
     }
     if (vec) hipLaunchKernelGGL(sum_into_kernel<4>, dim3(cdiv(sa.n / 4, 256), 2), dim3(256), 0, s, sa);
     else hipLaunchKernelGGL(sum_into_kernel<1>, dim3(cdiv(sa.n, 256), 2), dim3(256), 0, s, sa);
@@ -2219,6 +2248,7 @@ int mser_set_option(int32_t key, int32_t value) {
   switch (key) {
     case MSER_OPT_PERSISTENT: g_opt_persistent = value ? 1 : 0; return 0;
     case MSER_OPT_WGRAD_INKERNEL: g_opt_wgrad_inkernel = value ? 1 : 0; return 0;
+    case MSER_OPT_BPTT_KSPLIT: g_opt_ksplit = value ? 1 : 0; return 0;
     default: set_error("mser_set_option: unknown key %d", key); return -1;
   }
 }

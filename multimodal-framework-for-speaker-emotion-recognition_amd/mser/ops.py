@@ -461,6 +461,7 @@ def marn_cell_status(desc: L.CellDesc) -> None:
 
 MSER_OPT_PERSISTENT = 1
 MSER_OPT_WGRAD_INKERNEL = 2
+MSER_OPT_BPTT_KSPLIT = 3
 
 
 def set_option(key: int, value: int) -> None:

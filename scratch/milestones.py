@@ -47,5 +47,5 @@ def run_config(tag):
 
 for rep in range(2):
     for v in (0, 1):
-        ops.set_option(ops.MSER_OPT_WGRAD_INKERNEL, v)
-        run_config("wgrad_inkernel=%d" % v)
+        ops.set_option(ops.MSER_OPT_BPTT_KSPLIT, v)
+        run_config("bptt_ksplit=%d" % v)
