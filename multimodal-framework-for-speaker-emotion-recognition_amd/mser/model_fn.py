@@ -221,6 +221,37 @@ def _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams):
     dev = dlp.device
     lay = Layout.time_major(Ln, B)
     dlp = dlp.contiguous()
+    cur = torch.cuda.current_stream()
+    side = _Streams.get(dev) if use_streams else None
+    # ---- buffers of the backward; everything that only needs ZEROING (the attention branches' accumulators, the cell's carries
+    # and step counters: ~12 tiny launches) is issued on a side stream now, so that it is not queued between the head's backward
+    # and the BPTT launch on the critical path
+    dx_l = torch.empty(N, D, device=dev)                      # = d(y1r), then accumulates every x_l gradient
+    dx_a = torch.empty(N, D, device=dev)
+    dH = torch.empty(N, 10 * H, device=dev)
+    zbuf = torch.empty(2 * N * H + 4 * N * D, device=dev)     # ONE zero fill for the six accumulators of the attention branches
+    dA1, dA2 = zbuf[:N * H].view(N, H), zbuf[N * H:2 * N * H].view(N, H)
+    dxl_a, dxa_a, dxl_b, dxa_b = (zbuf[2 * N * H + i * N * D:2 * N * H + (i + 1) * N * D].view(N, D) for i in range(4))
+    for r, pre, sl in ((c.cell_dirs[0], "marn_cell_f.", slice(0, 4 * H)), (c.cell_dirs[1], "marn_cell_b.", slice(4 * H, 8 * H))):
+        r["g"] = ops.cell_param_struct(_sub(G, pre))
+        r["dout"] = dH[:, sl]
+    # the attention branches' partial input gradients are folded into dx_l / dx_a by the cell's BWD_DX phase (one launch)
+    desc = ops.make_cell_desc(Ln, B, D, H, c.x_l, c.x_a, c.cell_dirs, 10 * H, c.cell_ws, dx_l=dx_l, dx_a=dx_a,
+                              dx_l_add=(dxl_a, dxl_b), dx_a_add=(dxa_a, dxa_b))
+    c.cell_desc = desc
+    ev_prep = None
+    # (under stream capture the extra branch makes the graph executor order the attention branches behind the BPTT node: measured
+    # +290 us per replay, so the zeroing stays inline there)
+    if side is not None and not torch.cuda.is_current_stream_capturing():
+        s_prep = side[1]
+        s_prep.wait_stream(cur)
+        with torch.cuda.stream(s_prep):
+            zbuf.zero_()
+            ops.marn_cell_run(desc, ops.PHASE_BWD_PREP)
+            ev_prep = torch.cuda.Event()
+            ev_prep.record(s_prep)
+    else:
+        zbuf.zero_()
     # ---- head
     dy3 = torch.empty(N, d.n_classes, device=dev)
     ops.logsoftmax_tb_bwd(dlp, c.lp, dy3, Ln, B)
@@ -229,28 +260,21 @@ def _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams):
     ops.grad_weight(dy3, c.y2, G("nn_out.3.weight"))
     ops.colsum_acc(dy3, G("nn_out.3.bias"))
     ops.relu_bwd_(dy2, c.y2)
-    dx_l = torch.empty(N, D, device=dev)                      # = d(y1r), then accumulates every x_l gradient
     ops.matmul(dy2, P("nn_out.0.weight"), dx_l)
     ops.grad_weight(dy2, c.y1r, G("nn_out.0.weight"))
     ops.colsum_acc(dy2, G("nn_out.0.bias"))
     dy1 = torch.empty(N, D, device=dev)
     ops.add_rows(dy1, dx_l, None)
     ops.relu_bwd_(dy1, c.y1)
-    dx_a = torch.empty(N, D, device=dev)
     ops.add_rows(dx_a, dx_l, dx_a_out.reshape(N, D) if dx_a_out is not None else None)
     if dx_l_out is not None:
         ops.add_rows(dx_l, dx_l, dx_l_out.reshape(N, D))
-    dH = torch.empty(N, 10 * H, device=dev)
     ops.matmul(dy1, P("fc.0.weight"), dH)
     ops.grad_weight(dy1, c.Hcat, G("fc.0.weight"))
     ops.colsum_acc(dy1, G("fc.0.bias"))
     # ---- the four sequence-level attention modules (two independent chains, side streams) run beside the LSTHM BPTT chain.
     # Each chain accumulates its x_l / x_a gradients into its own buffers (no cross-stream read-modify-write).
     w, v, v1, v2 = P("w"), P("v"), P("v1"), P("v2")
-    dA1 = torch.zeros(N, H, device=dev)
-    dA2 = torch.zeros(N, H, device=dev)
-    dxl_a, dxa_a = torch.zeros(N, D, device=dev), torch.zeros(N, D, device=dev)
-    dxl_b, dxa_b = torch.zeros(N, D, device=dev), torch.zeros(N, D, device=dev)
     # the learnable scalars w, v receive contributions from both chains: float atomics on one word each, order-insensitive
 
     def xb(i, name, dout, dx1, dx2, ga1, ga2):
@@ -265,16 +289,7 @@ def _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams):
         xb(3, "crossatt_a2l_1", dH[:, 9 * H:10 * H], dxl_b, dA2, G("w"), G("v2"))
         xb(1, "crossatt_a2l", dA2, dxa_b, dxl_b, G("v"), G("w"))
 
-    for r, pre, sl in ((c.cell_dirs[0], "marn_cell_f.", slice(0, 4 * H)), (c.cell_dirs[1], "marn_cell_b.", slice(4 * H, 8 * H))):
-        r["g"] = ops.cell_param_struct(_sub(G, pre))
-        r["dout"] = dH[:, sl]
-    # the attention branches' partial input gradients are folded into dx_l / dx_a by the cell's BWD_DX phase (one launch)
-    desc = ops.make_cell_desc(Ln, B, D, H, c.x_l, c.x_a, c.cell_dirs, 10 * H, c.cell_ws, dx_l=dx_l, dx_a=dx_a,
-                              dx_l_add=(dxl_a, dxl_b), dx_a_add=(dxa_a, dxa_b))
-    c.cell_desc = desc
     Pl, Pa, Gl, Ga = _sub(P, "encoder_l."), _sub(P, "encoder_a."), _sub(G, "encoder_l."), _sub(G, "encoder_a.")
-    cur = torch.cuda.current_stream()
-    side = _Streams.get(dev) if use_streams else None
 
     def text_branch():
         d2 = F_.encoder_layer_bwd(c.enc[1], dx_l, Pl, Gl)          # grad of (xl0 + e1): flows to both
@@ -290,9 +305,13 @@ def _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams):
     if side is not None:
         s_audio, s_spk, s_xa, s_xb = side[:4]
         ev_h = torch.cuda.Event()
-        ev_h.record(cur)                                           # dH and the initial dx_l / dx_a are ready
+        if ev_prep is not None:
+            cur.wait_event(ev_prep)                                # zeroed accumulators, carries and step counters
+            ev_h.record(cur)                                       # dH and the initial dx_l / dx_a are ready
+        else:
+            ev_h.record(cur)                                       # (capture: the attention branches fork BEFORE the prep nodes)
+            ops.marn_cell_run(desc, ops.PHASE_BWD_PREP)
         # critical chain first (host issue order matters: ~10 us per launch)
-        ops.marn_cell_run(desc, ops.PHASE_BWD_PREP)
         if c.pipelined:
             s_spk.wait_stream(cur)
         ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD)               # BPTT chain (persistent kernel, 64 CUs)
