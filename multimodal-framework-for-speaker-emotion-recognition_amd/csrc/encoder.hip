@@ -31,7 +31,10 @@ int gemm_group(const mser_gemm_desc* d, int n, hipStream_t s);
 
 namespace {
 
-constexpr int ET = 512, EW = 8;           // threads / waves per workgroup
+// 1024 threads = 16 waves = 4 per SIMD: these kernels are phase-structured (stage, product, softmax / LayerNorm, product ...)
+// with a workgroup barrier between phases, and PMC showed their waves parked at s_waitcnt / s_barrier for half of their life with
+// 8 waves (MFMA pipe 20-27 % busy); twice the waves per SIMD hide the LDS / L2 latencies of one another.
+constexpr int ET = 1024, EW = 16;         // threads / waves per workgroup
 constexpr int RT = 32;                    // rows per workgroup of the row-tiled kernels
 
 __device__ __forceinline__ f32x16 mfma4(const float4& a, const float4& b, f32x16 acc) {
@@ -195,68 +198,73 @@ __global__ __launch_bounds__(ET) void attn_bwd_kernel(AttnArgs a) {
   }
   __syncthreads();
   const int nt = LP >> 5, ntn = (dk + 31) >> 5;
-  // ---- dV = P^T dO
-  for (int t = wave; t < nt * ntn; t += EW) {
-    const int ti = t / ntn, tn = t - ti * ntn;
-    const int col = tn * 32 + r;
-    const bool cok = col < dk;
-    f32x16 acc = {0};
-    acc = tile_cc(Pb + (half * 4) * SS + ti * 32 + r, SS, s0 + (half * 4) * SD + (cok ? col : 0), SD, LP, cok, acc);
-    if (cok) {
+  // ---- dV = P^T dO on the lower half of the waves, dP = dO V^T on the upper half (its tiles stay in registers: at most two
+  //      per wave since LP <= 128)
+  constexpr int HW = EW / 2;
+  f32x16 dp[2];
+  dp[0] = f32x16{0}; dp[1] = f32x16{0};
+  if (wave < HW) {
+    for (int t = wave; t < nt * ntn; t += HW) {
+      const int ti = t / ntn, tn = t - ti * ntn;
+      const int col = tn * 32 + r;
+      const bool cok = col < dk;
+      f32x16 acc = {0};
+      acc = tile_cc(Pb + (half * 4) * SS + ti * 32 + r, SS, s0 + (half * 4) * SD + (cok ? col : 0), SD, LP, cok, acc);
+      if (cok) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = ti * 32 + acc_row(i, half);
-        if (row < L) a.dv[((long)b * a.sb + (long)row * a.sl) * a.lddv + h * dk + col] = acc[i];
+        for (int i = 0; i < 16; ++i) {
+          const int row = ti * 32 + acc_row(i, half);
+          if (row < L) a.dv[((long)b * a.sb + (long)row * a.sl) * a.lddv + h * dk + col] = acc[i];
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = (wave - HW) + u * HW;
+      if (t < nt * nt) {
+        const int ti = t / nt, tj = t - ti * nt;
+        dp[u] = tile_rr(s0 + (ti * 32 + r) * SD + half * 4, s1 + (tj * 32 + r) * SD + half * 4, dk, dp[u]);
       }
     }
   }
-  // ---- dP tiles stay in registers (at most two per wave: LP <= 128)
-  f32x16 dp[2];
-  dp[0] = f32x16{0}; dp[1] = f32x16{0};
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int t = wave + u * EW;
-    if (t < nt * nt) {
-      const int ti = t / nt, tj = t - ti * nt;
-      dp[u] = tile_rr(s0 + (ti * 32 + r) * SD + half * 4, s1 + (tj * 32 + r) * SD + half * 4, dk, dp[u]);
-    }
-  }
   __syncthreads();                      // every wave is done with P (as P^T), dO and V
+  if (wave >= HW) {
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int t = wave + u * EW;
-    if (t < nt * nt) {
-      const int ti = t / nt, tj = t - ti * nt;
-      const int col = tj * 32 + r;
+    for (int u = 0; u < 2; ++u) {
+      const int t = (wave - HW) + u * HW;
+      if (t < nt * nt) {
+        const int ti = t / nt, tj = t - ti * nt;
+        const int col = tj * 32 + r;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = ti * 32 + acc_row(i, half);
-        float* p = Pb + row * SS + col;
-        *p = a.scale * *p * (dp[u][i] - delta[row]);
+        for (int i = 0; i < 16; ++i) {
+          const int row = ti * 32 + acc_row(i, half);
+          float* p = Pb + row * SS + col;
+          *p = a.scale * *p * (dp[u][i] - delta[row]);
+        }
       }
     }
   }
   stage_head(a.q, a.ldq, h * dk, b, a, LP, SD, s0);
   stage_head(a.k, a.ldk, h * dk, b, a, LP, SD, s1);
   __syncthreads();
-  // ---- dQ = dS K ;  dK = dS^T Q
-  for (int t = wave; t < nt * ntn; t += EW) {
+  // ---- dQ = dS K (work items [0, nt*ntn)) ;  dK = dS^T Q (work items [nt*ntn, 2 nt*ntn)), spread over all waves
+  for (int it = wave; it < 2 * nt * ntn; it += EW) {
+    const bool isk = it >= nt * ntn;
+    const int t = isk ? it - nt * ntn : it;
     const int ti = t / ntn, tn = t - ti * ntn;
     const int col = tn * 32 + r;
     const bool cok = col < dk;
     f32x16 acc = {0};
-    acc = tile_rc(Pb + (ti * 32 + r) * SS + half * 4, s1 + (half * 4) * SD + (cok ? col : 0), SD, LP, cok, acc);
-    f32x16 acc2 = {0};
-    acc2 = tile_cc(Pb + (half * 4) * SS + ti * 32 + r, SS, s0 + (half * 4) * SD + (cok ? col : 0), SD, LP, cok, acc2);
+    if (!isk) acc = tile_rc(Pb + (ti * 32 + r) * SS + half * 4, s1 + (half * 4) * SD + (cok ? col : 0), SD, LP, cok, acc);
+    else acc = tile_cc(Pb + (half * 4) * SS + ti * 32 + r, SS, s0 + (half * 4) * SD + (cok ? col : 0), SD, LP, cok, acc);
     if (cok) {
+      float* dst = isk ? a.dk_ : a.dq;
+      const long ldd = isk ? a.lddk : a.lddq;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = ti * 32 + acc_row(i, half);
-        if (row < L) {
-          const long g = (long)b * a.sb + (long)row * a.sl;
-          a.dq[g * a.lddq + h * dk + col] = acc[i];
-          a.dk_[g * a.lddk + h * dk + col] = acc2[i];
-        }
+        if (row < L) dst[((long)b * a.sb + (long)row * a.sl) * ldd + h * dk + col] = acc[i];
       }
     }
   }
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(ET) void attn_bwd_kernel(AttnArgs a) {
 // accumulators meet in `red` (8 x 32 x 33 floats) and emit(row, col, value) receives every finished element.
 // The B operand comes straight from global memory (the weights are a few hundred KB, L2-resident and shared by all
 // workgroups): loads run one pass (PASS chunks) ahead of the MFMAs, issued unconditionally from clamped addresses.
-constexpr int PASS = 8;
+constexpr int PASS = 4;
 constexpr int RED_LD = 33;
 
 template <int BT>
