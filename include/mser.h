@@ -147,6 +147,31 @@ int mser_encoder_layer_bwd(const mser_encoder_desc* d, int32_t phases, mser_stre
 int mser_encoder_layer_wgrad_descs(const mser_encoder_desc* d, mser_gemm_desc* out, int32_t cap);
 
 /* ------------------------------------------------------------------------------------------------
+ * Classifier tail of the fusion head (model/lsthm_sps.py:390-393 after `self.fc`): y1r = y1 + x_l + x_a,
+ * y2 = relu(nn_out.0(y1r)), y3 = nn_out.3(y2), lp[b*L+t] = log_softmax(y3[t*B+b]) -- one row-tiled launch, and its
+ * whole backward (log_softmax, both Linear layers, both ReLUs incl. the one of `fc`, the residual fan-out) as one launch.
+ * Dropout sites (:318,:323) are identities.  Weight gradients are left to the caller (mser_gemm_grouped over dy3 / dy2 / dy1).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct mser_head_tail_desc {
+  int32_t L, B, D, F, C;       /* rows = L*B time-major; D = d_l (100); F = nn_out hidden (32); C = classes */
+  const float* y1;             /* [rows, D] relu(fc(h)) */
+  const float* x_l; const float* x_a;            /* [rows, D] encoder outputs (residual, :390) */
+  const float* w0; const float* b0;              /* nn_out.0 [F, D], [F] */
+  const float* w3; const float* b3;              /* nn_out.3 [C, F], [C] */
+  float* y1r; float* y2;       /* saved: [rows, D], [rows, F] */
+  float* lp;                   /* [B*L, C] batch-major log-probabilities */
+  /* backward */
+  const float* dlp;            /* [B*L, C] */
+  const float* dx_l_in; const float* dx_a_in;    /* optional [rows, D]: gradients of the returned x_l / x_a */
+  float* dy3; float* dy2; float* dy1;            /* [rows, C], [rows, F], [rows, D] (dy1 = gradient at the fc output) */
+  float* dx_l; float* dx_a;    /* [rows, D] written: d(y1r) (+ dx_*_in) */
+  float* g_b0; float* g_b3; float* g_bfc;        /* ACCUMULATED bias gradients of nn_out.0, nn_out.3, fc.0 */
+} mser_head_tail_desc;
+
+int mser_head_tail_fwd(const mser_head_tail_desc* d, mser_stream_t stream);
+int mser_head_tail_bwd(const mser_head_tail_desc* d, mser_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Sequence bookkeeping (model/lsthm_sps.py:396-409 _reverse_seq; :177 argmax; :238-259 _select_parties).
  * ------------------------------------------------------------------------------------------------ */
 /* lens[b] = sum_t umask[b,t];  rev[t,b] = lens[b]-1-t if t < lens[b] else -1   (rev is int32 [L,B]) */

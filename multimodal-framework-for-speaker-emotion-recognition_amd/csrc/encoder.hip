@@ -531,6 +531,119 @@ __global__ __launch_bounds__(ET) void post_bwd_kernel(PostArgs p) {
   });
 }
 
+// ================================================================================================ classifier tail of the fusion head
+// model/lsthm_sps.py:390-393 after the fc GEMM: y1r = relu(fc(h)) + x_l + x_a ; y2 = relu(nn_out.0(y1r)) ; y3 = nn_out.3(y2) ;
+// log_probs[b*L + t] = log_softmax(y3[t*B + b]).  One row-tiled launch forward, one backward (instead of 5 / 9 small ones that
+// sat between the recurrent chains on the critical path).  The two products are K = D and K = hidden(32) wide: tiny.
+struct TailArgs {
+  int L, B, D, F, C;                      // F = nn_out hidden width (32), C = classes
+  const float* y1; const float* x_l; const float* x_a;
+  const float* W0; const float* b0; const float* W3; const float* b3;
+  float* y1r; float* y2; float* lp;
+  // backward
+  const float* dlp; const float* dxl_in; const float* dxa_in;
+  float* dy3; float* dy2; float* dy1; float* dx_l; float* dx_a;
+  float* g_b0; float* g_b3; float* g_bfc;
+};
+
+__global__ __launch_bounds__(ET) void tail_fwd_kernel(TailArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int D = p.D, F = p.F, C = p.C, rows = p.L * p.B;
+  const int DP = pad8(D), FP = pad8(F), CP = C + 1;
+  float* red = sm;
+  float* ys = red + EW * 32 * RED_LD;       // [32][DP] y1r
+  float* hs = ys + RT * DP;                 // [32][FP] y2
+  float* zs = hs + RT * FP;                 // [32][CP] y3
+  const int tid = threadIdx.x;
+  const long r0 = (long)blockIdx.x * RT;
+  for (int e = tid; e < RT * DP; e += ET) {
+    const int rr = e / DP, j = e - rr * DP;
+    float v = 0.f;
+    if (r0 + rr < rows && j < D) {
+      const long g = (r0 + rr) * D + j;
+      v = p.y1[g] + p.x_l[g] + p.x_a[g];
+      p.y1r[g] = v;
+    }
+    ys[e] = v;
+  }
+  for (int e = tid; e < RT * (FP - F); e += ET) hs[(e / (FP - F)) * FP + F + e % (FP - F)] = 0.f;
+  __syncthreads();
+  wg_gemm32<0>(ys, DP, D, p.W0, D, F, red, [&](int row, int n, float s) {
+    const float hv = fmaxf(s + p.b0[n], 0.f);
+    hs[row * FP + n] = hv;
+    if (r0 + row < rows) p.y2[(r0 + row) * F + n] = hv;
+  });
+  wg_gemm32<0>(hs, FP, F, p.W3, F, C, red, [&](int row, int n, float s) { zs[row * CP + n] = s + p.b3[n]; });
+  if (tid < RT && r0 + tid < rows) {
+    const long r = r0 + tid;
+    const int t = (int)(r / p.B), b = (int)(r - (long)t * p.B);
+    const float* z = zs + tid * CP;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, z[c]);
+    float ssum = 0.f;
+    for (int c = 0; c < C; ++c) ssum += expf(z[c] - mx);
+    const float lse = mx + logf(ssum);
+    float* dst = p.lp + ((long)b * p.L + t) * C;
+    for (int c = 0; c < C; ++c) dst[c] = z[c] - lse;
+  }
+}
+
+__global__ __launch_bounds__(ET) void tail_bwd_kernel(TailArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int D = p.D, F = p.F, C = p.C, rows = p.L * p.B;
+  const int DP = pad8(D), FP = pad8(F), CP8 = pad8(C);
+  float* red = sm;
+  float* zs = red + EW * 32 * RED_LD;       // [32][CP8] dy3
+  float* hs = zs + RT * CP8;                // [32][FP]  dy2
+  float* ds = hs + RT * FP;                 // [32][DP]  dy1 (masked)
+  const int tid = threadIdx.x;
+  const long r0 = (long)blockIdx.x * RT;
+  for (int e = tid; e < RT * CP8; e += ET) zs[e] = 0.f;
+  for (int e = tid; e < RT * (FP - F); e += ET) hs[(e / (FP - F)) * FP + F + e % (FP - F)] = 0.f;
+  __syncthreads();
+  if (tid < RT && r0 + tid < rows) {
+    const long r = r0 + tid;
+    const int t = (int)(r / p.B), b = (int)(r - (long)t * p.B);
+    const long q = ((long)b * p.L + t) * C;
+    float ssum = 0.f;
+    for (int c = 0; c < C; ++c) ssum += p.dlp[q + c];
+    for (int c = 0; c < C; ++c) {
+      const float v = p.dlp[q + c] - expf(p.lp[q + c]) * ssum;
+      zs[tid * CP8 + c] = v;
+      p.dy3[r * C + c] = v;
+    }
+  }
+  __syncthreads();
+  colsum_tile(zs, CP8, C, p.g_b3);
+  // dy2 = (dy3 W3) o (y2 > 0)
+  wg_gemm32<1>(zs, CP8, C, p.W3, F, F, red, [&](int row, int n, float s) {
+    const bool rok = r0 + row < rows;
+    const float v = (rok && p.y2[(r0 + row) * F + n] > 0.f) ? s : 0.f;
+    hs[row * FP + n] = v;
+    if (rok) p.dy2[(r0 + row) * F + n] = v;
+  });
+  colsum_tile(hs, FP, F, p.g_b0);
+  // d(y1r) = dy2 W0 -> dx_l, dx_a (+ the gradients of the returned x_l / x_a) ; dy1 = d(y1r) o (y1 > 0)
+  wg_gemm32<1>(hs, FP, F, p.W0, D, D, red, [&](int row, int n, float s) {
+    const bool rok = r0 + row < rows;
+    float m = 0.f;
+    if (rok) {
+      const long g = (r0 + row) * D + n;
+      p.dx_l[g] = s + (p.dxl_in ? p.dxl_in[g] : 0.f);
+      p.dx_a[g] = s + (p.dxa_in ? p.dxa_in[g] : 0.f);
+      m = p.y1[g] > 0.f ? s : 0.f;
+      p.dy1[g] = m;
+    }
+    ds[row * DP + n] = m;
+  });
+  colsum_tile(ds, DP, D, p.g_bfc);
+}
+
+size_t tail_lds_bytes(int D, int F, int C, bool bwd) {
+  const size_t DP = ((D + 7) & ~7) + 4, FP = ((F + 7) & ~7) + 4, red = EW * 32 * RED_LD;
+  return (red + RT * DP + RT * FP + RT * (bwd ? ((C + 7) & ~7) + 4 : C + 1)) * sizeof(float);
+}
+
 size_t attn_lds_bytes(int L, int dk, bool bwd) {
   const size_t LP = (size_t)((L + 31) & ~31), SD = dk + 4, SS = LP + 4;
   return (bwd ? LP * SS + 2 * LP * SD + LP : 3 * LP * SD + LP * SS) * sizeof(float);
@@ -711,10 +824,54 @@ int encoder_layer_bwd(const mser_encoder_desc& d, int phases, hipStream_t s) {
   return 0;
 }
 
+static int tail_validate(const mser_head_tail_desc& d, bool bwd) {
+  MSER_REQUIRE(d.L > 0 && d.B > 0 && d.D > 0 && d.F > 0 && d.C > 0, "mser_head_tail: bad sizes");
+  MSER_REQUIRE(d.D % 4 == 0 && d.F % 4 == 0 && d.D <= 1024 && d.F <= 256 && d.C <= 32, "mser_head_tail: unsupported widths D=%d F=%d C=%d", d.D, d.F, d.C);
+  MSER_REQUIRE(d.y1 && d.x_l && d.x_a && d.w0 && d.b0 && d.w3 && d.b3 && d.y1r && d.y2 && d.lp, "mser_head_tail: null pointer");
+  MSER_REQUIRE(al16(d.w0) && al16(d.w3), "mser_head_tail: weights must be 16-byte aligned");
+  MSER_REQUIRE(tail_lds_bytes(d.D, d.F, d.C, bwd) <= LDS_MAX, "mser_head_tail: row tile exceeds LDS");
+  if (bwd)
+    MSER_REQUIRE(d.dlp && d.dy3 && d.dy2 && d.dy1 && d.dx_l && d.dx_a && d.g_b0 && d.g_b3 && d.g_bfc, "mser_head_tail_bwd: null gradient buffer");
+  return 0;
+}
+static TailArgs tail_args(const mser_head_tail_desc& d) {
+  TailArgs p;
+  p.L = d.L; p.B = d.B; p.D = d.D; p.F = d.F; p.C = d.C;
+  p.y1 = d.y1; p.x_l = d.x_l; p.x_a = d.x_a; p.W0 = d.w0; p.b0 = d.b0; p.W3 = d.w3; p.b3 = d.b3;
+  p.y1r = d.y1r; p.y2 = d.y2; p.lp = d.lp;
+  p.dlp = d.dlp; p.dxl_in = d.dx_l_in; p.dxa_in = d.dx_a_in;
+  p.dy3 = d.dy3; p.dy2 = d.dy2; p.dy1 = d.dy1; p.dx_l = d.dx_l; p.dx_a = d.dx_a;
+  p.g_b0 = d.g_b0; p.g_b3 = d.g_b3; p.g_bfc = d.g_bfc;
+  return p;
+}
+int head_tail(const mser_head_tail_desc& d, bool bwd, hipStream_t s) {
+  MSER_TRY(tail_validate(d, bwd));
+  const TailArgs p = tail_args(d);
+  const size_t lds = tail_lds_bytes(d.D, d.F, d.C, bwd);
+  const int grid = cdiv((long)d.L * d.B, RT);
+  if (!bwd) {
+    MSER_TRY(allow((const void*)tail_fwd_kernel, lds));
+    hipLaunchKernelGGL(tail_fwd_kernel, dim3(grid), dim3(ET), lds, s, p);
+    return check_launch("tail_fwd_kernel");
+  }
+  MSER_TRY(allow((const void*)tail_bwd_kernel, lds));
+  hipLaunchKernelGGL(tail_bwd_kernel, dim3(grid), dim3(ET), lds, s, p);
+  return check_launch("tail_bwd_kernel");
+}
+
 }  // namespace mser
+
 
 extern "C" {
 
+int mser_head_tail_fwd(const mser_head_tail_desc* d, mser_stream_t stream) {
+  if (!d) { mser::set_error("mser_head_tail_fwd: null descriptor"); return -1; }
+  return mser::head_tail(*d, false, (hipStream_t)stream);
+}
+int mser_head_tail_bwd(const mser_head_tail_desc* d, mser_stream_t stream) {
+  if (!d) { mser::set_error("mser_head_tail_bwd: null descriptor"); return -1; }
+  return mser::head_tail(*d, true, (hipStream_t)stream);
+}
 int mser_encoder_layer_supported(const mser_encoder_desc* d) {
   if (!d) return 0;
   return mser::enc_unsupported(*d) == nullptr ? 1 : 0;

@@ -74,6 +74,17 @@ class EncoderDesc(C.Structure):
     ]
 
 
+class HeadTailDesc(C.Structure):
+    """mser_head_tail_desc (include/mser.h)."""
+    _fields_ = [("L", C.c_int32), ("B", C.c_int32), ("D", C.c_int32), ("F", C.c_int32), ("C", C.c_int32),
+                ("y1", C.c_void_p), ("x_l", C.c_void_p), ("x_a", C.c_void_p),
+                ("w0", C.c_void_p), ("b0", C.c_void_p), ("w3", C.c_void_p), ("b3", C.c_void_p),
+                ("y1r", C.c_void_p), ("y2", C.c_void_p), ("lp", C.c_void_p),
+                ("dlp", C.c_void_p), ("dx_l_in", C.c_void_p), ("dx_a_in", C.c_void_p),
+                ("dy3", C.c_void_p), ("dy2", C.c_void_p), ("dy1", C.c_void_p), ("dx_l", C.c_void_p), ("dx_a", C.c_void_p),
+                ("g_b0", C.c_void_p), ("g_b3", C.c_void_p), ("g_bfc", C.c_void_p)]
+
+
 MSER_GEMM_RELU = 1
 MSER_GEMM_ACCUM = 2
 
@@ -97,6 +108,8 @@ SIGNATURES = {
     "mser_encoder_layer_fwd": (C.c_int, [C.POINTER(EncoderDesc), _vp]),
     "mser_encoder_layer_bwd": (C.c_int, [C.POINTER(EncoderDesc), _i32, _vp]),
     "mser_encoder_layer_wgrad_descs": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(GemmDesc), _i32]),
+    "mser_head_tail_fwd": (C.c_int, [C.POINTER(HeadTailDesc), _vp]),
+    "mser_head_tail_bwd": (C.c_int, [C.POINTER(HeadTailDesc), _vp]),
     "mser_build_reverse_index": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "mser_reverse_by_length": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "mser_build_slot_tables": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),

@@ -57,6 +57,7 @@ class ModelCtx:
     y1r: Tensor = None
     y2: Tensor = None
     lp: Tensor = None
+    tail: object = None
     qmask: Tensor = None
 
 
@@ -189,16 +190,14 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
     # ---- fusion head (:390-393)
     c.y1 = torch.empty(N, D, device=x.device)
     ops.linear(c.Hcat, P("fc.0.weight"), c.y1, bias=P("fc.0.bias"), relu=True)
+    # residual + nn_out + log_softmax: one row-tiled launch (csrc/encoder.hip tail_fwd_kernel)
     c.y1r = torch.empty(N, D, device=x.device)
-    ops.add_rows(c.y1r, c.y1, c.x_l)
-    ops.add_rows(c.y1r, c.y1r, c.x_a)
     h_out = P("nn_out.0.weight").shape[0]
     c.y2 = torch.empty(N, h_out, device=x.device)
-    ops.linear(c.y1r, P("nn_out.0.weight"), c.y2, bias=P("nn_out.0.bias"), relu=True)
-    y3 = torch.empty(N, d.n_classes, device=x.device)
-    ops.linear(c.y2, P("nn_out.3.weight"), y3, bias=P("nn_out.3.bias"))
     c.lp = torch.empty(B * Ln, d.n_classes, device=x.device)
-    ops.logsoftmax_tb_fwd(y3, c.lp, Ln, B)
+    c.tail = ops.head_tail_desc(Ln, B, c.y1, c.x_l, c.x_a, P("nn_out.0.weight"), P("nn_out.0.bias"), P("nn_out.3.weight"),
+                                P("nn_out.3.bias"), c.y1r, c.y2, c.lp)
+    ops.head_tail_fwd(c.tail)
     return c.lp, c.x_l.view(Ln, B, D), c.x_a.view(Ln, B, D), c
 
 
@@ -252,26 +251,22 @@ def _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams):
             ev_prep.record(s_prep)
     else:
         zbuf.zero_()
-    # ---- head
+    # ---- head: log_softmax, nn_out and the residual fan-out backward in one launch (bias gradients included)
     dy3 = torch.empty(N, d.n_classes, device=dev)
-    ops.logsoftmax_tb_bwd(dlp, c.lp, dy3, Ln, B)
     dy2 = torch.empty_like(c.y2)
-    ops.matmul(dy3, P("nn_out.3.weight"), dy2)
-    ops.grad_weight(dy3, c.y2, G("nn_out.3.weight"))
-    ops.colsum_acc(dy3, G("nn_out.3.bias"))
-    ops.relu_bwd_(dy2, c.y2)
-    ops.matmul(dy2, P("nn_out.0.weight"), dx_l)
-    ops.grad_weight(dy2, c.y1r, G("nn_out.0.weight"))
-    ops.colsum_acc(dy2, G("nn_out.0.bias"))
     dy1 = torch.empty(N, D, device=dev)
-    ops.add_rows(dy1, dx_l, None)
-    ops.relu_bwd_(dy1, c.y1)
-    ops.add_rows(dx_a, dx_l, dx_a_out.reshape(N, D) if dx_a_out is not None else None)
-    if dx_l_out is not None:
-        ops.add_rows(dx_l, dx_l, dx_l_out.reshape(N, D))
+    t = c.tail
+    t.dlp, t.dy3, t.dy2, t.dy1, t.dx_l, t.dx_a = (x_.data_ptr() for x_ in (dlp, dy3, dy2, dy1, dx_l, dx_a))
+    dxl_in = dx_l_out.reshape(N, D).contiguous() if dx_l_out is not None else None
+    dxa_in = dx_a_out.reshape(N, D).contiguous() if dx_a_out is not None else None
+    t.dx_l_in = dxl_in.data_ptr() if dxl_in is not None else None
+    t.dx_a_in = dxa_in.data_ptr() if dxa_in is not None else None
+    t.g_b0, t.g_b3, t.g_bfc = G("nn_out.0.bias").data_ptr(), G("nn_out.3.bias").data_ptr(), G("fc.0.bias").data_ptr()
+    ops.head_tail_bwd(t)
+    ops.grad_weight(dy3, c.y2, G("nn_out.3.weight"))
+    ops.grad_weight(dy2, c.y1r, G("nn_out.0.weight"))
     ops.matmul(dy1, P("fc.0.weight"), dH)
     ops.grad_weight(dy1, c.Hcat, G("fc.0.weight"))
-    ops.colsum_acc(dy1, G("fc.0.bias"))
     # ---- the four sequence-level attention modules (two independent chains, side streams) run beside the LSTHM BPTT chain.
     # Each chain accumulates its x_l / x_a gradients into its own buffers (no cross-stream read-modify-write).
     w, v, v1, v2 = P("w"), P("v"), P("v1"), P("v2")

@@ -295,6 +295,26 @@ def encoder_layer_bwd(desc: L.EncoderDesc, phases: int, deferred: Optional[tuple
         L.check(_lib().mser_encoder_layer_bwd(C.byref(desc), phases, _stream()), "encoder_layer_bwd")
 
 
+def head_tail_desc(Ln: int, B: int, y1: Tensor, x_l: Tensor, x_a: Tensor, W0: Tensor, b0: Tensor, W3: Tensor, b3: Tensor,
+                   y1r: Tensor, y2: Tensor, lp: Tensor) -> L.HeadTailDesc:
+    d = L.HeadTailDesc()
+    d.L, d.B, d.D, d.F, d.C = Ln, B, y1.shape[1], W0.shape[0], W3.shape[0]
+    for t in (y1, x_l, x_a, W0, b0, W3, b3, y1r, y2, lp):
+        if not t.is_contiguous():
+            raise RuntimeError("head_tail: every operand must be contiguous")
+    d.y1, d.x_l, d.x_a, d.w0, d.b0, d.w3, d.b3 = (_p(t) for t in (y1, x_l, x_a, W0, b0, W3, b3))
+    d.y1r, d.y2, d.lp = _p(y1r), _p(y2), _p(lp)
+    return d
+
+
+def head_tail_fwd(desc: L.HeadTailDesc) -> None:
+    L.check(_lib().mser_head_tail_fwd(C.byref(desc), _stream()), "head_tail_fwd")
+
+
+def head_tail_bwd(desc: L.HeadTailDesc) -> None:
+    L.check(_lib().mser_head_tail_bwd(C.byref(desc), _stream()), "head_tail_bwd")
+
+
 def build_reverse_index(umask: Tensor, lens: Tensor, rev: Tensor) -> None:
     B, Ln = umask.shape
     L.check(_lib().mser_build_reverse_index(_p(umask), B, Ln, _p(lens), _p(rev), _stream()), "build_reverse_index")
