@@ -35,14 +35,23 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 B, L, D_R, D_A, H, NCLS = 32, 128, 768, 100, 128, 6
 
 
-def synth_batch(seed, device):
+def synth_batch(seed, device, ragged=False):
+    """x ~ N(0,1), speaker ~ Bernoulli(0.5) one-hot, labels ~ U{0..5}; full-length dialogues for the headline,
+    lengths ~ U{L/2..L} (tail zeroed in x, qmask, umask) for the ragged variant that exercises _reverse_seq / padding."""
     rs = np.random.RandomState(seed)
-    x = torch.tensor(rs.standard_normal((L, B, D_R + D_A)).astype(np.float32))
+    x = rs.standard_normal((L, B, D_R + D_A)).astype(np.float32)
     spk = rs.randint(0, 2, (L, B))
-    qmask = torch.tensor(np.eye(2, dtype=np.float32)[spk])
-    umask = torch.ones(B, L)
-    label = torch.tensor(rs.randint(0, NCLS, (B, L)).astype(np.int64))
-    return [t.to(device) for t in (x, qmask, umask, label)]
+    qmask = np.eye(2, dtype=np.float32)[spk]
+    umask = np.ones((B, L), dtype=np.float32)
+    if ragged:
+        lens = rs.randint(L // 2, L + 1, B)
+        lens[0] = L
+        for b in range(B):
+            x[lens[b]:, b] = 0.0
+            qmask[lens[b]:, b] = 0.0
+            umask[b, lens[b]:] = 0.0
+    label = rs.randint(0, NCLS, (B, L)).astype(np.int64)
+    return [torch.tensor(t).to(device) for t in (x, qmask, umask, label)]
 
 
 def init_attention_weights(model, seed=0):
@@ -125,6 +134,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="force hipGraph replay (default: whichever of eager / graph is faster)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the secondary workloads (ragged lengths, ones-initialised attention)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -256,6 +266,36 @@ def main():
         roofline["lsthm_forward"] = entry("lsthm_fwd_persist" if us_f > 200 else "lsthm_fwd_gates", us_f, n_f, False)
 
     log("roofline pass done")
+
+    # ---- secondary workloads of SURVEY.md 8(d), eager launches, a few steps each (reported, never the headline value)
+    variants = None
+    if rank == 0 and world == 1 and not args.no_variants:
+        def time_steps(batch, n=10):
+            for _ in range(3):
+                tr.train_step(*batch)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                tr.train_step(*batch)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n * 1e3
+        variants = {}
+        rb = synth_batch(2000, device, ragged=True)
+        ms_r = time_steps(rb)
+        variants["ragged_lengths_U(L/2..L)"] = {"ms_per_step": round(ms_r, 4), "utterances_per_s": round(float(rb[2].sum()) / (ms_r * 1e-3), 1),
+                                                "note": "masked utterances only; padded steps still run, as in the reference"}
+        with torch.no_grad():
+            saved = {n: p.detach().clone() for n, p in tr.model.named_parameters() if "crossatt" in n}
+            for n, p in tr.model.named_parameters():
+                if "crossatt" in n:
+                    p.fill_(1.0)                      # the reference's own initialisation (uniform softmaxes)
+        ms_o = time_steps((x, qmask, umask, label))
+        variants["attention_weights_as_initialised(ones)"] = {"ms_per_step": round(ms_o, 4), "utterances_per_s": round(B * L / (ms_o * 1e-3), 1)}
+        with torch.no_grad():
+            for n, p in tr.model.named_parameters():
+                if n in saved:
+                    p.copy_(saved[n])
+        log("variants done")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -276,6 +316,7 @@ def main():
                        "launch": "hipGraph replay" if use_graph else "eager"},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "variants": variants,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
