@@ -272,3 +272,56 @@ def test_eval_network_metrics_vs_sklearn(O):
     assert f1 == round(f1_score(labels, preds, sample_weight=masks, average="weighted") * 100, 2)
     sel = masks > 0
     assert np.array_equal(table["preds"][sel], preds[sel]) and np.array_equal(table["labels"], labels) and np.array_equal(table["masks"], masks)
+
+
+def test_model_long_sequence_vs_oracle(O):
+    """L = 150 > 128: the fused EncoderLayer does not cover the shape, so the composed path (generic GEMM + row kernels) runs;
+    the recurrent chains run 150 steps.  Forward and gradients against the CPU oracle (itself pinned by the reference's goldens)."""
+    from models.lsthm_sps import MARN1_sps
+    from loss import MaskedLoss
+    B, L, d_r = 2, 150, 768
+    P = O.seeded_params(seed=11, d_r=d_r)
+    net = MARN1_sps(6, d_r=d_r).cuda().eval()
+    load_params(net, P)
+    x, qmask, umask, label = O.seeded_batch(B, L, d_r=d_r, seed=12, ragged=True)
+    lp, _, _ = net(x.cuda(), qmask.cuda(), umask.cuda())
+    loss = MaskedLoss(torch.nn.NLLLoss)(lp, label.cuda().view(-1), umask.cuda())
+    loss.backward()
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    lp_ref, _, _ = O.marn1_sps_forward(Pr, x, qmask, umask, d_r=d_r)
+    loss_ref = O.masked_nll(lp_ref, label.view(-1), umask)
+    loss_ref.backward()
+    assert maxabs(lp, lp_ref) < LOGIT_TOL
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 2e-5
+    for n, p in net.named_parameters():
+        r = Pr[n].grad
+        if r is None:
+            continue
+        assert maxabs(p.grad, r) < 3e-4 * max(1e-3, float(r.norm())), n
+
+
+def test_backward_options_agree(O):
+    """In-launch weight gradients / K-split matvec (the defaults) against the grouped split-K GEMMs after the chains and the
+    unsplit matvec: same gradients up to summation order."""
+    from models.lsthm_sps import MARN1_sps
+    from loss import MaskedLoss
+    from mser import ops
+    B, L, d_r = 4, 24, 768
+    P = O.seeded_params(seed=13, d_r=d_r)
+    x, qmask, umask, label = (t.cuda() for t in O.seeded_batch(B, L, d_r=d_r, seed=14, ragged=True))
+    grads = []
+    try:
+        for wg, ks in ((1, 1), (0, 0)):
+            ops.set_option(ops.MSER_OPT_WGRAD_INKERNEL, wg)
+            ops.set_option(ops.MSER_OPT_BPTT_KSPLIT, ks)
+            net = MARN1_sps(6, d_r=d_r).cuda().eval()
+            load_params(net, P)
+            lp, _, _ = net(x, qmask, umask)
+            MaskedLoss(torch.nn.NLLLoss)(lp, label.view(-1), umask).backward()
+            grads.append({n: p.grad.detach().cpu().clone() for n, p in net.named_parameters() if p.grad is not None})
+    finally:
+        ops.set_option(ops.MSER_OPT_WGRAD_INKERNEL, 1)
+        ops.set_option(ops.MSER_OPT_BPTT_KSPLIT, 1)
+    assert grads[0].keys() == grads[1].keys()
+    for n in grads[0]:
+        assert maxabs(grads[0][n], grads[1][n]) < 2e-5 * max(1.0, float(grads[1][n].abs().max())), n
