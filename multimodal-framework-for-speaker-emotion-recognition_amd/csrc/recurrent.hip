@@ -1739,12 +1739,17 @@ static void carve_dir(Carver& cv, DirP& d, int T, int B, int D, int H) {
   d.cstate = cv.take<float>(2 * (T + 1) * SB);
   d.hz = cv.take<float>((T + 1) * (size_t)B * 3 * H);
   d.dgates = cv.take<float>(2 * TB * 4 * H);
-  d.dc_carry = cv.take<float>(2 * SB);
   d.dA = cv.take<float>(2 * 4 * SB);          // x2: K-split partial copies (CellK::ksplit)
-  d.attacc = cv.take<float>((size_t)B * 2 * H);
   d.dHQ = cv.take<float>(TB * H);
   d.dHQp = cv.take<float>(2 * 2 * TB * H);
-  d.dxc = cv.take<float>(2 * 2 * TB * D);
+  // zeroed before every backward in ONE memset: [dc_carry | attacc | dxc] back to back (sizes rounded to 64 floats)
+  {
+    auto r64 = [](size_t n) { return (n + 63) & ~size_t(63); };
+    float* z = cv.take<float>(r64(2 * SB) + r64((size_t)B * 2 * H) + 2 * 2 * TB * D);
+    d.dc_carry = z;
+    d.attacc = z ? z + r64(2 * SB) : nullptr;
+    d.dxc = z ? z + r64(2 * SB) + r64((size_t)B * 2 * H) : nullptr;
+  }
   d.dsg = cv.take<float>(2 * TB * 4 * H);
   d.Xb = cv.take<float>(2 * SB);
   d.dhprev = cv.take<float>(2 * 2 * SB);
@@ -1911,7 +1916,9 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
     MSER_TRY(check_launch("spk_fwd"));
   }
   if (!(phases & MSER_PHASE_LSTHM_FWD)) return 0;
-  // ---- hoisted pre-activations: pre_m = xdir W_m^T + W.bias + HQ S_m^T + S.bias
+  // ---- hoisted pre-activations: pre_m = xdir W_m^T + W.bias + HQ S_m^T + S.bias.  The x W^T products of both streams and
+  // directions are independent: ONE grouped launch (they sit on the critical path right in front of the chain).
+  std::vector<mser_gemm_desc> pg;
   for (int i = 0; i < d.ndir; ++i) {
     DirP& k = K.d[i];
     const float* xs[2] = {d.x_l, d.x_a};
@@ -1925,9 +1932,16 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       float* pre = k.pre + (long)m * TB * 4 * H;
       mser_gemm_desc g = gd(xs[m], lds[m], 1, k.W[m], 1, D, pre, 4 * H, (int)TB, 4 * H, D);
       g.bias = k.Wb[m];
-      MSER_TRY(gemm(g, s));
-      if (!persist) {      // the pipelined persistent kernel adds S h_q[t] (+ S.bias) inside the step instead
-        g = gd(k.HQ, H, 1, k.S[m], 1, H, pre, 4 * H, (int)TB, 4 * H, H);
+      pg.push_back(g);
+    }
+  }
+  MSER_TRY(gemm_group(pg.data(), (int)pg.size(), s));
+  if (!persist) {      // the pipelined persistent kernel adds S h_q[t] (+ S.bias) inside the step instead
+    for (int i = 0; i < d.ndir; ++i) {
+      DirP& k = K.d[i];
+      for (int m = 0; m < 2; ++m) {
+        float* pre = k.pre + (long)m * TB * 4 * H;
+        mser_gemm_desc g = gd(k.HQ, H, 1, k.S[m], 1, H, pre, 4 * H, (int)TB, 4 * H, H);
         g.bias = k.Sb[m];
         g.flags = MSER_GEMM_ACCUM;
         MSER_TRY(gemm(g, s));
@@ -2021,10 +2035,11 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   if (phases & MSER_PHASE_BWD_PREP) {
     for (int i = 0; i < d.ndir; ++i) {
       DirP& k = K.d[i];
-      MSER_CHECK_HIP(hipMemsetAsync(k.dc_carry, 0, 2 * SB * sizeof(float), s));
-      MSER_CHECK_HIP(hipMemsetAsync(k.attacc, 0, (size_t)B * 2 * H * sizeof(float), s));
-      if (persist && k.rev)    // rows at and beyond len_b receive no gradient from the reversed direction
-        MSER_CHECK_HIP(hipMemsetAsync(k.dxc, 0, (size_t)ksplit * 2 * TB * D * sizeof(float), s));
+      // dc_carry | attacc | dxc are carved back to back: one memset (dxc only where it is read without having been fully written:
+      // rows at and beyond len_b receive no gradient from the reversed direction)
+      const size_t zbytes = (persist && k.rev) ? (size_t)((char*)(k.dxc + (size_t)ksplit * 2 * TB * D) - (char*)k.dc_carry)
+                                               : (size_t)((char*)k.dxc - (char*)k.dc_carry);
+      MSER_CHECK_HIP(hipMemsetAsync(k.dc_carry, 0, zbytes, s));
     }
     MSER_CHECK_HIP(hipMemsetAsync(h.sync + SYNC_LSTHM_BWD, 0, 4 * SYNC_DIR * sizeof(unsigned), s));
   }
