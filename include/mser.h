@@ -22,7 +22,7 @@ extern "C" {
 
 typedef void* mser_stream_t; /* hipStream_t */
 
-#define MSER_VERSION 100
+#define MSER_VERSION 110   /* 110: + encoder layer, grouped GEMM, head tail, ingest, confusion, cell desc addends */
 
 int mser_version(void);
 const char* mser_last_error(void);

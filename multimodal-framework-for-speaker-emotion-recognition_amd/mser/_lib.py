@@ -152,7 +152,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.mser_version() < 100:
+    if lib.mser_version() < 110:
         raise RuntimeError("libmser.so is older than this binding")
     _lib = lib
     return lib

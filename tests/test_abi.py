@@ -19,7 +19,9 @@ def test_header_declares_the_expected_surface():
     fns = _header_functions()
     for must in ("mser_gemm", "mser_marn_cell_fwd", "mser_marn_cell_bwd", "mser_marn_cell_run", "mser_softmax_rows",
                  "mser_add_layernorm_fwd", "mser_layernorm_bwd", "mser_build_slot_tables", "mser_reverse_by_length",
-                 "mser_masked_nll_fwd", "mser_adam_flat", "mser_adam_flat_dev", "mser_dp_pack", "mser_version", "mser_last_error"):
+                 "mser_masked_nll_fwd", "mser_adam_flat", "mser_adam_flat_dev", "mser_dp_pack", "mser_version", "mser_last_error",
+                 "mser_gemm_grouped", "mser_encoder_layer_fwd", "mser_encoder_layer_bwd", "mser_head_tail_fwd", "mser_head_tail_bwd",
+                 "mser_ingest_features", "mser_confusion_update"):
         assert must in fns, must
 
 
@@ -31,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     missing = [f for f in _header_functions() if not hasattr(lib, f)]
     assert not missing, missing
     lib.mser_version.restype = ctypes.c_int
-    assert lib.mser_version() >= 100
+    assert lib.mser_version() >= 110
 
 
 def test_binding_table_matches_header():
@@ -44,7 +46,7 @@ def test_struct_layouts_match_the_header_sizes():
     import subprocess
     import tempfile
     from mser import _lib
-    src = '#include <stdio.h>\n#include "mser.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(mser_gemm_desc), sizeof(mser_cell_params), sizeof(mser_cell_dir), sizeof(mser_cell_desc), sizeof(mser_encoder_desc));return 0;}\n'
+    src = '#include <stdio.h>\n#include "mser.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(mser_gemm_desc), sizeof(mser_cell_params), sizeof(mser_cell_dir), sizeof(mser_cell_desc), sizeof(mser_encoder_desc), sizeof(mser_head_tail_desc));return 0;}\n'
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, "s.c")
         open(c, "w").write(src)
@@ -52,4 +54,4 @@ def test_struct_layouts_match_the_header_sizes():
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
     assert sizes == [ctypes.sizeof(_lib.GemmDesc), ctypes.sizeof(_lib.CellParams), ctypes.sizeof(_lib.CellDir), ctypes.sizeof(_lib.CellDesc),
-                     ctypes.sizeof(_lib.EncoderDesc)]
+                     ctypes.sizeof(_lib.EncoderDesc), ctypes.sizeof(_lib.HeadTailDesc)]
