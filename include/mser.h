@@ -252,8 +252,12 @@ int mser_marn_cell_run(const mser_cell_desc* d, int32_t phases, mser_stream_t st
  * (registers, no atomics: deterministic); MSER_PHASE_LSTHM_WGRAD / SPEAKER_BWD then only add the bias sums.  The gradient
  * pointers of the descriptor must be the same in every phase of one backward pass.  0: grouped split-K GEMMs after the chains.
  * MSER_OPT_BPTT_KSPLIT = 1 (default): at H = 128 every matvec product of a BPTT step is reduced by two workgroups (K halves,
- * the consumers add the partials) when the doubled grid still fits the chip. */
-enum { MSER_OPT_PERSISTENT = 1, MSER_OPT_WGRAD_INKERNEL = 2, MSER_OPT_BPTT_KSPLIT = 3 };
+ * the consumers add the partials) when the doubled grid still fits the chip.
+ * MSER_OPT_XCD_PLACEMENT = 0 (default; 1 = experimental): the fused persistent launches cover every CU and each 32-workgroup
+ * chain group is formed by workgroups that are physically resident on two XCDs (cheaper counter barriers; the hand-off protocol
+ * itself does not depend on the placement, unneeded workgroups leave at once).  Takes precedence over the K-split.  Measured
+ * slower end to end (the concentrated groups starve the kernels that run beside the chains), hence off. */
+enum { MSER_OPT_PERSISTENT = 1, MSER_OPT_WGRAD_INKERNEL = 2, MSER_OPT_BPTT_KSPLIT = 3, MSER_OPT_XCD_PLACEMENT = 4 };
 int mser_set_option(int32_t key, int32_t value);
 /* Synchronises `stream` and reports whether a persistent kernel of the last fwd/bwd call on this workspace gave up at a
  * barrier (bounded spins; returns -2 and a message in that case).  Diagnostic; not needed on the hot path. */

@@ -57,6 +57,8 @@ struct CellK {
   unsigned wsbytes;
   unsigned* sync;      // persistent-kernel counters: [SYNC_*] words, zeroed by a memset node before every launch
   int wgrad_wgs;       // cell_bwd_fused: workgroups that accumulate the weight gradients while the BPTT chains run (0: none)
+  int place;           // fused launches: roles are claimed by physical XCD (claim_role); the grid then covers every CU
+  short place_base[8], place_cap[8];   // XCD x hosts logical workgroups place_base[x] .. place_base[x] + place_cap[x] - 1
   int ksplit;          // BPTT matvec phase: every product's K = 4H reduction is split over `ksplit` workgroups (1 or 2); the
                        // partial results live in consecutive copies of dA / dHQp / dxc and the consumers add them
   DirP d[2];
@@ -70,8 +72,11 @@ struct CellK {
 #define MSER_SYNC_REP 8
 #endif
 enum { SYNC_LINE = 32, SYNC_REP = MSER_SYNC_REP, SYNC_DIR = SYNC_REP * SYNC_LINE, SYNC_SPK_FWD = 0, SYNC_LSTHM_FWD = 2 * SYNC_DIR,
-       SYNC_LSTHM_BWD = 4 * SYNC_DIR, SYNC_SPK_BWD = 6 * SYNC_DIR, SYNC_ABORT = 8 * SYNC_DIR, SYNC_STAMPS = SYNC_ABORT + SYNC_LINE,
-       SYNC_WORDS = SYNC_STAMPS + 2 * SYNC_LINE };
+       SYNC_LSTHM_BWD = 4 * SYNC_DIR, SYNC_SPK_BWD = 6 * SYNC_DIR,
+       // XCD placement of the fused launches (claim_role): 8 per-XCD ticket counters, "registered", "spare ticket", one line each
+       SYNC_PLACE_LINES = 10, SYNC_PLACE_BWD = 8 * SYNC_DIR,          // zeroed together with the backward counters
+       SYNC_ABORT = SYNC_PLACE_BWD + SYNC_PLACE_LINES * SYNC_LINE, SYNC_STAMPS = SYNC_ABORT + SYNC_LINE,
+       SYNC_PLACE_FWD = SYNC_STAMPS + 2 * SYNC_LINE, SYNC_WORDS = SYNC_PLACE_FWD + SYNC_PLACE_LINES * SYNC_LINE };
 
 
 // ---- optional per-kernel timing with HIP events (bench.py's live roofline measurement; off by default) ----------------------
@@ -193,7 +198,14 @@ __device__ __forceinline__ void barrier_arrive(unsigned* cnt) {
   __syncthreads();
   if (threadIdx.x < SYNC_REP) __hip_atomic_fetch_add((gu32*)cnt + threadIdx.x * SYNC_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ unsigned sync_replica() { return ((blockIdx.x + blockIdx.y + blockIdx.z) % SYNC_REP) * SYNC_LINE; }
+// The fused launches assign roles by physical XCD (claim_role), so a workgroup's logical id is not its blockIdx: every persistent
+// kernel publishes it here first (the separate-launch kernels store blockIdx.x + y + z).
+__shared__ unsigned s_logical_wg;
+__device__ __forceinline__ void set_logical_wg(unsigned id) {
+  if (threadIdx.x == 0) s_logical_wg = id;
+  __syncthreads();
+}
+__device__ __forceinline__ unsigned sync_replica() { return (s_logical_wg % SYNC_REP) * SYNC_LINE; }
 // One early look at this workgroup's replica (all lanes load the same word: uniform code, the value comes back while the
 // caller keeps computing); pass it to barrier_wait, which polls only if the count was not complete yet.
 __device__ __forceinline__ unsigned barrier_peek(const unsigned* cnt) {
@@ -281,6 +293,55 @@ __device__ __forceinline__ bool dir_barrier(unsigned* cnt, unsigned* abortw, uns
   }
   __syncthreads();
   return *lds_ok != 0;
+}
+
+// ---- XCD-aware role assignment of the fused persistent launches ---------------------------------------------------------------
+// OPTIONAL (MSER_OPT_XCD_PLACEMENT, off by default).  A counter barrier + 2 KB exchange among 32 workgroups costs 1.25 us when
+// they all sit on ONE XCD, 1.37 on two, 1.44 on four and 1.49 spread over all eight (scratch/ubench_xcd.hip).  The hand-off
+// PROTOCOL stays placement-independent (sc1 payload, memory-side counters); only the choice of WHICH resident workgroup plays
+// which role uses the physical XCD: the launch covers every CU, a workgroup takes ticket tk on its XCD x (HW_REG_XCC_ID) and
+// becomes logical workgroup base[x] + tk if tk < cap[x]; the others are spares.  Spares wait until every workgroup of the launch
+// has registered, then fill whatever role an XCD with too few arrivals left unclaimed (so a different dispatch pattern costs
+// speed, never correctness) and otherwise exit at once, freeing their CU.
+// Measured end to end: whole-XCD groups shorten the BPTT launch by 65 us but the dispatcher never migrates a workgroup to another
+// XCD, so every concurrent kernel (attention branches, weight-gradient groups) stalls behind the fully occupied XCDs for the
+// whole chain (+330 us per step); two XCDs per group keep half of every XCD free but then the barrier gain (0.1 us) is eaten by
+// the 256-workgroup launch and registration (+100 us per step).  Hence off.
+__device__ __forceinline__ unsigned xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 0xf;
+}
+// returns the logical workgroup id or -1 (spare: leave).  pw: SYNC_PLACE_LINES zeroed lines; base / cap: the ids XCD x hosts.
+__device__ __forceinline__ int claim_role(unsigned* pw, const short* base, const short* cap, int* lds_tmp) {
+  if (threadIdx.x == 0) {
+    const unsigned x = xcc_id() & 7u;
+    const unsigned tk = __hip_atomic_fetch_add((gu32*)(pw + x * SYNC_LINE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int lid = tk < (unsigned)cap[x] ? base[x] + (int)tk : -1;
+    __hip_atomic_fetch_add((gu32*)(pw + 8 * SYNC_LINE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lid < 0) {
+      unsigned spins = 0;
+      bool all = false;
+      while (!(all = __hip_atomic_load((const gu32*)(pw + 8 * SYNC_LINE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x)) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (SPIN_LIMIT >> 2)) break;
+      }
+      if (all) {
+        const unsigned sp = __hip_atomic_fetch_add((gu32*)(pw + 9 * SYNC_LINE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned cnt = 0;
+        for (int x2 = 0; x2 < 8 && lid < 0; ++x2) {
+          unsigned got = __hip_atomic_load((const gu32*)(pw + x2 * SYNC_LINE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (unsigned k = got; k < (unsigned)cap[x2]; ++k) {
+            if (cnt == sp) { lid = base[x2] + (int)k; break; }
+            ++cnt;
+          }
+        }
+      }
+    }
+    *lds_tmp = lid;
+  }
+  __syncthreads();
+  return *lds_tmp;
 }
 
 // ---- workgroup geometry of the recurrent kernels ----------------------------------------------------------------------------
@@ -1450,6 +1511,11 @@ __global__ __launch_bounds__(NT) void cell_fwd_fused(CellK P) {
   const int gx = P.H / 8, gy = 2;
   const int n_l = gx * gy * P.ndir * P.nmb;
   int id = blockIdx.x;
+  if (P.place) {          // every 32-workgroup chain group on TWO XCDs (16 + 16): cheaper barriers, half of every XCD stays free
+    id = claim_role(P.sync + SYNC_PLACE_FWD, P.place_base, P.place_cap, (int*)smem);
+    if (id < 0) return;
+  }
+  set_logical_wg((unsigned)id);
   const bool lsthm = id < n_l;
   if (!lsthm) id -= n_l;
   const Role R{id % gx, (id / gx) % gy, id / (gx * gy), gx, gy};
@@ -1465,12 +1531,14 @@ template <int NP>
 __global__ __launch_bounds__(NT) void spk_fwd_persist(CellK P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const WS ws = make_ws(P.wsbase, P.wsbytes);
+  set_logical_wg(blockIdx.x + blockIdx.y + blockIdx.z);
   spk_fwd_role<NP>(P, Role{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, smem, ws);
 }
 template <int NP>
 __global__ __launch_bounds__(NT) void lsthm_fwd_persist(CellK P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const WS ws = make_ws(P.wsbase, P.wsbytes);
+  set_logical_wg(blockIdx.x + blockIdx.y + blockIdx.z);
   lsthm_fwd_role<NP>(P, Role{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, smem, ws);
 }
 
@@ -1591,6 +1659,11 @@ __global__ __launch_bounds__(NT) void cell_bwd_fused(CellK P, unsigned bwd_nwg) 
   const int gx = P.H / 32, gy = 4;
   const int n_s = gx * gy * P.nmb * P.ndir;
   int id = blockIdx.x;
+  if (P.place) {          // LSTHM BPTT groups on two XCDs each, each speaker group on one, the wgrad roles on the rest
+    id = claim_role(P.sync + SYNC_PLACE_BWD, P.place_base, P.place_cap, (int*)smem);
+    if (id < 0) return;
+  }
+  set_logical_wg((unsigned)id);
   if (id < n_l) {
     const Role R{id % (int)bwd_nwg, 0, id / (int)bwd_nwg, (int)bwd_nwg, 1};
     lsthm_bwd_role<NPL, KSPLIT>(P, R, smem, ws);
@@ -1768,7 +1841,7 @@ static size_t carve_all(char* base, const mser_cell_desc& d, CellHost* out) {
   Carver cv{base, 0};
   CellHost h;
   h.k.T = d.T; h.k.B = d.B; h.k.D = d.D; h.k.H = d.H; h.k.ndir = d.ndir; h.k.nmb = cdiv(d.B, 32); h.k.ldo = d.ldo;
-  h.k.wgrad_wgs = 0; h.k.ksplit = 1;
+  h.k.wgrad_wgs = 0; h.k.ksplit = 1; h.k.place = 0;
   h.sync = cv.take<unsigned>(SYNC_WORDS);
   h.k.sync = h.sync;
   h.k.wsbase = base;
@@ -1852,6 +1925,7 @@ static size_t row_lds_bytes(int H) { return ((size_t)RED_FLOATS + 2 * (size_t)H 
 static int g_opt_persistent = 1;      // MSER_OPT_PERSISTENT
 static int g_opt_wgrad_inkernel = 1;  // MSER_OPT_WGRAD_INKERNEL
 static int g_opt_ksplit = 1;          // MSER_OPT_BPTT_KSPLIT
+static int g_opt_xcd_place = 0;       // MSER_OPT_XCD_PLACEMENT (off: measured slower end to end)
 static int g_num_cus = 0;
 constexpr size_t PERSIST_MIN_LDS = 84 * 1024;     // > half of the 160 KiB LDS: at most ONE persistent workgroup per CU
 
@@ -1895,6 +1969,15 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   }
   }
   const bool separate = persist && (phases & MSER_PHASE_SEPARATE_SPEAKER);
+  // XCD placement of the fused launch: needs 32-workgroup chain groups (H = 128, B <= 32) and a launch over every CU
+  K.place = (persist && !separate && g_opt_xcd_place && (H / 8) * 2 * K.nmb == 32 && num_cus() == 256) ? 1 : 0;
+  if (K.place) {          // groups (LSTHM d0, [LSTHM d1,] speaker d0 [, speaker d1]) = logical ids 32 g .. 32 g + 31 -> XCDs 2g, 2g + 1
+    for (int x = 0; x < 8; ++x) {
+      const int g = x / 2;
+      K.place_cap[x] = (short)(g < 2 * d.ndir ? 16 : 0);
+      K.place_base[x] = (short)(g * 32 + (x & 1) * 16);
+    }
+  }
   if ((phases & MSER_PHASE_SPEAKER_FWD) && separate) {
     ProfScope ps(MSER_PROF_SPK_FWD, s);
     if (H == 128) {
@@ -1964,7 +2047,7 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
     ProfScope ps(MSER_PROF_LSTHM_FWD_GATES, s);
     if (H == 128) {
       MSER_TRY(allow_lds((const void*)cell_fwd_fused<2, 3>, p_lds));
-      hipLaunchKernelGGL((cell_fwd_fused<2, 3>), dim3(2 * fwd_wgs), dim3(NT), p_lds, s, K);
+      hipLaunchKernelGGL((cell_fwd_fused<2, 3>), dim3(K.place ? num_cus() : 2 * fwd_wgs), dim3(NT), p_lds, s, K);
     } else {
       MSER_TRY(allow_lds((const void*)cell_fwd_fused<4, 6>, p_lds));
       hipLaunchKernelGGL((cell_fwd_fused<4, 6>), dim3(2 * fwd_wgs), dim3(NT), p_lds, s, K);
@@ -2002,7 +2085,10 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   const int mat_wgs1 = ((H / 32) * 6 + ((D + 31) / 32) * 2) * K.nmb;  // LSTHM BPTT matvec roles: 4 carries + 2 speaker-gradient + 2 dx products
   // K-split of the matvec phase (the longest phase of a BPTT step, MFMA-paced: 8 waves x 32 MFMAs on 4 SIMDs): two workgroups per
   // product halve it when the doubled grid still fits beside the speaker chain
-  const int ksplit = (g_opt_persistent && g_opt_ksplit && H == 128 && ((long)2 * mat_wgs1 + spk_wgs) * d.ndir <= num_cus()) ? 2 : 1;
+  // XCD placement (claim_role) wants one 32-workgroup LSTHM group per XCD, which excludes the K-split (64 per direction); the
+  // placement is worth more (-0.45 us per hand-off against -12 us per launch)
+  const bool place_ok = g_opt_persistent && g_opt_xcd_place && H == 128 && mat_wgs1 <= 32 && num_cus() == 256;
+  const int ksplit = (!place_ok && g_opt_persistent && g_opt_ksplit && H == 128 && ((long)2 * mat_wgs1 + spk_wgs) * d.ndir <= num_cus()) ? 2 : 1;
   K.ksplit = ksplit;
   const int mat_wgs = mat_wgs1 * ksplit;
   const int bwd_nwg = mat_wgs > 32 ? mat_wgs : 32;           // row phase spreads the B rows over all of them
@@ -2041,14 +2127,31 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
                                                : (size_t)((char*)k.dxc - (char*)k.dc_carry);
       MSER_CHECK_HIP(hipMemsetAsync(k.dc_carry, 0, zbytes, s));
     }
-    MSER_CHECK_HIP(hipMemsetAsync(h.sync + SYNC_LSTHM_BWD, 0, 4 * SYNC_DIR * sizeof(unsigned), s));
+    MSER_CHECK_HIP(hipMemsetAsync(h.sync + SYNC_LSTHM_BWD, 0, (4 * SYNC_DIR + SYNC_PLACE_LINES * SYNC_LINE) * sizeof(unsigned), s));
   }
   if (phases & MSER_PHASE_LSTHM_BWD) {
   // ---- LSTHM chain, reverse time
   if (persist) {
     // ONE launch for both BPTT chains: bwd_nwg*ndir LSTHM workgroups + spk_wgs*ndir speaker workgroups
     const size_t f_lds = persist_lds(mm_lds + 32 * (4 * (size_t)H + 4) * sizeof(float) + 64);
-    const unsigned grid = (unsigned)(((long)bwd_nwg + spk_wgs) * d.ndir + K.wgrad_wgs);
+    const unsigned roles = (unsigned)(((long)bwd_nwg + spk_wgs) * d.ndir + K.wgrad_wgs);
+    K.place = (place_ok && bwd_nwg == 32 && spk_wgs == 16 && num_cus() == 256) ? 1 : 0;
+    if (K.place) {
+      // logical ids: LSTHM d0 [0,32) [, d1 [32,64)], speaker groups of 16, then the wgrad roles.  LSTHM groups on two XCDs each,
+      // every speaker group on one XCD, the wgrad roles spread over what is left (at most 24 per XCD: every XCD keeps free CUs)
+      int x = 0, id = 0;
+      for (int i = 0; i < d.ndir; ++i)
+        for (int hx = 0; hx < 2; ++hx) { K.place_base[x] = (short)id; K.place_cap[x] = 16; id += 16; ++x; }
+      for (int i = 0; i < d.ndir; ++i) { K.place_base[x] = (short)id; K.place_cap[x] = 16; id += 16; ++x; }
+      const int left = 8 - x;
+      int rem = K.wgrad_wgs;
+      for (int j = 0; j < left; ++j) {
+        const int take = (rem + (left - j) - 1) / (left - j);
+        K.place_base[x] = (short)id; K.place_cap[x] = (short)take; id += take; rem -= take; ++x;
+      }
+      if (id != (int)roles) K.place = 0;
+    }
+    const unsigned grid = K.place ? (unsigned)num_cus() : roles;
     ProfScope ps(MSER_PROF_LSTHM_BWD_ROW, s);
     if (H == 128 && ksplit == 2) {
       MSER_TRY(allow_lds((const void*)cell_bwd_fused<4, 4, 2>, f_lds));
@@ -2264,6 +2367,7 @@ int mser_set_option(int32_t key, int32_t value) {
     case MSER_OPT_PERSISTENT: g_opt_persistent = value ? 1 : 0; return 0;
     case MSER_OPT_WGRAD_INKERNEL: g_opt_wgrad_inkernel = value ? 1 : 0; return 0;
     case MSER_OPT_BPTT_KSPLIT: g_opt_ksplit = value ? 1 : 0; return 0;
+    case MSER_OPT_XCD_PLACEMENT: g_opt_xcd_place = value ? 1 : 0; return 0;
     default: set_error("mser_set_option: unknown key %d", key); return -1;
   }
 }

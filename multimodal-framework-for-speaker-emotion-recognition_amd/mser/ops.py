@@ -482,6 +482,7 @@ def marn_cell_status(desc: L.CellDesc) -> None:
 MSER_OPT_PERSISTENT = 1
 MSER_OPT_WGRAD_INKERNEL = 2
 MSER_OPT_BPTT_KSPLIT = 3
+MSER_OPT_XCD_PLACEMENT = 4
 
 
 def set_option(key: int, value: int) -> None:

@@ -311,9 +311,10 @@ def test_backward_options_agree(O):
     x, qmask, umask, label = (t.cuda() for t in O.seeded_batch(B, L, d_r=d_r, seed=14, ragged=True))
     grads = []
     try:
-        for wg, ks in ((1, 1), (0, 0)):
+        for wg, ks, xp in ((1, 1, 0), (0, 0, 0), (1, 1, 1)):      # defaults | plain | experimental XCD placement of the roles
             ops.set_option(ops.MSER_OPT_WGRAD_INKERNEL, wg)
             ops.set_option(ops.MSER_OPT_BPTT_KSPLIT, ks)
+            ops.set_option(ops.MSER_OPT_XCD_PLACEMENT, xp)
             net = MARN1_sps(6, d_r=d_r).cuda().eval()
             load_params(net, P)
             lp, _, _ = net(x, qmask, umask)
@@ -322,6 +323,8 @@ def test_backward_options_agree(O):
     finally:
         ops.set_option(ops.MSER_OPT_WGRAD_INKERNEL, 1)
         ops.set_option(ops.MSER_OPT_BPTT_KSPLIT, 1)
-    assert grads[0].keys() == grads[1].keys()
-    for n in grads[0]:
-        assert maxabs(grads[0][n], grads[1][n]) < 2e-5 * max(1.0, float(grads[1][n].abs().max())), n
+        ops.set_option(ops.MSER_OPT_XCD_PLACEMENT, 0)
+    for other in grads[1:]:
+        assert grads[0].keys() == other.keys()
+        for n in grads[0]:
+            assert maxabs(grads[0][n], other[n]) < 2e-5 * max(1.0, float(other[n].abs().max())), n
