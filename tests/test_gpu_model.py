@@ -328,3 +328,33 @@ def test_backward_options_agree(O):
         assert grads[0].keys() == other.keys()
         for n in grads[0]:
             assert maxabs(grads[0][n], other[n]) < 2e-5 * max(1.0, float(other[n].abs().max())), n
+
+
+def test_single_stream_path_and_encoder_output_gradients(O):
+    """model.use_streams = False (every launch on one stream) must give the same result as the multi-stream schedule, and the
+    gradients that arrive through the model's second and third return values (x_l, x_a) must reach the parameters: loss =
+    NLL + <x_l, w_l> + <x_a, w_a> against the CPU oracle."""
+    from models.lsthm_sps import MARN1_sps
+    from loss import MaskedLoss
+    B, L, d_r = 3, 14, 768
+    P = O.seeded_params(seed=21, d_r=d_r)
+    x, qmask, umask, label = O.seeded_batch(B, L, d_r=d_r, seed=22, ragged=True)
+    rs = np.random.RandomState(23)
+    wl = torch.tensor(rs.standard_normal((L, B, 100)).astype(np.float32)) * 0.05
+    wa = torch.tensor(rs.standard_normal((L, B, 100)).astype(np.float32)) * 0.05
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    lp_ref, xl_ref, xa_ref = O.marn1_sps_forward(Pr, x, qmask, umask, d_r=d_r)
+    (O.masked_nll(lp_ref, label.view(-1), umask) + (xl_ref * wl).sum() + (xa_ref * wa).sum()).backward()
+    for streams in (True, False):
+        net = MARN1_sps(6, d_r=d_r).cuda().eval()
+        net.use_streams = streams
+        load_params(net, P)
+        lp, x_l, x_a = net(x.cuda(), qmask.cuda(), umask.cuda())
+        loss = MaskedLoss(torch.nn.NLLLoss)(lp, label.cuda().view(-1), umask.cuda()) + (x_l * wl.cuda()).sum() + (x_a * wa.cuda()).sum()
+        loss.backward()
+        assert maxabs(lp, lp_ref) < LOGIT_TOL and maxabs(x_l, xl_ref) < 3e-5 and maxabs(x_a, xa_ref) < 3e-5
+        for n, p in net.named_parameters():
+            r = Pr[n].grad
+            if r is None:
+                continue
+            assert maxabs(p.grad, r) < 3e-4 * max(1e-3, float(r.norm())), (streams, n)
