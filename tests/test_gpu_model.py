@@ -358,3 +358,31 @@ def test_single_stream_path_and_encoder_output_gradients(O):
             if r is None:
                 continue
             assert maxabs(p.grad, r) < 3e-4 * max(1e-3, float(r.norm())), (streams, n)
+
+
+@pytest.mark.parametrize("B,L", [(40, 6), (70, 4), (1, 3)])
+def test_model_batch_sizes_vs_oracle(O, B, L):
+    """Batches beyond one 32-row block: B = 40 runs the persistent chains with two row blocks per role (and the in-launch weight
+    gradients over 40 rows per step), B = 70 exceeds the co-residency budget and falls back to per-step launches, B = 1 is the
+    degenerate single dialogue.  Forward and gradients against the CPU oracle."""
+    from models.lsthm_sps import MARN1_sps
+    from loss import MaskedLoss
+    d_r = 768
+    P = O.seeded_params(seed=31, d_r=d_r)
+    net = MARN1_sps(6, d_r=d_r).cuda().eval()
+    load_params(net, P)
+    x, qmask, umask, label = O.seeded_batch(B, L, d_r=d_r, seed=32 + B, ragged=B > 1)
+    lp, _, _ = net(x.cuda(), qmask.cuda(), umask.cuda())
+    loss = MaskedLoss(torch.nn.NLLLoss)(lp, label.cuda().view(-1), umask.cuda())
+    loss.backward()
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    lp_ref, _, _ = O.marn1_sps_forward(Pr, x, qmask, umask, d_r=d_r)
+    loss_ref = O.masked_nll(lp_ref, label.view(-1), umask)
+    loss_ref.backward()
+    assert maxabs(lp, lp_ref) < LOGIT_TOL
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 2e-5
+    for n, p in net.named_parameters():
+        r = Pr[n].grad
+        if r is None:
+            continue
+        assert maxabs(p.grad, r) < 3e-4 * max(1e-3, float(r.norm())), n
