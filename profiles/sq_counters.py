@@ -8,7 +8,8 @@
 
 Units (MI355X_MICROARCH.md "rocprofv3 PMC slots"): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles summed over
 the waves; SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the SIMDs.  Reported per kernel (averages over its launches):
-  mfma_busy_frac   = MFMA_BUSY_CYCLES / (SIMDs the grid can occupy * kernel duration in cycles at the measured wave clock)
+  mfma_busy_frac   = MFMA_BUSY_CYCLES / (SIMDs the grid can occupy * kernel duration * 2.4 GHz nominal clock): a LOWER bound on
+                     the pipe utilisation (the real clock under load is lower) and directly comparable with achieved / peak FLOP/s
   wait_any_frac    = SQ_WAIT_ANY / SQ_WAVE_CYCLES        (waves parked at s_waitcnt / s_barrier)
   wait_inst_frac   = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES   (issue stalls: MFMA dependency / pipe busy)
   active_frac      = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES
@@ -44,8 +45,8 @@ def main():
         simds = min(1024, waves)                               # SIMDs that can hold a wave of this grid (1024 on the chip)
         us = a["_ns"] / 1e3
         wave_cycles = 4.0 * a.get("SQ_WAVE_CYCLES", 0.0)       # quad-cycles -> cycles, summed over waves
-        clk_ghz = wave_cycles / max(waves, 1) / max(a["_ns"], 1)     # upper bound: waves need not live for the whole kernel
-        kcycles = a["_ns"] * max(clk_ghz, 1e-9)
+        clk_ghz = wave_cycles / max(waves, 1) / max(a["_ns"], 1)     # lower bound: waves need not live for the whole kernel
+        kcycles = a["_ns"] * 2.4                                      # nominal 2.4 GHz
         wc = max(a.get("SQ_WAVE_CYCLES", 0.0), 1.0)
         out[k] = dict(launches=n[k]["_ns"], avg_us=round(us, 1), workgroups=wgs, waves=waves,
                       wave_clock_ghz_lower_bound=round(clk_ghz, 2),
