@@ -270,6 +270,14 @@ int mser_lsthm_step_fwd(const float* x, const float* c, const float* h, const fl
                         int32_t B, int32_t D, int32_t H, int32_t Hz, int32_t Hs, mser_stream_t stream);
 int mser_rank1_attention_fwd(const float* x1, const float* x2, const float* Wq, const float* Wk, float* out,
                              int32_t B, int32_t H, mser_stream_t stream);
+/* Their backward for the module-level API (training runs through the fused BPTT of mser_marn_cell_bwd instead).
+ * lsthm_step_bwd: from d(c_t) / d(h_t) (either may be NULL) and the saved gates to the pre-activation gradients dgates [B,4H]
+ * (order f,i,o,c~) and d(c_{t-1}); the products with W, U, V, S and the bias sums are mser_gemm / mser_colsum_acc calls.
+ * rank1_attention_bwd: dx1, dx2 written, gWq / gWk [H] ACCUMULATED over the rows. */
+int mser_lsthm_step_bwd(const float* gates, const float* c_prev, const float* c_new, const float* dc_new, const float* dh_new,
+                        float* dgates, float* dc_prev, int32_t B, int32_t H, mser_stream_t stream);
+int mser_rank1_attention_bwd(const float* x1, const float* x2, const float* Wq, const float* Wk, const float* dout, float* dx1,
+                             float* dx2, float* gWq, float* gWk, int32_t B, int32_t H, mser_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Head: log_softmax + permute to batch-major (model/lsthm_sps.py:391-393) and MaskedLoss (loss.py:13-21).

@@ -2356,6 +2356,78 @@ __global__ __launch_bounds__(NT) void rank1_attention_kernel(const float* x1, co
   }
 }
 
+
+// Gate backward of ONE LSTHM1 step (module-level API; training goes through the fused BPTT): from d(c_t), d(h_t) to the
+// pre-activation gradients [B, 4H] in gate order f, i, o, c~ and d(c_{t-1}).  The products with W, U, V, S are GEMMs.
+__global__ void lsthm_step_bwd_kernel(const float* gates, const float* c_prev, const float* c_new, const float* dc_new,
+                                      const float* dh_new, float* dgates, float* dc_prev, int B, int H) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * H) return;
+  const int b = (int)(i / H), u = (int)(i % H);
+  const float* g = gates + (long)b * 4 * H + u;
+  const float gf = g[0], gi = g[H], go = g[2 * H], gc = g[3 * H];
+  const float tc = tanhf(c_new[i]);
+  const float dh = dh_new ? dh_new[i] : 0.f;
+  const float dc = (dc_new ? dc_new[i] : 0.f) + dh * go * (1.f - tc * tc);
+  float* o = dgates + (long)b * 4 * H + u;
+  o[0] = dc * c_prev[i] * gf * (1.f - gf);
+  o[H] = dc * gc * gi * (1.f - gi);
+  o[2 * H] = dh * tc * go * (1.f - go);
+  o[3 * H] = dc * gi * (1.f - gc * gc);
+  dc_prev[i] = dc * gf;
+}
+
+// Backward of the rank-1 CrossAttention (module-level API): out[i] = sum_j a_ij x2[j], a_ij = softmax_j(u_i Wk[j]),
+// u_i = x1[i] * s, s = <Wq, x2> / sqrt(H).  One workgroup of H threads per row; pass A (thread = unit i) builds the softmax
+// statistics, pass B (thread = key j) the sums over i.  dWq / dWk are accumulated over the rows with float atomics.
+__global__ void rank1_attention_bwd_kernel(const float* x1, const float* x2, const float* Wq, const float* Wk, const float* dout,
+                                           float* dx1, float* dx2, float* gWq, float* gWk, int B, int H) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* ca = smem;            // x2
+  float* wk = ca + H;
+  float* cu = wk + H;          // u_i
+  float* cm = cu + H;          // row maximum
+  float* cz = cm + H;          // z_i
+  float* cd = cz + H;          // dz_i / Z_i
+  float* red = cd + H;         // [H] reduction scratch
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float rsH = 1.0f / sqrtf((float)H);
+  const float x2v = x2[(long)b * H + t], wq = Wq[t], wkv = Wk[t];
+  ca[t] = x2v; wk[t] = wkv; red[t] = wq * x2v;
+  __syncthreads();
+  for (int o = H / 2; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+  const float s = red[0] * rsH;
+  __syncthreads();
+  // ---- pass A: unit i = t
+  const float x1v = x1[(long)b * H + t];
+  const float u = x1v * s;
+  float mx = -INFINITY;
+  for (int j = 0; j < H; ++j) mx = fmaxf(mx, u * wk[j]);
+  float Z = 0.f, N = 0.f, M = 0.f, Wn = 0.f;
+  for (int j = 0; j < H; ++j) {
+    const float e = expf(u * wk[j] - mx);
+    Z += e; N = fmaf(e, ca[j], N); M = fmaf(e, ca[j] * wk[j], M); Wn = fmaf(e, wk[j], Wn);
+  }
+  const float z = N / Z, dz = dout[(long)b * H + t];
+  const float du = dz * (M - z * Wn) / Z;
+  cu[t] = u; cm[t] = mx; cz[t] = z; cd[t] = dz / Z;
+  dx1[(long)b * H + t] = du * s;
+  red[t] = du * x1v;
+  __syncthreads();
+  for (int o = H / 2; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+  const float ds = red[0];
+  // ---- pass B: key j = t
+  float dxj = 0.f, dwj = 0.f;
+  for (int i = 0; i < H; ++i) {
+    const float a = expf(cu[i] * wkv - cm[i]) * cd[i];
+    dxj += a;
+    dwj = fmaf(a * (x2v - cz[i]), cu[i], dwj);
+  }
+  dx2[(long)b * H + t] = dxj + ds * wq * rsH;
+  atomicAdd(gWq + t, ds * x2v * rsH);
+  atomicAdd(gWk + t, dwj);
+}
+
 }  // namespace mser
 
 using namespace mser;
@@ -2467,6 +2539,25 @@ int mser_lsthm_step_fwd(const float* x, const float* c, const float* h, const fl
   hipLaunchKernelGGL(lsthm_step_kernel, dim3(cdiv((long)B * H, 128)), dim3(128), 0, (hipStream_t)stream, x, c, h, z, s, W, Wb, U,
                      Ub, V, Vb, S, Sb, c_out, h_out, gates, B, D, H, Hz, Hs);
   return check_launch("mser_lsthm_step_fwd");
+}
+
+int mser_lsthm_step_bwd(const float* gates, const float* c_prev, const float* c_new, const float* dc_new, const float* dh_new,
+                        float* dgates, float* dc_prev, int32_t B, int32_t H, mser_stream_t stream) {
+  MSER_REQUIRE(gates && c_prev && c_new && dgates && dc_prev, "mser_lsthm_step_bwd: null pointer");
+  if (B <= 0 || H <= 0) return 0;
+  hipLaunchKernelGGL(lsthm_step_bwd_kernel, dim3(cdiv((long)B * H, 128)), dim3(128), 0, (hipStream_t)stream, gates, c_prev, c_new,
+                     dc_new, dh_new, dgates, dc_prev, B, H);
+  return check_launch("mser_lsthm_step_bwd");
+}
+
+int mser_rank1_attention_bwd(const float* x1, const float* x2, const float* Wq, const float* Wk, const float* dout, float* dx1,
+                             float* dx2, float* gWq, float* gWk, int32_t B, int32_t H, mser_stream_t stream) {
+  MSER_REQUIRE(x1 && x2 && Wq && Wk && dout && dx1 && dx2 && gWq && gWk, "mser_rank1_attention_bwd: null pointer");
+  MSER_REQUIRE(H >= 32 && H <= 1024 && (H & (H - 1)) == 0, "mser_rank1_attention_bwd: H=%d must be a power of two in [32,1024]", H);
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(rank1_attention_bwd_kernel, dim3(B), dim3(H), 7 * (size_t)H * sizeof(float), (hipStream_t)stream, x1, x2, Wq,
+                     Wk, dout, dx1, dx2, gWq, gWk, B, H);
+  return check_launch("mser_rank1_attention_bwd");
 }
 
 int mser_rank1_attention_fwd(const float* x1, const float* x2, const float* Wq, const float* Wk, float* out, int32_t B, int32_t H,

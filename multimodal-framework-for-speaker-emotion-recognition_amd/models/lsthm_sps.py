@@ -49,13 +49,29 @@ class LSTHM1(nn.Module):
 
             @staticmethod
             def bwd(saved, tensors, dc2, dh2):
+                # element-wise gate backward in one small launch; the four input products and the four weight gradients reuse
+                # the MFMA GEMM.  (Training a whole model goes through the fused BPTT of MARN_cell / MARN1_sps instead.)
                 x, c, h, z, s, pv, c2, gates = saved
-                H = c.shape[1]
-                # element-wise gate backward is tiny; the four products reuse the MFMA GEMM
-                gf, gi, go, gc = gates[:, :H], gates[:, H:2 * H], gates[:, 2 * H:3 * H], gates[:, 3 * H:]
-                raise NotImplementedError("LSTHM1 standalone backward: use MARN_cell / MARN1_sps (fused BPTT) for training")
+                W, Wb, U, Ub, V, Vb, S, Sb = pv
+                B, H = c.shape
+                dgates = torch.empty(B, 4 * H, device=c.device)
+                dc = torch.empty_like(c)
+                ops.lsthm_step_bwd(gates, c, c2, dc2.contiguous() if dc2 is not None else None,
+                                   dh2.contiguous() if dh2 is not None else None, dgates, dc)
+                grads_in, grads_w = [], []
+                for inp, Wm in ((x, W), (h, U), (z, V), (s, S)):
+                    d_in = torch.empty_like(inp)
+                    ops.matmul(dgates, Wm, d_in)                     # [B,4H] @ [4H,K]
+                    gW = torch.zeros_like(Wm)
+                    ops.grad_weight(dgates, inp, gW)                 # dW += dgates^T inp
+                    grads_in.append(d_in)
+                    grads_w.append(gW)
+                gb = torch.zeros(4 * H, device=c.device)
+                ops.colsum_acc(dgates, gb)                           # the four biases are summed into one pre-activation (:33)
+                dx, dh, dz, ds = grads_in
+                return (dx, dc, dh, dz, ds, grads_w[0], gb, grads_w[1], gb.clone(), grads_w[2], gb.clone(), grads_w[3], gb.clone())
 
-        return ModuleFn.apply(Impl, x, ctm, htm, ztm, speaker_affine, *[params[n].detach() for n in names])
+        return ModuleFn.apply(Impl, x, ctm, htm, ztm, speaker_affine, *[params[n] for n in names])
 
 
 class CrossAttention(nn.Module):
@@ -72,11 +88,24 @@ class CrossAttention(nn.Module):
 
     def forward(self, x_1, x_2):
         require_gpu(x_1, x_2)
-        if x_1.requires_grad or x_2.requires_grad:
-            raise NotImplementedError("CrossAttention standalone backward: use MARN_cell / MARN1_sps (fused BPTT) for training")
-        out = torch.empty_like(x_1)
-        ops.rank1_attention_fwd(x_1.detach().contiguous(), x_2.detach().contiguous(), self.Wq.detach(), self.Wk.detach(), out)
-        return out
+
+        class Impl:
+            @staticmethod
+            def fwd(x1, x2, Wq, Wk):
+                x1, x2 = x1.contiguous(), x2.contiguous()
+                out = torch.empty_like(x1)
+                ops.rank1_attention_fwd(x1, x2, Wq, Wk, out)
+                return out, (x1, x2, Wq, Wk)
+
+            @staticmethod
+            def bwd(saved, tensors, dout):
+                x1, x2, Wq, Wk = saved
+                dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
+                gWq, gWk = torch.zeros_like(Wq), torch.zeros_like(Wk)
+                ops.rank1_attention_bwd(x1, x2, Wq, Wk, dout.contiguous(), dx1, dx2, gWq, gWk)
+                return (dx1, dx2, gWq, gWk)
+
+        return ModuleFn.apply(Impl, x_1, x_2, self.Wq, self.Wk)
 
 
 class _SeqCrossAttention(nn.Module):

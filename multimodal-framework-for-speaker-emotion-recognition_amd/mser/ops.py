@@ -401,6 +401,20 @@ def lsthm_step_fwd(x, c, h, z, s, W, Wb, U, Ub, V, Vb, S, Sb, c_out, h_out, gate
                                          _p(Sb), _p(c_out), _p(h_out), _p(gates), B, D, H, Hz, Hs, _stream()), "lsthm_step_fwd")
 
 
+def lsthm_step_bwd(gates: Tensor, c_prev: Tensor, c_new: Tensor, dc_new: Optional[Tensor], dh_new: Optional[Tensor],
+                   dgates: Tensor, dc_prev: Tensor) -> None:
+    B, H = c_prev.shape
+    L.check(_lib().mser_lsthm_step_bwd(_p(gates), _p(c_prev), _p(c_new), _p(dc_new), _p(dh_new), _p(dgates), _p(dc_prev), B, H,
+                                         _stream()), "lsthm_step_bwd")
+
+
+def rank1_attention_bwd(x1: Tensor, x2: Tensor, Wq: Tensor, Wk: Tensor, dout: Tensor, dx1: Tensor, dx2: Tensor, gWq: Tensor,
+                        gWk: Tensor) -> None:
+    B, H = x1.shape
+    L.check(_lib().mser_rank1_attention_bwd(_p(x1), _p(x2), _p(Wq), _p(Wk), _p(dout), _p(dx1), _p(dx2), _p(gWq), _p(gWk), B, H,
+                                              _stream()), "rank1_attention_bwd")
+
+
 def rank1_attention_fwd(x1: Tensor, x2: Tensor, Wq: Tensor, Wk: Tensor, out: Tensor) -> None:
     B, H = x1.shape
     L.check(_lib().mser_rank1_attention_fwd(_p(x1), _p(x2), _p(Wq), _p(Wk), _p(out), B, H, _stream()), "rank1_attention_fwd")

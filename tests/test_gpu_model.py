@@ -386,3 +386,54 @@ def test_model_batch_sizes_vs_oracle(O, B, L):
         if r is None:
             continue
         assert maxabs(p.grad, r) < 3e-4 * max(1e-3, float(r.norm())), n
+
+
+def test_lsthm1_and_cross_attention_standalone_backward(O):
+    """Module-level LSTHM1 (reference :28-44) and CrossAttention (:59-72) with autograd: inputs and parameters receive the
+    gradients the CPU oracle's autograd computes (5e-5 of the tensor's scale)."""
+    from models.lsthm_sps import LSTHM1, CrossAttention
+    rs = np.random.RandomState(41)
+    B, D, H = 7, 100, 128
+    t = lambda *s, sc=1.0: torch.tensor(rs.standard_normal(s).astype(np.float32) * sc)
+    # ---- LSTHM1
+    m = LSTHM1(H, D, H, H).cuda()
+    P = {"l." + n: p.detach().cpu().clone().requires_grad_(True) for n, p in m.named_parameters()}
+    ins = [t(B, D), t(B, H), t(B, H), t(B, H), t(B, H)]
+    wc, wh = t(B, H), t(B, H)
+    gi = [x.clone().cuda().requires_grad_(True) for x in ins]
+    c2, h2 = m(*gi)
+    ((c2 * wc.cuda()).sum() + (h2 * wh.cuda()).sum()).backward()
+    ri = [x.clone().requires_grad_(True) for x in ins]
+    c2r, h2r = O.lsthm1(P, "l.", *ri)
+    ((c2r * wc).sum() + (h2r * wh).sum()).backward()
+    assert maxabs(c2, c2r) < 2e-6 and maxabs(h2, h2r) < 2e-6
+    for a, b in zip(gi, ri):
+        assert maxabs(a.grad, b.grad) < 5e-5 * max(1.0, float(b.grad.abs().max()))
+    for n, p in m.named_parameters():
+        r = P["l." + n].grad
+        assert maxabs(p.grad, r) < 5e-5 * max(1.0, float(r.abs().max())), n
+    # only d(h_t) flowing (d(c_t) absent)
+    gi2 = [x.clone().cuda().requires_grad_(True) for x in ins]
+    (m(*gi2)[1] * wh.cuda()).sum().backward()
+    ri2 = [x.clone().requires_grad_(True) for x in ins]
+    (O.lsthm1({k: v.detach() for k, v in P.items()}, "l.", *ri2)[1] * wh).sum().backward()
+    assert maxabs(gi2[1].grad, ri2[1].grad) < 5e-5 * max(1.0, float(ri2[1].grad.abs().max()))
+    # ---- CrossAttention (rank-1 form on the GPU, as-written [B,H,H] form in the oracle)
+    ca = CrossAttention().cuda()
+    with torch.no_grad():
+        ca.Wq.copy_(t(1, H, sc=0.4).cuda())
+        ca.Wk.copy_(t(1, H, sc=0.4).cuda())
+    Pc = {"a.Wq": ca.Wq.detach().cpu().clone().requires_grad_(True), "a.Wk": ca.Wk.detach().cpu().clone().requires_grad_(True)}
+    x1, x2, w = t(B, H, sc=0.8), t(B, H, sc=0.8), t(B, H)
+    g1, g2 = x1.clone().cuda().requires_grad_(True), x2.clone().cuda().requires_grad_(True)
+    out = ca(g1, g2)
+    (out * w.cuda()).sum().backward()
+    r1, r2 = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    outr = O.cross_attention(Pc, "a.", r1, r2)
+    (outr * w).sum().backward()
+    assert maxabs(out, outr) < 2e-5
+    assert maxabs(g1.grad, r1.grad) < 5e-5 * max(1.0, float(r1.grad.abs().max()))
+    assert maxabs(g2.grad, r2.grad) < 5e-5 * max(1.0, float(r2.grad.abs().max()))
+    assert maxabs(ca.Wq.grad, Pc["a.Wq"].grad) < 5e-5 * max(1.0, float(Pc["a.Wq"].grad.abs().max()))
+    assert maxabs(ca.Wk.grad, Pc["a.Wk"].grad) < 5e-5 * max(1.0, float(Pc["a.Wk"].grad.abs().max()))
+    assert ca.Wv.grad is None          # unused by the forward (:59-72), exactly like the reference
