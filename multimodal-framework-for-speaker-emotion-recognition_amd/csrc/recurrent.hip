@@ -1866,7 +1866,11 @@ static int validate(const mser_cell_desc& d, bool bwd) {
                mser_marn_cell_workspace_bytes(d.T, d.B, d.D, d.H, d.ndir));
   MSER_REQUIRE(d.ldo >= 4L * d.H, "marn_cell: ldo=%ld < 4H", (long)d.ldo);
   MSER_REQUIRE(d.workspace_bytes < 0x7fffffffULL, "marn_cell: workspace of %zu bytes exceeds the 2 GiB addressable through one buffer descriptor", d.workspace_bytes);
-  if (bwd) MSER_REQUIRE(d.H <= 256, "marn_cell_bwd: H=%d > 256 not supported yet (LDS gate-gradient tile)", d.H);
+  if (bwd) {
+    const size_t spk_tile = ((size_t)RED_FLOATS + 1024 + 32 * (4 * (size_t)d.H + 4)) * sizeof(float) + 64;
+    MSER_REQUIRE(spk_tile <= 160 * 1024, "marn_cell_bwd: H=%d not supported yet: the speaker BPTT's gate-gradient tile needs %zu bytes "
+                 "of LDS (> 160 KiB)", d.H, spk_tile);
+  }
   for (int i = 0; i < d.ndir; ++i) {
     const mser_cell_dir& r = d.dir[i];
     MSER_REQUIRE(r.qmask && r.out, "marn_cell: dir %d null qmask/out", i);
