@@ -38,6 +38,8 @@ struct DirP {
   // saved by the forward
   float *qsel, *hq_state, *cq_state, *sgates, *HQ, *tcq;   // tcq[2][T][B][H] = tanh(c_new) (saves the backward a tanhf per element)
   float *pre, *gates, *cstate, *hz;
+  float* rstat;        // [T][B][H][4]: softmax statistics of the rank-1 attention row (Z, N2 = sum e*c_a*Wk, N3 = sum e*Wk, s), saved by
+                       // the forward row phase so that the BPTT does not recompute its first exp2 pass
   float* out;
   const float* dout;
   // backward scratch
@@ -682,7 +684,8 @@ __device__ __forceinline__ void lsthm_gates_body(const CellK& P, const DirP& D, 
 }
 
 // Row phase, one dialogue row b per call (NT threads): z[b,i] = sum_j softmax_j(c_l[i] * s_b * Wk[j]) c_a[j]  (:59-72, rank-1 form)
-// thread (i = tid % H, q = tid / H) covers keys j in [q*JC, (q+1)*JC).  scr: ca[H] pZ[NT] pN[NT] sh[16]
+// thread (i = tid % H, q = tid / H) covers keys j in [q*JC, (q+1)*JC).  scr: ca[H] pZ[NT] pN[NT] sh[16] pN2[NT] pN3[NT] cw[H]
+// Besides z it leaves the softmax statistics of the row (Z, N2, N3, s) in rstat for the BPTT.
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // `after_loads` runs right behind the row's own operand loads: loads issued there are YOUNGER than the row's, so the row phase
 // does not wait for them (vmcnt retires in order) -- used to fetch the next step's early-product operands under the exp2 work.
@@ -695,6 +698,8 @@ __device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, cons
   float* pZ = ca + H;
   float* pN = pZ + NT;
   float* sh = pN + NT;
+  float* pN2 = sh + 16;
+  float* cw = pN2 + 2 * NT;          // c_a[j] * Wk[j] (behind pN2 / pN3)
   const float* wk = att;
   const float* wq = att + H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -705,6 +710,7 @@ __device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, cons
   if (tid < H) {
     const float cv = ldx<PS>(ws, c_a + tid);
     ca[tid] = cv;
+    cw[tid] = cv * wk[tid];
     sp = wq[tid] * cv;
   }
   const float cli = ldx<PS>(ws, c_l + i);
@@ -720,24 +726,30 @@ __device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, cons
   const float u = cli * s;
   const float mx = (u >= 0.f) ? u * att[2 * H] : u * att[2 * H + 1];
   const float u2 = u * LOG2E, m2 = mx * LOG2E;
-  float Z = 0.f, N = 0.f;
+  float Z = 0.f, N = 0.f, N2 = 0.f, N3 = 0.f;     // N2, N3: the two extra sums the backward needs (saved below)
   {
     const float* wkc = wk + q * JC;
     const float* cac = ca + q * JC;
+    const float* cwc = cw + q * JC;
 #pragma unroll
     for (int jj = 0; jj < (JCT ? JCT : JC); ++jj) {
-      const float e = __builtin_amdgcn_exp2f(fmaf(u2, wkc[jj], -m2));
+      const float wj = wkc[jj];
+      const float e = __builtin_amdgcn_exp2f(fmaf(u2, wj, -m2));
       Z += e;
       N = fmaf(e, cac[jj], N);
+      N2 = fmaf(e, cwc[jj], N2);
+      N3 = fmaf(e, wj, N3);
     }
   }
-  if (q > 0) { pZ[tid] = Z; pN[tid] = N; }
+  float* pN3 = pN2 + NT;
+  if (q > 0) { pZ[tid] = Z; pN[tid] = N; pN2[tid] = N2; pN3[tid] = N3; }
   __syncthreads();
   if (q == 0) {
-    for (int qq = 1; qq < Q; ++qq) { Z += pZ[qq * H + i]; N += pN[qq * H + i]; }
+    for (int qq = 1; qq < Q; ++qq) { Z += pZ[qq * H + i]; N += pN[qq * H + i]; N2 += pN2[qq * H + i]; N3 += pN3[qq * H + i]; }
     const float z = N / Z;
     stx<PS>(ws, D.hz + ((long)(t + 1) * B + b) * 3 * H + 2 * H + i, z);
     if (tau >= 0) D.out[((long)tau * B + b) * P.ldo + 2 * H + i] = z;
+    *reinterpret_cast<float4*>(D.rstat + (((long)t * B + b) * H + i) * 4) = make_float4(Z, N2, N3, s);
   }
   __syncthreads();     // scratch is reused by the next row / phase
 }
@@ -1057,6 +1069,26 @@ __device__ __forceinline__ RowMid lsthm_bwd_row_part1(const CellK& P, const floa
   return r;
 }
 
+// Persistent BPTT: the same RowMid from the statistics the forward row phase saved (rstat): no exp2 pass, no reductions.  The
+// first pass of the backward used to sit in the shadow of the carry barrier and was LONGER than that barrier (2.3 us against
+// 1.4), so it was on the chain; as three loads it is not.
+__device__ __forceinline__ RowMid lsthm_bwd_row_part1_saved(const CellK& P, const DirP& D, int t, int b, const float* att, float* scr,
+                                                            const RowPre& pre) {
+  const int H = P.H;
+  float* ca = scr;  float* cl = ca + H;  float* cw = cl + H;
+  const int tid = threadIdx.x, i = tid & (H - 1);
+  const float4 st = *reinterpret_cast<const float4*>(D.rstat + (((long)t * P.B + b) * H + i) * 4);
+  const float cli = D.cstate[((long)0 * (P.T + 1) + t + 1) * P.B * H + (long)b * H + i];
+  if (tid < H) {
+    const float cv = pre.cav;
+    ca[tid] = cv; cl[tid] = pre.clv; cw[tid] = cv * att[tid];
+  }
+  RowMid r;
+  r.s = st.w; r.u = cli * st.w; r.Z = st.x; r.N2 = st.y; r.N3 = st.z;
+  __syncthreads();
+  return r;
+}
+
 // carry[2]: the dc carry of this thread's unit, both streams (in: from step t+1, out: for step t-1).  The persistent kernel keeps it in
 // registers (the same thread owns the same (row, unit) every step); it is also written to dc_carry for the per-step launches.
 template <bool PS, int JCT>
@@ -1269,7 +1301,7 @@ __device__ __forceinline__ void lsthm_bwd_role(const CellK& P, const Role R, flo
   const int rowb = has_row ? w : 0;
   RowPre pre = lsthm_bwd_row_prefetch(P, D, P.T - 1, rowb);
   RowPre pre_n = lsthm_bwd_row_prefetch(P, D, P.T > 1 ? P.T - 2 : 0, rowb);
-  RowMid mid = lsthm_bwd_row_part1<JCB>(P, att, red, pre);
+  RowMid mid = lsthm_bwd_row_part1_saved(P, D, P.T - 1, rowb, att, red, pre);
   float carry[2] = {0.f, 0.f};
   for (int t = P.T - 1; t >= 0; --t) {
     if (has_row) lsthm_bwd_row_part2<true, JCB>(P, D, ws, t, w, att, red, pre, mid, carry);
@@ -1287,7 +1319,7 @@ __device__ __forceinline__ void lsthm_bwd_role(const CellK& P, const Role R, flo
     if (t > 0) {
       pre = pre_n;
       if (t > 1) pre_n = lsthm_bwd_row_prefetch(P, D, t - 2, rowb);
-      mid = lsthm_bwd_row_part1<JCB>(P, att, red, pre);
+      mid = lsthm_bwd_row_part1_saved(P, D, t - 1, rowb, att, red, pre);
       if (!barrier_wait(cnt, P.sync + SYNC_ABORT, nwg * nbar, lds_ok)) return;
     }
     STAMP_ACC(3);
@@ -1811,6 +1843,7 @@ static void carve_dir(Carver& cv, DirP& d, int T, int B, int D, int H) {
   d.gates = cv.take<float>(2 * TB * 4 * H);
   d.cstate = cv.take<float>(2 * (T + 1) * SB);
   d.hz = cv.take<float>((T + 1) * (size_t)B * 3 * H);
+  d.rstat = cv.take<float>(TB * H * 4);
   d.dgates = cv.take<float>(2 * TB * 4 * H);
   d.dA = cv.take<float>(2 * 4 * SB);          // x2: K-split partial copies (CellK::ksplit)
   d.dHQ = cv.take<float>(TB * H);

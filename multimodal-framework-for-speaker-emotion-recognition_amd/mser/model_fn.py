@@ -286,7 +286,7 @@ def _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams):
 
     Pl, Pa, Gl, Ga = _sub(P, "encoder_l."), _sub(P, "encoder_a."), _sub(G, "encoder_l."), _sub(G, "encoder_a.")
 
-    def text_branch(flush_stream=None):
+    def text_branch(flush_stream=None, audio_stream=None):
         d2 = F_.encoder_layer_bwd(c.enc[1], dx_l, Pl, Gl)          # grad of (xl0 + e1): flows to both
         if flush_stream is not None:
             # weight gradients collected so far (the audio branch's two layers, already issued, and this layer): one grouped launch
@@ -294,15 +294,13 @@ def _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams):
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             flush_stream.wait_event(ev)
-            flush_stream.wait_stream(s_audio_ref[0])
+            flush_stream.wait_stream(audio_stream)
             with torch.cuda.stream(flush_stream):
                 ops.wgrad_scope.flush()
         d1 = F_.encoder_layer_bwd(c.enc[0], d2, Pl, Gl)
         ops.add_rows(d1, d1, d2)                                   # d(xl0)
         ops.grad_weight(d1, c.x2d[:, :d.d_r], G("linear_in.weight"))
         ops.colsum_acc(d1, G("linear_in.bias"))
-
-    s_audio_ref = [None]
 
     def audio_branch():
         d2 = F_.encoder_layer_bwd(c.enc[3], dx_a, Pa, Ga)
@@ -348,8 +346,7 @@ def _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams):
             ops.marn_cell_run(desc, ops.PHASE_LSTHM_WGRAD)         # LSTHM parameter gradients: nothing downstream reads them
         with torch.cuda.stream(s_audio):
             audio_branch()
-        s_audio_ref[0] = s_audio
-        text_branch(flush_stream=s_xb)
+        text_branch(flush_stream=s_xb, audio_stream=s_audio)
         for st in (s_audio, s_spk, s_xa, s_xb):
             cur.wait_stream(st)
     else:
