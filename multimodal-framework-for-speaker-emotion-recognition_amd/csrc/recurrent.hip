@@ -684,7 +684,7 @@ __device__ __forceinline__ void lsthm_gates_body(const CellK& P, const DirP& D, 
 }
 
 // Row phase, one dialogue row b per call (NT threads): z[b,i] = sum_j softmax_j(c_l[i] * s_b * Wk[j]) c_a[j]  (:59-72, rank-1 form)
-// thread (i = tid % H, q = tid / H) covers keys j in [q*JC, (q+1)*JC).  scr: ca[H] pZ[NT] pN[NT] sh[16] pN2[NT] pN3[NT] cw[H]
+// thread (i = tid % H, q = tid / H) covers keys j in [q*JC, (q+1)*JC).  scr: kc[H] (float4) pZ[NT] pN[NT] sh[16] pN2[NT] pN3[NT]
 // Besides z it leaves the softmax statistics of the row (Z, N2, N3, s) in rstat for the BPTT.
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // `after_loads` runs right behind the row's own operand loads: loads issued there are YOUNGER than the row's, so the row phase
@@ -694,12 +694,12 @@ __device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, cons
                                              Hook after_loads = Hook()) {
   const int H = P.H, B = P.B, T = P.T;
   const int Q = NT / H, JC = JCT ? JCT : H / Q;
-  float* ca = scr;
-  float* pZ = ca + H;
+  // per key j ONE 16-byte LDS word (Wk[j], c_a[j], c_a[j] Wk[j], -): the inner loop issues one broadcast ds_read_b128 per key
+  float4* kc = reinterpret_cast<float4*>(scr);
+  float* pZ = scr + 4 * H;
   float* pN = pZ + NT;
   float* sh = pN + NT;
   float* pN2 = sh + 16;
-  float* cw = pN2 + 2 * NT;          // c_a[j] * Wk[j] (behind pN2 / pN3)
   const float* wk = att;
   const float* wq = att + H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -708,9 +708,8 @@ __device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, cons
   const int i = tid & (H - 1), q = tid / H;
   float sp = 0.f;
   if (tid < H) {
-    const float cv = ldx<PS>(ws, c_a + tid);
-    ca[tid] = cv;
-    cw[tid] = cv * wk[tid];
+    const float cv = ldx<PS>(ws, c_a + tid), w = wk[tid];
+    kc[tid] = make_float4(w, cv, cv * w, 0.f);
     sp = wq[tid] * cv;
   }
   const float cli = ldx<PS>(ws, c_l + i);
@@ -728,17 +727,15 @@ __device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, cons
   const float u2 = u * LOG2E, m2 = mx * LOG2E;
   float Z = 0.f, N = 0.f, N2 = 0.f, N3 = 0.f;     // N2, N3: the two extra sums the backward needs (saved below)
   {
-    const float* wkc = wk + q * JC;
-    const float* cac = ca + q * JC;
-    const float* cwc = cw + q * JC;
+    const float4* kcc = kc + q * JC;
 #pragma unroll
     for (int jj = 0; jj < (JCT ? JCT : JC); ++jj) {
-      const float wj = wkc[jj];
-      const float e = __builtin_amdgcn_exp2f(fmaf(u2, wj, -m2));
+      const float4 k4 = kcc[jj];
+      const float e = __builtin_amdgcn_exp2f(fmaf(u2, k4.x, -m2));
       Z += e;
-      N = fmaf(e, cac[jj], N);
-      N2 = fmaf(e, cwc[jj], N2);
-      N3 = fmaf(e, wj, N3);
+      N = fmaf(e, k4.y, N);
+      N2 = fmaf(e, k4.z, N2);
+      N3 = fmaf(e, k4.x, N3);
     }
   }
   float* pN3 = pN2 + NT;
