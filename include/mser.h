@@ -290,6 +290,16 @@ int mser_logsoftmax_tb_bwd(const float* dlp, const float* lp, float* dy, int32_t
 /* loss = -sum_r mask[r]*pred[r,target[r]] / sum(mask);  loss_out[0] = loss, loss_out[1] = sum(mask) */
 int mser_masked_nll_fwd(const float* pred, const int64_t* target, const float* mask, int64_t rows, int32_t C,
                         float* loss_out, mser_stream_t stream);
+/* The full MaskedLoss (loss.py:13-25): class weights (weight [C] or NULL) and both lossers of model_trainer.py:74-77.
+ *   is_ce = 0: NLLLoss(weight, 'sum')(pred*mask, target) / D ;  is_ce = 1: CrossEntropyLoss(weight, 'sum')(pred*mask, target) / D
+ *   D = sum(mask) (weight NULL) or sum(weight[target]*mask).  CrossEntropyLoss re-applies log_softmax to pred*mask, so a masked
+ *   row adds weight[y]*log(C) to the numerator (the reference's default --loss CrossEntropy reports that on padded batches).
+ * loss_out[0] = loss, loss_out[1] = D.  bwd: dpred = (*gscale_dev) * d loss / d pred (all columns written). */
+int mser_masked_loss_fwd(const float* pred, const int64_t* target, const float* mask, const float* weight, int32_t is_ce,
+                         int64_t rows, int32_t C, float* loss_out, mser_stream_t stream);
+int mser_masked_loss_bwd(const float* pred, const int64_t* target, const float* mask, const float* weight, int32_t is_ce,
+                         const float* loss_out, const float* gscale_dev, float* dpred, int64_t rows, int32_t C,
+                         mser_stream_t stream);
 /* dpred[r,c] = -(*gscale_dev) * mask[r] / sum(mask) * (c == target[r]) */
 int mser_masked_nll_bwd(const int64_t* target, const float* mask, const float* loss_out, const float* gscale_dev,
                         float* dpred, int64_t rows, int32_t C, mser_stream_t stream);

@@ -397,6 +397,62 @@ __global__ __launch_bounds__(1024) void masked_nll_fwd_kernel(const float* pred,
   }
 }
 
+// MaskedLoss in full (loss.py:13-25): losser in {NLLLoss, CrossEntropyLoss}(weight=w, reduction='sum') applied to pred * mask,
+// divided by sum(mask) (w == null) or sum(w[target] * mask).  CrossEntropyLoss re-applies log_softmax to pred * mask: on the
+// log-probabilities of a valid row that is the identity, but a masked row (pred * 0) contributes w[y] * log(C) to the numerator --
+// the reference's reported loss on padded batches with its default --loss CrossEntropy (train.py:117) includes that term.
+__global__ __launch_bounds__(1024) void masked_loss_fwd_kernel(const float* pred, const long* target, const float* mask,
+                                                               const float* weight, int is_ce, long rows, int C, float* loss_out) {
+  __shared__ float s_num[16], s_den[16];
+  float num = 0.f, den = 0.f;
+  for (long r = threadIdx.x; r < rows; r += 1024) {
+    const float m = mask[r];
+    const long y = target[r];
+    const float w = weight ? weight[y] : 1.f;
+    const float* p = pred + r * C;
+    if (is_ce) {
+      float mx = -INFINITY;
+      for (int c = 0; c < C; ++c) mx = fmaxf(mx, m * p[c]);
+      float se = 0.f;
+      for (int c = 0; c < C; ++c) se += expf(m * p[c] - mx);
+      num += w * (mx + logf(se) - m * p[y]);
+    } else {
+      num -= w * m * p[y];
+    }
+    den += weight ? w * m : m;
+  }
+  num = wave_sum(num);
+  den = wave_sum(den);
+  if ((threadIdx.x & 63) == 0) { s_num[threadIdx.x >> 6] = num; s_den[threadIdx.x >> 6] = den; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < 16; ++i) { a += s_num[i]; b += s_den[i]; }
+    loss_out[0] = a / b;
+    loss_out[1] = b;
+  }
+}
+
+__global__ void masked_loss_bwd_kernel(const float* pred, const long* target, const float* mask, const float* weight, int is_ce,
+                                       const float* loss_out, const float* gscale_dev, float* dpred, long rows, int C) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float m = mask[r];
+  const long y = target[r];
+  const float k = (gscale_dev ? *gscale_dev : 1.f) * (weight ? weight[y] : 1.f) / loss_out[1];
+  const float* p = pred + r * C;
+  float* d = dpred + r * C;
+  if (is_ce) {
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, m * p[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(m * p[c] - mx);
+    for (int c = 0; c < C; ++c) d[c] = k * m * (expf(m * p[c] - mx) / se - (c == (int)y ? 1.f : 0.f));
+  } else {
+    for (int c = 0; c < C; ++c) d[c] = (c == (int)y) ? -k * m : 0.f;
+  }
+}
+
 __global__ void masked_nll_bwd_kernel(const long* target, const float* mask, const float* loss_out, const float* gscale_dev,
                                       float* dpred, long rows, int C) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -622,6 +678,23 @@ int mser_masked_nll_bwd(const int64_t* target, const float* mask, const float* l
   hipLaunchKernelGGL(masked_nll_bwd_kernel, dim3(cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, (const long*)target, mask,
                      loss_out, gscale_dev, dpred, (long)rows, C);
   return check_launch("mser_masked_nll_bwd");
+}
+
+int mser_masked_loss_fwd(const float* pred, const int64_t* target, const float* mask, const float* weight, int32_t is_ce,
+                         int64_t rows, int32_t C, float* loss_out, mser_stream_t stream) {
+  MSER_REQUIRE(pred && target && mask && loss_out && rows > 0 && C > 0, "mser_masked_loss_fwd: bad arguments");
+  hipLaunchKernelGGL(masked_loss_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, (const long*)target, mask, weight,
+                     is_ce, (long)rows, C, loss_out);
+  return check_launch("mser_masked_loss_fwd");
+}
+
+int mser_masked_loss_bwd(const float* pred, const int64_t* target, const float* mask, const float* weight, int32_t is_ce,
+                         const float* loss_out, const float* gscale_dev, float* dpred, int64_t rows, int32_t C,
+                         mser_stream_t stream) {
+  MSER_REQUIRE(pred && target && mask && loss_out && dpred && rows > 0 && C > 0, "mser_masked_loss_bwd: bad arguments");
+  hipLaunchKernelGGL(masked_loss_bwd_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, pred, (const long*)target, mask,
+                     weight, is_ce, loss_out, gscale_dev, dpred, (long)rows, C);
+  return check_launch("mser_masked_loss_bwd");
 }
 
 int mser_adam_flat(float* p, const float* g, float* m, float* v, const uint8_t* live, int64_t n, int32_t step, float lr, float beta1,

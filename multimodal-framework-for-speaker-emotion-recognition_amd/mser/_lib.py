@@ -128,6 +128,8 @@ SIGNATURES = {
     "mser_masked_nll_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "mser_ingest_features": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "mser_confusion_update": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "mser_masked_loss_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp]),
+    "mser_masked_loss_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp]),
     "mser_adam_flat": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
     "mser_adam_flat_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _f32, _vp, _f32, _vp]),
     "mser_dp_pack": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),

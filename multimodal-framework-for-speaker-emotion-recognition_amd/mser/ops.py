@@ -377,6 +377,19 @@ def confusion_update(lp: Tensor, label: Tensor, mask: Tensor, conf: Tensor, pred
                                            _p(pred_out), _stream()), "confusion_update")
 
 
+def masked_loss_fwd(pred: Tensor, target: Tensor, mask: Tensor, weight: Optional[Tensor], is_ce: bool, loss_out: Tensor) -> None:
+    rows, Cn = pred.shape
+    L.check(_lib().mser_masked_loss_fwd(_p(pred), _p(target), _p(mask), _p(weight), int(is_ce), rows, Cn, _p(loss_out), _stream()),
+            "masked_loss_fwd")
+
+
+def masked_loss_bwd(pred: Tensor, target: Tensor, mask: Tensor, weight: Optional[Tensor], is_ce: bool, loss_out: Tensor,
+                    gscale: Optional[Tensor], dpred: Tensor) -> None:
+    rows, Cn = dpred.shape
+    L.check(_lib().mser_masked_loss_bwd(_p(pred), _p(target), _p(mask), _p(weight), int(is_ce), _p(loss_out), _p(gscale), _p(dpred),
+                                          rows, Cn, _stream()), "masked_loss_bwd")
+
+
 def adam_flat(p: Tensor, g: Tensor, m: Tensor, v: Tensor, live: Optional[Tensor], step: int, lr: float, beta1: float = 0.9,
               beta2: float = 0.999, eps: float = 1e-8, wd: float = 0.0, gscale: float = 1.0) -> None:
     L.check(_lib().mser_adam_flat(_p(p), _p(g), _p(m), _p(v), _p(live), p.numel(), step, lr, beta1, beta2, eps, wd, gscale,

@@ -437,3 +437,31 @@ def test_lsthm1_and_cross_attention_standalone_backward(O):
     assert maxabs(ca.Wq.grad, Pc["a.Wq"].grad) < 5e-5 * max(1.0, float(Pc["a.Wq"].grad.abs().max()))
     assert maxabs(ca.Wk.grad, Pc["a.Wk"].grad) < 5e-5 * max(1.0, float(Pc["a.Wk"].grad.abs().max()))
     assert ca.Wv.grad is None          # unused by the forward (:59-72), exactly like the reference
+
+
+@pytest.mark.parametrize("losser", ["NLL", "CE"])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_masked_loss_all_variants_vs_torch(losser, weighted):
+    """MaskedLoss (reference loss.py:13-25) for both lossers of model_trainer.py:74-77, with and without class weights, on a padded
+    batch: value and d loss / d pred against the reference expression evaluated by torch on the CPU."""
+    from loss import MaskedLoss
+    rs = np.random.RandomState(61)
+    B, L, C = 5, 9, 6
+    lp = torch.log_softmax(torch.tensor(rs.standard_normal((B * L, C)).astype(np.float32)), -1)
+    target = torch.tensor(rs.randint(0, C, B * L).astype(np.int64))
+    mask = torch.ones(B, L)
+    for b in range(1, B):
+        mask[b, L - b:] = 0
+    w = torch.tensor(rs.rand(C).astype(np.float32) + 0.5) if weighted else None
+    cls = torch.nn.NLLLoss if losser == "NLL" else torch.nn.CrossEntropyLoss
+    # reference expression (loss.py:19-24)
+    pr = lp.clone().requires_grad_(True)
+    m_ = mask.view(-1, 1)
+    ref = cls(weight=w, reduction="sum")(pr * m_, target)
+    ref = ref / (mask.sum() if w is None else (w[target] * m_.squeeze()).sum())
+    ref.backward()
+    pg = lp.clone().cuda().requires_grad_(True)
+    out = MaskedLoss(cls, weight=w)(pg, target.cuda(), mask.cuda())
+    out.backward()
+    assert abs(float(out.detach()) - float(ref.detach())) < 2e-6 * max(1.0, abs(float(ref.detach())))
+    assert maxabs(pg.grad, pr.grad) < 2e-7
