@@ -156,9 +156,9 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
             ops.marn_cell_run(desc, ops.PHASE_FWD_PREP)         # tables, initial states, counters: off the encoders' stream
             ev_prep.record(s_spk)
             ops.marn_cell_run(desc, ops.PHASE_SPEAKER_FWD | sep)   # qmask-only chain: overlaps the encoders AND the LSTHM chain
+        text_branch()                                           # the longer branch (linear_in in front) is issued first
         with torch.cuda.stream(s_audio):
             audio_branch()
-        text_branch()
         cur.wait_stream(s_audio)                                # x_l and x_a are final
         ev_x = torch.cuda.Event()
         ev_x.record(cur)
