@@ -296,6 +296,21 @@ def masked_nll(pred: Tensor, target: Tensor, mask: Tensor) -> Tensor:
     return F.nll_loss(pred * m, target, reduction="sum") / mask.sum()
 
 
+def masked_loss(pred: Tensor, target: Tensor, mask: Tensor, weight: Optional[Tensor] = None, is_ce: bool = False) -> Tensor:
+    """MaskedLoss.forward in full -- loss.py:13-25: losser(weight, reduction='sum')(pred * mask, target) divided by sum(mask)
+    or, with class weights, by sum(weight[target] * mask).  Written out instead of calling the torch losses: the
+    CrossEntropyLoss branch re-applies log_softmax to pred * mask (identity on the log-probabilities of a valid row; a masked
+    row becomes log_softmax(0) = -log C and contributes weight[y] * log C)."""
+    m = mask.reshape(-1, 1)
+    z = pred * m
+    if is_ce:
+        z = z - torch.logsumexp(z, dim=1, keepdim=True)
+    w = weight[target] if weight is not None else torch.ones_like(z[:, 0])
+    num = -(w * z.gather(1, target.view(-1, 1)).squeeze(1)).sum()
+    den = (w * m.squeeze(1)).sum() if weight is not None else mask.sum()
+    return num / den
+
+
 # --------------------------------------------------------------------------------------
 # optimiser (model_trainer.py:82-83, :92)
 # --------------------------------------------------------------------------------------

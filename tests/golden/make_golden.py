@@ -227,10 +227,38 @@ def trainer_case():
     print("trainer", rec["lr1"], rec["lr2"], rec["avg_loss1"], rec["avg_loss2"])
 
 
+def loss_cases():
+    """The reference's own loss.MaskedLoss (loss.py:6-25) for both lossers of model_trainer.py:74-77, with and without class
+    weights, on log-probabilities with a padded mask: value and d loss / d pred."""
+    import loss as ref_loss
+    rs = np.random.RandomState(61)
+    B, L, C = 5, 9, 6
+    lp = torch.log_softmax(torch.tensor(rs.standard_normal((B * L, C)).astype(np.float32)), -1)
+    target = torch.tensor(rs.randint(0, C, B * L).astype(np.int64))
+    mask = torch.ones(B, L)
+    for b in range(1, B):
+        mask[b, L - b:] = 0
+    w = torch.tensor(rs.rand(C).astype(np.float32) + 0.5)
+    rec = dict(lp=lp.numpy(), target=target.numpy(), mask=mask.numpy(), weight=w.numpy(), torch_version=torch.__version__)
+    for lname, cls in (("nll", torch.nn.NLLLoss), ("ce", torch.nn.CrossEntropyLoss)):
+        for wname, ww in (("plain", None), ("weighted", w)):
+            pr = lp.clone().requires_grad_(True)
+            out = ref_loss.MaskedLoss(cls, weight=ww)(pr, target, mask)
+            out.backward()
+            rec[f"{lname}_{wname}/loss"] = out.detach().double().numpy()
+            rec[f"{lname}_{wname}/dpred"] = pr.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "loss.npz"), **rec)
+    print("loss", {k: float(v) for k, v in rec.items() if k.endswith("/loss")})
+
+
 if __name__ == "__main__":
     _shim()
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "loss":       # regenerate only the loss fixture
+        loss_cases()
+        sys.exit(0)
     module_cases()
+    loss_cases()
     cell_case()
     model_case("c1_B2_L16_dr1024", 2, 16, 1024, False, 0, True)
     model_case("c1r_B3_L12_dr768_ragged", 3, 12, 768, True, 1, True)

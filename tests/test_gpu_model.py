@@ -465,3 +465,19 @@ def test_masked_loss_all_variants_vs_torch(losser, weighted):
     out.backward()
     assert abs(float(out.detach()) - float(ref.detach())) < 2e-6 * max(1.0, abs(float(ref.detach())))
     assert maxabs(pg.grad, pr.grad) < 2e-7
+
+
+def test_masked_loss_vs_reference_golden(golden_dir):
+    """The product MaskedLoss against the reference's own loss.MaskedLoss outputs (tests/golden/loss.npz): both lossers, with and
+    without class weights, padded mask -- value 2e-6 relative, d loss / d pred 2e-7."""
+    from loss import MaskedLoss
+    g = _g(golden_dir, "loss.npz")
+    lp, target, mask, w = torch.tensor(g["lp"]), torch.tensor(g["target"]), torch.tensor(g["mask"]), torch.tensor(g["weight"])
+    for lname, cls in (("nll", torch.nn.NLLLoss), ("ce", torch.nn.CrossEntropyLoss)):
+        for wname, ww in (("plain", None), ("weighted", w)):
+            pg = lp.clone().cuda().requires_grad_(True)
+            out = MaskedLoss(cls, weight=ww)(pg, target.cuda(), mask.cuda())
+            out.backward()
+            ref = float(g[f"{lname}_{wname}/loss"])
+            assert abs(float(out.detach()) - ref) < 2e-6 * max(1.0, abs(ref)), (lname, wname)
+            assert maxabs(pg.grad, g[f"{lname}_{wname}/dpred"]) < 2e-7, (lname, wname)
