@@ -192,13 +192,14 @@ def module_cases():
     print("modules ok")
 
 
-def trainer_case():
-    """3 ``train_network`` steps with every Dropout p set to 0: pins MaskedLoss + Adam(wd) + StepLR."""
+def trainer_case(loss="NLL", epochs=(1, 2), out="trainer.npz"):
+    """3 ``train_network`` steps per epoch with every Dropout p set to 0: pins MaskedLoss + Adam(wd) + StepLR.  The second
+    fixture (loss="CrossEntropy", the reference CLI's default, train.py:117) pins the reported loss on padded batches."""
     import torch.nn as nn
     from model_trainer import ModelTrainer
 
     torch.manual_seed(0)
-    tr = ModelTrainer(torch.device("cpu"), lr=1e-3, test_step=1, lr_decay=0.98, model="MARN1_sps", loss="NLL",
+    tr = ModelTrainer(torch.device("cpu"), lr=1e-3, test_step=1, lr_decay=0.98, model="MARN1_sps", loss=loss,
                       n_classes=6, dataset="IEMOCAP")
     for mod in tr.modules():
         if isinstance(mod, nn.Dropout):
@@ -215,7 +216,7 @@ def trainer_case():
         batches.append([r + d, r - d, r + 2 * d, r - 2 * d, torch.zeros(L, B, 4), x[:, :, 1024:], qmask, umask, label,
                         ["v"] * B])
     rec = {}
-    for ep in (1, 2):
+    for ep in epochs:
         lr, avg = tr.train_network(ep, batches)
         rec[f"lr{ep}"] = np.float64(lr)
         rec[f"avg_loss{ep}"] = np.float64(avg)
@@ -223,8 +224,8 @@ def trainer_case():
     for k in ("w", "v", "fc.0.bias", "nn_out.3.weight", "marn_cell_f.lsthm_l.U.bias", "encoder_l.slf_attn.layer_norm.weight",
               "marn_cell_b.lstm_q1.bias_hh", "crossatt_l2a_1.Wk", "linear_in.bias", "marn_cell_f.crossatt_l2a.Wk"):
         rec["p/" + k] = sd[k].detach().numpy().reshape(-1)[:16].copy()
-    np.savez_compressed(os.path.join(HERE, "trainer.npz"), **rec)
-    print("trainer", rec["lr1"], rec["lr2"], rec["avg_loss1"], rec["avg_loss2"])
+    np.savez_compressed(os.path.join(HERE, out), **rec)
+    print("trainer", loss, {k: float(v) for k, v in rec.items() if not k.startswith("p/")})
 
 
 def loss_cases():
@@ -254,8 +255,9 @@ def loss_cases():
 if __name__ == "__main__":
     _shim()
     torch.set_num_threads(8)
-    if len(sys.argv) > 1 and sys.argv[1] == "loss":       # regenerate only the loss fixture
+    if len(sys.argv) > 1 and sys.argv[1] == "loss":       # regenerate only the loss fixtures
         loss_cases()
+        trainer_case(loss="CrossEntropy", epochs=(1,), out="trainer_ce.npz")
         sys.exit(0)
     module_cases()
     loss_cases()
@@ -264,3 +266,4 @@ if __name__ == "__main__":
     model_case("c1r_B3_L12_dr768_ragged", 3, 12, 768, True, 1, True)
     model_case("c2_B32_L128_dr768", 32, 128, 768, False, 2, False)
     trainer_case()
+    trainer_case(loss="CrossEntropy", epochs=(1,), out="trainer_ce.npz")

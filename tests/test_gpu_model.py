@@ -481,3 +481,27 @@ def test_masked_loss_vs_reference_golden(golden_dir):
             ref = float(g[f"{lname}_{wname}/loss"])
             assert abs(float(out.detach()) - ref) < 2e-6 * max(1.0, abs(ref)), (lname, wname)
             assert maxabs(pg.grad, g[f"{lname}_{wname}/dpred"]) < 2e-7, (lname, wname)
+
+
+def test_trainer_cross_entropy_vs_reference_golden(O, golden_dir):
+    """ModelTrainer with the reference CLI's default losser (train.py:117 --loss CrossEntropy) on padded batches: the reported
+    epoch loss includes log(C) per masked utterance (loss.py:19-21 re-applies log_softmax to pred * mask); the parameter updates
+    equal the NLL run's.  Golden: the reference's own trainer, one epoch of three batches (tests/golden/trainer_ce.npz)."""
+    from model_trainer import ModelTrainer
+    g = _g(golden_dir, "trainer_ce.npz")
+    tr = ModelTrainer(torch.device("cuda:0"), lr=1e-3, test_step=1, lr_decay=0.98, model="MARN1_sps", loss="CrossEntropy", n_classes=6,
+                      dataset="IEMOCAP", quiet=True)
+    load_params(tr.model, O.seeded_params(seed=5, d_r=1024))
+    B, L = 3, 10
+    batches = []
+    for s in range(3):
+        x, qmask, umask, label = O.seeded_batch(B, L, d_r=1024, seed=40 + s, ragged=True)
+        r = x[:, :, :1024]
+        d = torch.tensor(np.random.RandomState(s).standard_normal(tuple(r.shape)).astype(np.float32)) * 0.1
+        batches.append([r + d, r - d, r + 2 * d, r - 2 * d, torch.zeros(L, B, 4), x[:, :, 1024:], qmask, umask, label, ["v"] * B])
+    lr, avg = tr.train_network(1, batches)
+    assert lr == pytest.approx(float(g["lr1"]), rel=1e-9)
+    assert abs(avg - float(g["avg_loss1"])) <= 2e-4, (avg, float(g["avg_loss1"]))
+    sd = tr.model.state_dict()
+    worst = max(float(np.abs(sd[k[2:]].detach().cpu().numpy().reshape(-1)[:16] - g[k]).max()) for k in g.files if k.startswith("p/"))
+    assert worst < 3e-4, worst
