@@ -50,6 +50,9 @@ struct DirP {
   // in-kernel weight-gradient roles (cell_bwd_fused): LSTHM input rows in direction time order and the gradient tensors
   const float* xw[2]; long ldxw[2];
   float *gW[2], *gU[2], *gV[2], *gS[2], *gWih[2], *gWhh[2];
+  float* gbias_s[2][4];
+  float* gbias[2][4];  // bias gradients that receive the column sums of the gate gradients: LSTHM stream m: W,U,V,S .bias; speaker
+                       // cell c (wgrad_role<true>): bias_ih, bias_hh, -, -
 };
 
 struct CellK {
@@ -1632,6 +1635,10 @@ __device__ __forceinline__ void wgrad_role(const CellK& P, int id, const WS& ws,
   f32x16 acc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc[j] = f32x16{0};
+  // the first wave of every row tile also sums its 32 gate columns over all rows: the bias gradients (a colsum launch less per
+  // stream / cell after the chains)
+  const bool do_bias = nt0 == 0;
+  float csum = 0.f;
   const unsigned* cnt = P.sync + (SPK ? SYNC_SPK_BWD : SYNC_LSTHM_BWD) + dir * SYNC_DIR;
   for (int t_hi = T - 1; t_hi >= 0; t_hi -= WG_CH) {
     const int t_lo = t_hi - WG_CH + 1 > 0 ? t_hi - WG_CH + 1 : 0;
@@ -1660,6 +1667,7 @@ __device__ __forceinline__ void wgrad_role(const CellK& P, int id, const WS& ws,
         for (int j = 0; j < 4; ++j) {
           const bool kok = k0 + 2 * j + half < B;
           const float av = kok ? a[j] : 0.f;
+          csum += av;
 #pragma unroll
           for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, ok[q] ? b[q][j] : 0.f, acc[q], 0, 0, 0);
         }
@@ -1667,6 +1675,14 @@ __device__ __forceinline__ void wgrad_role(const CellK& P, int id, const WS& ws,
     }
   }
   // ---- accumulate into the gradient tensors (each element has exactly one owner in the launch)
+  csum += __shfl_xor(csum, 32, 64);              // the two k-halves of the wave hold the same gate column
+  if (do_bias && half == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float* gb = SPK ? D.gbias_s[mc][q] : D.gbias[mc][q];
+      if (gb) gb[mt * 32 + r] += csum;
+    }
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int col = ((nt0 + q) % tps) * 32 + r;
@@ -2150,6 +2166,12 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
         k.gW[m] = G.lsthm_W[m]; k.gU[m] = G.lsthm_U[m]; k.gV[m] = G.lsthm_V[m]; k.gS[m] = G.lsthm_S[m];
         k.gWih[m] = G.q_Wih[m]; k.gWhh[m] = G.q_Whh[m];
       }
+      // NOTE: gbias is indexed [stream m] by the LSTHM roles and [cell c] by the speaker roles; both live in the same launch, so
+      // the two sets are kept in separate descriptors: LSTHM in gbias, speaker in gbias_s
+      for (int m = 0; m < 2; ++m) {
+        k.gbias[m][0] = G.lsthm_Wb[m]; k.gbias[m][1] = G.lsthm_Ub[m]; k.gbias[m][2] = G.lsthm_Vb[m]; k.gbias[m][3] = G.lsthm_Sb[m];
+        k.gbias_s[m][0] = G.q_bih[m]; k.gbias_s[m][1] = G.q_bhh[m]; k.gbias_s[m][2] = nullptr; k.gbias_s[m][3] = nullptr;
+      }
     }
   }
   if (phases & MSER_PHASE_BWD_PREP) {
@@ -2247,10 +2269,7 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       }
       if ((phases & MSER_PHASE_LSTHM_WGRAD) && G.lsthm_W[m]) {
         // dW_m += dg^T xdir ; dS_m += dg^T HQ ; dU_m += dg^T h_prev ; dV_m += dg^T z_prev  (unless the BPTT launch did them)
-        if (wgrad_in) {
-          MSER_TRY(colsum4(dg, TB, 4 * H, 4 * H, G.lsthm_Wb[m], G.lsthm_Ub[m], G.lsthm_Vb[m], G.lsthm_Sb[m], s));
-          continue;
-        }
+        if (wgrad_in) continue;        // weights AND biases were accumulated by the BPTT launch's wgrad roles
         g = gd(dg, 1, 4 * H, xs[m], lds[m], 1, G.lsthm_W[m], D, 4 * H, D, (int)TB);
         g.splitk = SPLITK;
         wg.push_back(g);
@@ -2312,10 +2331,7 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
     if (!G.q_Wih[0]) continue;
     for (int c = 0; c < 2; ++c) {
       const float* dsg = k.dsg + (long)c * TB * 4 * H;
-      if (wgrad_in) {
-        MSER_TRY(colsum4(dsg, TB, 4 * H, 4 * H, G.q_bih[c], G.q_bhh[c], nullptr, nullptr, s));
-        continue;
-      }
+      if (wgrad_in) continue;
       mser_gemm_desc g = gd(dsg, 1, 4 * H, k.qsel + (long)c * TB * H, H, 1, G.q_Wih[c], H, 4 * H, H, (int)TB);
       g.splitk = SPLITK;
       wg.push_back(g);
