@@ -35,10 +35,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 B, L, D_R, D_A, H, NCLS = 32, 128, 768, 100, 128, 6
 
 
-def synth_batch(seed, device, ragged=False):
+def synth_batch(seed, device, ragged=False, nb=None):
     """x ~ N(0,1), speaker ~ Bernoulli(0.5) one-hot, labels ~ U{0..5}; full-length dialogues for the headline,
     lengths ~ U{L/2..L} (tail zeroed in x, qmask, umask) for the ragged variant that exercises _reverse_seq / padding."""
     rs = np.random.RandomState(seed)
+    B = nb or globals()["B"]
     x = rs.standard_normal((L, B, D_R + D_A)).astype(np.float32)
     spk = rs.randint(0, 2, (L, B))
     qmask = np.eye(2, dtype=np.float32)[spk]
@@ -295,6 +296,10 @@ def main():
             for n, p in tr.model.named_parameters():
                 if n in saved:
                     p.copy_(saved[n])
+        b64 = synth_batch(3000, device, nb=64)
+        ms_b = time_steps(b64)
+        variants["batch_64_per_gpu"] = {"ms_per_step": round(ms_b, 4), "utterances_per_s": round(64 * L / (ms_b * 1e-3), 1),
+                                        "note": "two 32-row blocks per role in the persistent chains: the dependent steps are shared by twice the rows"}
         log("variants done")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
