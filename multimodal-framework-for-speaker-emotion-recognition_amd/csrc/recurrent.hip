@@ -62,6 +62,7 @@ struct CellK {
   unsigned wsbytes;
   unsigned* sync;      // persistent-kernel counters: [SYNC_*] words, zeroed by a memset node before every launch
   int wgrad_wgs;       // cell_bwd_fused: workgroups that accumulate the weight gradients while the BPTT chains run (0: none)
+  int stats_wgs;       // cell_fwd_fused: workgroups that compute the BPTT's softmax statistics beside the chains (0: the row phase does)
   int place;           // fused launches: roles are claimed by physical XCD (claim_role); the grid then covers every CU
   short place_base[8], place_cap[8];   // XCD x hosts logical workgroups place_base[x] .. place_base[x] + place_cap[x] - 1
   int ksplit;          // BPTT matvec phase: every product's K = 4H reduction is split over `ksplit` workgroups (1 or 2); the
@@ -692,7 +693,8 @@ __device__ __forceinline__ void lsthm_gates_body(const CellK& P, const DirP& D, 
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // `after_loads` runs right behind the row's own operand loads: loads issued there are YOUNGER than the row's, so the row phase
 // does not wait for them (vmcnt retires in order) -- used to fetch the next step's early-product operands under the exp2 work.
-template <bool PS, int JCT, class Hook = NoHook>       // JCT = keys per thread chunk when known at compile time (fully unrolled loops), 0 = runtime
+// STATS = false: the statistics are left to the stats roles of the fused launch (stats_fwd_role), off the chain.
+template <bool PS, int JCT, class Hook = NoHook, bool STATS = true>       // JCT = keys per thread chunk when known at compile time (fully unrolled loops), 0 = runtime
 __device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, const WS& ws, int t, int b, const float* att, float* scr,
                                              Hook after_loads = Hook()) {
   const int H = P.H, B = P.B, T = P.T;
@@ -737,19 +739,27 @@ __device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, cons
       const float e = __builtin_amdgcn_exp2f(fmaf(u2, k4.x, -m2));
       Z += e;
       N = fmaf(e, k4.y, N);
-      N2 = fmaf(e, k4.z, N2);
-      N3 = fmaf(e, k4.x, N3);
+      if (STATS) {
+        N2 = fmaf(e, k4.z, N2);
+        N3 = fmaf(e, k4.x, N3);
+      }
     }
   }
   float* pN3 = pN2 + NT;
-  if (q > 0) { pZ[tid] = Z; pN[tid] = N; pN2[tid] = N2; pN3[tid] = N3; }
+  if (q > 0) {
+    pZ[tid] = Z; pN[tid] = N;
+    if (STATS) { pN2[tid] = N2; pN3[tid] = N3; }
+  }
   __syncthreads();
   if (q == 0) {
-    for (int qq = 1; qq < Q; ++qq) { Z += pZ[qq * H + i]; N += pN[qq * H + i]; N2 += pN2[qq * H + i]; N3 += pN3[qq * H + i]; }
+    for (int qq = 1; qq < Q; ++qq) {
+      Z += pZ[qq * H + i]; N += pN[qq * H + i];
+      if (STATS) { N2 += pN2[qq * H + i]; N3 += pN3[qq * H + i]; }
+    }
     const float z = N / Z;
     stx<PS>(ws, D.hz + ((long)(t + 1) * B + b) * 3 * H + 2 * H + i, z);
     if (tau >= 0) D.out[((long)tau * B + b) * P.ldo + 2 * H + i] = z;
-    *reinterpret_cast<float4*>(D.rstat + (((long)t * B + b) * H + i) * 4) = make_float4(Z, N2, N3, s);
+    if (STATS) *reinterpret_cast<float4*>(D.rstat + (((long)t * B + b) * H + i) * 4) = make_float4(Z, N2, N3, s);
   }
   __syncthreads();     // scratch is reused by the next row / phase
 }
@@ -914,7 +924,7 @@ __global__ __launch_bounds__(NT) void lsthm_fwd_z(CellK P, int t) {
 
 // persistent launch: grid (H/8, 2 streams, ndir*nmb); two barriers per step (gates -> z -> next gates).  Runs concurrently with
 // spk_fwd_persist: step t starts only once the speaker counter shows h_q[t] published (checked inside the previous barrier).
-template <int NP>
+template <int NP, bool STATS = true>
 __device__ __forceinline__ void lsthm_fwd_role(const CellK& P, const Role R, float* smem, const WS& ws) {
   float* red = smem;
   float* tile = smem + RED_FLOATS;
@@ -956,7 +966,7 @@ __device__ __forceinline__ void lsthm_fwd_role(const CellK& P, const Role R, flo
     // h part of the next step's early product: requested behind the first row's own loads, in flight during the row phase
     bool fetched = !more;
     auto fetch = [&]() { if (!fetched) { lsthm_early_aload<NP, 0>(P, D, ws, t + 1, m, mb, a); fetched = true; } };
-    for (int b = w; b < P.B; b += (int)nwg) lsthm_z_body<true, JCT>(P, D, ws, t, b, att, red, fetch);
+    for (int b = w; b < P.B; b += (int)nwg) lsthm_z_body<true, JCT, decltype(fetch), STATS>(P, D, ws, t, b, att, red, fetch);
     fetch();                                                        // a workgroup that owns no row
     STAMP_ACC(4);
     if (!more) break;
@@ -1536,6 +1546,72 @@ __device__ __forceinline__ void spk_bwd_role(const CellK& P, const Role R, float
 // the speaker-chain workgroups.  They run concurrently as independent groups linked only by the producer's step counter
 // (forward: h_q[t]; backward: dHQ[t]).  One launch = one residency guarantee (grid <= CUs, one workgroup per CU through the LDS
 // request), independent of how a stream or hipGraph executor would have ordered two separate kernels.
+// Softmax statistics of the rank-1 attention rows for the BPTT (rstat: Z, N2 = sum e c_a Wk, N3 = sum e Wk, s), computed by
+// extra workgroups of the fused forward launch that follow the LSTHM chain through its step counter: in the row phase of the chain
+// the two extra sums cost 0.5-1 us per step of pure critical path; here they cost nothing (one workgroup handles rows
+// b = id, id + nsw, ... of a direction, ~1.2 us per row and step against a 7 us step).
+template <int JCT>
+__device__ __forceinline__ void stats_fwd_role(const CellK& P, int id, int nsw, float* smem, const WS& ws, unsigned nwg_l) {
+  const int H = P.H, B = P.B, T = P.T;
+  const int dir = id / nsw, w = id % nsw;
+  const DirP& D = P.d[dir];
+  float* scr = smem;
+  float* att = smem + RED_FLOATS;
+  int* lds_ok = (int*)(att + att_floats(H));
+  att_prepare(D, H, att, scr);
+  float4* kc = reinterpret_cast<float4*>(scr);
+  float* pZ = scr + 4 * H;
+  float* pN2 = pZ + NT;
+  float* pN3 = pN2 + NT;
+  float* sh = pN3 + NT;
+  const int Q = NT / H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = tid & (H - 1), q = tid / H;
+  const unsigned* cnt = P.sync + SYNC_LSTHM_FWD + dir * SYNC_DIR;
+  for (int t = 0; t < T; ++t) {
+    // c_l[t], c_a[t] are published behind the barrier that follows the gates phase of step t: barrier 2t + 1 of the chain
+    if (!lazy_wait(cnt, P.sync + SYNC_ABORT, nwg_l * (2u * (unsigned)t + 1u), lds_ok)) return;
+    for (int b = w; b < B; b += nsw) {
+      const float* c_l = D.cstate + ((long)0 * (T + 1) + t + 1) * B * H + (long)b * H;
+      const float* c_a = D.cstate + ((long)1 * (T + 1) + t + 1) * B * H + (long)b * H;
+      float sp = 0.f;
+      if (tid < H) {
+        const float cv = ldx<true>(ws, c_a + tid), wk = att[tid];
+        kc[tid] = make_float4(wk, cv, cv * wk, 0.f);
+        sp = att[H + tid] * cv;
+      }
+      const float cli = ldx<true>(ws, c_l + i);
+      sp = wave_sum(sp);
+      if (lane == 0) sh[wave] = sp;
+      __syncthreads();
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) s += sh[k];
+      s /= sqrtf((float)H);
+      const float u = cli * s;
+      const float mx = (u >= 0.f) ? u * att[2 * H] : u * att[2 * H + 1];
+      const float u2 = u * LOG2E, m2 = mx * LOG2E;
+      float Z = 0.f, N2 = 0.f, N3 = 0.f;
+      const float4* kcc = kc + q * JCT;
+#pragma unroll
+      for (int jj = 0; jj < JCT; ++jj) {
+        const float4 k4 = kcc[jj];
+        const float e = __builtin_amdgcn_exp2f(fmaf(u2, k4.x, -m2));
+        Z += e;
+        N2 = fmaf(e, k4.z, N2);
+        N3 = fmaf(e, k4.x, N3);
+      }
+      if (q > 0) { pZ[tid] = Z; pN2[tid] = N2; pN3[tid] = N3; }
+      __syncthreads();
+      if (q == 0) {
+        for (int qq = 1; qq < Q; ++qq) { Z += pZ[qq * H + i]; N2 += pN2[qq * H + i]; N3 += pN3[qq * H + i]; }
+        *reinterpret_cast<float4*>(D.rstat + (((long)t * B + b) * H + i) * 4) = make_float4(Z, N2, N3, s);
+      }
+      __syncthreads();
+    }
+  }
+}
+
 template <int NPS, int NPL>
 __global__ __launch_bounds__(NT) void cell_fwd_fused(CellK P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1548,11 +1624,20 @@ __global__ __launch_bounds__(NT) void cell_fwd_fused(CellK P) {
     if (id < 0) return;
   }
   set_logical_wg((unsigned)id);
+  if (id >= 2 * n_l) {        // statistics roles (P.stats_wgs > 0): off both chains
+    constexpr int JCT = (128 * NPL / 3) * (128 * NPL / 3) / NT;      // = H*H/NT, as in lsthm_fwd_role
+    stats_fwd_role<JCT>(P, id - 2 * n_l, P.stats_wgs / P.ndir, smem, ws, (unsigned)(gx * gy * P.nmb));
+    return;
+  }
   const bool lsthm = id < n_l;
   if (!lsthm) id -= n_l;
   const Role R{id % gx, (id / gx) % gy, id / (gx * gy), gx, gy};
-  if (lsthm) lsthm_fwd_role<NPL>(P, R, smem, ws);
-  else spk_fwd_role<NPS>(P, R, smem, ws);
+  if (lsthm) {
+    if (P.stats_wgs > 0) lsthm_fwd_role<NPL, false>(P, R, smem, ws);
+    else lsthm_fwd_role<NPL, true>(P, R, smem, ws);
+  } else {
+    spk_fwd_role<NPS>(P, R, smem, ws);
+  }
 }
 
 // The forward chains as two separate launches (MSER_PHASE_SEPARATE_SPEAKER): the speaker chain needs only qmask, so an eager
@@ -1887,7 +1972,7 @@ static size_t carve_all(char* base, const mser_cell_desc& d, CellHost* out) {
   Carver cv{base, 0};
   CellHost h;
   h.k.T = d.T; h.k.B = d.B; h.k.D = d.D; h.k.H = d.H; h.k.ndir = d.ndir; h.k.nmb = cdiv(d.B, 32); h.k.ldo = d.ldo;
-  h.k.wgrad_wgs = 0; h.k.ksplit = 1; h.k.place = 0;
+  h.k.wgrad_wgs = 0; h.k.ksplit = 1; h.k.place = 0; h.k.stats_wgs = 0;
   h.sync = cv.take<unsigned>(SYNC_WORDS);
   h.k.sync = h.sync;
   h.k.wsbase = base;
@@ -1975,6 +2060,7 @@ static size_t row_lds_bytes(int H) { return ((size_t)RED_FLOATS + 2 * (size_t)H 
 static int g_opt_persistent = 1;      // MSER_OPT_PERSISTENT
 static int g_opt_wgrad_inkernel = 1;  // MSER_OPT_WGRAD_INKERNEL
 static int g_opt_ksplit = 1;          // MSER_OPT_BPTT_KSPLIT
+static int g_opt_stats_roles = 1;     // MSER_OPT_FWD_STATS_ROLES
 static int g_opt_xcd_place = 0;       // MSER_OPT_XCD_PLACEMENT (off: measured slower end to end)
 static int g_num_cus = 0;
 constexpr size_t PERSIST_MIN_LDS = 84 * 1024;     // > half of the 160 KiB LDS: at most ONE persistent workgroup per CU
@@ -2093,11 +2179,13 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       hipLaunchKernelGGL(lsthm_fwd_persist<6>, dim3(H / 8, 2, d.ndir * K.nmb), dim3(NT), p_lds, s, K);
     }
   } else if (persist) {
-    // ONE launch for both chains: 2 x fwd_wgs workgroups (LSTHM roles first), linked by the speaker's step counter
+    // ONE launch for both chains: 2 x fwd_wgs workgroups (LSTHM roles first), linked by the speaker's step counter, plus (H = 128)
+    // 16 workgroups per direction that compute the BPTT's softmax statistics beside the chains
     ProfScope ps(MSER_PROF_LSTHM_FWD_GATES, s);
+    K.stats_wgs = (H == 128 && !K.place && g_opt_stats_roles && 2 * fwd_wgs + 16 * d.ndir <= num_cus()) ? 16 * d.ndir : 0;
     if (H == 128) {
       MSER_TRY(allow_lds((const void*)cell_fwd_fused<2, 3>, p_lds));
-      hipLaunchKernelGGL((cell_fwd_fused<2, 3>), dim3(K.place ? num_cus() : 2 * fwd_wgs), dim3(NT), p_lds, s, K);
+      hipLaunchKernelGGL((cell_fwd_fused<2, 3>), dim3(K.place ? num_cus() : 2 * fwd_wgs + K.stats_wgs), dim3(NT), p_lds, s, K);
     } else {
       MSER_TRY(allow_lds((const void*)cell_fwd_fused<4, 6>, p_lds));
       hipLaunchKernelGGL((cell_fwd_fused<4, 6>), dim3(2 * fwd_wgs), dim3(NT), p_lds, s, K);
@@ -2490,6 +2578,7 @@ int mser_set_option(int32_t key, int32_t value) {
     case MSER_OPT_WGRAD_INKERNEL: g_opt_wgrad_inkernel = value ? 1 : 0; return 0;
     case MSER_OPT_BPTT_KSPLIT: g_opt_ksplit = value ? 1 : 0; return 0;
     case MSER_OPT_XCD_PLACEMENT: g_opt_xcd_place = value ? 1 : 0; return 0;
+    case MSER_OPT_FWD_STATS_ROLES: g_opt_stats_roles = value ? 1 : 0; return 0;
     default: set_error("mser_set_option: unknown key %d", key); return -1;
   }
 }

@@ -510,6 +510,7 @@ MSER_OPT_PERSISTENT = 1
 MSER_OPT_WGRAD_INKERNEL = 2
 MSER_OPT_BPTT_KSPLIT = 3
 MSER_OPT_XCD_PLACEMENT = 4
+MSER_OPT_FWD_STATS_ROLES = 5
 
 
 def set_option(key: int, value: int) -> None:

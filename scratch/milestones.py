@@ -47,5 +47,5 @@ def run_config(tag):
 
 for rep in range(2):
     for v in (0, 1):
-        ops.set_option(ops.MSER_OPT_BPTT_KSPLIT, v)
-        run_config("bptt_ksplit=%d" % v)
+        ops.set_option(ops.MSER_OPT_FWD_STATS_ROLES, v)
+        run_config("fwd_stats_roles=%d" % v)
