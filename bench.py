@@ -260,11 +260,11 @@ def main():
                         note="dependency-latency bound recurrence (2 inter-workgroup hand-offs per time step); weights are "
                              "register-resident, so real HBM traffic is far below this streaming model")
         us_b, n_b = timed(4)     # MSER_PROF_LSTHM_BWD_ROW: brackets lsthm_bwd_persist (or each lsthm_bwd_row launch)
-        us_f, n_f = timed(2)     # MSER_PROF_LSTHM_FWD_GATES: brackets lsthm_fwd_persist (or each lsthm_fwd_gates launch)
+        us_f, n_f = timed(2)     # MSER_PROF_LSTHM_FWD_GATES: brackets cell_fwd_fused (or each lsthm_fwd_gates launch)
         # kernel = the symbol rocprofv3 reports (profiles/*_kernel_stats.csv): the BPTT launch is cell_bwd_fused (LSTHM BPTT with the
-        # speaker BPTT riding in the same grid), the forward chain is lsthm_fwd_persist (eager) / cell_fwd_fused (under capture)
+        # speaker BPTT riding in the same grid), the forward launch is cell_fwd_fused (LSTHM chain, speaker chain, statistics roles)
         roofline = entry("cell_bwd_fused" if us_b > 200 else "lsthm_bwd_row", us_b, n_b, True)
-        roofline["lsthm_forward"] = entry("lsthm_fwd_persist" if us_f > 200 else "lsthm_fwd_gates", us_f, n_f, False)
+        roofline["lsthm_forward"] = entry("cell_fwd_fused" if us_f > 200 else "lsthm_fwd_gates", us_f, n_f, False)
 
     log("roofline pass done")
 
@@ -300,6 +300,22 @@ def main():
         ms_b = time_steps(b64)
         variants["batch_64_per_gpu"] = {"ms_per_step": round(ms_b, 4), "utterances_per_s": round(64 * L / (ms_b * 1e-3), 1),
                                         "note": "two 32-row blocks per role in the persistent chains: the dependent steps are shared by twice the rows"}
+        # BASELINE.json configs[1] names hid=256 (in bf16; this build computes in fp32 to hold the 1e-4 logit gate): same batch, a
+        # second trainer at the wider cell.  Its chains run as persistent launches without the H = 128-only refinements
+        # (in-launch weight gradients, K-split, statistics roles).
+        tr256 = ModelTrainer(device, lr=1e-3, test_step=1, lr_decay=0.98, model="MARN1_sps", loss="NLL", n_classes=NCLS,
+                             dataset="IEMOCAP", d_r=D_R, hidden=256, quiet=True)
+        init_attention_weights(tr256.model)
+        tr256.train()
+        tr256.scheduler.step(0)
+        tr_main, tr = tr, tr256
+        try:
+            ms_h = time_steps((x, qmask, umask, label))
+        finally:
+            tr = tr_main
+        del tr256
+        variants["hidden_256_f32"] = {"ms_per_step": round(ms_h, 4), "utterances_per_s": round(B * L / (ms_h * 1e-3), 1),
+                                      "note": "configs[1] width; eager launches"}
         log("variants done")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -376,7 +376,8 @@ constexpr float LOG2E = 1.4426950408889634f;
 // NP > 0: the B fragments of this wave's NP k-passes were loaded once into bpre[][] (persistent kernels keep the weights in
 // registers across the whole time loop) and all A fragments are fetched before the first MFMA.
 template <int NP, class ALoad, class BLoad>
-__device__ __forceinline__ void wg_mm32(int K, ALoad aload, BLoad bload, const float (*bpre)[8], float* red, float* tile) {
+__device__ __forceinline__ void wg_mm32(int K, ALoad aload, BLoad bload, const float (*bpre)[8], float* red, float* tile,
+                                        bool red_aliases_a = false) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
   const int KC = ((K + NW * 16 - 1) / (NW * 16)) * 16;   // per-wave K chunk (multiple of 16)
@@ -404,6 +405,7 @@ __device__ __forceinline__ void wg_mm32(int K, ALoad aload, BLoad bload, const f
       for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
     }
   }
+  if (red_aliases_a) __syncthreads();        // `red` shares storage with the LDS-staged A operand: every wave has read its part
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
@@ -1347,6 +1349,22 @@ __device__ __forceinline__ void lsthm_bwd_role(const CellK& P, const Role R, flo
 // Prologue: every workgroup of the cell rebuilds the LSTMCell gate gradients for its 32 slots (element-wise, all loads issued
 // up front: one memory round trip), then raw = dsg @ W on the MFMA.  The redundant element-wise results are written to
 // global memory by exactly one workgroup per iteration slice (wsel), so no workgroup carries all the stores.
+// LDS of one speaker-BPTT workgroup: K-split partials `red` [NW][1024], reduced tile [1024], gate-gradient tile dsg_s [32][4H+4].
+// At H = 128 the three lie side by side (103 KB).  At H = 256 that would be 168 KB (> 160 KB): the partials then reuse the storage of
+// the gate-gradient tile, whose last read (A operand of the product) is separated from their first write by one barrier.
+struct SpkBwdLds { float* red; float* tile; float* dsg_s; int* lds_ok; bool alias; };
+__host__ __device__ __forceinline__ size_t spk_bwd_lds_floats(int H) {
+  return (H > 128 ? 0 : (size_t)RED_FLOATS) + 1024 + 32 * (4 * (size_t)H + 4);
+}
+__device__ __forceinline__ SpkBwdLds spk_bwd_lds(float* smem, int H) {
+  SpkBwdLds l;
+  l.alias = H > 128;
+  l.tile = smem + (l.alias ? 0 : RED_FLOATS);
+  l.dsg_s = l.tile + 1024;
+  l.red = l.alias ? l.dsg_s : smem;
+  l.lds_ok = (int*)(l.dsg_s + 32 * (4 * H + 4));
+  return l;
+}
 template <bool PS, int NP, bool WITHP = false>
 __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, const WS& ws, int t, int p, int n0, int mb, int wsel,
                                              const float (*bpre)[8], float* red, float* tile, float* dsg_s) {
@@ -1484,7 +1502,7 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, cons
 
   const float* Wp = (p & 1) ? D.Whh[c] : D.Wih[c];
   auto aload = [&](int r, int k, float* a) { load8(dsg_s + r * LDS_LD + k, a); };
-  wg_mm32<NP>(4 * H, aload, LsthmBwdB{Wp, n0, H}, bpre, red, tile);
+  wg_mm32<NP>(4 * H, aload, LsthmBwdB{Wp, n0, H}, bpre, red, tile, red == dsg_s);
   STAMP_ACC(1);
 #pragma unroll
   for (int e = 0; e < 1024 / NT; ++e) {
@@ -1504,18 +1522,20 @@ __global__ __launch_bounds__(NT) void spk_bwd_step(CellK P, int t) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const WS ws = make_ws(P.wsbase, P.wsbytes);
   const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
-  spk_bwd_body<false, 0>(P, P.d[dir], ws, t, blockIdx.y, blockIdx.x * 32, mb, (int)((blockIdx.y & 1) * gridDim.x + blockIdx.x), nullptr, smem, smem + RED_FLOATS,
-                         smem + RED_FLOATS + 1024);
+  const SpkBwdLds l = spk_bwd_lds(smem, P.H);
+  spk_bwd_body<false, 0>(P, P.d[dir], ws, t, blockIdx.y, blockIdx.x * 32, mb, (int)((blockIdx.y & 1) * gridDim.x + blockIdx.x), nullptr, l.red, l.tile,
+                         l.dsg_s);
 }
 
 // persistent launch: same grid, one barrier per step.  Runs concurrently with lsthm_bwd_persist: step t starts once that kernel's
 // counter shows dHQ[t] complete (value 2*(T-t)*nwg_l; checked inside the previous step's barrier).
 template <int NP>
 __device__ __forceinline__ void spk_bwd_role(const CellK& P, const Role R, float* smem, const WS& ws, unsigned nwg_l) {
-  float* red = smem;
-  float* tile = smem + RED_FLOATS;
-  float* dsg_s = tile + 1024;
-  int* lds_ok = (int*)(dsg_s + 32 * (4 * P.H + 4));
+  const SpkBwdLds l = spk_bwd_lds(smem, P.H);
+  float* red = l.red;
+  float* tile = l.tile;
+  float* dsg_s = l.dsg_s;
+  int* lds_ok = l.lds_ok;
   const int dir = R.z / P.nmb, mb = R.z % P.nmb;
   const DirP& D = P.d[dir];
   const int p = R.y, n0 = R.x * 32;
@@ -1998,8 +2018,8 @@ static int validate(const mser_cell_desc& d, bool bwd) {
   MSER_REQUIRE(d.ldo >= 4L * d.H, "marn_cell: ldo=%ld < 4H", (long)d.ldo);
   MSER_REQUIRE(d.workspace_bytes < 0x7fffffffULL, "marn_cell: workspace of %zu bytes exceeds the 2 GiB addressable through one buffer descriptor", d.workspace_bytes);
   if (bwd) {
-    const size_t spk_tile = ((size_t)RED_FLOATS + 1024 + 32 * (4 * (size_t)d.H + 4)) * sizeof(float) + 64;
-    MSER_REQUIRE(spk_tile <= 160 * 1024, "marn_cell_bwd: H=%d not supported yet: the speaker BPTT's gate-gradient tile needs %zu bytes "
+    const size_t spk_tile = spk_bwd_lds_floats(d.H) * sizeof(float) + 64;
+    MSER_REQUIRE(spk_tile <= 160 * 1024, "marn_cell_bwd: H=%d not supported: the speaker BPTT's gate-gradient tile needs %zu bytes "
                  "of LDS (> 160 KiB)", d.H, spk_tile);
   }
   for (int i = 0; i < d.ndir; ++i) {
@@ -2277,7 +2297,7 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   // ---- LSTHM chain, reverse time
   if (persist) {
     // ONE launch for both BPTT chains: bwd_nwg*ndir LSTHM workgroups + spk_wgs*ndir speaker workgroups
-    const size_t f_lds = persist_lds(mm_lds + 32 * (4 * (size_t)H + 4) * sizeof(float) + 64);
+    const size_t f_lds = persist_lds(std::max(p_lds, spk_bwd_lds_floats(H) * sizeof(float) + 64));
     const unsigned roles = (unsigned)(((long)bwd_nwg + spk_wgs) * d.ndir + K.wgrad_wgs);
     K.place = (place_ok && bwd_nwg == 32 && spk_wgs == 16 && num_cus() == 256) ? 1 : 0;
     if (K.place) {
@@ -2404,7 +2424,7 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   wg.clear();
   if (!(phases & MSER_PHASE_SPEAKER_BWD)) return 0;
   // ---- speaker chain, reverse time
-  const size_t spk_lds = mm_lds + 32 * (4 * (size_t)H + 4) * sizeof(float);
+  const size_t spk_lds = spk_bwd_lds_floats(H) * sizeof(float) + 64;
   if (!persist) {      // persistent mode: the speaker BPTT chain already ran inside the fused launch of the LSTHM_BWD phase
     MSER_TRY(allow_lds((const void*)spk_bwd_step, spk_lds));
     for (int t = T - 1; t >= 0; --t) {

@@ -33,7 +33,7 @@ class ModelTrainer(nn.Module):
         self.device = torch.device(device)
         self.dataset = dataset
         if model == 'MARN1_sps':
-            self.model = MARN1_sps(n_classes, d_r=kwargs.get("d_r", 1024)).to(self.device)
+            self.model = MARN1_sps(n_classes, d_r=kwargs.get("d_r", 1024), hidden=kwargs.get("hidden", 128)).to(self.device)
         elif model in _OUT_OF_SCOPE:
             raise NotImplementedError(f"model '{model}' is outside the accelerated hot path (SURVEY.md 8(f)); only 'MARN1_sps' is built")
         else:

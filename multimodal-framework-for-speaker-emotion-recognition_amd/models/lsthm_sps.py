@@ -6,8 +6,10 @@ arithmetic runs in libmser (HIP, gfx950): ``MARN1_sps.forward`` is ONE autograd 
 explicit kernel sequences of ``mser.model_fn``; parameters live in one flat buffer (``mser.flat``).
 
 Differences that are deliberate and documented (DESIGN.md): Dropout sites are identities (parity is defined at p = 0);
-extra keyword-only constructor arguments (``d_r``, ``xattn_heads``) default to the reference's hard-coded values; there is
-no CPU execution path.
+extra keyword-only constructor arguments (``d_r``, ``xattn_heads``, ``hidden``) default to the reference's hard-coded values;
+there is no CPU execution path.  ``hidden`` (128 or 256) sets every width the reference hard-codes as 128 (LSTHM cell, speaker
+cell, rank-1 attention, sequence-level attention); at 256 parity is checked against the oracle only (the reference cannot be
+constructed at that width).
 """
 import torch
 import torch.nn as nn
@@ -78,9 +80,9 @@ class CrossAttention(nn.Module):
     """Reference model/lsthm_sps.py:47-72: per-step attention over the FEATURE axis; computed in its rank-1 form
     (logits[b,i,j] = x1[b,i] * <Wq,x2[b]>/sqrt(dh) * Wk[j]) without materialising [B,dh,dh].  ``Wv`` is unused there too."""
 
-    def __init__(self, attn_dropout=0.2):
+    def __init__(self, attn_dropout=0.2, *, dh=128):
         super(CrossAttention, self).__init__()
-        self.dh = 128
+        self.dh = dh
         self.Wq = nn.Parameter(torch.ones(self.dh).unsqueeze(0))
         self.Wk = nn.Parameter(torch.ones(self.dh).unsqueeze(0))
         self.Wv = nn.Parameter(torch.ones(self.dh).unsqueeze(0))
@@ -112,8 +114,8 @@ class _SeqCrossAttention(nn.Module):
     """Shared body of CrossAttention2 / CrossAttention3 (reference :75-101, :103-129): single-head (or, as an extension for the
     MFMA stress config, ``heads``-way) attention over the utterance axis between two time-major streams."""
 
-    def _init(self, d1, d2, heads):
-        self.dh, self.dk, self.dv = 100, 128, 128          # the reference ignores its ctor arguments and hard-codes these
+    def _init(self, d1, d2, heads, hidden=128):
+        self.dh, self.dk, self.dv = 100, hidden, hidden    # the reference ignores its ctor arguments and hard-codes 100, 128, 128
         self.heads = heads
         self.Wq = nn.Parameter(torch.ones(d1, self.dk))
         self.Wk = nn.Parameter(torch.ones(d2, self.dk))
@@ -146,16 +148,16 @@ class _SeqCrossAttention(nn.Module):
 
 
 class CrossAttention2(_SeqCrossAttention):
-    def __init__(self, dh, dk, dv, attn_dropout=0.2, *, heads=1):
+    def __init__(self, dh, dk, dv, attn_dropout=0.2, *, heads=1, hidden=128):
         super(CrossAttention2, self).__init__()
-        self._init(100, 100, heads)
+        self._init(100, 100, heads, hidden)
         self.dropout = nn.Dropout(attn_dropout)
 
 
 class CrossAttention3(_SeqCrossAttention):
-    def __init__(self, dh, dk, dv, attn_dropout=0.2, *, heads=1):
+    def __init__(self, dh, dk, dv, attn_dropout=0.2, *, heads=1, hidden=128):
         super(CrossAttention3, self).__init__()
-        self._init(100, 128, heads)
+        self._init(100, hidden, heads, hidden)
         self.dropout = nn.Dropout(attn_dropout)
 
 
@@ -173,15 +175,15 @@ _CELL_DEAD = ["crossatt_l2a.Wv", "crossatt_a2l.Wq", "crossatt_a2l.Wk", "crossatt
 class MARN_cell(nn.Module):
     """Reference model/lsthm_sps.py:132-221.  forward(x, x_l, x_a, qmask) -> h [T,N,3*dh+dh_s] = cat(h_l,h_a,z_l,h_q)."""
 
-    def __init__(self, dh_l, dh_a, d_l, d_a, dropout=0.5) -> None:
+    def __init__(self, dh_l, dh_a, d_l, d_a, dropout=0.5, *, dh_s=128) -> None:
         super(MARN_cell, self).__init__()
-        self.crossatt_l2a = CrossAttention()
-        self.crossatt_a2l = CrossAttention()
+        self.crossatt_l2a = CrossAttention(dh=dh_s)
+        self.crossatt_a2l = CrossAttention(dh=dh_s)
         self.dh_l, self.dh_a = dh_l, dh_a
         self.dh_q = dh_l
         self.d_l, self.d_a = d_l, d_a
         self.speaker_size = 4 * self.dh_l
-        self.dh_s = 128
+        self.dh_s = dh_s
         self.lsthm_l = LSTHM1(self.dh_l, self.d_l, self.dh_l, self.dh_s)
         self.lsthm_a = LSTHM1(self.dh_a, self.d_a, self.dh_l, self.dh_s)
         self.lstm_q0 = nn.LSTMCell(self.dh_s, self.dh_s)
@@ -192,7 +194,7 @@ class MARN_cell(nn.Module):
     def forward(self, x, x_l, x_a, qmask):
         require_gpu(x_l, x_a, qmask)
         if not (self.dh_l == self.dh_a == self.dh_s):
-            raise RuntimeError("MARN_cell: the reference only runs with dh_l == dh_a == dh_s (=128)")
+            raise RuntimeError("MARN_cell: the reference only runs with dh_l == dh_a == dh_s (128 there)")
         H, D = self.dh_l, self.d_l
         params = dict(self.named_parameters())
         names = _CELL_LIVE
@@ -251,16 +253,18 @@ class MARN1_sps(nn.Module):
     """Reference model/lsthm_sps.py:298-409.  forward(x [L,B,d_r+d_a], qmask [L,B,2], umask [B,L]) ->
     (log_probs [B*L, n_classes], x_l [L,B,100], x_a [L,B,100])."""
 
-    def __init__(self, n_classes, *, d_r=1024, xattn_heads=1):
+    def __init__(self, n_classes, *, d_r=1024, xattn_heads=1, hidden=128):
         super(MARN1_sps, self).__init__()
+        if hidden not in (128, 256):
+            raise ValueError(f"hidden={hidden}: the recurrent chains are built for 128 (the reference's width) and 256")
         self.d_l, self.d_a, self.d_r = 100, 100, d_r
-        self.dh_l, self.dh_a = 128, 128
-        self.dh_sp, self.dh_li = 128, 128
+        self.dh_l, self.dh_a = hidden, hidden
+        self.dh_sp, self.dh_li = hidden, hidden
         self.total_h_dim = self.dh_l + self.dh_a
 
         self.linear_in = nn.Linear(self.d_r, self.d_l)
-        self.marn_cell_f = MARN_cell(self.dh_l, self.dh_a, self.d_l, self.d_a)
-        self.marn_cell_b = MARN_cell(self.dh_l, self.dh_a, self.d_l, self.d_a)
+        self.marn_cell_f = MARN_cell(self.dh_l, self.dh_a, self.d_l, self.d_a, dh_s=hidden)
+        self.marn_cell_b = MARN_cell(self.dh_l, self.dh_a, self.d_l, self.d_a, dh_s=hidden)
 
         output_dim = n_classes
         final_out = 2 * (self.total_h_dim + self.dh_l + self.dh_l) + self.dh_l + self.dh_a
@@ -273,10 +277,10 @@ class MARN1_sps(nn.Module):
         d_inner, n_head, d_k, d_v = 40, 8, 40, 40
         self.encoder_l = EncoderLayer(100, d_inner, n_head, d_k, d_v)
         self.encoder_a = EncoderLayer(100, d_inner, n_head, d_k, d_v)
-        self.crossatt_l2a = CrossAttention2(self.d_l, self.dh_l, self.dh_l, heads=xattn_heads)
-        self.crossatt_a2l = CrossAttention2(self.d_a, self.dh_a, self.dh_a, heads=xattn_heads)
-        self.crossatt_l2a_1 = CrossAttention3(self.dh_l, self.d_l, self.d_l, heads=xattn_heads)
-        self.crossatt_a2l_1 = CrossAttention3(self.dh_a, self.d_a, self.d_a, heads=xattn_heads)
+        self.crossatt_l2a = CrossAttention2(self.d_l, self.dh_l, self.dh_l, heads=xattn_heads, hidden=hidden)
+        self.crossatt_a2l = CrossAttention2(self.d_a, self.dh_a, self.dh_a, heads=xattn_heads, hidden=hidden)
+        self.crossatt_l2a_1 = CrossAttention3(self.dh_l, self.d_l, self.d_l, heads=xattn_heads, hidden=hidden)
+        self.crossatt_a2l_1 = CrossAttention3(self.dh_a, self.d_a, self.d_a, heads=xattn_heads, hidden=hidden)
 
         self.w = nn.Parameter(torch.ones(1))
         self.v = nn.Parameter(torch.ones(1))

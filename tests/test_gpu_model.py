@@ -388,6 +388,40 @@ def test_model_batch_sizes_vs_oracle(O, B, L):
         assert maxabs(p.grad, r) < 3e-4 * max(1e-3, float(r.norm())), n
 
 
+@pytest.mark.parametrize("persistent", [1, 0])
+def test_model_hidden_256_vs_oracle(O, persistent):
+    """``hidden=256`` (BASELINE.json configs[1] width; a keyword extension, the reference hard-codes 128): forward and every
+    gradient against the CPU oracle, which restates the reference for any width -- parity unpinned by reference outputs, since
+    the reference cannot be built at this width.  Both launch modes of the chains (one persistent launch / one launch per step)."""
+    from models.lsthm_sps import MARN1_sps
+    from loss import MaskedLoss
+    from mser import ops
+    d_r, H, B, L = 768, 256, 12, 9
+    P = O.seeded_params(seed=41, d_r=d_r, H=H)
+    net = MARN1_sps(6, d_r=d_r, hidden=H).cuda().eval()
+    load_params(net, P)
+    x, qmask, umask, label = O.seeded_batch(B, L, d_r=d_r, seed=43, ragged=True)
+    ops.set_option(ops.MSER_OPT_PERSISTENT, persistent)
+    try:
+        lp, _, _ = net(x.cuda(), qmask.cuda(), umask.cuda())
+        loss = MaskedLoss(torch.nn.NLLLoss)(lp, label.cuda().view(-1), umask.cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_option(ops.MSER_OPT_PERSISTENT, 1)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    lp_ref, _, _ = O.marn1_sps_forward(Pr, x, qmask, umask, d_r=d_r, H=H)
+    loss_ref = O.masked_nll(lp_ref, label.view(-1), umask)
+    loss_ref.backward()
+    assert maxabs(lp, lp_ref) < LOGIT_TOL
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 2e-5
+    for n, p in net.named_parameters():
+        r = Pr[n].grad
+        if r is None:
+            continue
+        assert maxabs(p.grad, r) < 3e-4 * max(1e-3, float(r.norm())), n
+
+
 def test_lsthm1_and_cross_attention_standalone_backward(O):
     """Module-level LSTHM1 (reference :28-44) and CrossAttention (:59-72) with autograd: inputs and parameters receive the
     gradients the CPU oracle's autograd computes (5e-5 of the tensor's scale)."""
