@@ -22,7 +22,7 @@ extern "C" {
 
 typedef void* mser_stream_t; /* hipStream_t */
 
-#define MSER_VERSION 110   /* 110: + encoder layer, grouped GEMM, head tail, ingest, confusion, cell desc addends */
+#define MSER_VERSION 111   /* 110: + encoder layer, grouped GEMM, head tail, ingest, confusion, cell desc addends */
 
 int mser_version(void);
 const char* mser_last_error(void);
@@ -150,7 +150,10 @@ int mser_encoder_layer_wgrad_descs(const mser_encoder_desc* d, mser_gemm_desc* o
  * Classifier tail of the fusion head (model/lsthm_sps.py:390-393 after `self.fc`): y1r = y1 + x_l + x_a,
  * y2 = relu(nn_out.0(y1r)), y3 = nn_out.3(y2), lp[b*L+t] = log_softmax(y3[t*B+b]) -- one row-tiled launch, and its
  * whole backward (log_softmax, both Linear layers, both ReLUs incl. the one of `fc`, the residual fan-out) as one launch.
- * Dropout sites (:318,:323) are identities.  Weight gradients are left to the caller (mser_gemm_grouped over dy3 / dy2 / dy1).
+ * Dropout (:318,:323): identity when rng == NULL.  Otherwise the nn_out site is drawn here (site_out, p_out, element index
+ * row*F + n) and the backward scales dy1 by 1/(1-p_fc): the caller has applied the fc site to y1 in place (mser_dropout_apply)
+ * before the forward, so a dropped unit reads 0 and fails the ReLU test by itself.
+ * Weight gradients are left to the caller (mser_gemm_grouped over dy3 / dy2 / dy1).
  * ------------------------------------------------------------------------------------------------ */
 typedef struct mser_head_tail_desc {
   int32_t L, B, D, F, C;       /* rows = L*B time-major; D = d_l (100); F = nn_out hidden (32); C = classes */
@@ -166,6 +169,9 @@ typedef struct mser_head_tail_desc {
   float* dy3; float* dy2; float* dy1;            /* [rows, C], [rows, F], [rows, D] (dy1 = gradient at the fc output) */
   float* dx_l; float* dx_a;    /* [rows, D] written: d(y1r) (+ dx_*_in) */
   float* g_b0; float* g_b3; float* g_bfc;        /* ACCUMULATED bias gradients of nn_out.0, nn_out.3, fc.0 */
+  const uint32_t* rng;         /* dropout state {seed, step} in device memory, or NULL */
+  uint32_t site_out;
+  float p_out, p_fc;
 } mser_head_tail_desc;
 
 int mser_head_tail_fwd(const mser_head_tail_desc* d, mser_stream_t stream);
@@ -311,6 +317,18 @@ int mser_masked_nll_bwd(const int64_t* target, const float* mask, const float* l
 /* ------------------------------------------------------------------------------------------------
  * The steps either side of the model in the trainer's loops.
  * ------------------------------------------------------------------------------------------------ */
+/* Dropout.  A site's mask is a pure function of (rng[0] = seed, rng[1] = step, site, element index): nothing is stored between
+ * the forward and the backward, both evaluate keep(idx) = hash(seed, step, site, idx) >= p * 2^32 (two rounds of a 32-bit
+ * avalanche mix; the streams of torch's CPU generators cannot be reproduced on a GPU, so train-mode parity is defined mask for
+ * mask: mser_dropout_scale hands the factors to the checker).  rng lives in device memory; mser_rng_advance increments the step
+ * word on the device, so a captured graph draws fresh masks at every replay.
+ *   mser_dropout_apply : x[r, c] *= keep(idx0 + r*cols + c) ? 1/(1-p) : 0   (in place; activations and gradients alike)
+ *   mser_dropout_scale : out[e]   = keep(idx0 + e)          ? 1/(1-p) : 0 */
+int mser_dropout_apply(float* x, int64_t rows, int32_t cols, int64_t ld, const uint32_t* rng, uint32_t site, float p,
+                       uint32_t idx0, mser_stream_t stream);
+int mser_dropout_scale(float* out, int64_t n, const uint32_t* rng, uint32_t site, float p, uint32_t idx0, mser_stream_t stream);
+int mser_rng_advance(uint32_t* rng, mser_stream_t stream);
+
 /* Batch ingest (model_trainer.py:104-105, :138-139): x[r, :d_r] = (((r1+r2)+r3)+r4)/4, x[r, d_r:d_r+d_a] = acouf[r, :]; all
  * inputs contiguous [rows, d_r] / [rows, d_a], x contiguous [rows, d_r+d_a].  Bit-identical to the reference expression. */
 int mser_ingest_features(const float* r1, const float* r2, const float* r3, const float* r4, const float* acouf, float* x,

@@ -60,6 +60,32 @@ __device__ __forceinline__ float wave_max(float v) {
 // so no fast-math approximations on the recurrent path)
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// ---- counter-based dropout (include/mser.h "Dropout") -----------------------------------------------------------------------
+// keep(site, idx) is a pure function of (seed, step, site, idx): the forward and the backward of a step evaluate the same mask
+// without storing it, and mser_dropout_scale writes it out for a checker.  rng = {seed, step} in device memory (the step word is
+// advanced on the device, so a captured graph draws new masks at every replay).  Two rounds of a 32-bit avalanche mix.
+struct DropKey { uint32_t k0, k1, thr; float scale; };
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {      // drop iff bits < thr
+  const double v = (double)p * 4294967296.0;
+  return v <= 0.0 ? 0u : (v >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)v);
+}
+__device__ __forceinline__ DropKey drop_key(const uint32_t* rng, uint32_t site, float p) {
+  DropKey k;
+  const uint32_t seed = rng[0], step = rng[1];
+  k.k0 = mix32(seed ^ (site * 0x9E3779B9U) ^ 0x2545F491U);
+  k.k1 = mix32(step * 0x85EBCA6BU + site + 1U);
+  k.thr = drop_threshold(p);
+  k.scale = 1.0f / (1.0f - p);
+  return k;
+}
+__device__ __forceinline__ float drop_scale(const DropKey& k, uint32_t idx) {
+  return mix32(mix32(idx ^ k.k0) + k.k1) >= k.thr ? k.scale : 0.f;
+}
+
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 

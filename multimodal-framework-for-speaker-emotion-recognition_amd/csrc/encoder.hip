@@ -544,6 +544,8 @@ struct TailArgs {
   const float* dlp; const float* dxl_in; const float* dxa_in;
   float* dy3; float* dy2; float* dy1; float* dx_l; float* dx_a;
   float* g_b0; float* g_b3; float* g_bfc;
+  // dropout (rng == nullptr: identity): nn_out's site is evaluated here, fc's is applied by the caller on y1 before the forward
+  const uint32_t* rng; uint32_t site_out; float p_out, scale_fc;
 };
 
 __global__ __launch_bounds__(ET) void tail_fwd_kernel(TailArgs p) {
@@ -568,8 +570,11 @@ __global__ __launch_bounds__(ET) void tail_fwd_kernel(TailArgs p) {
   }
   for (int e = tid; e < RT * (FP - F); e += ET) hs[(e / (FP - F)) * FP + F + e % (FP - F)] = 0.f;
   __syncthreads();
+  DropKey dk;
+  if (p.rng) dk = drop_key(p.rng, p.site_out, p.p_out);
   wg_gemm32<0>(ys, DP, D, p.W0, D, F, red, [&](int row, int n, float s) {
-    const float hv = fmaxf(s + p.b0[n], 0.f);
+    float hv = fmaxf(s + p.b0[n], 0.f);
+    if (p.rng) hv *= drop_scale(dk, (uint32_t)((r0 + row) * F + n));       // nn_out Dropout (:323)
     hs[row * FP + n] = hv;
     if (r0 + row < rows) p.y2[(r0 + row) * F + n] = hv;
   });
@@ -615,10 +620,12 @@ __global__ __launch_bounds__(ET) void tail_bwd_kernel(TailArgs p) {
   }
   __syncthreads();
   colsum_tile(zs, CP8, C, p.g_b3);
-  // dy2 = (dy3 W3) o (y2 > 0)
+  // dy2 = (dy3 W3) o (y2 > 0); with dropout the saved y2 is the dropped one: a dropped unit reads 0 here, a kept one needs 1/(1-p)
+  const float sc_out = p.rng ? 1.0f / (1.0f - p.p_out) : 1.0f;
+  const float sc_fc = p.rng ? p.scale_fc : 1.0f;
   wg_gemm32<1>(zs, CP8, C, p.W3, F, F, red, [&](int row, int n, float s) {
     const bool rok = r0 + row < rows;
-    const float v = (rok && p.y2[(r0 + row) * F + n] > 0.f) ? s : 0.f;
+    const float v = (rok && p.y2[(r0 + row) * F + n] > 0.f) ? s * sc_out : 0.f;
     hs[row * FP + n] = v;
     if (rok) p.dy2[(r0 + row) * F + n] = v;
   });
@@ -631,7 +638,7 @@ __global__ __launch_bounds__(ET) void tail_bwd_kernel(TailArgs p) {
       const long g = (r0 + row) * D + n;
       p.dx_l[g] = s + (p.dxl_in ? p.dxl_in[g] : 0.f);
       p.dx_a[g] = s + (p.dxa_in ? p.dxa_in[g] : 0.f);
-      m = p.y1[g] > 0.f ? s : 0.f;
+      m = p.y1[g] > 0.f ? s * sc_fc : 0.f;
       p.dy1[g] = m;
     }
     ds[row * DP + n] = m;
@@ -830,6 +837,7 @@ static int tail_validate(const mser_head_tail_desc& d, bool bwd) {
   MSER_REQUIRE(d.y1 && d.x_l && d.x_a && d.w0 && d.b0 && d.w3 && d.b3 && d.y1r && d.y2 && d.lp, "mser_head_tail: null pointer");
   MSER_REQUIRE(al16(d.w0) && al16(d.w3), "mser_head_tail: weights must be 16-byte aligned");
   MSER_REQUIRE(tail_lds_bytes(d.D, d.F, d.C, bwd) <= LDS_MAX, "mser_head_tail: row tile exceeds LDS");
+  MSER_REQUIRE(!d.rng || (d.p_out >= 0.f && d.p_out < 1.f && d.p_fc >= 0.f && d.p_fc < 1.f), "mser_head_tail: dropout p out of [0,1)");
   if (bwd)
     MSER_REQUIRE(d.dlp && d.dy3 && d.dy2 && d.dy1 && d.dx_l && d.dx_a && d.g_b0 && d.g_b3 && d.g_bfc, "mser_head_tail_bwd: null gradient buffer");
   return 0;
@@ -842,6 +850,7 @@ static TailArgs tail_args(const mser_head_tail_desc& d) {
   p.dlp = d.dlp; p.dxl_in = d.dx_l_in; p.dxa_in = d.dx_a_in;
   p.dy3 = d.dy3; p.dy2 = d.dy2; p.dy1 = d.dy1; p.dx_l = d.dx_l; p.dx_a = d.dx_a;
   p.g_b0 = d.g_b0; p.g_b3 = d.g_b3; p.g_bfc = d.g_bfc;
+  p.rng = d.rng; p.site_out = d.site_out; p.p_out = d.p_out; p.scale_fc = 1.0f / (1.0f - d.p_fc);
   return p;
 }
 int head_tail(const mser_head_tail_desc& d, bool bwd, hipStream_t s) {

@@ -2,6 +2,7 @@
 // All of these are HBM/L2-bandwidth kernels: one 64-lane wave per row with butterfly (DPP shuffle) reductions,
 // rows short enough (<= 1280 floats) to live in registers between the passes.
 #include "common.h"
+#include <algorithm>
 #include "../../include/mser.h"
 
 namespace mser {
@@ -513,6 +514,24 @@ __global__ void dp_pack_kernel(float* buf, const float* g, const float* cnt, lon
   if (i == 0) buf[n] = c;
 }
 
+
+// ================================================================================================ dropout
+// x[r, c] *= keep(site, idx0 + r*cols + c) ? 1/(1-p) : 0, in place (forward activations and backward gradients alike);
+// out != nullptr: write the factor itself instead (mser_dropout_scale, for a checker that needs the mask as data).
+__global__ void dropout_apply_kernel(float* x, float* out, long rows, int cols, long ld, const uint32_t* rng, uint32_t site, float p,
+                                     uint32_t idx0) {
+  const DropKey k = drop_key(rng, site, p);
+  const long n = rows * cols;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / cols;
+    const int c = (int)(e - r * cols);
+    const float f = drop_scale(k, idx0 + (uint32_t)e);
+    if (out) out[e] = f;
+    else x[r * ld + c] *= f;
+  }
+}
+__global__ void rng_advance_kernel(uint32_t* rng) { rng[1] += 1u; }
+
 }  // namespace mser
 
 using namespace mser;
@@ -588,6 +607,32 @@ int mser_add_rows(float* out, int64_t ldo, const float* a, int64_t lda, const fl
   hipLaunchKernelGGL(add_rows_kernel, dim3(cdiv(rows * D, 256)), dim3(256), 0, (hipStream_t)stream, out, (long)ldo, a, (long)lda,
                      b, (long)ldb, (long)rows, D);
   return check_launch("mser_add_rows");
+}
+
+int mser_dropout_apply(float* x, int64_t rows, int32_t cols, int64_t ld, const uint32_t* rng, uint32_t site, float p,
+                       uint32_t idx0, mser_stream_t stream) {
+  MSER_REQUIRE(x && rng, "mser_dropout_apply: null pointer");
+  MSER_REQUIRE(p >= 0.f && p < 1.f && cols > 0 && ld >= cols, "mser_dropout_apply: bad arguments (p=%f cols=%d ld=%ld)", p, cols, (long)ld);
+  if (rows <= 0) return 0;
+  const long n = rows * cols;
+  hipLaunchKernelGGL(dropout_apply_kernel, dim3(std::min<long>(cdiv(n, 256), 4096)), dim3(256), 0, (hipStream_t)stream, x, (float*)nullptr,
+                     (long)rows, cols, (long)ld, rng, site, p, idx0);
+  return check_launch("mser_dropout_apply");
+}
+
+int mser_dropout_scale(float* out, int64_t n, const uint32_t* rng, uint32_t site, float p, uint32_t idx0, mser_stream_t stream) {
+  MSER_REQUIRE(out && rng, "mser_dropout_scale: null pointer");
+  MSER_REQUIRE(p >= 0.f && p < 1.f, "mser_dropout_scale: p=%f", p);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(dropout_apply_kernel, dim3(std::min<long>(cdiv(n, 256), 4096)), dim3(256), 0, (hipStream_t)stream, (float*)nullptr, out,
+                     (long)n, 1, 1L, rng, site, p, idx0);
+  return check_launch("mser_dropout_scale");
+}
+
+int mser_rng_advance(uint32_t* rng, mser_stream_t stream) {
+  MSER_REQUIRE(rng, "mser_rng_advance: null pointer");
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng);
+  return check_launch("mser_rng_advance");
 }
 
 int mser_ingest_features(const float* r1, const float* r2, const float* r3, const float* r4, const float* acouf, float* x,

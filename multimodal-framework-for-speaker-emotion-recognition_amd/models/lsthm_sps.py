@@ -19,7 +19,7 @@ from mser import ops
 from mser.autograd import ModuleFn, require_gpu
 from mser.flat import FlatStore
 from mser.functional import Layout
-from mser.model_fn import ModelDims, marn1_backward, marn1_forward
+from mser.model_fn import DropCfg, ModelDims, marn1_backward, marn1_forward
 from models.encoder import EncoderLayer, _Grads
 
 
@@ -230,7 +230,8 @@ class _MARN1Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, hook, x, qmask, umask):
         store = model._store
-        lp, x_l, x_a, c = marn1_forward(store.p, x, qmask, umask, model.dims, use_streams=model.use_streams)
+        lp, x_l, x_a, c = marn1_forward(store.p, x, qmask, umask, model.dims, use_streams=model.use_streams,
+                                        drop=model._drop_cfg(x.device))
         ctx.model, ctx.c = model, c
         ctx.set_materialize_grads(False)
         return lp, x_l, x_a
@@ -290,6 +291,9 @@ class MARN1_sps(nn.Module):
         self.dims = ModelDims(d_r=d_r, d_a=self.d_a, D=self.d_l, H=self.dh_l, n_head=n_head, d_k=d_k, d_v=d_v,
                               n_classes=n_classes, xattn_heads=xattn_heads)
         self.use_streams = True
+        self.dropout_seed = 0x5EED
+        self.dropout_enabled = False         # train-mode dropout (opt-in until the in-loop sites of MARN_cell are drawn too)
+        self._rng = None
         dead = [c + n for c in ("marn_cell_f.", "marn_cell_b.") for n in _CELL_DEAD]
         dead += [e + n for e in ("encoder_l.", "encoder_a.") for n in ("pos_ffn.fc.weight", "pos_ffn.fc.bias")]
         self._store = FlatStore(self, dead=dead)
@@ -308,6 +312,27 @@ class MARN1_sps(nn.Module):
                 break
             self._store.attach(device)
             self._hook = torch.zeros(1, device=device, requires_grad=True)
+
+    def _drop_cfg(self, device):
+        """Train mode: the p of every nn.Dropout of the module tree (so ``m.p = 0`` switches a site off, as in the reference) and
+        this step's generator words; eval mode: None.  The step word advances on the device (capturable)."""
+        if not (self.training and self.dropout_enabled):
+            return None
+        el, ea = self.encoder_l, self.encoder_a
+        cfg = DropCfg(
+            p_enc_l=(el.slf_attn.attention.dropout.p, el.slf_attn.dropout.p, el.pos_ffn.dropout.p),
+            p_enc_a=(ea.slf_attn.attention.dropout.p, ea.slf_attn.dropout.p, ea.pos_ffn.dropout.p),
+            p_xattn=(self.crossatt_l2a.dropout.p, self.crossatt_a2l.dropout.p, self.crossatt_l2a_1.dropout.p, self.crossatt_a2l_1.dropout.p),
+            p_fc=self.fc[2].p, p_out=self.nn_out[2].p, p_rec=self.dropout_rec.p,
+            p_cell=(self.marn_cell_f.dropout.p, self.marn_cell_b.dropout.p),
+            p_cell_attn=(self.marn_cell_f.crossatt_l2a.dropout.p, self.marn_cell_b.crossatt_l2a.dropout.p))
+        if not cfg.any():
+            return None
+        if self._rng is None or self._rng.device != device:
+            self._rng = torch.tensor([self.dropout_seed & 0x7FFFFFFF, 0], dtype=torch.int32, device=device)
+        ops.rng_advance_(self._rng)
+        cfg.rng = self._rng.clone()          # this step's words: the backward reads them even if another forward has run since
+        return cfg
 
     def forward(self, x, qmask, umask):
         require_gpu(x, qmask, umask)

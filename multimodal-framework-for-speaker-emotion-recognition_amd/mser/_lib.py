@@ -82,7 +82,8 @@ class HeadTailDesc(C.Structure):
                 ("y1r", C.c_void_p), ("y2", C.c_void_p), ("lp", C.c_void_p),
                 ("dlp", C.c_void_p), ("dx_l_in", C.c_void_p), ("dx_a_in", C.c_void_p),
                 ("dy3", C.c_void_p), ("dy2", C.c_void_p), ("dy1", C.c_void_p), ("dx_l", C.c_void_p), ("dx_a", C.c_void_p),
-                ("g_b0", C.c_void_p), ("g_b3", C.c_void_p), ("g_bfc", C.c_void_p)]
+                ("g_b0", C.c_void_p), ("g_b3", C.c_void_p), ("g_bfc", C.c_void_p),
+                ("rng", C.c_void_p), ("site_out", C.c_uint32), ("p_out", C.c_float), ("p_fc", C.c_float)]
 
 
 MSER_GEMM_RELU = 1
@@ -126,6 +127,9 @@ SIGNATURES = {
     "mser_logsoftmax_tb_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mser_masked_nll_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "mser_masked_nll_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "mser_dropout_apply": (C.c_int, [_vp, _i64, _i32, _i64, _vp, C.c_uint32, _f32, C.c_uint32, _vp]),
+    "mser_dropout_scale": (C.c_int, [_vp, _i64, _vp, C.c_uint32, _f32, C.c_uint32, _vp]),
+    "mser_rng_advance": (C.c_int, [_vp, _vp]),
     "mser_ingest_features": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "mser_confusion_update": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "mser_masked_loss_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp]),

@@ -48,33 +48,63 @@ def _zeros(*shape, like: Tensor, dtype=torch.float32) -> Tensor:
     return torch.zeros(*shape, device=like.device, dtype=dtype)
 
 
+# ====================================================================================================== dropout sites
+# Site numbers of the MARN1_sps path (include/mser.h "Dropout"; the reference lines are the nn.Dropout calls they stand for).
+SITE_ENC = 0        # + 3*call + {0: attention (encoder.py:83), 1: after fc (:54), 2: after w_2 (:106)}, call = 0..3 (text 1st/2nd, audio 1st/2nd)
+SITE_XATTN = 12     # + {0: crossatt_l2a, 1: crossatt_a2l, 2: crossatt_l2a_1, 3: crossatt_a2l_1}   (lsthm_sps.py:98,:126)
+SITE_FC = 16        # fc Dropout (:318)
+SITE_OUT = 17       # nn_out Dropout (:323)
+SITE_REC = 18       # + direction: dropout_rec on the cell outputs (:365,:374)
+SITE_CELL = 20      # + 4*direction + {0: h_q0/h_q1 (:183,:188), 1: h_l/h_a (:211,:213), 2: rank-1 attention (:69)}
+
+
+@dataclass
+class DropSite:
+    """One dropout site of one step: the device rng words, the site number and p.  ``None`` stands for the identity."""
+    rng: Tensor
+    site: int
+    p: float
+
+    def apply_(self, x: Tensor) -> Tensor:
+        ops.dropout_apply_(x, self.rng, self.site, self.p)
+        return x
+
+    def scale(self, n: int) -> Tensor:
+        return ops.dropout_scale(n, self.rng, self.site, self.p)
+
+
 # ====================================================================================================== attention core
 def attn_core_fwd(q: Tensor, k: Tensor, v: Tensor, out: Tensor, lq: Layout, lk: Layout, nh: int, dk: int, dv: int,
                   scale: float, mul: Optional[Tensor] = None, mask: Optional[Tensor] = None, mask_on: int = 1,
-                  fill: float = float("-inf")) -> Tensor:
-    """P = softmax(scale * Q K^T [* mul, masked]) ; out = P V.  q/k/v/out are 2-D row views [rows, nh*d]. Returns P."""
+                  fill: float = float("-inf"), drop: Optional[DropSite] = None):
+    """P = softmax(scale * Q K^T [* mul, masked]) ; out = dropout(P) V.  q/k/v/out are 2-D row views [rows, nh*d].
+    Returns P, or (P, dropout(P)) when a dropout site is given (the softmax backward needs the undropped P)."""
     nb, Lq, Lk = lq.nb, lq.nl, lk.nl
     ldq, ldk, ldv, ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
     P = _empty(nb, nh, Lq, Lk, like=q)
     ops.gemm_raw(q, k, P, Lq, Lk, dk, lq.sl * ldq, 1, 1, lk.sl * ldk, Lk, batch=(nb, nh), sA=(lq.sb * ldq, dk),
                  sB=(lk.sb * ldk, dk), sC=(nh * Lq * Lk, Lq * Lk), alpha=scale)
     ops.softmax_rows_(P, nb * nh * Lq, Lk, Lk, mul=mul, mask=mask, mask_on=mask_on, fill=fill)
-    ops.gemm_raw(P, v, out, Lq, dv, Lk, Lk, 1, lk.sl * ldv, 1, lq.sl * ldo, batch=(nb, nh), sA=(nh * Lq * Lk, Lq * Lk),
+    Pd = drop.apply_(P.clone()) if drop is not None else P
+    ops.gemm_raw(Pd, v, out, Lq, dv, Lk, Lk, 1, lk.sl * ldv, 1, lq.sl * ldo, batch=(nb, nh), sA=(nh * Lq * Lk, Lq * Lk),
                  sB=(lk.sb * ldv, dv), sC=(lq.sb * ldo, dv))
-    return P
+    return P if drop is None else (P, Pd)
 
 
 def attn_core_bwd(dO: Tensor, q: Tensor, k: Tensor, v: Tensor, P: Tensor, dq: Tensor, dk_: Tensor, dv_: Tensor, lq: Layout,
-                  lk: Layout, nh: int, dk: int, dv: int, scale: float, mul: Optional[Tensor] = None) -> None:
-    """Writes dq, dk_, dv_ (2-D row views shaped like q, k, v)."""
+                  lk: Layout, nh: int, dk: int, dv: int, scale: float, mul: Optional[Tensor] = None,
+                  drop: Optional[DropSite] = None, Pd: Optional[Tensor] = None) -> None:
+    """Writes dq, dk_, dv_ (2-D row views shaped like q, k, v).  With a dropout site: dV = Pd^T dO, dP = mask o (dO V^T)."""
     nb, Lq, Lk = lq.nb, lq.nl, lk.nl
     ldq, ldk, ldv, lddo = q.stride(0), k.stride(0), v.stride(0), dO.stride(0)
     PP = (nh * Lq * Lk, Lq * Lk)
     dP = torch.empty_like(P)
     ops.gemm_raw(dO, v, dP, Lq, Lk, dv, lq.sl * lddo, 1, 1, lk.sl * ldv, Lk, batch=(nb, nh), sA=(lq.sb * lddo, dv),
                  sB=(lk.sb * ldv, dv), sC=PP)
-    ops.gemm_raw(P, dO, dv_, Lk, dv, Lq, 1, Lk, lq.sl * lddo, 1, lk.sl * dv_.stride(0), batch=(nb, nh), sA=PP,
+    ops.gemm_raw(P if drop is None else Pd, dO, dv_, Lk, dv, Lq, 1, Lk, lq.sl * lddo, 1, lk.sl * dv_.stride(0), batch=(nb, nh), sA=PP,
                  sB=(lq.sb * lddo, dv), sC=(lk.sb * dv_.stride(0), dv))
+    if drop is not None:
+        drop.apply_(dP)
     ops.softmax_bwd_rows_(P, dP, nb * nh * Lq, Lk, Lk, mul=mul)
     ops.gemm_raw(dP, k, dq, Lq, dk, Lk, Lk, 1, lk.sl * ldk, 1, lq.sl * dq.stride(0), batch=(nb, nh), sA=PP,
                  sB=(lk.sb * ldk, dk), sC=(lq.sb * dq.stride(0), dk), alpha=scale)
@@ -95,10 +125,13 @@ class MhaCtx:
     v: Tensor = None
     qkv: Tensor = None
     P: Tensor = None
+    Pd: Tensor = None
     O: Tensor = None
     y1: Tensor = None
     mean: Tensor = None
     rstd: Tensor = None
+    drop_attn: Optional[DropSite] = None
+    drop_fc: Optional[DropSite] = None
     nh: int = 0
     dk: int = 0
     dv: int = 0
@@ -130,7 +163,8 @@ def _fused_qkv(P: Getter, G: Optional[Getter] = None):
 
 
 def mha_fwd(xq: Tensor, xk: Tensor, xv: Tensor, P: Getter, lq: Layout, lk: Layout, nh: int, dk: int, dv: int,
-            mask: Optional[Tensor] = None, out: Optional[Tensor] = None):
+            mask: Optional[Tensor] = None, out: Optional[Tensor] = None, drop_attn: Optional[DropSite] = None,
+            drop_fc: Optional[DropSite] = None):
     """MultiHeadAttention.forward -- reference model/encoder.py:27-60: bias-free projections, softmax(q/sqrt(dk) k^T) v,
     fc, + residual(q input), LayerNorm(eps 1e-6).  Inputs are contiguous 2-D row matrices.  ``mask`` (uint8 [nb,nh,Lq,Lk],
     0 = masked) reproduces masked_fill(mask == 0, -1e9) (:75-77).  Returns (out, ctx); ctx.P is the attention [nb,nh,Lq,Lk]."""
@@ -152,9 +186,14 @@ def mha_fwd(xq: Tensor, xk: Tensor, xv: Tensor, P: Getter, lq: Layout, lk: Layou
         ops.linear(xk, P("w_ks.weight"), c.k)
         ops.linear(xv, P("w_vs.weight"), c.v)
     c.O = _empty(rows, nv, like=xq)
-    c.P = attn_core_fwd(c.q, c.k, c.v, c.O, lq, lk, nh, dk, dv, 1.0 / (dk ** 0.5), mask=mask, mask_on=0, fill=-1e9)
+    c.drop_attn, c.drop_fc = drop_attn, drop_fc
+    c.P = attn_core_fwd(c.q, c.k, c.v, c.O, lq, lk, nh, dk, dv, 1.0 / (dk ** 0.5), mask=mask, mask_on=0, fill=-1e9, drop=drop_attn)
+    if drop_attn is not None:
+        c.P, c.Pd = c.P
     t = _empty(rows, D, like=xq)
     ops.linear(c.O, P("fc.weight"), t)
+    if drop_fc is not None:
+        drop_fc.apply_(t)                                  # :54 dropout(fc(.)) before the residual
     c.y1 = _empty(rows, D, like=xq)
     if out is None:
         out = _empty(rows, D, like=xq)
@@ -170,18 +209,21 @@ def mha_bwd(c: MhaCtx, dout: Tensor, P: Getter, G: Getter, dxq: Tensor, dxk: Ten
     dy1 = _empty(rows, D, like=dout)          # never modified afterwards: the deferred fc weight gradient reads it
     ops.layernorm_bwd(dout, c.y1, c.mean, c.rstd, P("layer_norm.weight"), dy1, G("layer_norm.weight"), G("layer_norm.bias"))
     dO = _empty(rows, nh * dv, like=dout)
-    ops.matmul(dy1, P("fc.weight"), dO)
-    ops.grad_weight(dy1, c.O, G("fc.weight"))
+    dt = dy1 if c.drop_fc is None else c.drop_fc.apply_(dy1.clone())      # gradient at the fc output (dy1 itself: the residual's)
+    ops.matmul(dt, P("fc.weight"), dO)
+    ops.grad_weight(dt, c.O, G("fc.weight"))
+    dk_kw = dict(drop=c.drop_attn, Pd=c.Pd)
     Wqkv, gWqkv = _fused_qkv(P, G) if (c.qkv is not None and dxq is dxk and dxk is dxv and init_q) else (None, None)
     if Wqkv is not None:
         nq = nh * dk
         dqkv = torch.empty_like(c.qkv)
-        attn_core_bwd(dO, c.q, c.k, c.v, c.P, dqkv[:, :nq], dqkv[:, nq:2 * nq], dqkv[:, 2 * nq:], c.lq, c.lk, nh, dk, dv, 1.0 / (dk ** 0.5))
+        attn_core_bwd(dO, c.q, c.k, c.v, c.P, dqkv[:, :nq], dqkv[:, nq:2 * nq], dqkv[:, 2 * nq:], c.lq, c.lk, nh, dk, dv, 1.0 / (dk ** 0.5),
+                      **dk_kw)
         ops.matmul(dqkv, Wqkv, dxq, R1=dy1)            # residual gradient + [dq|dk|dv] @ [Wq;Wk;Wv]  (one K = 2nq+nv GEMM)
         ops.grad_weight(dqkv, c.xq, gWqkv)
         return
     dq, dk_, dv_ = torch.empty_like(c.q), torch.empty_like(c.k), torch.empty_like(c.v)
-    attn_core_bwd(dO, c.q, c.k, c.v, c.P, dq, dk_, dv_, c.lq, c.lk, nh, dk, dv, 1.0 / (dk ** 0.5))
+    attn_core_bwd(dO, c.q, c.k, c.v, c.P, dq, dk_, dv_, c.lq, c.lk, nh, dk, dv, 1.0 / (dk ** 0.5), **dk_kw)
     first = True
     for nm, dg, xin, dx in (("w_qs.weight", dq, c.xq, dxq), ("w_ks.weight", dk_, c.xk, dxk), ("w_vs.weight", dv_, c.xv, dxv)):
         if dx is not None:
@@ -202,16 +244,19 @@ class FfnCtx:
     y2: Tensor = None
     mean: Tensor = None
     rstd: Tensor = None
+    drop: Optional[DropSite] = None
 
 
-def ffn_fwd(x: Tensor, P: Getter, out: Optional[Tensor] = None):
+def ffn_fwd(x: Tensor, P: Getter, out: Optional[Tensor] = None, drop: Optional[DropSite] = None):
     """PositionwiseFeedForward.forward -- reference model/encoder.py:101-113 (w_2(relu(w_1 x)) + x, LayerNorm; ``fc`` unused)."""
     rows, D = x.shape
-    c = FfnCtx(x=x)
+    c = FfnCtx(x=x, drop=drop)
     c.hdn = _empty(rows, P("w_1.weight").shape[0], like=x)
     ops.linear(x, P("w_1.weight"), c.hdn, bias=P("w_1.bias"), relu=True)
     t = _empty(rows, D, like=x)
     ops.linear(c.hdn, P("w_2.weight"), t, bias=P("w_2.bias"))
+    if drop is not None:
+        drop.apply_(t)                                     # :106 dropout(w_2(.)) before the residual
     c.y2 = _empty(rows, D, like=x)
     if out is None:
         out = _empty(rows, D, like=x)
@@ -225,9 +270,10 @@ def ffn_bwd(c: FfnCtx, dout: Tensor, P: Getter, G: Getter) -> Tensor:
     dy2 = _empty(rows, D, like=dout)
     ops.layernorm_bwd(dout, c.y2, c.mean, c.rstd, P("layer_norm.weight"), dy2, G("layer_norm.weight"), G("layer_norm.bias"))
     dh = _empty(rows, c.hdn.shape[1], like=dout)
-    ops.matmul(dy2, P("w_2.weight"), dh)
-    ops.grad_weight(dy2, c.hdn, G("w_2.weight"))
-    ops.colsum_acc(dy2, G("w_2.bias"))
+    dt = dy2 if c.drop is None else c.drop.apply_(dy2.clone())           # gradient at the w_2 output (dy2 itself: the residual's)
+    ops.matmul(dt, P("w_2.weight"), dh)
+    ops.grad_weight(dt, c.hdn, G("w_2.weight"))
+    ops.colsum_acc(dt, G("w_2.bias"))
     ops.relu_bwd_(dh, c.hdn)
     dx = _empty(rows, D, like=dout)
     ops.matmul(dh, P("w_1.weight"), dx, R1=dy2)                       # residual + FFN input path (dy2 stays intact for its wgrads)
@@ -283,16 +329,18 @@ def encoder_attention(c) -> Tensor:
 
 
 def encoder_layer_fwd(x: Tensor, x2: Optional[Tensor], P: Getter, lay: Layout, nh: int, dk: int, dv: int,
-                      mask: Optional[Tensor] = None, out: Optional[Tensor] = None):
+                      mask: Optional[Tensor] = None, out: Optional[Tensor] = None, drops=None):
     """EncoderLayer.forward on input (x + x2) -- reference model/encoder.py:130-133; x2 carries the residual of the model's
-    second pass (model/lsthm_sps.py:357-358).  Returns (out [rows,D], ctx)."""
+    second pass (model/lsthm_sps.py:357-358).  Returns (out [rows,D], ctx).  ``drops`` = (attention, fc, ffn) DropSites (each may
+    be None) selects the composed path, where every dropout site is a materialised tensor."""
     rows, D = x.shape
     if x2 is None and x.stride(0) == D:
         e0 = x
     else:
         e0 = _empty(rows, D, like=x)
         ops.add_rows(e0, x, x2)
-    if FUSED_ENCODER:
+    drops = drops if (drops is not None and any(s_ is not None for s_ in drops)) else None
+    if FUSED_ENCODER and drops is None:
         d = _encoder_desc(e0, P, lay, nh, dk, dv, mask)
         if d is not None and ops.encoder_layer_supported(d):
             nq, F = nh * dk, d.dff
@@ -308,8 +356,9 @@ def encoder_layer_fwd(x: Tensor, x2: Optional[Tensor], P: Getter, lay: Layout, n
             d.mean1, d.rstd1, d.mean2, d.rstd2 = (st[i].data_ptr() for i in range(4))
             ops.encoder_layer_fwd(d)
             return out, EncFusedCtx(desc=d, keep=(e0, mask, qkv, Pm, O, y1, e1, hdn, y2, st, out), P=Pm, rows=rows, D=D)
-    e1, cm = mha_fwd(e0, e0, e0, _sub(P, "slf_attn."), lay, lay, nh, dk, dv, mask=mask)
-    out, cf = ffn_fwd(e1, _sub(P, "pos_ffn."), out=out)
+    da, dfc, dffn = drops if drops is not None else (None, None, None)
+    e1, cm = mha_fwd(e0, e0, e0, _sub(P, "slf_attn."), lay, lay, nh, dk, dv, mask=mask, drop_attn=da, drop_fc=dfc)
+    out, cf = ffn_fwd(e1, _sub(P, "pos_ffn."), out=out, drop=dffn)
     return out, (cm, cf)
 
 
@@ -348,6 +397,8 @@ class XAttnCtx:
     Q: Tensor = None
     KV: Tensor = None
     P: Tensor = None
+    drop: Optional[DropSite] = None
+    Pd: Tensor = None
     l1: Layout = None
     l2: Layout = None
     heads: int = 1
@@ -356,10 +407,10 @@ class XAttnCtx:
 
 
 def xattn_fwd(x1: Tensor, a1: Optional[Tensor], x2: Tensor, a2: Optional[Tensor], Wq: Tensor, Wk: Tensor, Wv: Tensor,
-              l1: Layout, l2: Layout, out: Tensor, heads: int = 1):
+              l1: Layout, l2: Layout, out: Tensor, heads: int = 1, drop: Optional[DropSite] = None):
     """CrossAttention2/3.forward(a1*x1, a2*x2) -- reference model/lsthm_sps.py:88-101 / :116-129 with the learnable scalars of
     :377-383 folded into the projection GEMMs.  x1 [rows1,D1], x2 [rows2,D2]; out [rows1,Dv] (any leading dimension)."""
-    c = XAttnCtx(x1=x1, x2=x2, a1=a1, a2=a2, l1=l1, l2=l2, heads=heads)
+    c = XAttnCtx(x1=x1, x2=x2, a1=a1, a2=a2, l1=l1, l2=l2, heads=heads, drop=drop)
     Dk, Dv = Wq.shape[1], Wv.shape[1]
     c.dk, c.dv = Dk // heads, Dv // heads
     c.Q = _empty(x1.shape[0], Dk, like=x1)
@@ -367,7 +418,9 @@ def xattn_fwd(x1: Tensor, a1: Optional[Tensor], x2: Tensor, a2: Optional[Tensor]
     ops.matmul(x1, Wq, c.Q, alpha_dev=a1)
     ops.matmul(x2, Wk, c.KV[:, :Dk], alpha_dev=a2)
     ops.matmul(x2, Wv, c.KV[:, Dk:], alpha_dev=a2)
-    c.P = attn_core_fwd(c.Q, c.KV[:, :Dk], c.KV[:, Dk:], out, l1, l2, heads, c.dk, c.dv, 1.0 / (c.dk ** 0.5))
+    c.P = attn_core_fwd(c.Q, c.KV[:, :Dk], c.KV[:, Dk:], out, l1, l2, heads, c.dk, c.dv, 1.0 / (c.dk ** 0.5), drop=drop)
+    if drop is not None:
+        c.P, c.Pd = c.P                                     # :98 / :126 dropout(softmax(.)) before .V
     return c
 
 
@@ -378,7 +431,7 @@ def xattn_bwd(c: XAttnCtx, dout: Tensor, Wq: Tensor, Wk: Tensor, Wv: Tensor, gWq
     dQ = torch.empty_like(c.Q)
     dKV = torch.empty_like(c.KV)
     attn_core_bwd(dout, c.Q, c.KV[:, :Dk], c.KV[:, Dk:], c.P, dQ, dKV[:, :Dk], dKV[:, Dk:], c.l1, c.l2, c.heads, c.dk, c.dv,
-                  1.0 / (c.dk ** 0.5))
+                  1.0 / (c.dk ** 0.5), drop=c.drop, Pd=c.Pd)
     ops.grad_weight(dQ, c.x1, gWq, transposed=True, alpha_dev=c.a1)
     ops.grad_weight(dKV[:, :Dk], c.x2, gWk, transposed=True, alpha_dev=c.a2)
     ops.grad_weight(dKV[:, Dk:], c.x2, gWv, transposed=True, alpha_dev=c.a2)

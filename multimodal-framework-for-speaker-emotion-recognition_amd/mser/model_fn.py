@@ -1,7 +1,8 @@
 """Forward / backward of the whole MARN1_sps path (reference model/lsthm_sps.py:349-394) as explicit kernel sequences.
 
-``marn1_forward`` returns the outputs and a context object; ``marn1_backward`` consumes it.  Dropout sites of the
-reference are identities here (parity is defined in eval mode / p = 0, SURVEY.md 7 "Dropout").
+``marn1_forward`` returns the outputs and a context object; ``marn1_backward`` consumes it.  Dropout: ``drop=None`` (eval mode,
+or every p = 0) is the identity and the parity configuration (SURVEY.md 7 "Dropout"); a ``DropCfg`` draws every site from the
+counter-based generator of include/mser.h, the same mask in the forward and the backward.
 The two encoder branches (text / audio) and the speaker chain are independent until the LSTHM chain, so they are
 enqueued on side streams (fork/join with events; capturable into one hipGraph).
 """
@@ -34,6 +35,28 @@ class ModelDims:
 
 
 @dataclass
+class DropCfg:
+    """Dropout probabilities of one training step, site by site (defaults = the reference's constructor defaults), and the
+    step's generator words {seed, step} (int32 [2] on the device)."""
+    rng: Tensor = None
+    p_enc_l: tuple = (0.1, 0.1, 0.1)        # encoder_l: attention (encoder.py:83), after fc (:54), after w_2 (:106)
+    p_enc_a: tuple = (0.1, 0.1, 0.1)
+    p_xattn: tuple = (0.2, 0.2, 0.2, 0.2)   # crossatt_l2a, crossatt_a2l, crossatt_l2a_1, crossatt_a2l_1 (lsthm_sps.py:98,:126)
+    p_fc: float = 0.5                       # :318
+    p_out: float = 0.5                      # :323
+    p_rec: float = 0.5                      # :365, :374
+    p_cell: tuple = (0.5, 0.5)              # per direction: h_q0/h_q1, h_l/h_a (:183,:188,:211,:213)
+    p_cell_attn: tuple = (0.2, 0.2)         # per direction: rank-1 attention (:69)
+
+    def site(self, sid: int, p: float):
+        return F_.DropSite(self.rng, sid, float(p)) if p > 0 else None
+
+    def any(self) -> bool:
+        return any(p > 0 for p in (*self.p_enc_l, *self.p_enc_a, *self.p_xattn, self.p_fc, self.p_out, self.p_rec, *self.p_cell,
+                                   *self.p_cell_attn))
+
+
+@dataclass
 class ModelCtx:
     dims: ModelDims = None
     L: int = 0
@@ -59,6 +82,7 @@ class ModelCtx:
     lp: Tensor = None
     tail: object = None
     qmask: Tensor = None
+    drop: DropCfg = None
 
 
 def _sub(P: Getter, prefix: str) -> Getter:
@@ -76,8 +100,11 @@ class _Streams:
         return cls._s
 
 
-def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: ModelDims, use_streams: bool = True):
+def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: ModelDims, use_streams: bool = True,
+                  drop: Optional[DropCfg] = None):
     """x [L,B,d_r+d_a] f32, qmask [L,B,2] f32, umask [B,L] f32 -> (log_probs [B*L,C], x_l [L,B,D], x_a [L,B,D], ctx)."""
+    if drop is not None and not drop.any():
+        drop = None
     Ln, B, Fin = x.shape
     d = dims
     if Fin < d.d_r + d.d_a:
@@ -90,7 +117,16 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
     umask = umask.contiguous()
     N, D, H = Ln * B, d.D, d.H
     lay = Layout.time_major(Ln, B)
-    c = ModelCtx(dims=d, L=Ln, B=B, qmask=qmask)
+    c = ModelCtx(dims=d, L=Ln, B=B, qmask=qmask, drop=drop)
+
+    def enc_drops(call):            # call: 0/1 = text first/second pass, 2/3 = audio
+        if drop is None:
+            return None
+        ps = drop.p_enc_l if call < 2 else drop.p_enc_a
+        return tuple(drop.site(F_.SITE_ENC + 3 * call + i, ps[i]) for i in range(3))
+
+    def xa_drop(i):
+        return drop.site(F_.SITE_XATTN + i, drop.p_xattn[i]) if drop is not None else None
     c.x2d = x.view(N, Fin)
     cur = torch.cuda.current_stream()
     side = _Streams.get(x.device) if use_streams else None
@@ -105,12 +141,12 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
 
     def text_branch():
         ops.linear(c.x2d[:, :d.d_r], P("linear_in.weight"), c.xl0, bias=P("linear_in.bias"))
-        e1, c.enc[0] = F_.encoder_layer_fwd(c.xl0, None, Pl, lay, d.n_head, d.d_k, d.d_v)
-        _, c.enc[1] = F_.encoder_layer_fwd(c.xl0, e1, Pl, lay, d.n_head, d.d_k, d.d_v, out=c.x_l)
+        e1, c.enc[0] = F_.encoder_layer_fwd(c.xl0, None, Pl, lay, d.n_head, d.d_k, d.d_v, drops=enc_drops(0))
+        _, c.enc[1] = F_.encoder_layer_fwd(c.xl0, e1, Pl, lay, d.n_head, d.d_k, d.d_v, out=c.x_l, drops=enc_drops(1))
 
     def audio_branch():
-        e1, c.enc[2] = F_.encoder_layer_fwd(xa0, None, Pa, lay, d.n_head, d.d_k, d.d_v)
-        _, c.enc[3] = F_.encoder_layer_fwd(xa0, e1, Pa, lay, d.n_head, d.d_k, d.d_v, out=c.x_a)
+        e1, c.enc[2] = F_.encoder_layer_fwd(xa0, None, Pa, lay, d.n_head, d.d_k, d.d_v, drops=enc_drops(2))
+        _, c.enc[3] = F_.encoder_layer_fwd(xa0, e1, Pa, lay, d.n_head, d.d_k, d.d_v, out=c.x_a, drops=enc_drops(3))
 
     c.lens = torch.empty(B, device=x.device, dtype=torch.int32)
     c.rev = torch.empty(Ln, B, device=x.device, dtype=torch.int32)
@@ -133,14 +169,16 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
 
     # sequence-level cross-modal attention (:377-383): needs only the encoder outputs, so it runs beside the LSTHM chain
     def xattn_a():      # attn1 path
-        c.xa[0] = F_.xattn_fwd(c.x_l, w, c.x_a, v, P("crossatt_l2a.Wq"), P("crossatt_l2a.Wk"), P("crossatt_l2a.Wv"), lay, lay, c.A1, hh)
+        c.xa[0] = F_.xattn_fwd(c.x_l, w, c.x_a, v, P("crossatt_l2a.Wq"), P("crossatt_l2a.Wk"), P("crossatt_l2a.Wv"), lay, lay, c.A1, hh,
+                               drop=xa_drop(0))
         c.xa[2] = F_.xattn_fwd(c.x_a, v, c.A1, v1, P("crossatt_l2a_1.Wq"), P("crossatt_l2a_1.Wk"), P("crossatt_l2a_1.Wv"), lay, lay,
-                               c.Hcat[:, 8 * H:9 * H], hh)
+                               c.Hcat[:, 8 * H:9 * H], hh, drop=xa_drop(2))
 
     def xattn_b():      # attn2 path
-        c.xa[1] = F_.xattn_fwd(c.x_a, v, c.x_l, w, P("crossatt_a2l.Wq"), P("crossatt_a2l.Wk"), P("crossatt_a2l.Wv"), lay, lay, c.A2, hh)
+        c.xa[1] = F_.xattn_fwd(c.x_a, v, c.x_l, w, P("crossatt_a2l.Wq"), P("crossatt_a2l.Wk"), P("crossatt_a2l.Wv"), lay, lay, c.A2, hh,
+                               drop=xa_drop(1))
         c.xa[3] = F_.xattn_fwd(c.x_l, w, c.A2, v2, P("crossatt_a2l_1.Wq"), P("crossatt_a2l_1.Wk"), P("crossatt_a2l_1.Wv"), lay, lay,
-                               c.Hcat[:, 9 * H:10 * H], hh)
+                               c.Hcat[:, 9 * H:10 * H], hh, drop=xa_drop(3))
 
     # Counter-linked concurrent kernels need REAL concurrency: a hipGraph executor may serialise parallel branches in an order that
     # starts the consumer first (it would spin until its bounded time-out), so under stream capture the phases are ordered instead.
@@ -189,9 +227,15 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
         xattn_a()
         xattn_b()
 
+    # ---- dropout_rec on the two directions' outputs (:365, :374; the backward direction is already back in time order)
+    if drop is not None and drop.p_rec > 0:
+        for i in range(2):
+            drop.site(F_.SITE_REC + i, drop.p_rec).apply_(c.Hcat[:, 4 * H * i:4 * H * (i + 1)])
     # ---- fusion head (:390-393)
     c.y1 = torch.empty(N, D, device=x.device)
     ops.linear(c.Hcat, P("fc.0.weight"), c.y1, bias=P("fc.0.bias"), relu=True)
+    if drop is not None and drop.p_fc > 0:
+        drop.site(F_.SITE_FC, drop.p_fc).apply_(c.y1)
     # residual + nn_out + log_softmax: one row-tiled launch (csrc/encoder.hip tail_fwd_kernel)
     c.y1r = torch.empty(N, D, device=x.device)
     h_out = P("nn_out.0.weight").shape[0]
@@ -199,6 +243,8 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
     c.lp = torch.empty(B * Ln, d.n_classes, device=x.device)
     c.tail = ops.head_tail_desc(Ln, B, c.y1, c.x_l, c.x_a, P("nn_out.0.weight"), P("nn_out.0.bias"), P("nn_out.3.weight"),
                                 P("nn_out.3.bias"), c.y1r, c.y2, c.lp)
+    if drop is not None and (drop.p_fc > 0 or drop.p_out > 0):
+        c.tail.rng, c.tail.site_out, c.tail.p_out, c.tail.p_fc = drop.rng.data_ptr(), F_.SITE_OUT, drop.p_out, drop.p_fc
     ops.head_tail_fwd(c.tail)
     return c.lp, c.x_l.view(Ln, B, D), c.x_a.view(Ln, B, D), c
 
@@ -269,6 +315,9 @@ def _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams):
     ops.grad_weight(dy2, c.y1r, G("nn_out.0.weight"))
     ops.matmul(dy1, P("fc.0.weight"), dH)
     ops.grad_weight(dy1, c.Hcat, G("fc.0.weight"))
+    if c.drop is not None and c.drop.p_rec > 0:
+        for i in range(2):
+            c.drop.site(F_.SITE_REC + i, c.drop.p_rec).apply_(dH[:, 4 * H * i:4 * H * (i + 1)])
     # ---- the four sequence-level attention modules (two independent chains, side streams) run beside the LSTHM BPTT chain.
     # Each chain accumulates its x_l / x_a gradients into its own buffers (no cross-stream read-modify-write).
     w, v, v1, v2 = P("w"), P("v"), P("v1"), P("v2")

@@ -350,6 +350,32 @@ def masked_nll_bwd(target: Tensor, mask: Tensor, loss_out: Tensor, gscale: Optio
             "masked_nll_bwd")
 
 
+# ---- dropout (include/mser.h "Dropout"): rng = int32 tensor {seed, step} on the device
+def dropout_apply_(x: Tensor, rng: Tensor, site: int, p: float, idx0: int = 0) -> None:
+    """In place x[r, c] *= keep ? 1/(1-p) : 0 over a 2-D row view (unit column stride) or any contiguous tensor."""
+    _f32(x, "dropout_apply")
+    if x.dim() == 2 and x.stride(1) == 1:
+        rows, cols, ld = x.shape[0], x.shape[1], x.stride(0)
+    elif x.is_contiguous():
+        rows, cols, ld = 1, x.numel(), x.numel()
+    else:
+        raise RuntimeError("dropout_apply: need a contiguous tensor or a 2-D row view")
+    if rows * cols >= 1 << 32:
+        raise RuntimeError("dropout_apply: more than 2^32 elements in one site")
+    L.check(_lib().mser_dropout_apply(_p(x), rows, cols, ld, _p(rng), site, float(p), idx0, _stream()), "dropout_apply")
+
+
+def dropout_scale(n: int, rng: Tensor, site: int, p: float, idx0: int = 0) -> Tensor:
+    """The factors keep ? 1/(1-p) : 0 of elements idx0 .. idx0+n-1 of a site as data (for the checker)."""
+    out = torch.empty(n, device=rng.device)
+    L.check(_lib().mser_dropout_scale(_p(out), n, _p(rng), site, float(p), idx0, _stream()), "dropout_scale")
+    return out
+
+
+def rng_advance_(rng: Tensor) -> None:
+    L.check(_lib().mser_rng_advance(_p(rng), _stream()), "rng_advance")
+
+
 def ingest_features(r1: Tensor, r2: Tensor, r3: Tensor, r4: Tensor, acouf: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """x = cat((r1+r2+r3+r4)/4, acouf) along the last dim (reference model_trainer.py:104-105) in one launch."""
     for t in (r1, r2, r3, r4, acouf):

@@ -70,7 +70,7 @@ def lstm_cell(P: Params, pre: str, x: Tensor, h: Tensor, c: Tensor):
     return h2, c2
 
 
-def cross_attention(P: Params, pre: str, x1: Tensor, x2: Tensor) -> Tensor:
+def cross_attention(P: Params, pre: str, x1: Tensor, x2: Tensor, drop: Optional[Tensor] = None) -> Tensor:
     """CrossAttention.forward (per-step, over the FEATURE axis) -- model/lsthm_sps.py:59-72.
 
     As written: Q = x1 (x) Wq, K = x2 (x) Wk are [B,H,H]; softmax(Q/sqrt(dh) K, -1) x2.
@@ -81,10 +81,12 @@ def cross_attention(P: Params, pre: str, x1: Tensor, x2: Tensor) -> Tensor:
     Q = x1.unsqueeze(-1).matmul(P[pre + "Wq"])          # [B,H,H]
     K = x2.unsqueeze(-1).matmul(P[pre + "Wk"])          # [B,H,H]
     attn = F.softmax((Q / (H ** 0.5)).matmul(K), dim=-1)
+    if drop is not None:                                 # :69 self.dropout(attn); ``drop`` holds the factors 0 | 1/(1-p), [B,H,H]
+        attn = attn * drop
     return attn.matmul(x2.unsqueeze(-1)).squeeze(-1)
 
 
-def cross_attention_seq(P: Params, pre: str, x1: Tensor, x2: Tensor, heads: int = 1) -> Tensor:
+def cross_attention_seq(P: Params, pre: str, x1: Tensor, x2: Tensor, heads: int = 1, drop: Optional[Tensor] = None) -> Tensor:
     """CrossAttention2 / CrossAttention3 (over the UTTERANCE axis) -- model/lsthm_sps.py:88-101, :116-129.
 
     x1 [L1,B,D1], x2 [L2,B,D2] time-major -> [L1,B,Dv].  ``heads`` > 1 is the build's
@@ -98,6 +100,8 @@ def cross_attention_seq(P: Params, pre: str, x1: Tensor, x2: Tensor, heads: int 
     dk = Wq.shape[1]
     if heads == 1:
         attn = F.softmax((Q / (dk ** 0.5)).matmul(K.transpose(1, 2)), dim=-1)
+        if drop is not None:                             # :98 / :126; factors [B,L1,L2]
+            attn = attn * drop.reshape(attn.shape)
         return attn.matmul(V).permute(1, 0, 2)
     Bn, L1, _ = Q.shape
     L2 = K.shape[1]
@@ -106,23 +110,27 @@ def cross_attention_seq(P: Params, pre: str, x1: Tensor, x2: Tensor, heads: int 
     Kh = K.view(Bn, L2, heads, hd).transpose(1, 2)
     Vh = V.view(Bn, L2, heads, -1).transpose(1, 2)
     attn = F.softmax((Qh / (hd ** 0.5)).matmul(Kh.transpose(2, 3)), dim=-1)
+    if drop is not None:
+        attn = attn * drop.reshape(attn.shape)
     return attn.matmul(Vh).transpose(1, 2).reshape(Bn, L1, -1).permute(1, 0, 2)
 
 
 # --------------------------------------------------------------------------------------
 # encoder (model/encoder.py)
 # --------------------------------------------------------------------------------------
-def sdpa(q: Tensor, k: Tensor, v: Tensor, temperature: float, mask: Optional[Tensor] = None):
+def sdpa(q: Tensor, k: Tensor, v: Tensor, temperature: float, mask: Optional[Tensor] = None, drop: Optional[Tensor] = None):
     """ScaledDotProductAttention.forward -- model/encoder.py:71-86."""
     attn = (q / temperature).matmul(k.transpose(2, 3))
     if mask is not None:
         attn = attn.masked_fill(mask == 0, -1e9)
     attn = F.softmax(attn, dim=-1)
+    if drop is not None:                                 # :83 self.dropout(softmax); factors [B,nh,Lq,Lk]
+        attn = attn * drop
     return attn.matmul(v), attn
 
 
 def mha(P: Params, pre: str, q: Tensor, k: Tensor, v: Tensor, n_head: int, d_k: int, d_v: int,
-        mask: Optional[Tensor] = None):
+        mask: Optional[Tensor] = None, drops=(None, None)):
     """MultiHeadAttention.forward -- model/encoder.py:27-60 (bias-free projections, post-LN eps 1e-6)."""
     B, Lq, Lk = q.shape[0], q.shape[1], k.shape[1]
     residual = q
@@ -131,25 +139,31 @@ def mha(P: Params, pre: str, q: Tensor, k: Tensor, v: Tensor, n_head: int, d_k: 
     vh = linear(v, P[pre + "w_vs.weight"]).view(B, Lk, n_head, d_v).transpose(1, 2)
     if mask is not None:
         mask = mask.unsqueeze(1)
-    o, attn = sdpa(qh, kh, vh, d_k ** 0.5, mask)
+    o, attn = sdpa(qh, kh, vh, d_k ** 0.5, mask, drops[0])
     o = o.transpose(1, 2).contiguous().view(B, Lq, -1)
-    o = linear(o, P[pre + "fc.weight"]) + residual
+    o = linear(o, P[pre + "fc.weight"])
+    if drops[1] is not None:                             # :54 self.dropout(self.fc(q)); factors [B,Lq,D]
+        o = o * drops[1]
+    o = o + residual
     o = F.layer_norm(o, (o.shape[-1],), P[pre + "layer_norm.weight"], P[pre + "layer_norm.bias"], 1e-6)
     return o, attn
 
 
-def ffn(P: Params, pre: str, x: Tensor) -> Tensor:
+def ffn(P: Params, pre: str, x: Tensor, drop: Optional[Tensor] = None) -> Tensor:
     """PositionwiseFeedForward.forward -- model/encoder.py:101-113 (``fc`` is dead)."""
     y = linear(F.relu(linear(x, P[pre + "w_1.weight"], P[pre + "w_1.bias"])),
-               P[pre + "w_2.weight"], P[pre + "w_2.bias"]) + x
+               P[pre + "w_2.weight"], P[pre + "w_2.bias"])
+    if drop is not None:                                 # :106
+        y = y * drop
+    y = y + x
     return F.layer_norm(y, (y.shape[-1],), P[pre + "layer_norm.weight"], P[pre + "layer_norm.bias"], 1e-6)
 
 
 def encoder_layer(P: Params, pre: str, x: Tensor, n_head: int = 8, d_k: int = 40, d_v: int = 40,
-                  mask: Optional[Tensor] = None):
-    """EncoderLayer.forward -- model/encoder.py:130-133."""
-    o, attn = mha(P, pre + "slf_attn.", x, x, x, n_head, d_k, d_v, mask)
-    return ffn(P, pre + "pos_ffn.", o), attn
+                  mask: Optional[Tensor] = None, drops=(None, None, None)):
+    """EncoderLayer.forward -- model/encoder.py:130-133.  ``drops``: dropout factors of (attention, fc, ffn), each optional."""
+    o, attn = mha(P, pre + "slf_attn.", x, x, x, n_head, d_k, d_v, mask, drops[:2])
+    return ffn(P, pre + "pos_ffn.", o, drops[2]), attn
 
 
 def self_attention_lib(P: Params, pre: str, queries: Tensor, keys: Tensor, values: Tensor, h: int,
@@ -186,7 +200,7 @@ def slot_tables(qmask: Tensor):
     return party, perm, n0
 
 
-def speaker_recurrence(P: Params, pre: str, qmask: Tensor, Hs: int):
+def speaker_recurrence(P: Params, pre: str, qmask: Tensor, Hs: int, drop: Optional[Tensor] = None):
     """The qmask-only recurrence inside MARN_cell.forward (:172-207): returns h_q[t] for every step.
 
     Rows of the two LSTMCell states are indexed by compaction slot, not dialogue; padded slots
@@ -211,9 +225,13 @@ def speaker_recurrence(P: Params, pre: str, qmask: Tensor, Hs: int):
         if N0:
             q0_sel = torch.cat([h0[:N0], zeros[:B - N0]], 0)
             hq0, cq0 = lstm_cell(P, pre + "lstm_q0.", q0_sel, hq0, cq0)
+            if drop is not None:                         # :183 dropout on the carried state; factors [T,2,B,Hs] by slot row
+                hq0 = hq0 * drop[t, 0]
         if N1:
             q1_sel = torch.cat([h0[N0:], zeros[:B - N1]], 0)
             hq1, cq1 = lstm_cell(P, pre + "lstm_q1.", q1_sel, hq1, cq1)
+            if drop is not None:                         # :188
+                hq1 = hq1 * drop[t, 1]
         hq = torch.cat([hq0[:N0], hq1[:N1]], 0)
         m = qmask[t].unsqueeze(2)
         q = h0.unsqueeze(1) * (1 - m) + hq.unsqueeze(1) * m
@@ -221,11 +239,14 @@ def speaker_recurrence(P: Params, pre: str, qmask: Tensor, Hs: int):
     return torch.stack(out, 0)                                          # [T,B,Hs]
 
 
-def marn_cell(P: Params, pre: str, x_l: Tensor, x_a: Tensor, qmask: Tensor, H: int = 128, Hs: int = 128) -> Tensor:
-    """MARN_cell.forward -- model/lsthm_sps.py:156-221.  Returns h [T,B,3H+Hs] = cat(h_l,h_a,z_l,h_q)."""
+def marn_cell(P: Params, pre: str, x_l: Tensor, x_a: Tensor, qmask: Tensor, H: int = 128, Hs: int = 128,
+              drops: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """MARN_cell.forward -- model/lsthm_sps.py:156-221.  Returns h [T,B,3H+Hs] = cat(h_l,h_a,z_l,h_q).
+    ``drops`` (train mode): dropout factors "hq" [T,2,B,Hs] (:183,:188), "h" [T,2,B,H] (:211,:213), "attn" [T,B,H,H] (:69)."""
+    drops = drops or {}
     T, B, _ = x_l.shape
     dt, dev = x_l.dtype, x_l.device
-    hq_all = speaker_recurrence(P, pre, qmask.to(dt), Hs)
+    hq_all = speaker_recurrence(P, pre, qmask.to(dt), Hs, drops.get("hq"))
     h_l = torch.zeros(B, H, dtype=dt, device=dev)
     h_a, c_l, c_a, z = (torch.zeros_like(h_l) for _ in range(4))
     outs = []
@@ -233,7 +254,9 @@ def marn_cell(P: Params, pre: str, x_l: Tensor, x_a: Tensor, qmask: Tensor, H: i
         hq = hq_all[t]
         c_l, h_l = lsthm1(P, pre + "lsthm_l.", x_l[t], c_l, h_l, z, hq)     # :210
         c_a, h_a = lsthm1(P, pre + "lsthm_a.", x_a[t], c_a, h_a, z, hq)     # :212 (also z_l)
-        z = cross_attention(P, pre + "crossatt_l2a.", c_l, c_a)             # :215
+        if "h" in drops:                                                    # :211, :213 (the dropped h is the carried state)
+            h_l, h_a = h_l * drops["h"][t, 0], h_a * drops["h"][t, 1]
+        z = cross_attention(P, pre + "crossatt_l2a.", c_l, c_a, drops["attn"][t] if "attn" in drops else None)   # :215
         outs.append(torch.cat([h_l, h_a, z, hq], 1))
     return torch.stack(outs, 0)
 
@@ -253,35 +276,54 @@ def reverse_seq(X: Tensor, umask: Tensor) -> Tensor:
 
 def marn1_sps_forward(P: Params, x: Tensor, qmask: Tensor, umask: Tensor, d_r: int = 1024, d_a: int = 100,
                       H: int = 128, n_head: int = 8, d_k: int = 40, d_v: int = 40, xattn_heads: int = 1,
-                      return_intermediates: bool = False):
-    """MARN1_sps.forward -- model/lsthm_sps.py:349-394 (eval mode: every Dropout is the identity)."""
+                      return_intermediates: bool = False, drops: Optional[Dict[str, Tensor]] = None):
+    """MARN1_sps.forward -- model/lsthm_sps.py:349-394.  ``drops`` = None: eval mode (every Dropout is the identity).  Train mode
+    is restated with the dropout factors (0 | 1/(1-p)) as explicit inputs, keyed by site: "enc{0..3}.{attn,fc,ffn}" (text first /
+    second pass, audio first / second pass; [B,nh,L,L], [B,L,D], [B,L,D]), "xattn{0..3}" (crossatt_l2a, crossatt_a2l,
+    crossatt_l2a_1, crossatt_a2l_1; [B,L,L]), "rec0"/"rec1" ([L,B,4H], :365/:374), "fc" ([L,B,100], :318), "out" ([L,B,32], :323)
+    and "cell{0,1}.{hq,h,attn}" (see marn_cell).  Missing keys are identities."""
+    dr = drops or {}
+
+    def enc_dr(k):
+        return tuple(dr.get(f"enc{k}.{n}") for n in ("attn", "fc", "ffn"))
+
+    def cell_dr(k):
+        return {n: dr[f"cell{k}.{n}"] for n in ("hq", "h", "attn") if f"cell{k}.{n}" in dr}
     x_l = x[:, :, :d_r].permute(1, 0, 2)
     x_a = x[:, :, d_r:d_r + d_a].permute(1, 0, 2)
     x_l = linear(x_l, P["linear_in.weight"], P["linear_in.bias"])
-    x_l_1, _ = encoder_layer(P, "encoder_l.", x_l, n_head, d_k, d_v)
-    x_a_1, _ = encoder_layer(P, "encoder_a.", x_a, n_head, d_k, d_v)
-    x_l, _ = encoder_layer(P, "encoder_l.", x_l + x_l_1, n_head, d_k, d_v)
-    x_a, _ = encoder_layer(P, "encoder_a.", x_a + x_a_1, n_head, d_k, d_v)
+    x_l_1, _ = encoder_layer(P, "encoder_l.", x_l, n_head, d_k, d_v, drops=enc_dr(0))
+    x_a_1, _ = encoder_layer(P, "encoder_a.", x_a, n_head, d_k, d_v, drops=enc_dr(2))
+    x_l, _ = encoder_layer(P, "encoder_l.", x_l + x_l_1, n_head, d_k, d_v, drops=enc_dr(1))
+    x_a, _ = encoder_layer(P, "encoder_a.", x_a + x_a_1, n_head, d_k, d_v, drops=enc_dr(3))
     x_l = x_l.permute(1, 0, 2)
     x_a = x_a.permute(1, 0, 2)
 
-    h_f = marn_cell(P, "marn_cell_f.", x_l, x_a, qmask, H, H)
+    h_f = marn_cell(P, "marn_cell_f.", x_l, x_a, qmask, H, H, cell_dr(0))
+    if "rec0" in dr:
+        h_f = h_f * dr["rec0"]                                                # :365
     rev_x_l = reverse_seq(x_l, umask)
     rev_x_a = reverse_seq(x_a, umask)
     rev_qmask = reverse_seq(qmask, umask)
-    h_b_raw = marn_cell(P, "marn_cell_b.", rev_x_l, rev_x_a, rev_qmask, H, H)
+    h_b_raw = marn_cell(P, "marn_cell_b.", rev_x_l, rev_x_a, rev_qmask, H, H, cell_dr(1))
     h_b = reverse_seq(h_b_raw, umask)
+    if "rec1" in dr:
+        h_b = h_b * dr["rec1"]                                                # :374
     h = torch.cat([h_f, h_b], -1)
 
     w, v, v1, v2 = P["w"], P["v"], P["v1"], P["v2"]
-    attn1 = cross_attention_seq(P, "crossatt_l2a.", w * x_l, v * x_a, xattn_heads)
-    attn2 = cross_attention_seq(P, "crossatt_a2l.", v * x_a, w * x_l, xattn_heads)
-    attn1 = cross_attention_seq(P, "crossatt_l2a_1.", v * x_a, v1 * attn1, xattn_heads)
-    attn2 = cross_attention_seq(P, "crossatt_a2l_1.", w * x_l, v2 * attn2, xattn_heads)
+    attn1 = cross_attention_seq(P, "crossatt_l2a.", w * x_l, v * x_a, xattn_heads, dr.get("xattn0"))
+    attn2 = cross_attention_seq(P, "crossatt_a2l.", v * x_a, w * x_l, xattn_heads, dr.get("xattn1"))
+    attn1 = cross_attention_seq(P, "crossatt_l2a_1.", v * x_a, v1 * attn1, xattn_heads, dr.get("xattn2"))
+    attn2 = cross_attention_seq(P, "crossatt_a2l_1.", w * x_l, v2 * attn2, xattn_heads, dr.get("xattn3"))
 
     out = F.relu(linear(torch.cat([h, attn1, attn2], -1), P["fc.0.weight"], P["fc.0.bias"]))
+    if "fc" in dr:
+        out = out * dr["fc"]                                                  # :318
     out = out + x_l + x_a
     out = F.relu(linear(out, P["nn_out.0.weight"], P["nn_out.0.bias"]))
+    if "out" in dr:
+        out = out * dr["out"]                                                 # :323
     out = linear(out, P["nn_out.3.weight"], P["nn_out.3.bias"])
     lp = F.log_softmax(out, 2).permute(1, 0, 2)
     lp = lp.reshape(-1, lp.shape[-1])

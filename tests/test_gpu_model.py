@@ -539,3 +539,102 @@ def test_trainer_cross_entropy_vs_reference_golden(O, golden_dir):
     sd = tr.model.state_dict()
     worst = max(float(np.abs(sd[k[2:]].detach().cpu().numpy().reshape(-1)[:16] - g[k]).max()) for k in g.files if k.startswith("p/"))
     assert worst < 3e-4, worst
+
+
+# ---------------------------------------------------------------------------------------------------------------- dropout
+def _dropout_factors(net, cfg, L, B, H, D=100, nh=8, F=32, cell=False):
+    """The factors (0 | 1/(1-p)) of every site of one step, laid out as the oracle's ``drops`` expects (oracle/ref_cpu.py
+    marn1_sps_forward), read back from the generator through mser_dropout_scale."""
+    from mser import functional as F_
+    N = L * B
+    dr = {}
+
+    def fac(site, p, n):
+        return cfg.site(site, p).scale(n).cpu()
+
+    for k in range(4):
+        ps = cfg.p_enc_l if k < 2 else cfg.p_enc_a
+        if ps[0] > 0:
+            dr[f"enc{k}.attn"] = fac(F_.SITE_ENC + 3 * k, ps[0], B * nh * L * L).view(B, nh, L, L)
+        for j, nm in ((1, "fc"), (2, "ffn")):
+            if ps[j] > 0:       # rows of the encoder tensors are time-major here, batch-major in the oracle
+                dr[f"enc{k}.{nm}"] = fac(F_.SITE_ENC + 3 * k + j, ps[j], N * D).view(L, B, D).permute(1, 0, 2)
+    for i in range(4):
+        if cfg.p_xattn[i] > 0:
+            dr[f"xattn{i}"] = fac(F_.SITE_XATTN + i, cfg.p_xattn[i], B * L * L).view(B, L, L)
+    if cfg.p_fc > 0:
+        dr["fc"] = fac(F_.SITE_FC, cfg.p_fc, N * D).view(L, B, D)
+    if cfg.p_out > 0:
+        dr["out"] = fac(F_.SITE_OUT, cfg.p_out, N * F).view(L, B, F)
+    if cfg.p_rec > 0:
+        for i in range(2):
+            dr[f"rec{i}"] = fac(F_.SITE_REC + i, cfg.p_rec, N * 4 * H).view(L, B, 4 * H)
+    if cell:
+        for i in range(2):
+            if cfg.p_cell[i] > 0:
+                dr[f"cell{i}.hq"] = fac(F_.SITE_CELL + 4 * i, cfg.p_cell[i], L * 2 * B * H).view(L, 2, B, H)
+                dr[f"cell{i}.h"] = fac(F_.SITE_CELL + 4 * i + 1, cfg.p_cell[i], L * 2 * B * H).view(L, 2, B, H)
+            if cfg.p_cell_attn[i] > 0:
+                dr[f"cell{i}.attn"] = fac(F_.SITE_CELL + 4 * i + 2, cfg.p_cell_attn[i], L * B * H * H).view(L, B, H, H)
+    return dr
+
+
+def _zero_cell_dropout(net):
+    for cell in (net.marn_cell_f, net.marn_cell_b):
+        cell.dropout.p = 0.0
+        cell.crossatt_l2a.dropout.p = 0.0
+
+
+@pytest.mark.parametrize("persistent", [1, 0])
+def test_train_mode_dropout_mask_for_mask_vs_oracle(O, persistent):
+    """Train mode: torch's CPU dropout streams cannot be reproduced on a GPU, so parity is defined mask for mask -- the factors the
+    HIP path drew for this step are read back (mser_dropout_scale) and handed to the oracle as explicit inputs; log-probs, loss and
+    every gradient must then agree to the eval-mode tolerances.  Also checks that the masks are not degenerate."""
+    from models.lsthm_sps import MARN1_sps
+    from loss import MaskedLoss
+    from mser import ops
+    d_r, H, B, L = 768, 128, 5, 7
+    P = O.seeded_params(seed=51, d_r=d_r)
+    net = MARN1_sps(6, d_r=d_r).cuda().train()
+    net.dropout_enabled = True
+    if not getattr(net, "dropout_in_cell", False):
+        _zero_cell_dropout(net)
+    load_params(net, P)
+    x, qmask, umask, label = O.seeded_batch(B, L, d_r=d_r, seed=53, ragged=True)
+    ops.set_option(ops.MSER_OPT_PERSISTENT, persistent)
+    try:
+        captured = {}
+        orig = net._drop_cfg
+        net._drop_cfg = lambda dev: captured.setdefault("cfg", orig(dev))
+        lp, _, _ = net(x.cuda(), qmask.cuda(), umask.cuda())
+        loss = MaskedLoss(torch.nn.NLLLoss)(lp, label.cuda().view(-1), umask.cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_option(ops.MSER_OPT_PERSISTENT, 1)
+        net._drop_cfg = orig
+    cfg = captured["cfg"]
+    assert cfg is not None and cfg.any()
+    dr = _dropout_factors(net, cfg, L, B, H, cell=getattr(net, "dropout_in_cell", False))
+    for k, v in dr.items():
+        p = 1.0 - 1.0 / float(v.max())
+        frac = float((v == 0).float().mean())
+        assert abs(frac - p) < 0.06 + 2.0 / v.numel() ** 0.5, (k, p, frac)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    lp_ref, _, _ = O.marn1_sps_forward(Pr, x, qmask, umask, d_r=d_r, drops=dr)
+    loss_ref = O.masked_nll(lp_ref, label.view(-1), umask)
+    loss_ref.backward()
+    assert maxabs(lp, lp_ref) < LOGIT_TOL
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 2e-5
+    for n, p in net.named_parameters():
+        r = Pr[n].grad
+        if r is None:
+            continue
+        assert maxabs(p.grad, r) < 3e-4 * max(1e-3, float(r.norm())), n
+    # a second step draws different masks; eval mode is untouched
+    lp2, _, _ = net(x.cuda(), qmask.cuda(), umask.cuda())
+    assert maxabs(lp2, lp) > 1e-3
+    net.eval()
+    lp_e, _, _ = net(x.cuda(), qmask.cuda(), umask.cuda())
+    lp_eref, _, _ = O.marn1_sps_forward(P, x, qmask, umask, d_r=d_r)
+    assert maxabs(lp_e, lp_eref) < LOGIT_TOL
