@@ -229,6 +229,14 @@ typedef struct mser_cell_desc {
    * launch that adds the cell's own input gradients (the caller's partial sums from other branches of the backward graph) */
   const float* dx_l_add[2];
   const float* dx_a_add[2];
+  /* Dropout inside the cell (see "Dropout" below; rng == NULL: identity).  Per direction i: site drop_site[i] = h_q0 / h_q1
+   * (:183,:188; element ((t*2 + cell)*B + slot)*H + unit), drop_site[i]+1 = h_l / h_a (:211,:213; ((t*2 + stream)*B + b)*H + unit),
+   * both with p_state[i]; drop_site[i]+2 = the rank-1 attention (:69; ((t*B + b)*H + i)*H + j) with p_attn[i].  t is the
+   * direction's own time index.  The same rng words must be passed to every phase of the forward and the backward of one step. */
+  const uint32_t* rng;
+  uint32_t drop_site[2];
+  float p_state[2];
+  float p_attn[2];
 } mser_cell_desc;
 
 size_t mser_marn_cell_workspace_bytes(int32_t T, int32_t B, int32_t D, int32_t H, int32_t ndir);

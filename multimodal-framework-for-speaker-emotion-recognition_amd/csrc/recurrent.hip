@@ -51,6 +51,9 @@ struct DirP {
   const float* xw[2]; long ldxw[2];
   float *gW[2], *gU[2], *gV[2], *gS[2], *gWih[2], *gWhh[2];
   float* gbias_s[2][4];
+  // dropout (CellK::rng != nullptr): sites drop_site (h_q0/h_q1, :183,:188), +1 (h_l/h_a, :211,:213), +2 (rank-1 attention, :69)
+  unsigned drop_site;
+  float p_state, p_attn;
   float* gbias[2][4];  // bias gradients that receive the column sums of the gate gradients: LSTHM stream m: W,U,V,S .bias; speaker
                        // cell c (wgrad_role<true>): bias_ih, bias_hh, -, -
 };
@@ -65,10 +68,23 @@ struct CellK {
   int stats_wgs;       // cell_fwd_fused: workgroups that compute the BPTT's softmax statistics beside the chains (0: the row phase does)
   int place;           // fused launches: roles are claimed by physical XCD (claim_role); the grid then covers every CU
   short place_base[8], place_cap[8];   // XCD x hosts logical workgroups place_base[x] .. place_base[x] + place_cap[x] - 1
+  const uint32_t* rng; // dropout generator words {seed, step} (nullptr: every dropout site of the cell is the identity)
   int ksplit;          // BPTT matvec phase: every product's K = 4H reduction is split over `ksplit` workgroups (1 or 2); the
                        // partial results live in consecutive copies of dA / dHQp / dxc and the consumers add them
   DirP d[2];
 };
+// Dropout inside the cell.  Element indices: h_q: ((t*2 + cell)*B + slot)*H + unit; h_l/h_a: ((t*2 + stream)*B + b)*H + unit;
+// rank-1 attention: ((t*B + b)*H + i)*H + j  (t = the direction's own time index).
+__device__ __forceinline__ bool drop_state_on(const CellK& P, const DirP& D) { return P.rng != nullptr && D.p_state > 0.f; }
+__device__ __forceinline__ bool drop_attn_on(const CellK& P, const DirP& D) { return P.rng != nullptr && D.p_attn > 0.f; }
+__device__ __forceinline__ float drop_hq(const CellK& P, const DirP& D, int t, int c, int slot, int u) {
+  return drop_scale(drop_key(P.rng, D.drop_site, D.p_state), (uint32_t)((((long)t * 2 + c) * P.B + slot) * P.H + u));
+}
+__device__ __forceinline__ float drop_h(const CellK& P, const DirP& D, int t, int m, int b, int u) {
+  return drop_scale(drop_key(P.rng, D.drop_site + 1u, D.p_state), (uint32_t)((((long)t * 2 + m) * P.B + b) * P.H + u));
+}
+__device__ __forceinline__ uint32_t drop_attn_row(const CellK& P, int t, int b) { return (uint32_t)(((long)t * P.B + b) * P.H * P.H); }
+
 // Every counter sits on a 128-byte line of its own (SYNC_LINE words apart): arrivals (atomics) and polls of one chain never queue
 // behind another chain's at the memory side.  Measured: with all eight counters on one line a second direction cost +56 % per
 // forward step and +24 % per backward step although the two directions share no data.
@@ -570,7 +586,8 @@ __device__ __forceinline__ void spk_fwd_body(const CellK& P, const DirP& D, cons
       const float go = sigmoidf_(tile[rr * 32 + 24 + uu] + bias4[3]);
       const float cn = gf * cq_prev + gi * gg;
       const float tcn = tanhf(cn);
-      const float hn = go * tcn;
+      float hn = go * tcn;
+      if (drop_state_on(P, D)) hn *= drop_hq(P, D, t, c, slot, u);          // :183 / :188: the dropped h_q IS the carried state
       D.tcq[((long)c * T + t) * SB + (long)slot * H + u] = tcn;
       stx<PS>(ws, cq_new + (long)slot * H + u, cn);
       stx<PS>(ws, hq_new + (long)slot * H + u, hn);
@@ -678,7 +695,8 @@ __device__ __forceinline__ void lsthm_gates_body(const CellK& P, const DirP& D, 
       const float go = sigmoidf_(tile[rr * 32 + 16 + uu] + pre4[2]);
       const float gc = tanhf(tile[rr * 32 + 24 + uu] + pre4[3]);
       const float cn = gf * c_prev + gi * gc;
-      const float hn = tanhf(cn) * go;
+      float hn = tanhf(cn) * go;
+      if (drop_state_on(P, D)) hn *= drop_h(P, D, t, m, b, u);               // :211 / :213
       stx<PS>(ws, c_new + (long)b * H + u, cn);
       stx<PS>(ws, hz_new + (long)b * 3 * H + m * H + u, hn);
       float* g = D.gates + ((long)m * T * B + (long)t * B + b) * 4 * H + u;
@@ -733,7 +751,20 @@ __device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, cons
   const float mx = (u >= 0.f) ? u * att[2 * H] : u * att[2 * H + 1];
   const float u2 = u * LOG2E, m2 = mx * LOG2E;
   float Z = 0.f, N = 0.f, N2 = 0.f, N3 = 0.f;     // N2, N3: the two extra sums the backward needs (saved below)
-  {
+  if (drop_attn_on(P, D)) {      // :69 dropout(softmax): the normaliser Z (and N3) stay unmasked, the value sums take the factor
+    const DropKey dk = drop_key(P.rng, D.drop_site + 2u, D.p_attn);
+    const uint32_t e0 = drop_attn_row(P, t, b) + (uint32_t)(i * H + q * JC);
+    const float4* kcc = kc + q * JC;
+    for (int jj = 0; jj < JC; ++jj) {
+      const float4 k4 = kcc[jj];
+      const float e = __builtin_amdgcn_exp2f(fmaf(u2, k4.x, -m2));
+      const float ef = e * drop_scale(dk, e0 + (uint32_t)jj);
+      Z += e;
+      N = fmaf(ef, k4.y, N);
+      N2 = fmaf(ef, k4.z, N2);
+      N3 = fmaf(e, k4.x, N3);
+    }
+  } else {
     const float4* kcc = kc + q * JC;
 #pragma unroll
     for (int jj = 0; jj < (JCT ? JCT : JC); ++jj) {
@@ -897,7 +928,8 @@ __device__ __forceinline__ void lsthm_gates_late(const CellK& P, const DirP& D, 
       const float go = sigmoidf_(tile[rr * 32 + 16 + uu] + gp.pre4[2]);
       const float gc = tanhf(tile[rr * 32 + 24 + uu] + gp.pre4[3]);
       const float cn = gf * c_state + gi * gc;
-      const float hn = tanhf(cn) * go;
+      float hn = tanhf(cn) * go;
+      if (drop_state_on(P, D)) hn *= drop_h(P, D, t, m, b, u);               // :211 / :213
       c_state = cn;
       stx<true>(ws, c_new + (long)b * H + u, cn);
       stx<true>(ws, hz_new + (long)b * 3 * H + m * H + u, hn);
@@ -1027,7 +1059,8 @@ __device__ __forceinline__ RowPre lsthm_bwd_row_prefetch(const CellK& P, const D
 struct RowMid { float s, u, Z, N2, N3; };
 
 template <int JCT>
-__device__ __forceinline__ RowMid lsthm_bwd_row_part1(const CellK& P, const float* att, float* scr, const RowPre& pre) {
+__device__ __forceinline__ RowMid lsthm_bwd_row_part1(const CellK& P, const DirP& D, int t, int b, const float* att, float* scr,
+                                                      const RowPre& pre) {
   const int H = P.H;
   const int Q = NT / H, JC = JCT ? JCT : H / Q;
   float* ca = scr;           float* cl = ca + H;   float* cw = cl + H;   float* coef = cw + H;
@@ -1059,7 +1092,17 @@ __device__ __forceinline__ RowMid lsthm_bwd_row_part1(const CellK& P, const floa
   const float mx = (u >= 0.f) ? u * att[2 * H] : u * att[2 * H + 1];
   const float u2 = u * LOG2E, m2 = mx * LOG2E;
   float Z = 0.f, N2 = 0.f, N3 = 0.f;
-  {
+  if (drop_attn_on(P, D)) {      // as in the forward: only the value sum N2 takes the dropout factor
+    const DropKey dk = drop_key(P.rng, D.drop_site + 2u, D.p_attn);
+    const uint32_t e0 = drop_attn_row(P, t, b) + (uint32_t)(i * H + q * JC);
+    for (int jj = 0; jj < JC; ++jj) {
+      const float wj = wk[q * JC + jj];
+      const float e = __builtin_amdgcn_exp2f(fmaf(u2, wj, -m2));
+      Z += e;
+      N2 = fmaf(e * drop_scale(dk, e0 + (uint32_t)jj), cw[q * JC + jj], N2);
+      N3 = fmaf(e, wj, N3);
+    }
+  } else {
     const float* wkc = wk + q * JC;
     const float* cwc = cw + q * JC;
 #pragma unroll
@@ -1152,7 +1195,21 @@ __device__ __forceinline__ void lsthm_bwd_row_part2(const CellK& P, const DirP& 
   // ---- pass 2: per key index j (= i), sums over the units ii of chunk q
   const int j = i;
   float S1 = 0.f, S2 = 0.f, S3 = 0.f;
-  {
+  if (drop_attn_on(P, D)) {      // S1, S2 run over the dropped attention (mask element (i, j), i = q*JC + ii), S3 over the plain softmax
+    const DropKey dk = drop_key(P.rng, D.drop_site + 2u, D.p_attn);
+    const uint32_t e0 = drop_attn_row(P, t, b) + (uint32_t)(q * JC * H + j);
+    const float wkj = wk[j];
+    const float* cfc = coef + 8 * q * JC;
+    for (int ii = 0; ii < JC; ++ii) {
+      const float4 c4 = *reinterpret_cast<const float4*>(cfc + 8 * ii);
+      const float c5 = cfc[8 * ii + 4];
+      const float e = __builtin_amdgcn_exp2f(fmaf(c4.x, wkj, -c4.y));
+      const float ef = e * drop_scale(dk, e0 + (uint32_t)(ii * H));
+      S1 = fmaf(c4.z, ef, S1);
+      S2 = fmaf(c4.w, ef, S2);
+      S3 = fmaf(c5, e, S3);
+    }
+  } else {
     const float wkj = wk[j];
     const float* cfc = coef + 8 * q * JC;
 #pragma unroll
@@ -1181,7 +1238,8 @@ __device__ __forceinline__ void lsthm_bwd_row_part2(const CellK& P, const DirP& 
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const float gf = pre.gsv[m][0], gi = pre.gsv[m][1], go = pre.gsv[m][2], gc = pre.gsv[m][3];
-      const float dh = dh2[m];
+      float dh = dh2[m];                                   // gradient at the dropped h (:211 / :213): the same factor again
+      if (drop_state_on(P, D)) dh *= drop_h(P, D, t, m, b, i);
       const float cc = m ? pre.cav : pre.clv;
       const float tc = tanhf(cc);
       const float dc = carry[m] + dh * go * (1.f - tc * tc) + (m ? dca_att : dcl_att);
@@ -1201,7 +1259,7 @@ __device__ __forceinline__ void lsthm_bwd_row_part2(const CellK& P, const DirP& 
 template <bool PS, int JCT>
 __device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D, const WS& ws, int t, int b, const float* att, float* scr,
                                                    const RowPre& pre) {
-  const RowMid mid = lsthm_bwd_row_part1<JCT>(P, att, scr, pre);
+  const RowMid mid = lsthm_bwd_row_part1<JCT>(P, D, t, b, att, scr, pre);
   float carry[2] = {pre.carry[0], pre.carry[1]};
   lsthm_bwd_row_part2<PS, JCT>(P, D, ws, t, b, att, scr, pre, mid, carry);
 }
@@ -1467,9 +1525,10 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, cons
       float dcp[4], dhp[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float dh = f4(v_dh[ii], j) + f4(v_hq[ii], j) + v_m[ii] * f4(v_x[ii], j);
+        float dh = f4(v_dh[ii], j) + f4(v_hq[ii], j) + v_m[ii] * f4(v_x[ii], j);
         const float dc_in = f4(v_dc[ii], j);
-        dhp[j] = dh;
+        dhp[j] = dh;                                      // skipped cell: no dropout was drawn (:180 / :185)
+        if (Nc != 0 && slot < B && drop_state_on(P, D)) dh *= drop_hq(P, D, t, c, slot, u + j);
         if (Nc == 0) {                                    // skipped cell: identity on (h, c)
           dcp[j] = dc_in;
           d4[0][j] = d4[1][j] = d4[2][j] = d4[3][j] = 0.f;
@@ -2016,6 +2075,10 @@ static int validate(const mser_cell_desc& d, bool bwd) {
                "marn_cell: workspace too small (%zu < %zu)", d.workspace_bytes,
                mser_marn_cell_workspace_bytes(d.T, d.B, d.D, d.H, d.ndir));
   MSER_REQUIRE(d.ldo >= 4L * d.H, "marn_cell: ldo=%ld < 4H", (long)d.ldo);
+  if (d.rng)
+    for (int i = 0; i < d.ndir; ++i)
+      MSER_REQUIRE(d.p_state[i] >= 0.f && d.p_state[i] < 1.f && d.p_attn[i] >= 0.f && d.p_attn[i] < 1.f,
+                   "marn_cell: dropout p out of [0,1) (direction %d: %f, %f)", i, d.p_state[i], d.p_attn[i]);
   MSER_REQUIRE(d.workspace_bytes < 0x7fffffffULL, "marn_cell: workspace of %zu bytes exceeds the 2 GiB addressable through one buffer descriptor", d.workspace_bytes);
   if (bwd) {
     const size_t spk_tile = spk_bwd_lds_floats(d.H) * sizeof(float) + 64;
@@ -2045,6 +2108,14 @@ static void fill_params(DirP& k, const mser_cell_dir& r) {
   }
   k.attWq = r.p.att_Wq; k.attWk = r.p.att_Wk;
   k.rev = r.rev; k.out = r.out; k.dout = r.dout;
+}
+static void fill_dropout(CellK& K, const mser_cell_desc& d) {
+  K.rng = d.rng;
+  for (int i = 0; i < d.ndir; ++i) {
+    K.d[i].drop_site = d.drop_site[i];
+    K.d[i].p_state = d.rng ? d.p_state[i] : 0.f;
+    K.d[i].p_attn = d.rng ? d.p_attn[i] : 0.f;
+  }
 }
 
 static mser_gemm_desc gd(const float* A, long sAm, long sAk, const float* Bm, long sBk, long sBn, float* C, long ldc, int M,
@@ -2109,6 +2180,7 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   const int T = d.T, B = d.B, D = d.D, H = d.H;
   const long TB = (long)T * B, SB = (long)B * H;
   for (int i = 0; i < d.ndir; ++i) fill_params(K.d[i], d.dir[i]);
+  fill_dropout(K, d);
   const size_t mm_lds = (RED_FLOATS + 1024) * sizeof(float);
   const long fwd_wgs = (long)(H / 8) * 2 * d.ndir * K.nmb;
   const bool persist = persist_ok(H, 2 * fwd_wgs);        // speaker and LSTHM chains share one launch: all workgroups co-resident
@@ -2202,7 +2274,7 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
     // ONE launch for both chains: 2 x fwd_wgs workgroups (LSTHM roles first), linked by the speaker's step counter, plus (H = 128)
     // 16 workgroups per direction that compute the BPTT's softmax statistics beside the chains
     ProfScope ps(MSER_PROF_LSTHM_FWD_GATES, s);
-    K.stats_wgs = (H == 128 && !K.place && g_opt_stats_roles && 2 * fwd_wgs + 16 * d.ndir <= num_cus()) ? 16 * d.ndir : 0;
+    K.stats_wgs = (H == 128 && !K.place && g_opt_stats_roles && !d.rng && 2 * fwd_wgs + 16 * d.ndir <= num_cus()) ? 16 * d.ndir : 0;
     if (H == 128) {
       MSER_TRY(allow_lds((const void*)cell_fwd_fused<2, 3>, p_lds));
       hipLaunchKernelGGL((cell_fwd_fused<2, 3>), dim3(K.place ? num_cus() : 2 * fwd_wgs + K.stats_wgs), dim3(NT), p_lds, s, K);
@@ -2237,6 +2309,7 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   const int T = d.T, B = d.B, D = d.D, H = d.H;
   const long TB = (long)T * B, SB = (long)B * H;
   for (int i = 0; i < d.ndir; ++i) fill_params(K.d[i], d.dir[i]);
+  fill_dropout(K, d);
   const size_t mm_lds = (RED_FLOATS + 1024) * sizeof(float);
   const size_t row_lds = row_lds_bytes(H);
   const int spk_wgs = (H / 32) * 4 * K.nmb;                  // speaker BPTT: 4 products

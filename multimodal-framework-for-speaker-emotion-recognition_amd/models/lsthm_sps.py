@@ -292,7 +292,8 @@ class MARN1_sps(nn.Module):
                               n_classes=n_classes, xattn_heads=xattn_heads)
         self.use_streams = True
         self.dropout_seed = 0x5EED
-        self.dropout_enabled = False         # train-mode dropout (opt-in until the in-loop sites of MARN_cell are drawn too)
+        self.dropout_enabled = False         # train-mode dropout: opt-in for now (flipped once every site is verified)
+        self.dropout_in_cell = True
         self._rng = None
         dead = [c + n for c in ("marn_cell_f.", "marn_cell_b.") for n in _CELL_DEAD]
         dead += [e + n for e in ("encoder_l.", "encoder_a.") for n in ("pos_ffn.fc.weight", "pos_ffn.fc.bias")]

@@ -51,6 +51,7 @@ class CellDesc(C.Structure):
         ("dx_l", C.c_void_p), ("dx_a", C.c_void_p), ("ldo", C.c_int64),
         ("dir", CellDir * 2), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("dx_l_add", _P2), ("dx_a_add", _P2),
+        ("rng", C.c_void_p), ("drop_site", C.c_uint32 * 2), ("p_state", C.c_float * 2), ("p_attn", C.c_float * 2),
     ]
 
 

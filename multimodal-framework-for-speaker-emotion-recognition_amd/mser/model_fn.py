@@ -83,6 +83,7 @@ class ModelCtx:
     tail: object = None
     qmask: Tensor = None
     drop: DropCfg = None
+    cell_drop: tuple = None
 
 
 def _sub(P: Getter, prefix: str) -> Getter:
@@ -159,7 +160,10 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
         dict(p=ops.cell_param_struct(_sub(P, "marn_cell_f.")), qmask=qmask, rev=None, out=c.Hcat[:, 0:4 * H]),
         dict(p=ops.cell_param_struct(_sub(P, "marn_cell_b.")), qmask=qmask, rev=c.rev, out=c.Hcat[:, 4 * H:8 * H]),
     ]
-    desc = ops.make_cell_desc(Ln, B, D, H, c.x_l, c.x_a, c.cell_dirs, 10 * H, c.cell_ws)
+    c.cell_drop = None
+    if drop is not None and (any(p_ > 0 for p_ in drop.p_cell) or any(p_ > 0 for p_ in drop.p_cell_attn)):
+        c.cell_drop = (drop.rng, [F_.SITE_CELL, F_.SITE_CELL + 4], drop.p_cell, drop.p_cell_attn)
+    desc = ops.make_cell_desc(Ln, B, D, H, c.x_l, c.x_a, c.cell_dirs, 10 * H, c.cell_ws, drop=c.cell_drop)
     c.cell_desc = desc
     w, v, v1, v2 = P("w"), P("v"), P("v1"), P("v2")
     c.A1 = torch.empty(N, H, device=x.device)
@@ -284,7 +288,7 @@ def _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams):
         r["dout"] = dH[:, sl]
     # the attention branches' partial input gradients are folded into dx_l / dx_a by the cell's BWD_DX phase (one launch)
     desc = ops.make_cell_desc(Ln, B, D, H, c.x_l, c.x_a, c.cell_dirs, 10 * H, c.cell_ws, dx_l=dx_l, dx_a=dx_a,
-                              dx_l_add=(dxl_a, dxl_b), dx_a_add=(dxa_a, dxa_b))
+                              dx_l_add=(dxl_a, dxl_b), dx_a_add=(dxa_a, dxa_b), drop=c.cell_drop)
     c.cell_desc = desc
     ev_prep = None
     # (under stream capture the extra branch makes the graph executor order the attention branches behind the BPTT node: measured

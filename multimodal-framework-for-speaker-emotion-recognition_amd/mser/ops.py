@@ -490,8 +490,9 @@ def cell_workspace_bytes(T: int, B: int, D: int, H: int, ndir: int) -> int:
 
 def make_cell_desc(T: int, B: int, D: int, H: int, x_l: Tensor, x_a: Tensor, dirs: Sequence[dict], ldo: int,
                    workspace: Tensor, dx_l: Optional[Tensor] = None, dx_a: Optional[Tensor] = None,
-                   dx_l_add: Sequence[Tensor] = (), dx_a_add: Sequence[Tensor] = ()) -> L.CellDesc:
-    """dirs: list of dicts with keys p (CellParams), g (CellParams or None), qmask, rev (or None), out, dout (or None)."""
+                   dx_l_add: Sequence[Tensor] = (), dx_a_add: Sequence[Tensor] = (), drop=None) -> L.CellDesc:
+    """dirs: list of dicts with keys p (CellParams), g (CellParams or None), qmask, rev (or None), out, dout (or None).
+    drop: None or (rng int32[2] tensor, [site per direction], [p_state per direction], [p_attn per direction])."""
     d = L.CellDesc()
     d.T, d.B, d.D, d.H, d.ndir = T, B, D, H, len(dirs)
     d.x_l, d.ldxl = _p(x_l), _ld(x_l)
@@ -516,6 +517,11 @@ def make_cell_desc(T: int, B: int, D: int, H: int, x_l: Tensor, x_a: Tensor, dir
         if not t.is_contiguous():
             raise RuntimeError("dx_a_add entries must be contiguous")
         d.dx_a_add[i] = _p(t)
+    if drop is not None:
+        rng, sites, p_state, p_attn = drop
+        d.rng = _p(rng)
+        for i in range(len(dirs)):
+            d.drop_site[i], d.p_state[i], d.p_attn[i] = int(sites[i]), float(p_state[i]), float(p_attn[i])
     return d
 
 
