@@ -157,8 +157,10 @@ def main():
     lib = _lib.load()
 
     torch.manual_seed(0)
+    # headline = parity configuration (every Dropout p = 0, SURVEY.md 7 "Dropout"); the train-mode step with the reference's
+    # dropout probabilities is reported under variants
     tr = ModelTrainer(device, lr=1e-3, test_step=1, lr_decay=0.98, model="MARN1_sps", loss="NLL", n_classes=NCLS,
-                      dataset="IEMOCAP", d_r=D_R, quiet=True)
+                      dataset="IEMOCAP", d_r=D_R, quiet=True, dropout=False)
     init_attention_weights(tr.model)
     tr.train()
     tr.scheduler.step(0)
@@ -304,7 +306,7 @@ def main():
         # second trainer at the wider cell.  Its chains run as persistent launches without the H = 128-only refinements
         # (in-launch weight gradients, K-split, statistics roles).
         tr256 = ModelTrainer(device, lr=1e-3, test_step=1, lr_decay=0.98, model="MARN1_sps", loss="NLL", n_classes=NCLS,
-                             dataset="IEMOCAP", d_r=D_R, hidden=256, quiet=True)
+                             dataset="IEMOCAP", d_r=D_R, hidden=256, quiet=True, dropout=False)
         init_attention_weights(tr256.model)
         tr256.train()
         tr256.scheduler.step(0)
@@ -316,6 +318,20 @@ def main():
         del tr256
         variants["hidden_256_f32"] = {"ms_per_step": round(ms_h, 4), "utterances_per_s": round(B * L / (ms_h * 1e-3), 1),
                                       "note": "configs[1] width; eager launches"}
+        # train mode as the reference runs it: all 13 dropout sites live (p = 0.1 encoders, 0.2 attention, 0.5 elsewhere)
+        trd = ModelTrainer(device, lr=1e-3, test_step=1, lr_decay=0.98, model="MARN1_sps", loss="NLL", n_classes=NCLS,
+                           dataset="IEMOCAP", d_r=D_R, quiet=True, dropout=True)
+        init_attention_weights(trd.model)
+        trd.train()
+        trd.scheduler.step(0)
+        tr_main, tr = tr, trd
+        try:
+            ms_d = time_steps((x, qmask, umask, label))
+        finally:
+            tr = tr_main
+        del trd
+        variants["dropout_on"] = {"ms_per_step": round(ms_d, 4), "utterances_per_s": round(B * L / (ms_d * 1e-3), 1),
+                                  "note": "counter-based masks re-evaluated in the backward; encoder layers on the composed (unfused) path; eager launches"}
         log("variants done")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -332,7 +348,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"lsthm_sps + cross-modal attn train step (fwd+bwd+Adam), per-GPU batch={B} seq={L} "
-                                   f"d_text={D_R} d_audio={D_A} hid={H} (reference width), {NCLS} classes",
+                                   f"d_text={D_R} d_audio={D_A} hid={H} (reference width), {NCLS} classes, dropout p=0 (parity configuration)",
                        "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}",
                        "launch": "hipGraph replay" if use_graph else "eager"},
             "roofline": roofline,

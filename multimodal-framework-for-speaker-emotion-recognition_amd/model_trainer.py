@@ -19,6 +19,7 @@ from loss import MaskedLoss
 from models.lsthm_sps import MARN1_sps
 from mser import ops
 from mser.dist import FlatAllReduce
+from mser.functional import zero_dropout
 from mser.metrics import accuracy_and_weighted_f1
 from mser.optim import FlatAdam, StepLR
 
@@ -34,6 +35,8 @@ class ModelTrainer(nn.Module):
         self.dataset = dataset
         if model == 'MARN1_sps':
             self.model = MARN1_sps(n_classes, d_r=kwargs.get("d_r", 1024), hidden=kwargs.get("hidden", 128)).to(self.device)
+            if not kwargs.get("dropout", True):       # extension: dropout=False sets every Dropout p to 0 (parity configuration)
+                zero_dropout(self.model)
         elif model in _OUT_OF_SCOPE:
             raise NotImplementedError(f"model '{model}' is outside the accelerated hot path (SURVEY.md 8(f)); only 'MARN1_sps' is built")
         else:

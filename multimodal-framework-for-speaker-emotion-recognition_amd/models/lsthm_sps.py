@@ -5,7 +5,9 @@ Class names, constructor / forward signatures, parameter names, shapes and initi
 arithmetic runs in libmser (HIP, gfx950): ``MARN1_sps.forward`` is ONE autograd node whose forward and backward are the
 explicit kernel sequences of ``mser.model_fn``; parameters live in one flat buffer (``mser.flat``).
 
-Differences that are deliberate and documented (DESIGN.md): Dropout sites are identities (parity is defined at p = 0);
+Differences that are deliberate and documented: in train mode the 13 Dropout sites draw their masks from libmser's
+counter-based generator (the reference's CPU generator streams cannot be reproduced on a GPU; parity is defined at p = 0 / eval
+and, in train mode, mask for mask against the oracle);
 extra keyword-only constructor arguments (``d_r``, ``xattn_heads``, ``hidden``) default to the reference's hard-coded values;
 there is no CPU execution path.  ``hidden`` (128 or 256) sets every width the reference hard-codes as 128 (LSTHM cell, speaker
 cell, rank-1 attention, sequence-level attention); at 256 parity is checked against the oracle only (the reference cannot be
@@ -292,8 +294,7 @@ class MARN1_sps(nn.Module):
                               n_classes=n_classes, xattn_heads=xattn_heads)
         self.use_streams = True
         self.dropout_seed = 0x5EED
-        self.dropout_enabled = False         # train-mode dropout: opt-in for now (flipped once every site is verified)
-        self.dropout_in_cell = True
+        self.dropout_enabled = True          # train mode draws the 13 dropout sites like the reference; False: identities
         self._rng = None
         dead = [c + n for c in ("marn_cell_f.", "marn_cell_b.") for n in _CELL_DEAD]
         dead += [e + n for e in ("encoder_l.", "encoder_a.") for n in ("pos_ffn.fc.weight", "pos_ffn.fc.bias")]

@@ -73,6 +73,15 @@ class DropSite:
         return ops.dropout_scale(n, self.rng, self.site, self.p)
 
 
+def zero_dropout(module):
+    """Set p = 0 on every nn.Dropout of a module tree: the parity configuration (what tests/golden/make_golden.py does to the
+    reference before it records trainer goldens).  Returns the module."""
+    for m in module.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    return module
+
+
 # ====================================================================================================== attention core
 def attn_core_fwd(q: Tensor, k: Tensor, v: Tensor, out: Tensor, lq: Layout, lk: Layout, nh: int, dk: int, dv: int,
                   scale: float, mul: Optional[Tensor] = None, mask: Optional[Tensor] = None, mask_on: int = 1,

@@ -6,7 +6,7 @@ import sys, os
 sys.path[:0] = [%r, os.path.join(%r, "multimodal-framework-for-speaker-emotion-recognition_amd")]
 import torch, bench
 from model_trainer import ModelTrainer
-tr = ModelTrainer(torch.device("cuda:0"), lr=1e-3, test_step=1, lr_decay=0.98, model="MARN1_sps", loss="NLL", n_classes=6, dataset="IEMOCAP", d_r=768, quiet=True)
+tr = ModelTrainer(torch.device("cuda:0"), lr=1e-3, test_step=1, lr_decay=0.98, model="MARN1_sps", loss="NLL", n_classes=6, dataset="IEMOCAP", d_r=768, quiet=True, dropout=False)
 tr.train(); tr.scheduler.step(0)
 x, q, u, l = bench.synth_batch(1000, torch.device("cuda:0"))
 tr.train_step(x, q, u, l); torch.cuda.synchronize()

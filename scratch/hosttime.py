@@ -5,7 +5,7 @@ import torch
 import bench
 from model_trainer import ModelTrainer
 dev = torch.device("cuda:0")
-tr = ModelTrainer(dev, lr=1e-3, test_step=1, lr_decay=0.98, model="MARN1_sps", loss="NLL", n_classes=6, dataset="IEMOCAP", d_r=768, quiet=True)
+tr = ModelTrainer(dev, lr=1e-3, test_step=1, lr_decay=0.98, model="MARN1_sps", loss="NLL", n_classes=6, dataset="IEMOCAP", d_r=768, quiet=True, dropout=False)
 bench.init_attention_weights(tr.model); tr.train()
 x, qmask, umask, label = bench.synth_batch(1000, dev)
 for _ in range(3): tr.train_step(x, qmask, umask, label)

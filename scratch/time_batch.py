@@ -10,7 +10,7 @@ for B in [int(a) for a in sys.argv[1].split(",")]:
     bench.B, bench.L = B, L
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    tr = ModelTrainer(dev, 1e-3, 1, 0.98, "MARN1_sps", "NLL", 6, "IEMOCAP", d_r=768, quiet=True)
+    tr = ModelTrainer(dev, 1e-3, 1, 0.98, "MARN1_sps", "NLL", 6, "IEMOCAP", d_r=768, quiet=True, dropout=False)
     bench.init_attention_weights(tr.model)
     tr.train(); tr.scheduler.step(0)
     batch = bench.synth_batch(1, dev)

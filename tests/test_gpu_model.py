@@ -210,7 +210,7 @@ def test_trainer_three_steps_vs_reference_golden(O, golden_dir):
     from model_trainer import ModelTrainer
     g = _g(golden_dir, "trainer.npz")
     tr = ModelTrainer(torch.device("cuda:0"), lr=1e-3, test_step=1, lr_decay=0.98, model="MARN1_sps", loss="NLL", n_classes=6,
-                      dataset="IEMOCAP", quiet=True)
+                      dataset="IEMOCAP", quiet=True, dropout=False)
     load_params(tr.model, O.seeded_params(seed=5, d_r=1024))
     B, L = 3, 10
     batches = []
@@ -524,7 +524,7 @@ def test_trainer_cross_entropy_vs_reference_golden(O, golden_dir):
     from model_trainer import ModelTrainer
     g = _g(golden_dir, "trainer_ce.npz")
     tr = ModelTrainer(torch.device("cuda:0"), lr=1e-3, test_step=1, lr_decay=0.98, model="MARN1_sps", loss="CrossEntropy", n_classes=6,
-                      dataset="IEMOCAP", quiet=True)
+                      dataset="IEMOCAP", quiet=True, dropout=False)
     load_params(tr.model, O.seeded_params(seed=5, d_r=1024))
     B, L = 3, 10
     batches = []
@@ -542,7 +542,7 @@ def test_trainer_cross_entropy_vs_reference_golden(O, golden_dir):
 
 
 # ---------------------------------------------------------------------------------------------------------------- dropout
-def _dropout_factors(net, cfg, L, B, H, D=100, nh=8, F=32, cell=False):
+def _dropout_factors(net, cfg, L, B, H, D=100, nh=8, F=32, cell=True):
     """The factors (0 | 1/(1-p)) of every site of one step, laid out as the oracle's ``drops`` expects (oracle/ref_cpu.py
     marn1_sps_forward), read back from the generator through mser_dropout_scale."""
     from mser import functional as F_
@@ -579,12 +579,6 @@ def _dropout_factors(net, cfg, L, B, H, D=100, nh=8, F=32, cell=False):
     return dr
 
 
-def _zero_cell_dropout(net):
-    for cell in (net.marn_cell_f, net.marn_cell_b):
-        cell.dropout.p = 0.0
-        cell.crossatt_l2a.dropout.p = 0.0
-
-
 @pytest.mark.parametrize("persistent", [1, 0])
 def test_train_mode_dropout_mask_for_mask_vs_oracle(O, persistent):
     """Train mode: torch's CPU dropout streams cannot be reproduced on a GPU, so parity is defined mask for mask -- the factors the
@@ -596,9 +590,6 @@ def test_train_mode_dropout_mask_for_mask_vs_oracle(O, persistent):
     d_r, H, B, L = 768, 128, 5, 7
     P = O.seeded_params(seed=51, d_r=d_r)
     net = MARN1_sps(6, d_r=d_r).cuda().train()
-    net.dropout_enabled = True
-    if not getattr(net, "dropout_in_cell", False):
-        _zero_cell_dropout(net)
     load_params(net, P)
     x, qmask, umask, label = O.seeded_batch(B, L, d_r=d_r, seed=53, ragged=True)
     ops.set_option(ops.MSER_OPT_PERSISTENT, persistent)
@@ -615,7 +606,8 @@ def test_train_mode_dropout_mask_for_mask_vs_oracle(O, persistent):
         net._drop_cfg = orig
     cfg = captured["cfg"]
     assert cfg is not None and cfg.any()
-    dr = _dropout_factors(net, cfg, L, B, H, cell=getattr(net, "dropout_in_cell", False))
+    dr = _dropout_factors(net, cfg, L, B, H)
+    assert len(dr) == 12 + 4 + 2 + 2 + 6           # every site of the path is live
     for k, v in dr.items():
         p = 1.0 - 1.0 / float(v.max())
         frac = float((v == 0).float().mean())
