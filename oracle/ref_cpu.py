@@ -463,6 +463,39 @@ def seeded_params(seed: int = 0, dtype=torch.float32, **dims) -> Params:
     return P
 
 
+DEFAULT_DROPOUT = dict(enc=0.1, xattn=0.2, fc=0.5, out=0.5, rec=0.5, cell=0.5, cell_attn=0.2)   # the reference's constructor defaults
+
+
+def seeded_drops(B: int, L: int, H: int = 128, seed: int = 0, D: int = 100, n_head: int = 8, F_out: int = 32,
+                 p: Optional[Dict[str, float]] = None) -> Dict[str, Tensor]:
+    """Deterministic dropout factors (0 | 1/(1-p)) for every site of marn1_sps_forward, keyed and shaped as its ``drops`` argument
+    expects; one numpy RandomState stream per key (platform independent)."""
+    import zlib
+
+    import numpy as np
+
+    p = {**DEFAULT_DROPOUT, **(p or {})}
+    shapes = {}
+    for k in range(4):
+        shapes[f"enc{k}.attn"] = ((B, n_head, L, L), p["enc"])
+        shapes[f"enc{k}.fc"] = ((B, L, D), p["enc"])
+        shapes[f"enc{k}.ffn"] = ((B, L, D), p["enc"])
+        shapes[f"xattn{k}"] = ((B, L, L), p["xattn"])
+    shapes["fc"] = ((L, B, D), p["fc"])
+    shapes["out"] = ((L, B, F_out), p["out"])
+    for k in range(2):
+        shapes[f"rec{k}"] = ((L, B, 4 * H), p["rec"])
+        shapes[f"cell{k}.hq"] = ((L, 2, B, H), p["cell"])
+        shapes[f"cell{k}.h"] = ((L, 2, B, H), p["cell"])
+        shapes[f"cell{k}.attn"] = ((L, B, H, H), p["cell_attn"])
+    out = {}
+    for key, (shp, pk) in shapes.items():
+        rs = np.random.RandomState((zlib.crc32(key.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
+        keep = rs.random_sample(shp) >= pk
+        out[key] = torch.tensor(keep.astype(np.float32) / np.float32(1.0 - pk))
+    return out
+
+
 def seeded_batch(B: int, L: int, d_r: int = 1024, d_a: int = 100, seed: int = 1, ragged: bool = False,
                  n_classes: int = 6, dtype=torch.float32):
     """Synthetic batch in the reference's layout: x [L,B,d_r+d_a], qmask [L,B,2], umask [B,L], label [B,L]."""

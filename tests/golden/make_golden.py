@@ -228,6 +228,74 @@ def trainer_case(loss="NLL", epochs=(1, 2), out="trainer.npz"):
     print("trainer", loss, {k: float(v) for k, v in rec.items() if not k.startswith("p/")})
 
 
+def train_mode_case():
+    """The reference in TRAIN mode with its 13 dropout sites fed from known masks: nn.Dropout.forward is replaced, for the duration
+    of this case, by a function that multiplies by the next factor tensor of that module's queue (O.seeded_drops, laid out in the
+    order the reference's forward calls the module).  Pins the oracle's train-mode restatement (the ``drops`` argument of
+    marn1_sps_forward): log-probs, loss and gradient samples of the reference itself.  Only seeds and outputs are stored."""
+    import torch.nn as nn
+    from models.lsthm_sps import MARN1_sps
+
+    B, L, d_r, seed = 3, 6, 1024, 21
+    torch.manual_seed(0)
+    net = MARN1_sps(6).train()
+    P = O.seeded_params(seed=seed, d_r=d_r)
+    _load(net, P)
+    x, qmask, umask, label = O.seeded_batch(B, L, d_r=d_r, seed=seed + 1, ragged=True)
+    dr = O.seeded_drops(B, L, seed=seed + 2)
+    # queues in the reference's call order
+    q = {}
+    for k, e in ((0, "encoder_l"), (2, "encoder_a")):
+        q[e + ".slf_attn.attention.dropout"] = [dr[f"enc{k}.attn"], dr[f"enc{k + 1}.attn"]]
+        q[e + ".slf_attn.dropout"] = [dr[f"enc{k}.fc"], dr[f"enc{k + 1}.fc"]]
+        q[e + ".pos_ffn.dropout"] = [dr[f"enc{k}.ffn"], dr[f"enc{k + 1}.ffn"]]
+    for i, nm in enumerate(("crossatt_l2a", "crossatt_a2l", "crossatt_l2a_1", "crossatt_a2l_1")):
+        q[nm + ".dropout"] = [dr[f"xattn{i}"]]
+    q["fc.2"] = [dr["fc"]]
+    q["nn_out.2"] = [dr["out"]]
+    q["dropout_rec"] = [dr["rec0"], dr["rec1"]]
+    qm_dirs = (qmask, O.reverse_seq(qmask, umask))
+    for k, cell in enumerate(("marn_cell_f", "marn_cell_b")):
+        T = qm_dirs[k].shape[0]
+        _, _, n0 = O.slot_tables(qm_dirs[k])
+        lst = []
+        for t in range(T):
+            if int(n0[t]) > 0:
+                lst.append(dr[f"cell{k}.hq"][t, 0])          # :183
+            if B - int(n0[t]) > 0:
+                lst.append(dr[f"cell{k}.hq"][t, 1])          # :188
+            lst += [dr[f"cell{k}.h"][t, 0], dr[f"cell{k}.h"][t, 1]]      # :211, :213
+        q[cell + ".dropout"] = lst
+        q[cell + ".crossatt_l2a.dropout"] = [dr[f"cell{k}.attn"][t] for t in range(T)]      # :69
+    names = {m: n for n, m in net.named_modules() if isinstance(m, nn.Dropout)}
+    used = {n: 0 for n in q}
+    orig = nn.Dropout.forward
+
+    def fed(self, inp):
+        n = names[self]
+        f = q[n][used[n]]
+        used[n] += 1
+        assert tuple(f.shape) == tuple(inp.shape), (n, f.shape, inp.shape)
+        assert abs(float(f.max()) - 1.0 / (1.0 - self.p)) < 1e-6, (n, self.p)
+        return inp * f
+
+    nn.Dropout.forward = fed
+    try:
+        lp, _, _ = net(x, qmask, umask)
+        m = umask.reshape(-1, 1)
+        loss = torch.nn.functional.nll_loss(lp * m, label.view(-1), reduction="sum") / umask.sum()
+        loss.backward()
+    finally:
+        nn.Dropout.forward = orig
+    for n in q:
+        assert used[n] == len(q[n]), (n, used[n], len(q[n]))
+    assert all(used[n] > 0 for n in names.values() if n in q)
+    rec = dict(B=B, L=L, d_r=d_r, seed=seed, logits=lp.detach().numpy(), loss=np.float64(float(loss)))
+    rec.update(_grad_samples(net.named_parameters()))
+    np.savez_compressed(os.path.join(HERE, "model_train_mode.npz"), **rec)
+    print("train mode", float(loss))
+
+
 def loss_cases():
     """The reference's own loss.MaskedLoss (loss.py:6-25) for both lossers of model_trainer.py:74-77, with and without class
     weights, on log-probabilities with a padded mask: value and d loss / d pred."""
@@ -255,6 +323,9 @@ def loss_cases():
 if __name__ == "__main__":
     _shim()
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "train_mode":
+        train_mode_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "loss":       # regenerate only the loss fixtures
         loss_cases()
         trainer_case(loss="CrossEntropy", epochs=(1,), out="trainer_ce.npz")
@@ -267,3 +338,4 @@ if __name__ == "__main__":
     model_case("c2_B32_L128_dr768", 32, 128, 768, False, 2, False)
     trainer_case()
     trainer_case(loss="CrossEntropy", epochs=(1,), out="trainer_ce.npz")
+    train_mode_case()

@@ -95,6 +95,26 @@ def test_model(golden_dir, name):
     _check_grads(g, list(P.items()))
 
 
+def test_model_train_mode_with_fed_dropout_masks(golden_dir):
+    """Train mode: the reference's own forward/backward with its 13 nn.Dropout calls fed from O.seeded_drops
+    (tests/golden/make_golden.py::train_mode_case) against the oracle's ``drops`` restatement -- pins where each dropout sits
+    (carried states, unnormalised attention rows, before the residuals) and the call order inside MARN_cell (:180-188, :210-215)."""
+    g = _g(golden_dir, "model_train_mode.npz")
+    B, L, d_r, seed = int(g["B"]), int(g["L"]), int(g["d_r"]), int(g["seed"])
+    P = {k: v.clone().requires_grad_(True) for k, v in O.seeded_params(seed=seed, d_r=d_r).items()}
+    x, qmask, umask, label = O.seeded_batch(B, L, d_r=d_r, seed=seed + 1, ragged=True)
+    dr = O.seeded_drops(B, L, seed=seed + 2)
+    lp, _, _ = O.marn1_sps_forward(P, x, qmask, umask, d_r=d_r, drops=dr)
+    loss = O.masked_nll(lp, label.view(-1), umask)
+    loss.backward()
+    assert np.abs(lp.detach().numpy() - g["logits"]).max() < 2e-5
+    assert abs(float(loss) - float(g["loss"])) < 2e-6
+    _check_grads(g, list(P.items()))
+    # and the masks matter: eval mode differs by far more than the tolerance
+    lp0, _, _ = O.marn1_sps_forward(P, x, qmask, umask, d_r=d_r)
+    assert np.abs(lp0.detach().numpy() - g["logits"]).max() > 1e-2
+
+
 def test_trainer_lr_schedule(golden_dir):
     g = _g(golden_dir, "trainer.npz")
     assert O.step_lr(1e-3, 0.98, 1, 1) == pytest.approx(float(g["lr1"]), rel=1e-12)
