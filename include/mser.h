@@ -102,7 +102,8 @@ int mser_scale_acc_dot(float* acc, int64_t ldacc, const float* t, int64_t ldt, c
  * (dialogue, head) + one row-tiled launch (fc, residual, LayerNorm, FFN, residual, LayerNorm);
  * backward = row-tiled launch + attention launch + input-gradient GEMM (MSER_ENC_BWD_ACT) and the four
  * weight-gradient GEMMs (MSER_ENC_BWD_WGRAD, any stream, any time after ACT).
- * Dropout sites (:54,:83,:106) are identities (eval mode / p = 0).  Rows: row(b, l) = b*sb + l*sl.
+ * Dropout sites (:54,:83,:106) are identities in this fused form (eval mode / p = 0); with dropout the caller composes the layer
+ * from mser_gemm + row kernels + mser_dropout_apply (mser/functional.py mha_fwd / ffn_fwd).  Rows: row(b, l) = b*sb + l*sl.
  * The caller owns every buffer; `mser_encoder_layer_supported` tells whether the fused kernels cover the
  * shape (L <= 128, d_k == d_v <= 64 and % 8 == 0, D <= 128, ...); otherwise compose the layer from mser_gemm + row kernels.
  * ------------------------------------------------------------------------------------------------ */
@@ -286,8 +287,9 @@ int mser_lsthm_step_fwd(const float* x, const float* c, const float* h, const fl
                         const float* W, const float* Wb, const float* U, const float* Ub, const float* V,
                         const float* Vb, const float* S, const float* Sb, float* c_out, float* h_out, float* gates,
                         int32_t B, int32_t D, int32_t H, int32_t Hz, int32_t Hs, mser_stream_t stream);
+/* rng != NULL: the attention's Dropout (:69) with site `site`, probability p, element index (b*H + i)*H + j (see "Dropout"). */
 int mser_rank1_attention_fwd(const float* x1, const float* x2, const float* Wq, const float* Wk, float* out,
-                             int32_t B, int32_t H, mser_stream_t stream);
+                             int32_t B, int32_t H, const uint32_t* rng, uint32_t site, float p, mser_stream_t stream);
 /* Their backward for the module-level API (training runs through the fused BPTT of mser_marn_cell_bwd instead).
  * lsthm_step_bwd: from d(c_t) / d(h_t) (either may be NULL) and the saved gates to the pre-activation gradients dgates [B,4H]
  * (order f,i,o,c~) and d(c_{t-1}); the products with W, U, V, S and the bias sums are mser_gemm / mser_colsum_acc calls.
@@ -295,7 +297,8 @@ int mser_rank1_attention_fwd(const float* x1, const float* x2, const float* Wq, 
 int mser_lsthm_step_bwd(const float* gates, const float* c_prev, const float* c_new, const float* dc_new, const float* dh_new,
                         float* dgates, float* dc_prev, int32_t B, int32_t H, mser_stream_t stream);
 int mser_rank1_attention_bwd(const float* x1, const float* x2, const float* Wq, const float* Wk, const float* dout, float* dx1,
-                             float* dx2, float* gWq, float* gWk, int32_t B, int32_t H, mser_stream_t stream);
+                             float* dx2, float* gWq, float* gWk, int32_t B, int32_t H, const uint32_t* rng, uint32_t site, float p,
+                             mser_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Head: log_softmax + permute to batch-major (model/lsthm_sps.py:391-393) and MaskedLoss (loss.py:13-21).

@@ -41,6 +41,7 @@ class ScaledDotProductAttention(nn.Module):
         names = ["fc_q.weight", "fc_q.bias", "fc_k.weight", "fc_k.bias", "fc_v.weight", "fc_v.bias", "fc_o.weight", "fc_o.bias"]
         params = dict(self.named_parameters())
         h, dk, dv = self.h, self.d_k, self.d_v
+        drop = self._last_drop = F_.module_site(self.dropout, queries.device, 5)       # :72 att = self.dropout(att)
 
         class Impl:
             @staticmethod
@@ -61,14 +62,15 @@ class ScaledDotProductAttention(nn.Module):
                 o = torch.empty(b * nq, h * dv, device=dev)
                 lq, lk = Layout.batch_major(b, nq), Layout.batch_major(b, nk)
                 Pm = F_.attn_core_fwd(q, k, v, o, lq, lk, h, dk, dv, 1.0 / float(np.sqrt(dk)), mul=mul, mask=msk, mask_on=1,
-                                      fill=float("-inf"))
+                                      fill=float("-inf"), drop=drop)
+                Pm, Pd = Pm if drop is not None else (Pm, None)
                 out = torch.empty(b * nq, dm, device=dev)
                 ops.linear(o, P["fc_o.weight"], out, bias=P["fc_o.bias"])
-                return out.view(b, nq, dm), (xq, xk, xv, q, k, v, o, Pm, mul, lq, lk, P)
+                return out.view(b, nq, dm), (xq, xk, xv, q, k, v, o, Pm, Pd, mul, lq, lk, P)
 
             @staticmethod
             def bwd(saved, tensors, dout):
-                xq, xk, xv, q, k, v, o, Pm, mul, lq, lk, P = saved
+                xq, xk, xv, q, k, v, o, Pm, Pd, mul, lq, lk, P = saved
                 G = {n: torch.zeros_like(params[n]) for n in names}
                 d2 = dout.contiguous().view(xq.shape[0], -1)
                 do = torch.empty_like(o)
@@ -76,7 +78,7 @@ class ScaledDotProductAttention(nn.Module):
                 ops.grad_weight(d2, o, G["fc_o.weight"])
                 ops.colsum_acc(d2, G["fc_o.bias"])
                 dq, dk_, dv_ = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-                F_.attn_core_bwd(do, q, k, v, Pm, dq, dk_, dv_, lq, lk, h, dk, dv, 1.0 / float(np.sqrt(dk)), mul=mul)
+                F_.attn_core_bwd(do, q, k, v, Pm, dq, dk_, dv_, lq, lk, h, dk, dv, 1.0 / float(np.sqrt(dk)), mul=mul, drop=drop, Pd=Pd)
                 outs = []
                 for g, x, wn, bn in ((dq, xq, "fc_q.weight", "fc_q.bias"), (dk_, xk, "fc_k.weight", "fc_k.bias"),
                                      (dv_, xv, "fc_v.weight", "fc_v.bias")):

@@ -2554,7 +2554,7 @@ __global__ void lsthm_step_kernel(const float* x, const float* c, const float* h
 }
 
 __global__ __launch_bounds__(NT) void rank1_attention_kernel(const float* x1, const float* x2, const float* Wq, const float* Wk,
-                                                             float* out, int B, int H) {
+                                                             float* out, int B, int H, const uint32_t* rng, uint32_t site, float p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Q = NT / H, JC = H / Q;
   float* ca = smem; float* wk = ca + H; float* pZ = wk + H; float* pN = pZ + NT; float* sh = pN + NT;
@@ -2575,10 +2575,20 @@ __global__ __launch_bounds__(NT) void rank1_attention_kernel(const float* x1, co
   const float mx = (u >= 0.f) ? u * wmx : u * wmn;
   const float u2 = u * LOG2E, m2 = mx * LOG2E;
   float Z = 0.f, N = 0.f;
-  for (int j = q * JC; j < (q + 1) * JC; ++j) {
-    const float e = __builtin_amdgcn_exp2f(fmaf(u2, wk[j], -m2));
-    Z += e;
-    N = fmaf(e, ca[j], N);
+  if (rng) {               // :69 dropout on the normalised attention: element (b, i, j)
+    const DropKey dk = drop_key(rng, site, p);
+    const uint32_t e0 = (uint32_t)(((long)b * H + i) * H);
+    for (int j = q * JC; j < (q + 1) * JC; ++j) {
+      const float e = __builtin_amdgcn_exp2f(fmaf(u2, wk[j], -m2));
+      Z += e;
+      N = fmaf(e * drop_scale(dk, e0 + (uint32_t)j), ca[j], N);
+    }
+  } else {
+    for (int j = q * JC; j < (q + 1) * JC; ++j) {
+      const float e = __builtin_amdgcn_exp2f(fmaf(u2, wk[j], -m2));
+      Z += e;
+      N = fmaf(e, ca[j], N);
+    }
   }
   pZ[tid] = Z; pN[tid] = N;
   __syncthreads();
@@ -2613,7 +2623,8 @@ __global__ void lsthm_step_bwd_kernel(const float* gates, const float* c_prev, c
 // u_i = x1[i] * s, s = <Wq, x2> / sqrt(H).  One workgroup of H threads per row; pass A (thread = unit i) builds the softmax
 // statistics, pass B (thread = key j) the sums over i.  dWq / dWk are accumulated over the rows with float atomics.
 __global__ void rank1_attention_bwd_kernel(const float* x1, const float* x2, const float* Wq, const float* Wk, const float* dout,
-                                           float* dx1, float* dx2, float* gWq, float* gWk, int B, int H) {
+                                           float* dx1, float* dx2, float* gWq, float* gWk, int B, int H, const uint32_t* rng,
+                                           uint32_t site, float p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* ca = smem;            // x2
   float* wk = ca + H;
@@ -2636,9 +2647,13 @@ __global__ void rank1_attention_bwd_kernel(const float* x1, const float* x2, con
   float mx = -INFINITY;
   for (int j = 0; j < H; ++j) mx = fmaxf(mx, u * wk[j]);
   float Z = 0.f, N = 0.f, M = 0.f, Wn = 0.f;
+  DropKey dk;
+  if (rng) dk = drop_key(rng, site, p);
+  const uint32_t e0 = (uint32_t)((long)b * H * H);
   for (int j = 0; j < H; ++j) {
     const float e = expf(u * wk[j] - mx);
-    Z += e; N = fmaf(e, ca[j], N); M = fmaf(e, ca[j] * wk[j], M); Wn = fmaf(e, wk[j], Wn);
+    const float ef = rng ? e * drop_scale(dk, e0 + (uint32_t)(t * H + j)) : e;     // the value sums see the dropped attention
+    Z += e; N = fmaf(ef, ca[j], N); M = fmaf(ef, ca[j] * wk[j], M); Wn = fmaf(e, wk[j], Wn);
   }
   const float z = N / Z, dz = dout[(long)b * H + t];
   const float du = dz * (M - z * Wn) / Z;
@@ -2652,8 +2667,9 @@ __global__ void rank1_attention_bwd_kernel(const float* x1, const float* x2, con
   float dxj = 0.f, dwj = 0.f;
   for (int i = 0; i < H; ++i) {
     const float a = expf(cu[i] * wkv - cm[i]) * cd[i];
-    dxj += a;
-    dwj = fmaf(a * (x2v - cz[i]), cu[i], dwj);
+    const float f = rng ? drop_scale(dk, e0 + (uint32_t)(i * H + t)) : 1.f;
+    dxj = fmaf(a, f, dxj);
+    dwj = fmaf(a * (f * x2v - cz[i]), cu[i], dwj);
   }
   dx2[(long)b * H + t] = dxj + ds * wq * rsH;
   atomicAdd(gWq + t, ds * x2v * rsH);
@@ -2784,22 +2800,25 @@ int mser_lsthm_step_bwd(const float* gates, const float* c_prev, const float* c_
 }
 
 int mser_rank1_attention_bwd(const float* x1, const float* x2, const float* Wq, const float* Wk, const float* dout, float* dx1,
-                             float* dx2, float* gWq, float* gWk, int32_t B, int32_t H, mser_stream_t stream) {
+                             float* dx2, float* gWq, float* gWk, int32_t B, int32_t H, const uint32_t* rng, uint32_t site, float p,
+                             mser_stream_t stream) {
+  MSER_REQUIRE(!rng || (p >= 0.f && p < 1.f), "mser_rank1_attention_bwd: dropout p=%f", p);
   MSER_REQUIRE(x1 && x2 && Wq && Wk && dout && dx1 && dx2 && gWq && gWk, "mser_rank1_attention_bwd: null pointer");
   MSER_REQUIRE(H >= 32 && H <= 1024 && (H & (H - 1)) == 0, "mser_rank1_attention_bwd: H=%d must be a power of two in [32,1024]", H);
   if (B <= 0) return 0;
   hipLaunchKernelGGL(rank1_attention_bwd_kernel, dim3(B), dim3(H), 7 * (size_t)H * sizeof(float), (hipStream_t)stream, x1, x2, Wq,
-                     Wk, dout, dx1, dx2, gWq, gWk, B, H);
+                     Wk, dout, dx1, dx2, gWq, gWk, B, H, rng, site, p);
   return check_launch("mser_rank1_attention_bwd");
 }
 
 int mser_rank1_attention_fwd(const float* x1, const float* x2, const float* Wq, const float* Wk, float* out, int32_t B, int32_t H,
-                             mser_stream_t stream) {
+                             const uint32_t* rng, uint32_t site, float p, mser_stream_t stream) {
+  MSER_REQUIRE(!rng || (p >= 0.f && p < 1.f), "mser_rank1_attention_fwd: dropout p=%f", p);
   MSER_REQUIRE(x1 && x2 && Wq && Wk && out, "mser_rank1_attention_fwd: null pointer");
   MSER_REQUIRE(H >= 32 && H <= 512 && (H & (H - 1)) == 0, "mser_rank1_attention_fwd: H=%d must be a power of two in [32,512]", H);
   if (B <= 0) return 0;
   hipLaunchKernelGGL(rank1_attention_kernel, dim3(B), dim3(NT), (2 * (size_t)H + 2 * NT + 16) * sizeof(float), (hipStream_t)stream, x1, x2,
-                     Wq, Wk, out, B, H);
+                     Wq, Wk, out, B, H, rng, site, p);
   return check_launch("mser_rank1_attention_fwd");
 }
 

@@ -1,8 +1,9 @@
 """MI355X-native mirror of the reference's ``models.encoder`` (reference file model/encoder.py).
 
 Same class names, constructor/forward signatures, parameter names and initialisers; the arithmetic runs in libmser's HIP
-kernels (strided MFMA fp32 GEMMs, wave-per-row softmax / LayerNorm) with hand-written backward passes.  Dropout sites are
-identities (parity is defined at p = 0).  Inputs are batch-major [B, L, D] like the reference's.
+kernels (strided MFMA fp32 GEMMs, wave-per-row softmax / LayerNorm) with hand-written backward passes.  In train mode the
+Dropout sites draw from libmser's counter-based generator (mser.functional.module_site; parity is defined at p = 0 / eval and,
+in train mode, mask for mask: the sites of the last call are kept in ``_last_drop(s)``).  Inputs are batch-major [B, L, D] like the reference's.
 """
 import torch
 import torch.nn as nn
@@ -45,6 +46,7 @@ class ScaledDotProductAttention(nn.Module):
     def forward(self, q, k, v, mask=None):
         require_gpu(q, k, v)
         temperature = self.temperature
+        drop = self._last_drop = F_.module_site(self.dropout, q.device, 0)
 
         class Impl:
             @staticmethod
@@ -56,16 +58,19 @@ class ScaledDotProductAttention(nn.Module):
                 out = torch.empty(B * n * Lq, dv, device=q.device)
                 lq, lk = Layout.batch_major(B * n, Lq), Layout.batch_major(B * n, Lk)
                 P = F_.attn_core_fwd(q2, k2, v2, out, lq, lk, 1, d, dv, 1.0 / temperature,
-                                     mask=_mask_u8(mask, B, n, Lq, Lk), mask_on=0, fill=-1e9)
-                return (out.view(B, n, Lq, dv), P.view(B, n, Lq, Lk)), (q2, k2, v2, P, lq, lk, d, dv)
+                                     mask=_mask_u8(mask, B, n, Lq, Lk), mask_on=0, fill=-1e9, drop=drop)
+                P, Pd = P if drop is not None else (P, None)
+                # the reference returns the attention AFTER its dropout (:83-86)
+                return (out.view(B, n, Lq, dv), (P if Pd is None else Pd).view(B, n, Lq, Lk)), (q2, k2, v2, P, Pd, lq, lk, d, dv)
 
             @staticmethod
             def bwd(saved, tensors, dout, dattn):
-                q2, k2, v2, P, lq, lk, d, dv = saved
+                q2, k2, v2, P, Pd, lq, lk, d, dv = saved
                 if dout is None:
                     return (None, None, None)
                 dq, dk, dv_ = torch.empty_like(q2), torch.empty_like(k2), torch.empty_like(v2)
-                F_.attn_core_bwd(dout.contiguous().view(-1, dv), q2, k2, v2, P, dq, dk, dv_, lq, lk, 1, d, dv, 1.0 / temperature)
+                F_.attn_core_bwd(dout.contiguous().view(-1, dv), q2, k2, v2, P, dq, dk, dv_, lq, lk, 1, d, dv, 1.0 / temperature,
+                                 drop=drop, Pd=Pd)
                 return tuple(g.view(t.shape) for g, t in zip((dq, dk, dv_), tensors))
 
         return ModuleFn.apply(Impl, q, k, v)
@@ -91,6 +96,7 @@ class MultiHeadAttention(nn.Module):
         params = dict(self.named_parameters())
         nh, dk, dv = self.n_head, self.d_k, self.d_v
         same = (q is k) and (k is v)
+        drops = self._last_drops = (F_.module_site(self.attention.dropout, q.device, 0), F_.module_site(self.dropout, q.device, 1))
 
         class Impl:
             @staticmethod
@@ -102,8 +108,9 @@ class MultiHeadAttention(nn.Module):
                 k2 = q2 if same else k.contiguous().view(B * Lk, -1)
                 v2 = q2 if same else v.contiguous().view(B * Lk, -1)
                 m = _mask_u8(mask.unsqueeze(1) if mask is not None else None, B, nh, Lq, Lk)
-                out, c = F_.mha_fwd(q2, k2, v2, P, Layout.batch_major(B, Lq), Layout.batch_major(B, Lk), nh, dk, dv, mask=m)
-                return (out.view(B, Lq, D), c.P), (c, P)
+                out, c = F_.mha_fwd(q2, k2, v2, P, Layout.batch_major(B, Lq), Layout.batch_major(B, Lk), nh, dk, dv, mask=m,
+                                    drop_attn=drops[0], drop_fc=drops[1])
+                return (out.view(B, Lq, D), c.P if c.Pd is None else c.Pd), (c, P)
 
             @staticmethod
             def bwd(saved, tensors, dout, dattn):
@@ -142,13 +149,14 @@ class PositionwiseFeedForward(nn.Module):
         require_gpu(x)
         names = ["w_1.weight", "w_1.bias", "w_2.weight", "w_2.bias", "layer_norm.weight", "layer_norm.bias"]
         params = dict(self.named_parameters())
+        drop = self._last_drop = F_.module_site(self.dropout, x.device, 2)
 
         class Impl:
             @staticmethod
             def fwd(x, *pv):
                 P = dict(zip(names, pv)).__getitem__
                 x2 = x.contiguous().view(-1, x.shape[-1])
-                out, c = F_.ffn_fwd(x2, P)
+                out, c = F_.ffn_fwd(x2, P, drop=drop)
                 return out.view(x.shape), (c, P)
 
             @staticmethod
@@ -178,6 +186,9 @@ class EncoderLayer(nn.Module):
         names = self._NAMES
         params = dict(self.named_parameters())
         nh, dk, dv = self.slf_attn.n_head, self.slf_attn.d_k, self.slf_attn.d_v
+        dev = enc_input.device
+        drops = self._last_drops = (F_.module_site(self.slf_attn.attention.dropout, dev, 0), F_.module_site(self.slf_attn.dropout, dev, 1),
+                                    F_.module_site(self.pos_ffn.dropout, dev, 2))
 
         class Impl:
             @staticmethod
@@ -186,7 +197,7 @@ class EncoderLayer(nn.Module):
                 B, L, D = x.shape
                 x2 = x.contiguous().view(B * L, D)
                 m = _mask_u8(slf_attn_mask.unsqueeze(1) if slf_attn_mask is not None else None, B, nh, L, L)
-                out, c = F_.encoder_layer_fwd(x2, None, P, Layout.batch_major(B, L), nh, dk, dv, mask=m)
+                out, c = F_.encoder_layer_fwd(x2, None, P, Layout.batch_major(B, L), nh, dk, dv, mask=m, drops=drops)
                 return (out.view(B, L, D), F_.encoder_attention(c)), (c, P)
 
             @staticmethod

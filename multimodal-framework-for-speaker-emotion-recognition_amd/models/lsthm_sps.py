@@ -92,13 +92,14 @@ class CrossAttention(nn.Module):
 
     def forward(self, x_1, x_2):
         require_gpu(x_1, x_2)
+        drop = self._last_drop = F_.module_site(self.dropout, x_1.device, 3)
 
         class Impl:
             @staticmethod
             def fwd(x1, x2, Wq, Wk):
                 x1, x2 = x1.contiguous(), x2.contiguous()
                 out = torch.empty_like(x1)
-                ops.rank1_attention_fwd(x1, x2, Wq, Wk, out)
+                ops.rank1_attention_fwd(x1, x2, Wq, Wk, out, drop=drop)
                 return out, (x1, x2, Wq, Wk)
 
             @staticmethod
@@ -106,7 +107,7 @@ class CrossAttention(nn.Module):
                 x1, x2, Wq, Wk = saved
                 dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
                 gWq, gWk = torch.zeros_like(Wq), torch.zeros_like(Wk)
-                ops.rank1_attention_bwd(x1, x2, Wq, Wk, dout.contiguous(), dx1, dx2, gWq, gWk)
+                ops.rank1_attention_bwd(x1, x2, Wq, Wk, dout.contiguous(), dx1, dx2, gWq, gWk, drop=drop)
                 return (dx1, dx2, gWq, gWk)
 
         return ModuleFn.apply(Impl, x_1, x_2, self.Wq, self.Wk)
@@ -126,6 +127,7 @@ class _SeqCrossAttention(nn.Module):
     def forward(self, x_1, x_2):
         require_gpu(x_1, x_2)
         heads = self.heads
+        drop = self._last_drop = F_.module_site(self.dropout, x_1.device, 4)
 
         class Impl:
             @staticmethod
@@ -135,7 +137,7 @@ class _SeqCrossAttention(nn.Module):
                 a = x1.contiguous().view(L1 * B, D1)
                 b = x2.contiguous().view(L2 * B, -1)
                 out = torch.empty(L1 * B, Wv.shape[1], device=x1.device)
-                c = F_.xattn_fwd(a, None, b, None, Wq, Wk, Wv, Layout.time_major(L1, B), Layout.time_major(L2, B), out, heads)
+                c = F_.xattn_fwd(a, None, b, None, Wq, Wk, Wv, Layout.time_major(L1, B), Layout.time_major(L2, B), out, heads, drop=drop)
                 return out.view(L1, B, -1), (c, Wq, Wk, Wv)
 
             @staticmethod
@@ -200,6 +202,12 @@ class MARN_cell(nn.Module):
         H, D = self.dh_l, self.d_l
         params = dict(self.named_parameters())
         names = _CELL_LIVE
+        # train mode on its own (outside MARN1_sps): sites +8 (h_q), +9 (h_l/h_a), +10 (rank-1 attention) of the module generator
+        ds, da = F_.module_site(self.dropout, x_l.device, 8), F_.module_site(self.crossatt_l2a.dropout, x_l.device, 8)
+        self._last_drops = (ds, da)
+        cell_drop = None
+        if ds is not None or da is not None:
+            cell_drop = ((ds or da).rng, [F_.SITE_MODULE + 8], [ds.p if ds else 0.0], [da.p if da else 0.0])
 
         class Impl:
             @staticmethod
@@ -212,7 +220,7 @@ class MARN_cell(nn.Module):
                 out = torch.empty(T * N, 4 * H, device=x_l.device)
                 ws = torch.empty(ops.cell_workspace_bytes(T, N, D, H, 1), device=x_l.device, dtype=torch.uint8)
                 dirs = [dict(p=ops.cell_param_struct(P), qmask=qm, rev=None, out=out)]
-                ops.marn_cell_fwd(ops.make_cell_desc(T, N, D, H, xl2, xa2, dirs, 4 * H, ws))
+                ops.marn_cell_fwd(ops.make_cell_desc(T, N, D, H, xl2, xa2, dirs, 4 * H, ws, drop=cell_drop))
                 return out.view(T, N, 4 * H), (xl2, xa2, dirs, ws, T, N)
 
             @staticmethod
@@ -222,7 +230,7 @@ class MARN_cell(nn.Module):
                 dirs[0]["g"] = ops.cell_param_struct(G.g.get)
                 dirs[0]["dout"] = dout.contiguous().view(T * N, 4 * H)
                 dx_l, dx_a = torch.zeros_like(xl2), torch.zeros_like(xa2)
-                ops.marn_cell_bwd(ops.make_cell_desc(T, N, D, H, xl2, xa2, dirs, 4 * H, ws, dx_l=dx_l, dx_a=dx_a))
+                ops.marn_cell_bwd(ops.make_cell_desc(T, N, D, H, xl2, xa2, dirs, 4 * H, ws, dx_l=dx_l, dx_a=dx_a, drop=cell_drop))
                 return (dx_l.view(tensors[0].shape), dx_a.view(tensors[1].shape), None, *[G(n) for n in names])
 
         return ModuleFn.apply(Impl, x_l, x_a, qmask, *[params[n] for n in names])

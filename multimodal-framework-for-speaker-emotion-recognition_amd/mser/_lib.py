@@ -122,8 +122,8 @@ SIGNATURES = {
     "mser_marn_cell_pipelined": (C.c_int, [_i32, _i32, _i32]),
     "mser_lsthm_step_fwd": (C.c_int, [_vp] * 16 + [_i32] * 5 + [_vp]),
     "mser_lsthm_step_bwd": (C.c_int, [_vp] * 7 + [_i32, _i32, _vp]),
-    "mser_rank1_attention_bwd": (C.c_int, [_vp] * 9 + [_i32, _i32, _vp]),
-    "mser_rank1_attention_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "mser_rank1_attention_bwd": (C.c_int, [_vp] * 9 + [_i32, _i32, _vp, C.c_uint32, _f32, _vp]),
+    "mser_rank1_attention_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, C.c_uint32, _f32, _vp]),
     "mser_logsoftmax_tb_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "mser_logsoftmax_tb_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mser_masked_nll_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),

@@ -73,6 +73,23 @@ class DropSite:
         return ops.dropout_scale(n, self.rng, self.site, self.p)
 
 
+SITE_MODULE = 64    # module mirrors used on their own (outside MARN1_sps): + a per-class offset; every draw advances the step word
+MODULE_DROPOUT_SEED = 0x0D15EA5E
+_MODULE_RNG = {}
+
+
+def module_site(dropout: "torch.nn.Dropout", device, offset: int = 0) -> Optional[DropSite]:
+    """Train-mode dropout site of a module mirror used on its own: one generator per device, advanced at every draw.  None when
+    the module is in eval mode or p = 0 (``dropout.training`` follows the owning module's .train() / .eval())."""
+    if not dropout.training or dropout.p <= 0:
+        return None
+    rng = _MODULE_RNG.get(device)
+    if rng is None:
+        rng = _MODULE_RNG[device] = torch.tensor([MODULE_DROPOUT_SEED & 0x7FFFFFFF, 0], dtype=torch.int32, device=device)
+    ops.rng_advance_(rng)
+    return DropSite(rng.clone(), SITE_MODULE + offset, float(dropout.p))
+
+
 def zero_dropout(module):
     """Set p = 0 on every nn.Dropout of a module tree: the parity configuration (what tests/golden/make_golden.py does to the
     reference before it records trainer goldens).  Returns the module."""
@@ -333,8 +350,11 @@ def _encoder_desc(e0: Tensor, P: Getter, lay: Layout, nh: int, dk: int, dv: int,
 
 
 def encoder_attention(c) -> Tensor:
-    """The attention tensor [nb, nh, L, L] of an encoder_layer_fwd context (either path)."""
-    return c.P if isinstance(c, EncFusedCtx) else c[0].P
+    """The attention tensor [nb, nh, L, L] of an encoder_layer_fwd context (either path); with dropout the dropped one, which is
+    what the reference returns (model/encoder.py:83-86)."""
+    if isinstance(c, EncFusedCtx):
+        return c.P
+    return c[0].Pd if c[0].Pd is not None else c[0].P
 
 
 def encoder_layer_fwd(x: Tensor, x2: Optional[Tensor], P: Getter, lay: Layout, nh: int, dk: int, dv: int,

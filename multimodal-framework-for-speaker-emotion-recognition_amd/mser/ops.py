@@ -448,15 +448,19 @@ def lsthm_step_bwd(gates: Tensor, c_prev: Tensor, c_new: Tensor, dc_new: Optiona
 
 
 def rank1_attention_bwd(x1: Tensor, x2: Tensor, Wq: Tensor, Wk: Tensor, dout: Tensor, dx1: Tensor, dx2: Tensor, gWq: Tensor,
-                        gWk: Tensor) -> None:
+                        gWk: Tensor, drop=None) -> None:
+    """drop: None or an object with .rng (int32[2] tensor), .site, .p (mser.functional.DropSite)."""
     B, H = x1.shape
+    rng, site, p = (_p(drop.rng), drop.site, float(drop.p)) if drop is not None else (None, 0, 0.0)
     L.check(_lib().mser_rank1_attention_bwd(_p(x1), _p(x2), _p(Wq), _p(Wk), _p(dout), _p(dx1), _p(dx2), _p(gWq), _p(gWk), B, H,
-                                              _stream()), "rank1_attention_bwd")
+                                              rng, site, p, _stream()), "rank1_attention_bwd")
 
 
-def rank1_attention_fwd(x1: Tensor, x2: Tensor, Wq: Tensor, Wk: Tensor, out: Tensor) -> None:
+def rank1_attention_fwd(x1: Tensor, x2: Tensor, Wq: Tensor, Wk: Tensor, out: Tensor, drop=None) -> None:
     B, H = x1.shape
-    L.check(_lib().mser_rank1_attention_fwd(_p(x1), _p(x2), _p(Wq), _p(Wk), _p(out), B, H, _stream()), "rank1_attention_fwd")
+    rng, site, p = (_p(drop.rng), drop.site, float(drop.p)) if drop is not None else (None, 0, 0.0)
+    L.check(_lib().mser_rank1_attention_fwd(_p(x1), _p(x2), _p(Wq), _p(Wk), _p(out), B, H, rng, site, p, _stream()),
+            "rank1_attention_fwd")
 
 
 # ---------------------------------------------------------------------------------------------- MARN cell

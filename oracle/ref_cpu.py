@@ -168,7 +168,7 @@ def encoder_layer(P: Params, pre: str, x: Tensor, n_head: int = 8, d_k: int = 40
 
 def self_attention_lib(P: Params, pre: str, queries: Tensor, keys: Tensor, values: Tensor, h: int,
                        d_k: int, d_v: int, attention_mask: Optional[Tensor] = None,
-                       attention_weights: Optional[Tensor] = None) -> Tensor:
+                       attention_weights: Optional[Tensor] = None, drop: Optional[Tensor] = None) -> Tensor:
     """attention:/SelfAttention.py::ScaledDotProductAttention.forward -- :49-76 (biased projections)."""
     b, nq, nk = queries.shape[0], queries.shape[1], keys.shape[1]
     q = linear(queries, P[pre + "fc_q.weight"], P[pre + "fc_q.bias"]).view(b, nq, h, d_k).permute(0, 2, 1, 3)
@@ -180,6 +180,8 @@ def self_attention_lib(P: Params, pre: str, queries: Tensor, keys: Tensor, value
     if attention_mask is not None:
         att = att.masked_fill(attention_mask, float("-inf"))
     att = torch.softmax(att, -1)
+    if drop is not None:                                 # :72 att = self.dropout(att); factors [b,h,nq,nk]
+        att = att * drop
     out = att.matmul(v).permute(0, 2, 1, 3).contiguous().view(b, nq, h * d_v)
     return linear(out, P[pre + "fc_o.weight"], P[pre + "fc_o.bias"])
 

@@ -46,7 +46,7 @@ def _check_grads(g, named, rel=3e-4):
 def test_encoder_layer_module(O, golden_dir):
     from models.encoder import EncoderLayer
     g = _g(golden_dir, "modules.npz")
-    m = EncoderLayer(100, 40, 8, 40, 40).cuda()
+    m = EncoderLayer(100, 40, 8, 40, 40).cuda().eval()
     P = O.seeded_params(seed=4)
     load_params(m, {k[len("encoder_l."):]: v for k, v in P.items() if k.startswith("encoder_l.")})
     x = torch.tensor(g["enc_x"]).cuda().requires_grad_(True)
@@ -73,7 +73,7 @@ def test_seq_cross_attention_modules(O, golden_dir):
     g = _g(golden_dir, "modules.npz")
     P = O.seeded_params(seed=4)
     for cls, pre, x2k, outk in ((CrossAttention2, "crossatt_l2a.", "ca2_x2", "ca2_out"), (CrossAttention3, "crossatt_l2a_1.", "ca3_x2", "ca3_out")):
-        m = cls(100, 128, 128).cuda()
+        m = cls(100, 128, 128).cuda().eval()
         load_params(m, {k[len(pre):]: v for k, v in P.items() if k.startswith(pre)})
         a = torch.tensor(g["ca2_x1"]).cuda().requires_grad_(True)
         b = torch.tensor(g[x2k]).cuda().requires_grad_(True)
@@ -93,7 +93,7 @@ def test_seq_cross_attention_modules(O, golden_dir):
 def test_library_self_attention(O, golden_dir):
     from attention.SelfAttention import ScaledDotProductAttention
     g = _g(golden_dir, "modules.npz")
-    m = ScaledDotProductAttention(64, 16, 16, 4).cuda()
+    m = ScaledDotProductAttention(64, 16, 16, 4).cuda().eval()
     load_params(m, {k[len("sa_p/"):]: torch.tensor(g[k]) for k in g.files if k.startswith("sa_p/")})
     q, k = torch.tensor(g["sa_q"]).cuda(), torch.tensor(g["sa_k"]).cuda()
     assert maxabs(m(q, k, k), g["sa_out"]) < 2e-5
@@ -105,7 +105,7 @@ def test_marn_cell_module(O, golden_dir):
     """MARN_cell alone against the reference's own outputs: padded tail, all-party-0 and all-party-1 steps."""
     from models.lsthm_sps import MARN_cell
     g = _g(golden_dir, "cell_T24_N6.npz")
-    m = MARN_cell(128, 128, 100, 100).cuda()
+    m = MARN_cell(128, 128, 100, 100).cuda().eval()
     P = O.seeded_params(seed=3)
     load_params(m, {k[len("marn_cell_f."):]: v for k, v in P.items() if k.startswith("marn_cell_f.")})
     x_l = torch.tensor(g["x_l"]).cuda().requires_grad_(True)
@@ -186,7 +186,7 @@ def test_persistent_vs_per_step_launches(O):
 def test_persistent_status_clean(O):
     from models.lsthm_sps import MARN_cell
     from mser import ops
-    m = MARN_cell(128, 128, 100, 100).cuda()
+    m = MARN_cell(128, 128, 100, 100).cuda().eval()
     T, N = 50, 32
     rs = np.random.RandomState(0)
     x_l = torch.tensor(rs.standard_normal((T, N, 100)).astype(np.float32)).cuda()
@@ -453,7 +453,7 @@ def test_lsthm1_and_cross_attention_standalone_backward(O):
     (O.lsthm1({k: v.detach() for k, v in P.items()}, "l.", *ri2)[1] * wh).sum().backward()
     assert maxabs(gi2[1].grad, ri2[1].grad) < 5e-5 * max(1.0, float(ri2[1].grad.abs().max()))
     # ---- CrossAttention (rank-1 form on the GPU, as-written [B,H,H] form in the oracle)
-    ca = CrossAttention().cuda()
+    ca = CrossAttention().cuda().eval()
     with torch.no_grad():
         ca.Wq.copy_(t(1, H, sc=0.4).cuda())
         ca.Wk.copy_(t(1, H, sc=0.4).cuda())
@@ -630,3 +630,92 @@ def test_train_mode_dropout_mask_for_mask_vs_oracle(O, persistent):
     lp_e, _, _ = net(x.cuda(), qmask.cuda(), umask.cuda())
     lp_eref, _, _ = O.marn1_sps_forward(P, x, qmask, umask, d_r=d_r)
     assert maxabs(lp_e, lp_eref) < LOGIT_TOL
+
+
+def test_module_mirrors_train_mode_dropout_vs_oracle(O):
+    """The module mirrors used on their own (outside MARN1_sps) in .train(): EncoderLayer, CrossAttention2, CrossAttention (rank-1),
+    MARN_cell and the library ScaledDotProductAttention draw their Dropout from the module generator (mser.functional.module_site);
+    the factors of the call are read back and handed to the oracle -- outputs and input gradients must agree."""
+    from models.encoder import EncoderLayer
+    from models.lsthm_sps import CrossAttention, CrossAttention2, MARN_cell
+    from attention.SelfAttention import ScaledDotProductAttention as LibSDPA
+    from mser import functional as F_
+    P = O.seeded_params(seed=61)
+    rs = np.random.RandomState(7)
+
+    def rnd(*shape):
+        return torch.tensor(rs.standard_normal(shape).astype(np.float32))
+
+    def sub(prefix):
+        return {k[len(prefix):]: v for k, v in P.items() if k.startswith(prefix)}
+
+    def check(out, ref, xs, xrefs, tol=2e-5):
+        assert maxabs(out, ref) < tol, maxabs(out, ref)
+        w = rnd(*ref.shape)
+        (out * w.cuda()).sum().backward()
+        (ref * w).sum().backward()
+        for a, b in zip(xs, xrefs):
+            assert maxabs(a.grad, b.grad) < 3e-4 * max(1e-3, float(b.grad.norm())), (a.shape,)
+
+    # ---- EncoderLayer: three sites
+    B, L, D, nh = 3, 9, 100, 8
+    enc = EncoderLayer(100, 40, 8, 40, 40).cuda().train()
+    load_params(enc, sub("encoder_l."))
+    x = rnd(B, L, D)
+    xg, xr = x.clone().cuda().requires_grad_(True), x.clone().requires_grad_(True)
+    out, attn = enc(xg)
+    da, dfc, dffn = enc._last_drops
+    drops = (da.scale(B * nh * L * L).cpu().view(B, nh, L, L), dfc.scale(B * L * D).cpu().view(B, L, D),
+             dffn.scale(B * L * D).cpu().view(B, L, D))
+    ref, attn_ref = O.encoder_layer(P, "encoder_l.", xr, drops=drops)
+    assert maxabs(attn, attn_ref) < 1e-5                 # the returned attention is the dropped one (encoder.py:83-86)
+    check(out, ref, [xg], [xr])
+    out_e, _ = enc.eval()(xg.detach())
+    assert maxabs(out_e, O.encoder_layer(P, "encoder_l.", x)[0]) < 2e-5
+
+    # ---- CrossAttention2 (sequence level)
+    ca2 = CrossAttention2(100, 128, 128).cuda().train()
+    load_params(ca2, sub("crossatt_l2a."))
+    x1, x2 = rnd(L, B, 100), rnd(L, B, 100)
+    g1, g2 = x1.clone().cuda().requires_grad_(True), x2.clone().cuda().requires_grad_(True)
+    r1, r2 = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    out = ca2(g1, g2)
+    f = ca2._last_drop.scale(B * L * L).cpu().view(B, L, L)
+    check(out, O.cross_attention_seq(P, "crossatt_l2a.", r1, r2, drop=f), [g1, g2], [r1, r2])
+
+    # ---- CrossAttention (rank-1, per step)
+    H = 128
+    ca = CrossAttention().cuda().train()
+    load_params(ca, sub("marn_cell_f.crossatt_l2a."))
+    x1, x2 = rnd(5, H), rnd(5, H)
+    g1, g2 = x1.clone().cuda().requires_grad_(True), x2.clone().cuda().requires_grad_(True)
+    r1, r2 = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    out = ca(g1, g2)
+    f = ca._last_drop.scale(5 * H * H).cpu().view(5, H, H)
+    assert abs(float((f == 0).float().mean()) - 0.2) < 0.02
+    check(out, O.cross_attention(P, "marn_cell_f.crossatt_l2a.", r1, r2, drop=f), [g1, g2], [r1, r2])
+
+    # ---- MARN_cell on its own
+    T, N = 6, 4
+    cell = MARN_cell(128, 128, 100, 100).cuda().train()
+    load_params(cell, sub("marn_cell_f."))
+    xl, xa = rnd(T, N, 100), rnd(T, N, 100)
+    qmask = torch.tensor(np.eye(2, dtype=np.float32)[rs.randint(0, 2, (T, N))])
+    gl, ga = xl.clone().cuda().requires_grad_(True), xa.clone().cuda().requires_grad_(True)
+    rl, ra = xl.clone().requires_grad_(True), xa.clone().requires_grad_(True)
+    out = cell(torch.zeros(T, N, 1).cuda(), gl, ga, qmask.cuda())
+    ds, da = cell._last_drops
+    base = F_.DropSite(ds.rng, ds.site, ds.p)
+    dr = {"hq": base.scale(T * 2 * N * H).cpu().view(T, 2, N, H),
+          "h": F_.DropSite(ds.rng, ds.site + 1, ds.p).scale(T * 2 * N * H).cpu().view(T, 2, N, H),
+          "attn": F_.DropSite(ds.rng, ds.site + 2, da.p).scale(T * N * H * H).cpu().view(T, N, H, H)}
+    check(out, O.marn_cell(P, "marn_cell_f.", rl, ra, qmask, drops=dr), [gl, ga], [rl, ra], tol=5e-5)
+
+    # ---- library ScaledDotProductAttention (attention:/SelfAttention.py)
+    lib = LibSDPA(d_model=64, d_k=16, d_v=16, h=4).cuda().train()
+    Pl = {k: v.detach().cpu().clone() for k, v in lib.state_dict().items()}
+    q = rnd(2, 7, 64)
+    qg, qr = q.clone().cuda().requires_grad_(True), q.clone().requires_grad_(True)
+    out = lib(qg, qg, qg)
+    f = lib._last_drop.scale(2 * 4 * 7 * 7).cpu().view(2, 4, 7, 7)
+    check(out, O.self_attention_lib({"x." + k: v for k, v in Pl.items()}, "x.", qr, qr, qr, 4, 16, 16, drop=f), [qg], [qr])
