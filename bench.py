@@ -331,7 +331,7 @@ def main():
             tr = tr_main
         del trd
         variants["dropout_on"] = {"ms_per_step": round(ms_d, 4), "utterances_per_s": round(B * L / (ms_d * 1e-3), 1),
-                                  "note": "counter-based masks re-evaluated in the backward; encoder layers on the composed (unfused) path; eager launches"}
+                                  "note": "all 13 sites live; counter-based masks, re-evaluated in the backward instead of stored; eager launches"}
         log("variants done")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -102,8 +102,7 @@ int mser_scale_acc_dot(float* acc, int64_t ldacc, const float* t, int64_t ldt, c
  * (dialogue, head) + one row-tiled launch (fc, residual, LayerNorm, FFN, residual, LayerNorm);
  * backward = row-tiled launch + attention launch + input-gradient GEMM (MSER_ENC_BWD_ACT) and the four
  * weight-gradient GEMMs (MSER_ENC_BWD_WGRAD, any stream, any time after ACT).
- * Dropout sites (:54,:83,:106) are identities in this fused form (eval mode / p = 0); with dropout the caller composes the layer
- * from mser_gemm + row kernels + mser_dropout_apply (mser/functional.py mha_fwd / ffn_fwd).  Rows: row(b, l) = b*sb + l*sl.
+ * Dropout sites (:54,:83,:106): see the rng fields at the end of the descriptor.  Rows: row(b, l) = b*sb + l*sl.
  * The caller owns every buffer; `mser_encoder_layer_supported` tells whether the fused kernels cover the
  * shape (L <= 128, d_k == d_v <= 64 and % 8 == 0, D <= 128, ...); otherwise compose the layer from mser_gemm + row kernels.
  * ------------------------------------------------------------------------------------------------ */
@@ -138,6 +137,13 @@ typedef struct mser_encoder_desc {
   float* dx;                   /* [rows, D] gradient of the layer input (written) */
   float* g_w_qs; float* g_w_ks; float* g_w_vs; float* g_fc; float* g_ln1_g; float* g_ln1_b;   /* ACCUMULATED */
   float* g_w1; float* g_b1; float* g_w2; float* g_b2; float* g_ln2_g; float* g_ln2_b;
+  /* Dropout (see "Dropout"; rng == NULL: identity): sites drop_site (attention :83, element = flat index of P), drop_site+1
+   * (after fc :54, element row*D + col), drop_site+2 (after w_2 :106, same indexing).  With p_fc or p_ffn > 0 the backward
+   * needs dt1 [rows, D] (gradient at the fc output; dy1 stays the residual's).  P keeps the plain softmax. */
+  const uint32_t* rng;
+  uint32_t drop_site;
+  float p_attn, p_fc, p_ffn;
+  float* dt1;
 } mser_encoder_desc;
 
 int mser_encoder_layer_supported(const mser_encoder_desc* d);

@@ -58,6 +58,7 @@ struct AttnArgs {
   int nb, nh, L, dk;
   long sb, sl;                                         // row of (dialogue b, position l) = b*sb + l*sl
   float scale, fill;
+  const uint32_t* rng; uint32_t site; float p;      // attention Dropout (encoder.py:83); rng == nullptr: identity
 };
 
 __device__ __forceinline__ void stage_head(const float* src, long ld, int col0, int b, const AttnArgs& a, int LP, int SD, float* dst) {
@@ -129,7 +130,10 @@ __global__ __launch_bounds__(ET) void attn_fwd_kernel(AttnArgs a) {
     }
   }
   __syncthreads();
-  // ---- row softmax (one wave per row, two columns per lane); padded query rows become zero rows
+  // ---- row softmax (one wave per row, two columns per lane); padded query rows become zero rows.  With dropout the global copy
+  //      keeps the plain softmax (its backward needs it), the LDS copy that feeds O = P v takes the factor of element pbase + row*L + col
+  DropKey dk_;
+  if (a.rng) dk_ = drop_key(a.rng, a.site, a.p);
   for (int row = wave; row < LP; row += EW) {
     float* Sr = S + row * SS;
     const bool has1 = lane + 64 < LP;
@@ -143,8 +147,14 @@ __global__ __launch_bounds__(ET) void attn_fwd_kernel(AttnArgs a) {
     const float e0 = expf(v0 - m), e1 = expf(v1 - m);
     const float inv = 1.0f / wave_sum(e0 + e1);
     const float p0 = e0 * inv, p1 = e1 * inv;
-    if (lane < LP) Sr[lane] = p0;
-    if (has1) Sr[lane + 64] = p1;
+    float q0 = p0, q1 = p1;
+    if (a.rng) {
+      const uint32_t e0i = (uint32_t)(pbase + (long)row * L);
+      q0 *= drop_scale(dk_, e0i + (uint32_t)lane);
+      q1 *= drop_scale(dk_, e0i + (uint32_t)(lane + 64));
+    }
+    if (lane < LP) Sr[lane] = q0;
+    if (has1) Sr[lane + 64] = q1;
     if (a.P) {
       if (lane < L) a.P[pbase + (long)row * L + lane] = p0;
       if (lane + 64 < L) a.P[pbase + (long)row * L + lane + 64] = p1;
@@ -181,9 +191,13 @@ __global__ __launch_bounds__(ET) void attn_bwd_kernel(AttnArgs a) {
   float* delta = s1 + LP * SD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
   const long pbase = ((long)b * a.nh + h) * L * L;
-  for (int e = tid; e < LP * LP; e += ET) {
+  DropKey dk_;
+  if (a.rng) dk_ = drop_key(a.rng, a.site, a.p);
+  for (int e = tid; e < LP * LP; e += ET) {        // dropout: the dropped attention (what multiplied V in the forward) for dV
     const int row = e / LP, col = e - row * LP;
-    Pb[row * SS + col] = (row < L && col < L) ? a.P[pbase + (long)row * L + col] : 0.f;
+    float pv = (row < L && col < L) ? a.P[pbase + (long)row * L + col] : 0.f;
+    if (a.rng) pv *= drop_scale(dk_, (uint32_t)(pbase + (long)row * L + col));
+    Pb[row * SS + col] = pv;
   }
   stage_head(a.dO, a.lddo, h * dk, b, a, LP, SD, s0);
   stage_head(a.v, a.ldv, h * dk, b, a, LP, SD, s1);
@@ -240,7 +254,14 @@ __global__ __launch_bounds__(ET) void attn_bwd_kernel(AttnArgs a) {
         for (int i = 0; i < 16; ++i) {
           const int row = ti * 32 + acc_row(i, half);
           float* p = Pb + row * SS + col;
-          *p = a.scale * *p * (dp[u][i] - delta[row]);
+          if (a.rng) {       // dS = scale * P o (mask o dP - delta) with the plain softmax P (re-read: the tile holds the dropped one)
+            const bool in = row < L && col < L;
+            const long g = pbase + (long)row * L + col;
+            const float pv = in ? a.P[g] : 0.f;
+            *p = a.scale * pv * (dp[u][i] * drop_scale(dk_, (uint32_t)g) - delta[row]);
+          } else {
+            *p = a.scale * *p * (dp[u][i] - delta[row]);
+          }
         }
       }
     }
@@ -365,6 +386,9 @@ struct PostArgs {
   // backward
   const float* dout; float* dy2; float* dh; float* dy1; float* dO;
   float* gg1; float* gbe1; float* gbb1; float* gbb2; float* gg2; float* gbe2;
+  // Dropout after fc (encoder.py:54, site_fc) and after w_2 (:106, site_fc + 1), element row*D + col; rng == nullptr: identity.
+  // dt1: the gradient at the fc output (masked dy1) for the fc weight gradient; dy1 itself stays the residual's gradient.
+  const uint32_t* rng; uint32_t site_fc; float p_fc, p_ffn; float* dt1;
 };
 
 __device__ __forceinline__ int pad8(int n) { return ((n + 7) & ~7) + 4; }   // LDS row stride: k padded to 8, +4 (= 4 * odd mod 32 for D=100,F=40,NO=320)
@@ -421,8 +445,12 @@ __global__ __launch_bounds__(ET) void post_fwd_kernel(PostArgs p) {
     }
   }
   __syncthreads();
-  // t = O fc^T
-  wg_gemm32<0>(As, NOP, NO, p.fc, NO, D, red, [&](int row, int n, float s) { ys[row * DP + n] = s; });
+  // t = dropout(O fc^T)
+  DropKey dk1, dk2;
+  if (p.rng) { dk1 = drop_key(p.rng, p.site_fc, p.p_fc); dk2 = drop_key(p.rng, p.site_fc + 1u, p.p_ffn); }
+  wg_gemm32<0>(As, NOP, NO, p.fc, NO, D, red, [&](int row, int n, float s) {
+    ys[row * DP + n] = p.rng ? s * drop_scale(dk1, (uint32_t)((r0 + row) * D + n)) : s;
+  });
   // y1 = t + e0 ; e1 = LayerNorm(y1)
   ln_rows(p, r0, D, [&](int rr, int j) { return ys[rr * DP + j] + p.x[(r0 + rr) * D + j]; }, p.g1, p.be1, p.y1, p.mean1, p.rstd1,
           p.e1, e1s, DP);
@@ -435,7 +463,11 @@ __global__ __launch_bounds__(ET) void post_fwd_kernel(PostArgs p) {
     if (r0 + row < p.rows) p.hdn[(r0 + row) * F + n] = hv;
   });
   // t2 = hdn W2^T + b2 ; y2 = t2 + e1 ; out = LayerNorm(y2)
-  wg_gemm32<0>(hs, FP, F, p.W2, F, D, red, [&](int row, int n, float s) { ys[row * DP + n] = s + p.bb2[n] + e1s[row * DP + n]; });
+  wg_gemm32<0>(hs, FP, F, p.W2, F, D, red, [&](int row, int n, float s) {
+    float t2 = s + p.bb2[n];
+    if (p.rng) t2 *= drop_scale(dk2, (uint32_t)((r0 + row) * D + n));
+    ys[row * DP + n] = t2 + e1s[row * DP + n];
+  });
   ln_rows(p, r0, D, [&](int rr, int j) { return ys[rr * DP + j]; }, p.g2, p.be2, p.y2, p.mean2, p.rstd2, p.out, nullptr, 0);
 }
 
@@ -510,9 +542,26 @@ __global__ __launch_bounds__(ET) void post_bwd_kernel(PostArgs p) {
   for (int e = tid; e < RT * (FP - F); e += ET) dhs[(e / (FP - F)) * FP + F + e % (FP - F)] = 0.f;
   __syncthreads();
   flush_cs(cs, D, p.gg2, p.gbe2);
-  colsum_tile(dys, DP, D, p.gbb2);
+  // dropout after w_2: the FFN path (bias sum, dh, the deferred W2 gradient through p.dy2) sees mask o dy2, the residual (de1
+  // below) the plain dy2.  The masked tile borrows `des`, which is only written by the W1 product further down.
+  float* dms = dys;
+  if (p.rng) {
+    const DropKey dk2 = drop_key(p.rng, p.site_fc + 1u, p.p_ffn);
+    dms = des;
+    for (int e = tid; e < RT * DP; e += ET) {
+      const int rr = e / DP, j = e - rr * DP;
+      float v = 0.f;
+      if (j < D && r0 + rr < p.rows) {
+        v = dys[e] * drop_scale(dk2, (uint32_t)((r0 + rr) * D + j));
+        p.dy2[(r0 + rr) * D + j] = v;
+      }
+      des[e] = v;
+    }
+    __syncthreads();
+  }
+  colsum_tile(dms, DP, D, p.gbb2);
   // ---- dh = (dy2 W2) o (hdn > 0)
-  wg_gemm32<1>(dys, DP, D, p.W2, F, F, red, [&](int row, int n, float s) {
+  wg_gemm32<1>(dms, DP, D, p.W2, F, F, red, [&](int row, int n, float s) {
     const bool rok = r0 + row < p.rows;
     const float v = (rok && p.hdn[(r0 + row) * F + n] > 0.f) ? s : 0.f;
     dhs[row * FP + n] = v;
@@ -525,6 +574,18 @@ __global__ __launch_bounds__(ET) void post_bwd_kernel(PostArgs p) {
   ln_bwd_rows(p, r0, D, [&](int rr, int j) { return des[rr * DP + j]; }, p.y1, p.mean1, p.rstd1, p.g1, dys, DP, p.dy1, cs);
   __syncthreads();
   flush_cs(cs, D, p.gg1, p.gbe1);
+  if (p.rng) {      // dropout after fc: dO and the fc weight gradient (through p.dt1) see mask o dy1; p.dy1 stays the residual's gradient
+    const DropKey dk1 = drop_key(p.rng, p.site_fc, p.p_fc);
+    for (int e = tid; e < RT * DP; e += ET) {
+      const int rr = e / DP, j = e - rr * DP;
+      if (j < D && r0 + rr < p.rows) {
+        const float v = dys[e] * drop_scale(dk1, (uint32_t)((r0 + rr) * D + j));
+        dys[e] = v;
+        p.dt1[(r0 + rr) * D + j] = v;
+      }
+    }
+    __syncthreads();
+  }
   // ---- dO = dy1 fc
   wg_gemm32<1>(dys, DP, D, p.fc, NO, NO, red, [&](int row, int n, float s) {
     if (r0 + row < p.rows) p.dO[(r0 + row) * NO + n] = s;
@@ -695,6 +756,7 @@ static int enc_validate(const mser_encoder_desc& d, bool bwd) {
   if (bwd) {
     MSER_REQUIRE(d.dout && d.dy2 && d.dh && d.dy1 && d.dO && d.dqkv && d.dx, "mser_encoder_layer_bwd: null gradient buffer");
     MSER_REQUIRE(al16(d.dO) && al16(d.dqkv), "mser_encoder_layer_bwd: buffers must be 16-byte aligned");
+    MSER_REQUIRE(!(d.rng && (d.p_fc > 0.f || d.p_ffn > 0.f)) || d.dt1, "mser_encoder_layer_bwd: dropout needs the dt1 buffer");
   }
   return 0;
 }
@@ -712,6 +774,7 @@ static AttnArgs attn_args(const mser_encoder_desc& d) {
   a.nb = d.nb; a.nh = d.nh; a.L = d.nl; a.dk = d.dk;
   a.sb = d.sb; a.sl = d.sl;
   a.scale = 1.0f / sqrtf((float)d.dk); a.fill = -1e9f;
+  a.rng = (d.rng && d.p_attn > 0.f) ? d.rng : nullptr; a.site = d.drop_site; a.p = d.p_attn;
   return a;
 }
 static PostArgs post_args(const mser_encoder_desc& d) {
@@ -723,6 +786,8 @@ static PostArgs post_args(const mser_encoder_desc& d) {
   p.out = d.out;
   p.dout = d.dout; p.dy2 = d.dy2; p.dh = d.dh; p.dy1 = d.dy1; p.dO = d.dO;
   p.gg1 = d.g_ln1_g; p.gbe1 = d.g_ln1_b; p.gbb1 = d.g_b1; p.gbb2 = d.g_b2; p.gg2 = d.g_ln2_g; p.gbe2 = d.g_ln2_b;
+  p.rng = (d.rng && (d.p_fc > 0.f || d.p_ffn > 0.f)) ? d.rng : nullptr;
+  p.site_fc = d.drop_site + 1u; p.p_fc = d.p_fc; p.p_ffn = d.p_ffn; p.dt1 = d.dt1;
   return p;
 }
 // w_qs, w_ks, w_vs back to back (the flat parameter buffer lays them out that way) -> one N = 3*nh*dk projection
@@ -784,7 +849,7 @@ int encoder_layer_wgrad_descs(const mser_encoder_desc& d, mser_gemm_desc* out, i
     float* gw[3] = {d.g_w_qs, d.g_w_ks, d.g_w_vs};
     for (int i = 0; i < 3; ++i) wgrad(d.dqkv + i * nq, 3L * nq, nq, d.x, D, D, gw[i]);
   }
-  wgrad(d.dy1, D, D, d.O, nq, nq, d.g_fc);
+  wgrad((d.rng && (d.p_fc > 0.f || d.p_ffn > 0.f)) ? d.dt1 : d.dy1, D, D, d.O, nq, nq, d.g_fc);
   wgrad(d.dh, F, F, d.e1, D, D, d.g_w1);
   wgrad(d.dy2, D, D, d.hdn, F, F, d.g_w2);
   return n;

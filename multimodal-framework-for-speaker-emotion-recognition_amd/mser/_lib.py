@@ -72,6 +72,8 @@ class EncoderDesc(C.Structure):
         ("g_w_qs", C.c_void_p), ("g_w_ks", C.c_void_p), ("g_w_vs", C.c_void_p), ("g_fc", C.c_void_p),
         ("g_ln1_g", C.c_void_p), ("g_ln1_b", C.c_void_p), ("g_w1", C.c_void_p), ("g_b1", C.c_void_p),
         ("g_w2", C.c_void_p), ("g_b2", C.c_void_p), ("g_ln2_g", C.c_void_p), ("g_ln2_b", C.c_void_p),
+        ("rng", C.c_void_p), ("drop_site", C.c_uint32), ("p_attn", C.c_float), ("p_fc", C.c_float), ("p_ffn", C.c_float),
+        ("dt1", C.c_void_p),
     ]
 
 

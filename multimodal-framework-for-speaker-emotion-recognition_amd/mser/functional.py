@@ -358,10 +358,11 @@ def encoder_attention(c) -> Tensor:
 
 
 def encoder_layer_fwd(x: Tensor, x2: Optional[Tensor], P: Getter, lay: Layout, nh: int, dk: int, dv: int,
-                      mask: Optional[Tensor] = None, out: Optional[Tensor] = None, drops=None):
+                      mask: Optional[Tensor] = None, out: Optional[Tensor] = None, drops=None, need_attn: bool = True):
     """EncoderLayer.forward on input (x + x2) -- reference model/encoder.py:130-133; x2 carries the residual of the model's
     second pass (model/lsthm_sps.py:357-358).  Returns (out [rows,D], ctx).  ``drops`` = (attention, fc, ffn) DropSites (each may
-    be None) selects the composed path, where every dropout site is a materialised tensor."""
+    be None) with consecutive site numbers and one rng.  The fused kernels draw them in place but keep only the plain softmax, so a
+    caller that returns the (dropped) attention tensor like the reference (``need_attn``) gets the composed path instead."""
     rows, D = x.shape
     if x2 is None and x.stride(0) == D:
         e0 = x
@@ -369,8 +370,17 @@ def encoder_layer_fwd(x: Tensor, x2: Optional[Tensor], P: Getter, lay: Layout, n
         e0 = _empty(rows, D, like=x)
         ops.add_rows(e0, x, x2)
     drops = drops if (drops is not None and any(s_ is not None for s_ in drops)) else None
-    if FUSED_ENCODER and drops is None:
+    fused_drop = None
+    if drops is not None and not need_attn:
+        live = [s_ for s_ in drops if s_ is not None]
+        base = live[0].site - drops.index(live[0])
+        if all(s_ is None or (s_.rng is live[0].rng and s_.site == base + i) for i, s_ in enumerate(drops)):
+            fused_drop = (live[0].rng, base, tuple(s_.p if s_ is not None else 0.0 for s_ in drops))
+    if FUSED_ENCODER and (drops is None or fused_drop is not None):
         d = _encoder_desc(e0, P, lay, nh, dk, dv, mask)
+        if d is not None and fused_drop is not None:
+            d.rng, d.drop_site = fused_drop[0].data_ptr(), fused_drop[1]
+            d.p_attn, d.p_fc, d.p_ffn = fused_drop[2]
         if d is not None and ops.encoder_layer_supported(d):
             nq, F = nh * dk, d.dff
             if out is None:
@@ -401,13 +411,17 @@ def encoder_layer_bwd(c, dout: Tensor, P: Getter, G: Getter) -> Tensor:
         dy2, dy1 = _empty(rows, D, like=dout), _empty(rows, D, like=dout)
         dh, dO, dqkv = _empty(rows, F, like=dout), _empty(rows, d.nh * d.dv, like=dout), _empty(rows, nq3, like=dout)
         d.dout, d.dx, d.dy2, d.dy1, d.dh, d.dO, d.dqkv = (t.data_ptr() for t in (dout, dx, dy2, dy1, dh, dO, dqkv))
+        dt1 = None
+        if d.rng and (d.p_fc > 0 or d.p_ffn > 0):
+            dt1 = _empty(rows, D, like=dout)
+            d.dt1 = dt1.data_ptr()
         for f, n in _ENC_PARAMS:
             g = G(n)
             if g is None or not g.is_contiguous():
                 raise RuntimeError(f"encoder_layer_bwd: gradient buffer for {n} missing or not contiguous")
             setattr(d, "g_" + f, g.data_ptr())
         ops.encoder_layer_bwd(d, ops.ENC_BWD_ACT)
-        ops.encoder_layer_bwd(d, ops.ENC_BWD_WGRAD, deferred=(dout, dx, dy2, dy1, dh, dO, dqkv) + tuple(c.keep))
+        ops.encoder_layer_bwd(d, ops.ENC_BWD_WGRAD, deferred=(dout, dx, dy2, dy1, dh, dO, dqkv, dt1) + tuple(c.keep))
         return dx
     cm, cf = c
     de1 = ffn_bwd(cf, dout, _sub(P, "pos_ffn."), _sub(G, "pos_ffn."))

@@ -9,7 +9,7 @@ from mser import ops
 from model_trainer import ModelTrainer
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-tr = ModelTrainer(dev, lr=1e-3, test_step=1, lr_decay=0.98, model="MARN1_sps", loss="NLL", n_classes=6, dataset="IEMOCAP", d_r=768, quiet=True, dropout=False)
+tr = ModelTrainer(dev, lr=1e-3, test_step=1, lr_decay=0.98, model="MARN1_sps", loss="NLL", n_classes=6, dataset="IEMOCAP", d_r=768, quiet=True, dropout=("--dropout" in sys.argv))
 bench.init_attention_weights(tr.model)
 tr.train(); tr.scheduler.step(0)
 x, qmask, umask, label = bench.synth_batch(1000, dev)
@@ -46,6 +46,4 @@ def run_config(tag):
 
 
 for rep in range(2):
-    for v in (0, 1):
-        ops.set_option(ops.MSER_OPT_FWD_STATS_ROLES, v)
-        run_config("fwd_stats_roles=%d" % v)
+    run_config("dropout=%s" % ("--dropout" in sys.argv))
