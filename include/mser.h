@@ -335,15 +335,18 @@ int mser_masked_nll_bwd(const int64_t* target, const float* mask, const float* l
  * The steps either side of the model in the trainer's loops.
  * ------------------------------------------------------------------------------------------------ */
 /* Dropout.  A site's mask is a pure function of (rng[0] = seed, rng[1] = step, site, element index): nothing is stored between
- * the forward and the backward, both evaluate keep(idx) = hash(seed, step, site, idx) >= p * 2^32 (two rounds of a 32-bit
- * avalanche mix; the streams of torch's CPU generators cannot be reproduced on a GPU, so train-mode parity is defined mask for
- * mask: mser_dropout_scale hands the factors to the checker).  rng lives in device memory; mser_rng_advance increments the step
+ * the forward and the backward, both evaluate keep(idx) = mix32(idx ^ key(seed, step, site)) >= p * 2^32 (a full-avalanche
+ * 32-bit mix; the streams of torch's CPU generators cannot be reproduced on a GPU, so train-mode parity is defined mask for
+ * mask: mser_dropout_scale hands the factors to the checker).  The rank-1 attention sites (mser_cell_desc drop_site+2,
+ * mser_rank1_attention_*) draw 16 bits per element -- elements 2w, 2w+1 share one mixed word, p resolved to 1/65536 -- because
+ * their masks are evaluated inside the recurrent chains: read them back with draw_bits = 16, every other site with 32.  rng lives in device memory; mser_rng_advance increments the step
  * word on the device, so a captured graph draws fresh masks at every replay.
  *   mser_dropout_apply : x[r, c] *= keep(idx0 + r*cols + c) ? 1/(1-p) : 0   (in place; activations and gradients alike)
  *   mser_dropout_scale : out[e]   = keep(idx0 + e)          ? 1/(1-p) : 0 */
 int mser_dropout_apply(float* x, int64_t rows, int32_t cols, int64_t ld, const uint32_t* rng, uint32_t site, float p,
                        uint32_t idx0, mser_stream_t stream);
-int mser_dropout_scale(float* out, int64_t n, const uint32_t* rng, uint32_t site, float p, uint32_t idx0, mser_stream_t stream);
+int mser_dropout_scale(float* out, int64_t n, const uint32_t* rng, uint32_t site, float p, uint32_t idx0, int32_t draw_bits,
+                       mser_stream_t stream);
 int mser_rng_advance(uint32_t* rng, mser_stream_t stream);
 
 /* Batch ingest (model_trainer.py:104-105, :138-139): x[r, :d_r] = (((r1+r2)+r3)+r4)/4, x[r, d_r:d_r+d_a] = acouf[r, :]; all

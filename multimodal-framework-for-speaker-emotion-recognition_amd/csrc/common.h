@@ -63,8 +63,10 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // ---- counter-based dropout (include/mser.h "Dropout") -----------------------------------------------------------------------
 // keep(site, idx) is a pure function of (seed, step, site, idx): the forward and the backward of a step evaluate the same mask
 // without storing it, and mser_dropout_scale writes it out for a checker.  rng = {seed, step} in device memory (the step word is
-// advanced on the device, so a captured graph draws new masks at every replay).  Two rounds of a 32-bit avalanche mix.
-struct DropKey { uint32_t k0, k1, thr; float scale; };
+// advanced on the device, so a captured graph draws new masks at every replay).  bits(idx) = mix32(idx ^ key), one round of a
+// full-avalanche 32-bit mix per element; key = mix(seed, site) ^ mix(step, site).  The rank-1 attention sites, whose masks are
+// evaluated inside the recurrent chains ([B, H, H] elements per step), draw 16 bits per element: one mix per two elements.
+struct DropKey { uint32_t k0, thr; float scale; };
 __host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
@@ -76,15 +78,20 @@ __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {      // d
 __device__ __forceinline__ DropKey drop_key(const uint32_t* rng, uint32_t site, float p) {
   DropKey k;
   const uint32_t seed = rng[0], step = rng[1];
-  k.k0 = mix32(seed ^ (site * 0x9E3779B9U) ^ 0x2545F491U);
-  k.k1 = mix32(step * 0x85EBCA6BU + site + 1U);
+  k.k0 = mix32(seed ^ (site * 0x9E3779B9U) ^ 0x2545F491U) ^ mix32(step * 0x85EBCA6BU + site + 1U);
   k.thr = drop_threshold(p);
   k.scale = 1.0f / (1.0f - p);
   return k;
 }
 __device__ __forceinline__ float drop_scale(const DropKey& k, uint32_t idx) {
-  return mix32(mix32(idx ^ k.k0) + k.k1) >= k.thr ? k.scale : 0.f;
+  return mix32(idx ^ k.k0) >= k.thr ? k.scale : 0.f;
 }
+// 16-bit draws: elements 2w and 2w+1 share the word mix32(w ^ key) (low / high half); p is resolved to 1/65536
+__device__ __forceinline__ uint32_t drop_word16(const DropKey& k, uint32_t idx) { return mix32((idx >> 1) ^ k.k0); }
+__device__ __forceinline__ float drop_half16(const DropKey& k, uint32_t word, uint32_t odd) {
+  return ((odd ? word >> 16 : word & 0xFFFFu) >= (k.thr >> 16)) ? k.scale : 0.f;
+}
+__device__ __forceinline__ float drop_scale16(const DropKey& k, uint32_t idx) { return drop_half16(k, drop_word16(k, idx), idx & 1u); }
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;

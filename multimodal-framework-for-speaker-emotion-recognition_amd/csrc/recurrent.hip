@@ -78,11 +78,19 @@ struct CellK {
 // (Cost of these branches on the p = 0 path, A/B of two builds on one box: step 3.354 ms with them, 3.362 ms without.)
 __device__ __forceinline__ bool drop_state_on(const CellK& P, const DirP& D) { return P.rng != nullptr && D.p_state > 0.f; }
 __device__ __forceinline__ bool drop_attn_on(const CellK& P, const DirP& D) { return P.rng != nullptr && D.p_attn > 0.f; }
+// The three keys of the workgroup's direction are derived ONCE per kernel / role (drop_init: two global loads and four mixes) and
+// kept in LDS: inside the chains a key fetched from global memory would put an L2 round trip on every step's critical path.
+__shared__ DropKey s_drop[3];
+__device__ __forceinline__ void drop_init(const CellK& P, const DirP& D) {
+  if (P.rng == nullptr) return;          // uniform
+  if (threadIdx.x < 3) s_drop[threadIdx.x] = drop_key(P.rng, D.drop_site + threadIdx.x, threadIdx.x == 2 ? D.p_attn : D.p_state);
+  __syncthreads();
+}
 __device__ __forceinline__ float drop_hq(const CellK& P, const DirP& D, int t, int c, int slot, int u) {
-  return drop_scale(drop_key(P.rng, D.drop_site, D.p_state), (uint32_t)((((long)t * 2 + c) * P.B + slot) * P.H + u));
+  return drop_scale(s_drop[0], (uint32_t)((((long)t * 2 + c) * P.B + slot) * P.H + u));
 }
 __device__ __forceinline__ float drop_h(const CellK& P, const DirP& D, int t, int m, int b, int u) {
-  return drop_scale(drop_key(P.rng, D.drop_site + 1u, D.p_state), (uint32_t)((((long)t * 2 + m) * P.B + b) * P.H + u));
+  return drop_scale(s_drop[1], (uint32_t)((((long)t * 2 + m) * P.B + b) * P.H + u));
 }
 __device__ __forceinline__ uint32_t drop_attn_row(const CellK& P, int t, int b) { return (uint32_t)(((long)t * P.B + b) * P.H * P.H); }
 
@@ -610,6 +618,7 @@ __global__ __launch_bounds__(NT) void spk_fwd_step(CellK P, int t) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const WS ws = make_ws(P.wsbase, P.wsbytes);
   const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
+  drop_init(P, P.d[dir]);
   spk_fwd_body<false, 0>(P, P.d[dir], ws, t, blockIdx.y, blockIdx.x * 8, mb, blockIdx.x == 0, nullptr, smem, smem + RED_FLOATS);
 }
 
@@ -623,6 +632,7 @@ __device__ __forceinline__ void spk_fwd_role(const CellK& P, const Role R, float
   const DirP& D = P.d[dir];
   const int c = R.y, u0 = R.x * 8;
   const unsigned nwg = R.gx * R.gy * P.nmb;
+  drop_init(P, D);
   float bpre[NP][8];
   preload_b<NP>(2 * P.H, SpkFwdB{D, c, u0, P.H}, bpre);
   STAMP_INIT();
@@ -753,17 +763,21 @@ __device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, cons
   const float u2 = u * LOG2E, m2 = mx * LOG2E;
   float Z = 0.f, N = 0.f, N2 = 0.f, N3 = 0.f;     // N2, N3: the two extra sums the backward needs (saved below)
   if (drop_attn_on(P, D)) {      // :69 dropout(softmax): the normaliser Z (and N3) stay unmasked, the value sums take the factor
-    const DropKey dk = drop_key(P.rng, D.drop_site + 2u, D.p_attn);
+    const DropKey dk = s_drop[2];
     const uint32_t e0 = drop_attn_row(P, t, b) + (uint32_t)(i * H + q * JC);
     const float4* kcc = kc + q * JC;
-    for (int jj = 0; jj < JC; ++jj) {
-      const float4 k4 = kcc[jj];
-      const float e = __builtin_amdgcn_exp2f(fmaf(u2, k4.x, -m2));
-      const float ef = e * drop_scale(dk, e0 + (uint32_t)jj);
-      Z += e;
-      N = fmaf(ef, k4.y, N);
-      N2 = fmaf(ef, k4.z, N2);
-      N3 = fmaf(e, k4.x, N3);
+    for (int jj = 0; jj < JC; jj += 2) {          // e0 and JC are even: keys jj, jj+1 share one 16+16-bit word
+      const uint32_t w = drop_word16(dk, e0 + (uint32_t)jj);
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        const float4 k4 = kcc[jj + o];
+        const float e = __builtin_amdgcn_exp2f(fmaf(u2, k4.x, -m2));
+        const float ef = e * drop_half16(dk, w, (uint32_t)o);
+        Z += e;
+        N = fmaf(ef, k4.y, N);
+        N2 = fmaf(ef, k4.z, N2);
+        N3 = fmaf(e, k4.x, N3);
+      }
     }
   } else {
     const float4* kcc = kc + q * JC;
@@ -947,6 +961,7 @@ __global__ __launch_bounds__(NT) void lsthm_fwd_gates(CellK P, int t) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const WS ws = make_ws(P.wsbase, P.wsbytes);
   const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
+  drop_init(P, P.d[dir]);
   lsthm_gates_body<false, 0>(P, P.d[dir], ws, t, blockIdx.y, blockIdx.x * 8, mb, nullptr, smem, smem + RED_FLOATS);
 }
 __global__ __launch_bounds__(NT) void lsthm_fwd_z(CellK P, int t) {
@@ -954,6 +969,7 @@ __global__ __launch_bounds__(NT) void lsthm_fwd_z(CellK P, int t) {
   const WS ws = make_ws(P.wsbase, P.wsbytes);
   float* att = smem + RED_FLOATS;
   att_prepare(P.d[blockIdx.y], P.H, att, smem);
+  drop_init(P, P.d[blockIdx.y]);
   lsthm_z_body<false, 0>(P, P.d[blockIdx.y], ws, t, blockIdx.x, att, smem);
 }
 
@@ -974,6 +990,7 @@ __device__ __forceinline__ void lsthm_fwd_role(const CellK& P, const Role R, flo
   float bpre[NP][8];
   lsthm_preload_b_split<NP>(D, m, u0, P.H, bpre);
   att_prepare(D, P.H, att, red);
+  drop_init(P, D);
   unsigned* cnt = P.sync + SYNC_LSTHM_FWD + dir * SYNC_DIR;
   const unsigned* spk = P.sync + SYNC_SPK_FWD + dir * SYNC_DIR;
   unsigned nbar = 0;
@@ -1094,13 +1111,13 @@ __device__ __forceinline__ RowMid lsthm_bwd_row_part1(const CellK& P, const DirP
   const float u2 = u * LOG2E, m2 = mx * LOG2E;
   float Z = 0.f, N2 = 0.f, N3 = 0.f;
   if (drop_attn_on(P, D)) {      // as in the forward: only the value sum N2 takes the dropout factor
-    const DropKey dk = drop_key(P.rng, D.drop_site + 2u, D.p_attn);
+    const DropKey dk = s_drop[2];
     const uint32_t e0 = drop_attn_row(P, t, b) + (uint32_t)(i * H + q * JC);
     for (int jj = 0; jj < JC; ++jj) {
       const float wj = wk[q * JC + jj];
       const float e = __builtin_amdgcn_exp2f(fmaf(u2, wj, -m2));
       Z += e;
-      N2 = fmaf(e * drop_scale(dk, e0 + (uint32_t)jj), cw[q * JC + jj], N2);
+      N2 = fmaf(e * drop_scale16(dk, e0 + (uint32_t)jj), cw[q * JC + jj], N2);
       N3 = fmaf(e, wj, N3);
     }
   } else {
@@ -1197,7 +1214,7 @@ __device__ __forceinline__ void lsthm_bwd_row_part2(const CellK& P, const DirP& 
   const int j = i;
   float S1 = 0.f, S2 = 0.f, S3 = 0.f;
   if (drop_attn_on(P, D)) {      // S1, S2 run over the dropped attention (mask element (i, j), i = q*JC + ii), S3 over the plain softmax
-    const DropKey dk = drop_key(P.rng, D.drop_site + 2u, D.p_attn);
+    const DropKey dk = s_drop[2];
     const uint32_t e0 = drop_attn_row(P, t, b) + (uint32_t)(q * JC * H + j);
     const float wkj = wk[j];
     const float* cfc = coef + 8 * q * JC;
@@ -1205,7 +1222,7 @@ __device__ __forceinline__ void lsthm_bwd_row_part2(const CellK& P, const DirP& 
       const float4 c4 = *reinterpret_cast<const float4*>(cfc + 8 * ii);
       const float c5 = cfc[8 * ii + 4];
       const float e = __builtin_amdgcn_exp2f(fmaf(c4.x, wkj, -c4.y));
-      const float ef = e * drop_scale(dk, e0 + (uint32_t)(ii * H));
+      const float ef = e * drop_scale16(dk, e0 + (uint32_t)(ii * H));
       S1 = fmaf(c4.z, ef, S1);
       S2 = fmaf(c4.w, ef, S2);
       S3 = fmaf(c5, e, S3);
@@ -1323,6 +1340,7 @@ __global__ __launch_bounds__(NT) void lsthm_bwd_row(CellK P, int t) {
   const WS ws = make_ws(P.wsbase, P.wsbytes);
   float* att = smem + RED_FLOATS;
   att_prepare(P.d[blockIdx.y], P.H, att, smem);
+  drop_init(P, P.d[blockIdx.y]);
   lsthm_bwd_row_body<false, 0>(P, P.d[blockIdx.y], ws, t, blockIdx.x, att, smem, lsthm_bwd_row_prefetch(P, P.d[blockIdx.y], t, blockIdx.x));
 }
 __global__ __launch_bounds__(NT) void lsthm_bwd_mat(CellK P, int t) {
@@ -1347,6 +1365,7 @@ __device__ __forceinline__ void lsthm_bwd_role(const CellK& P, const Role R, flo
   const int H = P.H;
   const unsigned nwg = R.gx;
   const int w = R.x;
+  drop_init(P, D);
   // matvec roles: 6 products x H/32 slices (carries + speaker gradient), then 2 products x ceil(D/32) slices (dx = dgates W)
   const int nsl = H / 32, nslx = (P.D + 31) / 32;
   const int per_kh = 6 * nsl + 2 * nslx;
@@ -1583,6 +1602,7 @@ __global__ __launch_bounds__(NT) void spk_bwd_step(CellK P, int t) {
   const WS ws = make_ws(P.wsbase, P.wsbytes);
   const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
   const SpkBwdLds l = spk_bwd_lds(smem, P.H);
+  drop_init(P, P.d[dir]);
   spk_bwd_body<false, 0>(P, P.d[dir], ws, t, blockIdx.y, blockIdx.x * 32, mb, (int)((blockIdx.y & 1) * gridDim.x + blockIdx.x), nullptr, l.red, l.tile,
                          l.dsg_s);
 }
@@ -1600,6 +1620,7 @@ __device__ __forceinline__ void spk_bwd_role(const CellK& P, const Role R, float
   const DirP& D = P.d[dir];
   const int p = R.y, n0 = R.x * 32;
   const unsigned nwg = R.gx * R.gy * P.nmb;
+  drop_init(P, D);
   float bpre[NP][8];
   preload_b<NP>(4 * P.H, LsthmBwdB{(p & 1) ? D.Whh[p >> 1] : D.Wih[p >> 1], n0, P.H}, bpre);
   unsigned* cnt = P.sync + SYNC_SPK_BWD + dir * SYNC_DIR;
@@ -2581,7 +2602,7 @@ __global__ __launch_bounds__(NT) void rank1_attention_kernel(const float* x1, co
     for (int j = q * JC; j < (q + 1) * JC; ++j) {
       const float e = __builtin_amdgcn_exp2f(fmaf(u2, wk[j], -m2));
       Z += e;
-      N = fmaf(e * drop_scale(dk, e0 + (uint32_t)j), ca[j], N);
+      N = fmaf(e * drop_scale16(dk, e0 + (uint32_t)j), ca[j], N);
     }
   } else {
     for (int j = q * JC; j < (q + 1) * JC; ++j) {
@@ -2652,7 +2673,7 @@ __global__ void rank1_attention_bwd_kernel(const float* x1, const float* x2, con
   const uint32_t e0 = (uint32_t)((long)b * H * H);
   for (int j = 0; j < H; ++j) {
     const float e = expf(u * wk[j] - mx);
-    const float ef = rng ? e * drop_scale(dk, e0 + (uint32_t)(t * H + j)) : e;     // the value sums see the dropped attention
+    const float ef = rng ? e * drop_scale16(dk, e0 + (uint32_t)(t * H + j)) : e;   // the value sums see the dropped attention
     Z += e; N = fmaf(ef, ca[j], N); M = fmaf(ef, ca[j] * wk[j], M); Wn = fmaf(e, wk[j], Wn);
   }
   const float z = N / Z, dz = dout[(long)b * H + t];
@@ -2667,7 +2688,7 @@ __global__ void rank1_attention_bwd_kernel(const float* x1, const float* x2, con
   float dxj = 0.f, dwj = 0.f;
   for (int i = 0; i < H; ++i) {
     const float a = expf(cu[i] * wkv - cm[i]) * cd[i];
-    const float f = rng ? drop_scale(dk, e0 + (uint32_t)(i * H + t)) : 1.f;
+    const float f = rng ? drop_scale16(dk, e0 + (uint32_t)(i * H + t)) : 1.f;
     dxj = fmaf(a, f, dxj);
     dwj = fmaf(a * (f * x2v - cz[i]), cu[i], dwj);
   }

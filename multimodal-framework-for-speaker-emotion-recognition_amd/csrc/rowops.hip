@@ -519,13 +519,13 @@ __global__ void dp_pack_kernel(float* buf, const float* g, const float* cnt, lon
 // x[r, c] *= keep(site, idx0 + r*cols + c) ? 1/(1-p) : 0, in place (forward activations and backward gradients alike);
 // out != nullptr: write the factor itself instead (mser_dropout_scale, for a checker that needs the mask as data).
 __global__ void dropout_apply_kernel(float* x, float* out, long rows, int cols, long ld, const uint32_t* rng, uint32_t site, float p,
-                                     uint32_t idx0) {
+                                     uint32_t idx0, int draw16) {
   const DropKey k = drop_key(rng, site, p);
   const long n = rows * cols;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
     const long r = e / cols;
     const int c = (int)(e - r * cols);
-    const float f = drop_scale(k, idx0 + (uint32_t)e);
+    const float f = draw16 ? drop_scale16(k, idx0 + (uint32_t)e) : drop_scale(k, idx0 + (uint32_t)e);
     if (out) out[e] = f;
     else x[r * ld + c] *= f;
   }
@@ -616,16 +616,18 @@ int mser_dropout_apply(float* x, int64_t rows, int32_t cols, int64_t ld, const u
   if (rows <= 0) return 0;
   const long n = rows * cols;
   hipLaunchKernelGGL(dropout_apply_kernel, dim3(std::min<long>(cdiv(n, 256), 4096)), dim3(256), 0, (hipStream_t)stream, x, (float*)nullptr,
-                     (long)rows, cols, (long)ld, rng, site, p, idx0);
+                     (long)rows, cols, (long)ld, rng, site, p, idx0, 0);
   return check_launch("mser_dropout_apply");
 }
 
-int mser_dropout_scale(float* out, int64_t n, const uint32_t* rng, uint32_t site, float p, uint32_t idx0, mser_stream_t stream) {
+int mser_dropout_scale(float* out, int64_t n, const uint32_t* rng, uint32_t site, float p, uint32_t idx0, int32_t draw_bits,
+                       mser_stream_t stream) {
   MSER_REQUIRE(out && rng, "mser_dropout_scale: null pointer");
+  MSER_REQUIRE(draw_bits == 32 || draw_bits == 16, "mser_dropout_scale: draw_bits=%d (32 or 16)", draw_bits);
   MSER_REQUIRE(p >= 0.f && p < 1.f, "mser_dropout_scale: p=%f", p);
   if (n <= 0) return 0;
   hipLaunchKernelGGL(dropout_apply_kernel, dim3(std::min<long>(cdiv(n, 256), 4096)), dim3(256), 0, (hipStream_t)stream, (float*)nullptr, out,
-                     (long)n, 1, 1L, rng, site, p, idx0);
+                     (long)n, 1, 1L, rng, site, p, idx0, draw_bits == 16 ? 1 : 0);
   return check_launch("mser_dropout_scale");
 }
 

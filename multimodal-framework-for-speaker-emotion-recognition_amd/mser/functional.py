@@ -69,8 +69,8 @@ class DropSite:
         ops.dropout_apply_(x, self.rng, self.site, self.p)
         return x
 
-    def scale(self, n: int) -> Tensor:
-        return ops.dropout_scale(n, self.rng, self.site, self.p)
+    def scale(self, n: int, draw_bits: int = 32) -> Tensor:
+        return ops.dropout_scale(n, self.rng, self.site, self.p, draw_bits=draw_bits)
 
 
 SITE_MODULE = 64    # module mirrors used on their own (outside MARN1_sps): + a per-class offset; every draw advances the step word

@@ -365,10 +365,11 @@ def dropout_apply_(x: Tensor, rng: Tensor, site: int, p: float, idx0: int = 0) -
     L.check(_lib().mser_dropout_apply(_p(x), rows, cols, ld, _p(rng), site, float(p), idx0, _stream()), "dropout_apply")
 
 
-def dropout_scale(n: int, rng: Tensor, site: int, p: float, idx0: int = 0) -> Tensor:
-    """The factors keep ? 1/(1-p) : 0 of elements idx0 .. idx0+n-1 of a site as data (for the checker)."""
+def dropout_scale(n: int, rng: Tensor, site: int, p: float, idx0: int = 0, draw_bits: int = 32) -> Tensor:
+    """The factors keep ? 1/(1-p) : 0 of elements idx0 .. idx0+n-1 of a site as data (for the checker); draw_bits = 16 for the
+    rank-1 attention sites."""
     out = torch.empty(n, device=rng.device)
-    L.check(_lib().mser_dropout_scale(_p(out), n, _p(rng), site, float(p), idx0, _stream()), "dropout_scale")
+    L.check(_lib().mser_dropout_scale(_p(out), n, _p(rng), site, float(p), idx0, draw_bits, _stream()), "dropout_scale")
     return out
 
 

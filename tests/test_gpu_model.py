@@ -575,7 +575,7 @@ def _dropout_factors(net, cfg, L, B, H, D=100, nh=8, F=32, cell=True):
                 dr[f"cell{i}.hq"] = fac(F_.SITE_CELL + 4 * i, cfg.p_cell[i], L * 2 * B * H).view(L, 2, B, H)
                 dr[f"cell{i}.h"] = fac(F_.SITE_CELL + 4 * i + 1, cfg.p_cell[i], L * 2 * B * H).view(L, 2, B, H)
             if cfg.p_cell_attn[i] > 0:
-                dr[f"cell{i}.attn"] = fac(F_.SITE_CELL + 4 * i + 2, cfg.p_cell_attn[i], L * B * H * H).view(L, B, H, H)
+                dr[f"cell{i}.attn"] = cfg.site(F_.SITE_CELL + 4 * i + 2, cfg.p_cell_attn[i]).scale(L * B * H * H, 16).cpu().view(L, B, H, H)
     return dr
 
 
@@ -691,7 +691,7 @@ def test_module_mirrors_train_mode_dropout_vs_oracle(O):
     g1, g2 = x1.clone().cuda().requires_grad_(True), x2.clone().cuda().requires_grad_(True)
     r1, r2 = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
     out = ca(g1, g2)
-    f = ca._last_drop.scale(5 * H * H).cpu().view(5, H, H)
+    f = ca._last_drop.scale(5 * H * H, 16).cpu().view(5, H, H)
     assert abs(float((f == 0).float().mean()) - 0.2) < 0.02
     check(out, O.cross_attention(P, "marn_cell_f.crossatt_l2a.", r1, r2, drop=f), [g1, g2], [r1, r2])
 
@@ -708,7 +708,7 @@ def test_module_mirrors_train_mode_dropout_vs_oracle(O):
     base = F_.DropSite(ds.rng, ds.site, ds.p)
     dr = {"hq": base.scale(T * 2 * N * H).cpu().view(T, 2, N, H),
           "h": F_.DropSite(ds.rng, ds.site + 1, ds.p).scale(T * 2 * N * H).cpu().view(T, 2, N, H),
-          "attn": F_.DropSite(ds.rng, ds.site + 2, da.p).scale(T * N * H * H).cpu().view(T, N, H, H)}
+          "attn": F_.DropSite(ds.rng, ds.site + 2, da.p).scale(T * N * H * H, 16).cpu().view(T, N, H, H)}
     check(out, O.marn_cell(P, "marn_cell_f.", rl, ra, qmask, drops=dr), [gl, ga], [rl, ra], tol=5e-5)
 
     # ---- library ScaledDotProductAttention (attention:/SelfAttention.py)
