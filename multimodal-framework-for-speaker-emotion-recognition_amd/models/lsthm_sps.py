@@ -339,7 +339,10 @@ class MARN1_sps(nn.Module):
         if not cfg.any():
             return None
         if self._rng is None or self._rng.device != device:
-            self._rng = torch.tensor([self.dropout_seed & 0x7FFFFFFF, 0], dtype=torch.int32, device=device)
+            seed = self.dropout_seed
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                seed += 0x9E3779B1 * torch.distributed.get_rank()        # data-parallel ranks draw independent masks
+            self._rng = torch.tensor([seed & 0x7FFFFFFF, 0], dtype=torch.int32, device=device)
         ops.rng_advance_(self._rng)
         cfg.rng = self._rng.clone()          # this step's words: the backward reads them even if another forward has run since
         return cfg

@@ -719,3 +719,35 @@ def test_module_mirrors_train_mode_dropout_vs_oracle(O):
     out = lib(qg, qg, qg)
     f = lib._last_drop.scale(2 * 4 * 7 * 7).cpu().view(2, 4, 7, 7)
     check(out, O.self_attention_lib({"x." + k: v for k, v in Pl.items()}, "x.", qr, qr, qr, 4, 16, 16, drop=f), [qg], [qr])
+
+
+def test_dropout_step_inside_a_captured_graph_draws_fresh_masks(O):
+    """The generator's step word advances ON THE DEVICE (mser_rng_advance), so one captured train step (hipGraph) draws new masks
+    at every replay; with every p = 0 the same capture replays bit-identically."""
+    from model_trainer import ModelTrainer
+    dev = torch.device("cuda:0")
+    x, qmask, umask, label = (t.cuda() for t in O.seeded_batch(4, 8, d_r=768, seed=71, ragged=True))
+    losses = {}
+    for dropout in (True, False):
+        tr = ModelTrainer(dev, 1e-3, 1, 0.98, "MARN1_sps", "NLL", 6, "IEMOCAP", d_r=768, quiet=True, dropout=dropout)
+        load_params(tr.model, O.seeded_params(seed=72, d_r=768))
+        tr.train()
+        tr.forward_backward(x, qmask, umask, label)          # warm-up outside the capture
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            tr.forward_backward(x, qmask, umask, label)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss = tr.forward_backward(x, qmask, umask, label)
+        vals = []
+        for _ in range(3):
+            g.replay()
+            torch.cuda.synchronize()
+            vals.append(float(loss))
+        losses[dropout] = vals
+    assert len(set(losses[True])) == 3, losses[True]
+    assert len(set(losses[False])) == 1, losses[False]
