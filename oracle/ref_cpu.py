@@ -263,6 +263,94 @@ def marn_cell(P: Params, pre: str, x_l: Tensor, x_a: Tensor, qmask: Tensor, H: i
     return torch.stack(outs, 0)
 
 
+# --------------------------------------------------------------------------------------
+# GRU-speaker variant: model/lsthm_onlysp.py -- the reference CLI's default model (train.py:126)
+# --------------------------------------------------------------------------------------
+def gru_cell(P: Params, pre: str, x: Tensor, h: Tensor) -> Tensor:
+    """torch.nn.GRUCell semantics (gates r, z, n; n = tanh(W_in x + b_in + r * (W_hn h + b_hn))) -- model/lsthm_onlysp.py:177."""
+    gi = linear(x, P[pre + "weight_ih"], P[pre + "bias_ih"])
+    gh = linear(h, P[pre + "weight_hh"], P[pre + "bias_hh"])
+    H = h.shape[1]
+    r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+    z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+    n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+    return (1 - z) * n + z * h
+
+
+def marn_cell_onlysp(P: Params, pre: str, x_l: Tensor, x_a: Tensor, qmask: Tensor, H: int = 128,
+                     drops: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """MARN_cell.forward of model/lsthm_onlysp.py:158-197: ONE speaker GRU per dialogue, fed [x_l[t] | x_a[t]] and the state of the
+    party speaking at t (no slot compaction: batch-independent); its dropped output h_s is the LSTHM streams' speaker input and the
+    new state of that party.  Returns [T,B,4H] = cat(h_l, h_a, z_l, h_s).
+    ``drops``: "hs" [T,B,H] (:177), "h" [T,2,B,H] (:184,:186), "attn" [T,B,H,H] (:69)."""
+    drops = drops or {}
+    T, B, _ = x_l.shape
+    dt, dev = x_l.dtype, x_l.device
+    qm = qmask.to(dt)
+    q = torch.zeros(B, 2, H, dtype=dt, device=dev)
+    h_l = torch.zeros(B, H, dtype=dt, device=dev)
+    h_a, c_l, c_a, z = (torch.zeros_like(h_l) for _ in range(4))
+    rows = torch.arange(B, device=dev)
+    outs = []
+    for t in range(T):
+        U = torch.cat([x_l[t], x_a[t]], 1)                                  # :172
+        idx = torch.argmax(qm[t], 1)                                        # :175
+        h_s = gru_cell(P, pre + "gru_s.", U, q[rows, idx])                  # :176-177
+        if "hs" in drops:
+            h_s = h_s * drops["hs"][t]
+        m = qm[t].unsqueeze(2)
+        q = q * (1 - m) + h_s.unsqueeze(1) * m                              # :179-181
+        c_l, h_l = lsthm1(P, pre + "lsthm_l.", x_l[t], c_l, h_l, z, h_s)     # :183
+        c_a, h_a = lsthm1(P, pre + "lsthm_a.", x_a[t], c_a, h_a, z, h_s)     # :185
+        if "h" in drops:
+            h_l, h_a = h_l * drops["h"][t, 0], h_a * drops["h"][t, 1]
+        z = cross_attention(P, pre + "crossatt_l2a.", c_l, c_a, drops["attn"][t] if "attn" in drops else None)   # :188
+        outs.append(torch.cat([h_l, h_a, z, h_s], 1))
+    return torch.stack(outs, 0)
+
+
+def marn1_onlysp_forward(P: Params, x: Tensor, qmask: Tensor, umask: Tensor, d_r: int = 1024, d_a: int = 100, H: int = 128,
+                         n_head: int = 8, d_k: int = 40, d_v: int = 40, drops: Optional[Dict[str, Tensor]] = None):
+    """MARN1_onlysp.forward -- model/lsthm_onlysp.py:260-300.  Against MARN1_sps: the second encoder pass takes the first pass's output
+    (no residual add, :264-267), the cell is marn_cell_onlysp, and the head is nn_out (10H -> 32 -> C) directly on
+    cat[h, attn1, attn2] (:287).  ``drops`` as in marn1_sps_forward, with "cell{k}.hs" instead of "cell{k}.hq" and no "fc"."""
+    dr = drops or {}
+
+    def enc_dr(k):
+        return tuple(dr.get(f"enc{k}.{n}") for n in ("attn", "fc", "ffn"))
+
+    def cell_dr(k):
+        return {n: dr[f"cell{k}.{n}"] for n in ("hs", "h", "attn") if f"cell{k}.{n}" in dr}
+
+    x_l = x[:, :, :d_r].permute(1, 0, 2)
+    x_a = x[:, :, d_r:d_r + d_a].permute(1, 0, 2)
+    x_l = linear(x_l, P["linear_in.weight"], P["linear_in.bias"])
+    x_l, _ = encoder_layer(P, "encoder_l.", x_l, n_head, d_k, d_v, drops=enc_dr(0))
+    x_a, _ = encoder_layer(P, "encoder_a.", x_a, n_head, d_k, d_v, drops=enc_dr(2))
+    x_l, _ = encoder_layer(P, "encoder_l.", x_l, n_head, d_k, d_v, drops=enc_dr(1))
+    x_a, _ = encoder_layer(P, "encoder_a.", x_a, n_head, d_k, d_v, drops=enc_dr(3))
+    x_l = x_l.permute(1, 0, 2)
+    x_a = x_a.permute(1, 0, 2)
+    h_f = marn_cell_onlysp(P, "marn_cell_f.", x_l, x_a, qmask, H, cell_dr(0))
+    if "rec0" in dr:
+        h_f = h_f * dr["rec0"]
+    h_b = marn_cell_onlysp(P, "marn_cell_b.", reverse_seq(x_l, umask), reverse_seq(x_a, umask), reverse_seq(qmask, umask), H, cell_dr(1))
+    h_b = reverse_seq(h_b, umask)
+    if "rec1" in dr:
+        h_b = h_b * dr["rec1"]
+    w, v, v1, v2 = P["w"], P["v"], P["v1"], P["v2"]
+    attn1 = cross_attention_seq(P, "crossatt_l2a.", w * x_l, v * x_a, 1, dr.get("xattn0"))
+    attn2 = cross_attention_seq(P, "crossatt_a2l.", v * x_a, w * x_l, 1, dr.get("xattn1"))
+    attn1 = cross_attention_seq(P, "crossatt_l2a_1.", v * x_a, v1 * attn1, 1, dr.get("xattn2"))
+    attn2 = cross_attention_seq(P, "crossatt_a2l_1.", w * x_l, v2 * attn2, 1, dr.get("xattn3"))
+    out = F.relu(linear(torch.cat([h_f, h_b, attn1, attn2], -1), P["nn_out.0.weight"], P["nn_out.0.bias"]))
+    if "out" in dr:
+        out = out * dr["out"]
+    out = linear(out, P["nn_out.3.weight"], P["nn_out.3.bias"])
+    lp = F.log_softmax(out, 2).permute(1, 0, 2)
+    return lp.reshape(-1, lp.shape[-1]), x_l, x_a
+
+
 def reverse_seq(X: Tensor, umask: Tensor) -> Tensor:
     """MARN1_sps._reverse_seq -- model/lsthm_sps.py:396-409 (flip the first len_b steps, zero-pad)."""
     L, B = X.shape[0], X.shape[1]
@@ -379,8 +467,10 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, 
 # deterministic parameter / input generators shared by tests, golden maker, bench
 # --------------------------------------------------------------------------------------
 def param_shapes(n_classes: int = 6, d_r: int = 1024, D: int = 100, H: int = 128, n_head: int = 8,
-                 d_k: int = 40, d_v: int = 40, d_inner: int = 40, h_out: int = 32) -> Dict[str, Tuple[int, ...]]:
-    """state_dict key -> shape, in the reference's registration order."""
+                 d_k: int = 40, d_v: int = 40, d_inner: int = 40, h_out: int = 32, variant: str = "sps") -> Dict[str, Tuple[int, ...]]:
+    """state_dict key -> shape, in the reference's registration order.  variant "onlysp": MARN1_onlysp
+    (model/lsthm_onlysp.py:209-258): every cell also owns ``gru_s`` = GRUCell(2D, H); the head is ``nn_out`` on the 10H-wide
+    concatenation (plus a dead ``linear``), there is no ``fc``."""
     S: Dict[str, Tuple[int, ...]] = {}
     for k in ("w", "v", "v1", "v2"):
         S[k] = (1,)
@@ -399,9 +489,18 @@ def param_shapes(n_classes: int = 6, d_r: int = 1024, D: int = 100, H: int = 128
             S[cell + lc + "weight_hh"] = (4 * H, H)
             S[cell + lc + "bias_ih"] = (4 * H,)
             S[cell + lc + "bias_hh"] = (4 * H,)
-    S["fc.0.weight"] = (D, 8 * H + 2 * H)
-    S["fc.0.bias"] = (D,)
-    S["nn_out.0.weight"] = (h_out, D)
+        if variant == "onlysp":
+            S[cell + "gru_s.weight_ih"] = (3 * H, 2 * D)
+            S[cell + "gru_s.weight_hh"] = (3 * H, H)
+            S[cell + "gru_s.bias_ih"] = (3 * H,)
+            S[cell + "gru_s.bias_hh"] = (3 * H,)
+    if variant == "onlysp":
+        S["linear.weight"] = (h_out, 10 * H)
+        S["linear.bias"] = (h_out,)
+    else:
+        S["fc.0.weight"] = (D, 8 * H + 2 * H)
+        S["fc.0.bias"] = (D,)
+    S["nn_out.0.weight"] = (h_out, 10 * H if variant == "onlysp" else D)
     S["nn_out.0.bias"] = (h_out,)
     S["nn_out.3.weight"] = (n_classes, h_out)
     S["nn_out.3.bias"] = (n_classes,)

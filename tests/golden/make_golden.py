@@ -228,6 +228,28 @@ def trainer_case(loss="NLL", epochs=(1, 2), out="trainer.npz"):
     print("trainer", loss, {k: float(v) for k, v in rec.items() if not k.startswith("p/")})
 
 
+def onlysp_case():
+    """MARN1_onlysp (model/lsthm_onlysp.py), the reference CLI's default model (train.py:126) and SURVEY 8(f) row f1: eval-mode
+    forward/backward on a ragged batch.  Pins the oracle's restatement (oracle.marn1_onlysp_forward) ahead of the HIP build."""
+    from models.lsthm_onlysp import MARN1_onlysp
+
+    B, L, d_r, seed = 3, 9, 1024, 31
+    torch.manual_seed(0)
+    net = MARN1_onlysp(6).eval()
+    P = O.seeded_params(seed=seed, d_r=d_r, variant="onlysp")
+    _load(net, P)
+    x, qmask, umask, label = O.seeded_batch(B, L, d_r=d_r, seed=seed + 1, ragged=True)
+    lp, x_l, x_a = net(x, qmask, umask)
+    m = umask.reshape(-1, 1)
+    loss = torch.nn.functional.nll_loss(lp * m, label.view(-1), reduction="sum") / umask.sum()
+    loss.backward()
+    rec = dict(B=B, L=L, d_r=d_r, seed=seed, logits=lp.detach().numpy(), loss=np.float64(float(loss.detach())),
+               x_l_sum=np.float64(float(x_l.double().sum())))
+    rec.update(_grad_samples(net.named_parameters()))
+    np.savez_compressed(os.path.join(HERE, "model_onlysp.npz"), **rec)
+    print("onlysp", float(loss.detach()))
+
+
 def train_mode_case():
     """The reference in TRAIN mode with its 13 dropout sites fed from known masks: nn.Dropout.forward is replaced, for the duration
     of this case, by a function that multiplies by the next factor tensor of that module's queue (O.seeded_drops, laid out in the
@@ -326,6 +348,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "train_mode":
         train_mode_case()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "onlysp":
+        onlysp_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "loss":       # regenerate only the loss fixtures
         loss_cases()
         trainer_case(loss="CrossEntropy", epochs=(1,), out="trainer_ce.npz")
@@ -339,3 +364,4 @@ if __name__ == "__main__":
     trainer_case()
     trainer_case(loss="CrossEntropy", epochs=(1,), out="trainer_ce.npz")
     train_mode_case()
+    onlysp_case()

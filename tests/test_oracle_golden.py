@@ -115,6 +115,22 @@ def test_model_train_mode_with_fed_dropout_masks(golden_dir):
     assert np.abs(lp0.detach().numpy() - g["logits"]).max() > 1e-2
 
 
+def test_onlysp_variant_vs_reference(golden_dir):
+    """SURVEY 8(f) row f1 groundwork: the oracle's restatement of MARN1_onlysp (GRU speaker state per dialogue, no residual on the
+    second encoder pass, nn_out head on the concatenation) against the reference's own eval-mode forward/backward."""
+    g = _g(golden_dir, "model_onlysp.npz")
+    B, L, d_r, seed = int(g["B"]), int(g["L"]), int(g["d_r"]), int(g["seed"])
+    P = {k: v.clone().requires_grad_(True) for k, v in O.seeded_params(seed=seed, d_r=d_r, variant="onlysp").items()}
+    x, qmask, umask, label = O.seeded_batch(B, L, d_r=d_r, seed=seed + 1, ragged=True)
+    lp, x_l, _ = O.marn1_onlysp_forward(P, x, qmask, umask, d_r=d_r)
+    loss = O.masked_nll(lp, label.view(-1), umask)
+    loss.backward()
+    assert np.abs(lp.detach().numpy() - g["logits"]).max() < 2e-5
+    assert abs(float(loss) - float(g["loss"])) < 2e-6
+    assert abs(float(x_l.double().sum()) - float(g["x_l_sum"])) < 1e-2
+    _check_grads(g, list(P.items()))
+
+
 def test_trainer_lr_schedule(golden_dir):
     g = _g(golden_dir, "trainer.npz")
     assert O.step_lr(1e-3, 0.98, 1, 1) == pytest.approx(float(g["lr1"]), rel=1e-12)
