@@ -22,7 +22,7 @@ extern "C" {
 
 typedef void* mser_stream_t; /* hipStream_t */
 
-#define MSER_VERSION 111   /* 110: + encoder layer, grouped GEMM, head tail, ingest, confusion, cell desc addends */
+#define MSER_VERSION 112   /* 110: + encoder layer, grouped GEMM, head tail, ingest, confusion, cell desc addends */
 
 int mser_version(void);
 const char* mser_last_error(void);
@@ -334,6 +334,37 @@ int mser_masked_nll_bwd(const int64_t* target, const float* mask, const float* l
 /* ------------------------------------------------------------------------------------------------
  * The steps either side of the model in the trainer's loops.
  * ------------------------------------------------------------------------------------------------ */
+/* ------------------------------------------------------------------------------------------------
+ * Speaker state of the GRU-speaker variants (model/lsthm_onlysp.py:170-181, the reference CLI's default
+ * model): per dialogue b and step t (the direction's own time order)
+ *   qs0 = q[b, argmax(qmask[t, b])] ; h_s = dropout(GRUCell(U_t, qs0)) ; q[b, p] = q[b, p] (1 - qmask[t,b,p]) + h_s qmask[t,b,p]
+ * with gi = U W_ih^T + b_ih supplied by the caller (one mser_gemm over all steps).  One workgroup carries a 32-dialogue block
+ * through the whole sequence (W_hh in registers, party states in LDS, no inter-workgroup hand-off).  H = 128.
+ * Backward: dhs (+ up to two addends) is the gradient at hs from every consumer outside this recurrence; dgi / dgh are the
+ * gradients at gi and at gh = qs0 W_hh^T + b_hh, from which the caller forms dW_ih = dgi^T U, db_ih = colsum(dgi),
+ * dW_hh = dgh^T qs0 (qs0 = save[:, 0:H], row stride 5H), db_hh = colsum(dgh), dU = dgi W_ih with GEMMs.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct mser_gru_speaker_desc {
+  int32_t T, B, H;
+  const float* gi;             /* [T*B, 3H] gates r | z | n */
+  const float* w_hh;           /* [3H, H] */
+  const float* b_hh;           /* [3H] */
+  const float* qmask;          /* [T, B, 2] */
+  float* hs;                   /* [T*B, H] written: the (dropped) speaker state fed to the LSTHM streams */
+  float* out; int64_t ldo;     /* optional: h_s also goes to out[tau*B + b, 0:H], tau = rev ? rev[t*B+b] : t (skipped when < 0) */
+  const int32_t* rev;
+  float* save;                 /* mser_gru_speaker_save_bytes(): [T*B, 5H] = qs0 | r | z | n | W_hn qs0 + b_hn */
+  /* backward */
+  const float* dhs;            /* [T*B, H] */
+  const float* dhs_add[2];     /* optional further addends of the same shape */
+  float* dgi; float* dgh;      /* [T*B, 3H] written */
+  const uint32_t* rng; uint32_t drop_site; float p;      /* dropout on h_s (:177), element (t*B + b)*H + u; NULL: identity */
+} mser_gru_speaker_desc;
+
+size_t mser_gru_speaker_save_bytes(int32_t T, int32_t B, int32_t H);
+int mser_gru_speaker_fwd(const mser_gru_speaker_desc* d, mser_stream_t stream);
+int mser_gru_speaker_bwd(const mser_gru_speaker_desc* d, mser_stream_t stream);
+
 /* Dropout.  A site's mask is a pure function of (rng[0] = seed, rng[1] = step, site, element index): nothing is stored between
  * the forward and the backward, both evaluate keep(idx) = mix32(idx ^ key(seed, step, site)) >= p * 2^32 (a full-avalanche
  * 32-bit mix; the streams of torch's CPU generators cannot be reproduced on a GPU, so train-mode parity is defined mask for

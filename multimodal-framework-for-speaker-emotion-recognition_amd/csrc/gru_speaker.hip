@@ -1,0 +1,274 @@
+// Speaker state of the GRU-speaker variants (reference model/lsthm_onlysp.py:170-181, the CLI's default model):
+//   U_t = [x_l[t] | x_a[t]],  qs0 = q[b, party_t[b]],  h_s = dropout(GRUCell(U_t, qs0)),  q[b, p] = q[b, p] (1 - qmask_t[b, p]) + h_s qmask_t[b, p]
+// There is no slot compaction: every dialogue carries its own two party states, so the recurrence is batch-independent and ONE
+// workgroup owns a 32-dialogue block for the whole sequence -- no inter-workgroup hand-off at all.  The input product
+// gi = U W_ih^T + b_ih is one GEMM before the chain (caller); only W_hh [3H, H] sits in the loop, register-resident: 12 waves,
+// wave w = (gate g = w / 4, unit slice s = w % 4) owns the 32 x 32 tile gh[:, g*H + s*32 ..] = qs0 W_hh[g*H + s*32 .., :]^T
+// (64 MFMA 32x32x2 per step, its 64 B values per lane loaded once).  The party states live in LDS.
+// The backward is the same structure in reverse time: dqs0 = dgh W_hh (wave = (unit slice, gate third of K)), the three partial
+// tiles meet in LDS.  Weight gradients (dW_ih = dgi^T U, dW_hh = dgh^T qs0), bias sums and dU = dgi W_ih are GEMMs after the chain
+// (caller).  gfx950 only; H = 128.
+#include "common.h"
+#include "../../include/mser.h"
+
+namespace mser {
+namespace {
+
+constexpr int GH = 128;            // the reference's dh_s
+constexpr int GNT = 768;           // 12 waves
+constexpr int QS = 2 * GH + 1;     // LDS row stride of the party states [32][2][H] (odd: the 32 rows of an A fragment hit 32 banks)
+constexpr int TS = 3 * GH + 1;     // LDS row stride of the gate tiles [32][3H]
+constexpr int NEL = (32 * GH + GNT - 1) / GNT;     // (row, unit) elements per thread and step
+
+struct GruArgs {
+  int T, B;
+  const float* gi; const float* w_hh; const float* b_hh; const float* qmask;
+  float* hs; float* out; long ldo; const int* rev;
+  float* save;           // [T*B][5H]: qs0 | r | z | n | gh_n
+  const float* dhs; const float* dhs2; const float* dhs3; float* dgi; float* dgh;
+  const uint32_t* rng; uint32_t site; float p;
+};
+
+__global__ __launch_bounds__(GNT) void gru_speaker_fwd_kernel(GruArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* q = sm;                   // [32][QS]
+  float* gh = q + 32 * QS;         // [32][TS]
+  int* party = (int*)(gh + 32 * TS);      // [32]
+  float* qmv = (float*)(party + 32);      // [32][2]
+  const int H = GH, B = a.B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int g = wave >> 2, s = wave & 3;
+  const int b0 = blockIdx.x * 32;
+  // W_hh slice of this wave: B[k][n] = W_hh[g*H + s*32 + n][k], k = 2j + half
+  float breg[64];
+  {
+    const float* w = a.w_hh + (long)(g * H + s * 32 + r) * H + half;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) breg[j] = w[2 * j];
+  }
+  const float bias = a.b_hh[g * H + s * 32 + r];
+  for (int e = tid; e < 32 * QS; e += GNT) q[e] = 0.f;
+  DropKey dk;
+  if (a.rng) dk = drop_key(a.rng, a.site, a.p);
+  __syncthreads();
+  for (int t = 0; t < a.T; ++t) {
+    if (tid < 32) {
+      const int b = b0 + tid;
+      float m0 = 0.f, m1 = 0.f;
+      if (b < B) { m0 = a.qmask[((long)t * B + b) * 2]; m1 = a.qmask[((long)t * B + b) * 2 + 1]; }
+      qmv[tid * 2] = m0; qmv[tid * 2 + 1] = m1;
+      party[tid] = m1 > m0 ? 1 : 0;          // argmax(qmask[t], 1): ties and padded (all-zero) rows -> party 0 (:175)
+    }
+    // this step's input-side pre-activations: in flight during the product
+    float gi3[NEL][3];
+#pragma unroll
+    for (int k = 0; k < NEL; ++k) {
+      const int e = tid + k * GNT;
+      const int row = e / H, u = e - row * H;
+      gi3[k][0] = gi3[k][1] = gi3[k][2] = 0.f;
+      if (e < 32 * H && b0 + row < B) {
+        const float* p = a.gi + ((long)t * B + b0 + row) * 3 * H + u;
+        gi3[k][0] = p[0]; gi3[k][1] = p[H]; gi3[k][2] = p[2 * H];
+      }
+    }
+    __syncthreads();
+    // gh tile = qs0 W_hh^T: A[r][k] = q[r][party_r][k]
+    {
+      const float* arow = q + r * QS + party[r] * H + half;
+      f32x16 acc = {0};
+#pragma unroll
+      for (int j = 0; j < 64; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * j], breg[j], acc, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
+        gh[row * TS + g * H + s * 32 + r] = acc[i] + bias;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NEL; ++k) {
+      const int e = tid + k * GNT;
+      const int row = e / H, u = e - row * H;
+      const int b = b0 + row;
+      if (e < 32 * H && b < B) {
+        const float* gr = gh + row * TS + u;
+        const float hprev = q[row * QS + party[row] * H + u];
+        const float rg = sigmoidf_(gi3[k][0] + gr[0]);
+        const float zg = sigmoidf_(gi3[k][1] + gr[H]);
+        const float ghn = gr[2 * H];
+        const float ng = tanhf(gi3[k][2] + rg * ghn);
+        float hv = (1.f - zg) * ng + zg * hprev;
+        const long rowt = (long)t * B + b;
+        if (a.rng) hv *= drop_scale(dk, (uint32_t)(rowt * H + u));         // :177 dropout(gru_s(U, qs_0)): the dropped value is the state
+        a.hs[rowt * H + u] = hv;
+        if (a.out) {
+          const int tau = a.rev ? a.rev[rowt] : t;
+          if (tau >= 0) a.out[((long)tau * B + b) * a.ldo + u] = hv;
+        }
+        float* sv = a.save + rowt * 5 * H + u;
+        sv[0] = hprev; sv[H] = rg; sv[2 * H] = zg; sv[3 * H] = ng; sv[4 * H] = ghn;
+        const float m0 = qmv[row * 2], m1 = qmv[row * 2 + 1];
+        float* q0 = q + row * QS + u;
+        q0[0] = q0[0] * (1.f - m0) + hv * m0;                                // :179-181
+        q0[H] = q0[H] * (1.f - m1) + hv * m1;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* dq = sm;                  // [32][QS]   gradient at the party states
+  float* dg = dq + 32 * QS;        // [32][TS]   gradient at gh (A operand of dqs0 = dgh W_hh)
+  float* part = dg + 32 * TS;      // [3][32][H + 1] partial products per gate third
+  int* party = (int*)(part + 3 * 32 * (GH + 1));
+  float* qmv = (float*)(party + 32);
+  const int H = GH, B = a.B, PS = GH + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int g = wave >> 2, s = wave & 3;
+  const int b0 = blockIdx.x * 32;
+  // B[k][n] = W_hh[g*H + k][s*32 + n], k = 2j + half
+  float breg[64];
+  {
+    const float* w = a.w_hh + (long)(g * H + half) * H + s * 32 + r;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) breg[j] = w[(long)2 * j * H];
+  }
+  for (int e = tid; e < 32 * QS; e += GNT) dq[e] = 0.f;
+  for (int e = tid; e < 32 * TS; e += GNT) dg[e] = 0.f;
+  DropKey dk;
+  if (a.rng) dk = drop_key(a.rng, a.site, a.p);
+  __syncthreads();
+  for (int t = a.T - 1; t >= 0; --t) {
+    if (tid < 32) {
+      const int b = b0 + tid;
+      float m0 = 0.f, m1 = 0.f;
+      if (b < B) { m0 = a.qmask[((long)t * B + b) * 2]; m1 = a.qmask[((long)t * B + b) * 2 + 1]; }
+      qmv[tid * 2] = m0; qmv[tid * 2 + 1] = m1;
+      party[tid] = m1 > m0 ? 1 : 0;
+    }
+    __syncthreads();
+    float direct[NEL];
+#pragma unroll
+    for (int k = 0; k < NEL; ++k) {
+      const int e = tid + k * GNT;
+      const int row = e / H, u = e - row * H;
+      const int b = b0 + row;
+      direct[k] = 0.f;
+      if (e < 32 * H && b < B) {
+        const long rowt = (long)t * B + b;
+        const float m0 = qmv[row * 2], m1 = qmv[row * 2 + 1];
+        float* q0 = dq + row * QS + u;
+        float dh = a.dhs[rowt * H + u] + q0[0] * m0 + q0[H] * m1;            // every consumer of h_s[t]: the cell, and the party states
+        if (a.dhs2) dh += a.dhs2[rowt * H + u];
+        if (a.dhs3) dh += a.dhs3[rowt * H + u];
+        q0[0] *= (1.f - m0);
+        q0[H] *= (1.f - m1);
+        if (a.rng) dh *= drop_scale(dk, (uint32_t)(rowt * H + u));
+        const float* sv = a.save + rowt * 5 * H + u;
+        const float hprev = sv[0], rg = sv[H], zg = sv[2 * H], ng = sv[3 * H], ghn = sv[4 * H];
+        const float dan = dh * (1.f - zg) * (1.f - ng * ng);
+        const float daz = dh * (hprev - ng) * zg * (1.f - zg);
+        const float dar = dan * ghn * rg * (1.f - rg);
+        float* o = a.dgi + rowt * 3 * H + u;
+        o[0] = dar; o[H] = daz; o[2 * H] = dan;
+        float* o2 = a.dgh + rowt * 3 * H + u;
+        o2[0] = dar; o2[H] = daz; o2[2 * H] = dan * rg;
+        float* l = dg + row * TS + u;
+        l[0] = dar; l[H] = daz; l[2 * H] = dan * rg;
+        direct[k] = dh * zg;
+      }
+    }
+    __syncthreads();
+    {
+      const float* arow = dg + r * TS + g * H + half;
+      f32x16 acc = {0};
+#pragma unroll
+      for (int j = 0; j < 64; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * j], breg[j], acc, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
+        part[(g * 32 + row) * PS + s * 32 + r] = acc[i];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NEL; ++k) {
+      const int e = tid + k * GNT;
+      const int row = e / H, u = e - row * H;
+      if (e < 32 * H && b0 + row < B) {
+        const float v = part[row * PS + u] + part[(32 + row) * PS + u] + part[(64 + row) * PS + u] + direct[k];
+        dq[row * QS + party[row] * H + u] += v;                              // gradient at qs0 = q[b, party_t[b]] (:176)
+      }
+    }
+    __syncthreads();
+  }
+}
+
+size_t gru_lds_bytes(bool bwd) {
+  return ((size_t)32 * QS + 32 * TS + (bwd ? 3 * 32 * (GH + 1) : 0) + 32 + 64) * sizeof(float);
+}
+
+int gru_validate(const mser_gru_speaker_desc& d, bool bwd) {
+  MSER_REQUIRE(d.T > 0 && d.B > 0, "mser_gru_speaker: bad sizes T=%d B=%d", d.T, d.B);
+  MSER_REQUIRE(d.H == GH, "mser_gru_speaker: H=%d (built for the reference's 128)", d.H);
+  MSER_REQUIRE(d.gi && d.w_hh && d.b_hh && d.qmask && d.hs && d.save, "mser_gru_speaker: null pointer");
+  MSER_REQUIRE(!d.out || d.ldo >= d.H, "mser_gru_speaker: ldo=%ld < H", (long)d.ldo);
+  MSER_REQUIRE(!d.rng || (d.p >= 0.f && d.p < 1.f), "mser_gru_speaker: dropout p=%f", d.p);
+  if (bwd) MSER_REQUIRE(d.dhs && d.dgi && d.dgh, "mser_gru_speaker_bwd: null gradient buffer");
+  return 0;
+}
+
+GruArgs gru_args(const mser_gru_speaker_desc& d) {
+  GruArgs a;
+  a.T = d.T; a.B = d.B;
+  a.gi = d.gi; a.w_hh = d.w_hh; a.b_hh = d.b_hh; a.qmask = d.qmask;
+  a.hs = d.hs; a.out = d.out; a.ldo = d.ldo; a.rev = d.rev; a.save = d.save;
+  a.dhs = d.dhs; a.dhs2 = d.dhs_add[0]; a.dhs3 = d.dhs_add[1]; a.dgi = d.dgi; a.dgh = d.dgh;
+  a.rng = (d.rng && d.p > 0.f) ? d.rng : nullptr; a.site = d.drop_site; a.p = d.p;
+  return a;
+}
+
+int allow_gru(const void* kernel, size_t bytes) {
+  static const void* seen[2];
+  for (int i = 0; i < 2; ++i)
+    if (seen[i] == kernel) return 0;
+  MSER_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  for (int i = 0; i < 2; ++i)
+    if (!seen[i]) { seen[i] = kernel; break; }
+  return 0;
+}
+
+}  // namespace
+}  // namespace mser
+
+using namespace mser;
+
+extern "C" {
+
+size_t mser_gru_speaker_save_bytes(int32_t T, int32_t B, int32_t H) { return (size_t)T * B * 5 * H * sizeof(float); }
+
+int mser_gru_speaker_fwd(const mser_gru_speaker_desc* d, mser_stream_t stream) {
+  if (!d) { set_error("mser_gru_speaker_fwd: null descriptor"); return -1; }
+  MSER_TRY(gru_validate(*d, false));
+  const GruArgs a = gru_args(*d);
+  const size_t lds = gru_lds_bytes(false);
+  MSER_TRY(allow_gru((const void*)gru_speaker_fwd_kernel, lds));
+  hipLaunchKernelGGL(gru_speaker_fwd_kernel, dim3(cdiv(d->B, 32)), dim3(GNT), lds, (hipStream_t)stream, a);
+  return check_launch("gru_speaker_fwd_kernel");
+}
+
+int mser_gru_speaker_bwd(const mser_gru_speaker_desc* d, mser_stream_t stream) {
+  if (!d) { set_error("mser_gru_speaker_bwd: null descriptor"); return -1; }
+  MSER_TRY(gru_validate(*d, true));
+  const GruArgs a = gru_args(*d);
+  const size_t lds = gru_lds_bytes(true);
+  MSER_TRY(allow_gru((const void*)gru_speaker_bwd_kernel, lds));
+  hipLaunchKernelGGL(gru_speaker_bwd_kernel, dim3(cdiv(d->B, 32)), dim3(GNT), lds, (hipStream_t)stream, a);
+  return check_launch("gru_speaker_bwd_kernel");
+}
+
+}  // extern "C"

@@ -77,6 +77,15 @@ class EncoderDesc(C.Structure):
     ]
 
 
+class GruSpeakerDesc(C.Structure):
+    """mser_gru_speaker_desc (include/mser.h)."""
+    _fields_ = [("T", C.c_int32), ("B", C.c_int32), ("H", C.c_int32),
+                ("gi", C.c_void_p), ("w_hh", C.c_void_p), ("b_hh", C.c_void_p), ("qmask", C.c_void_p),
+                ("hs", C.c_void_p), ("out", C.c_void_p), ("ldo", C.c_int64), ("rev", C.c_void_p), ("save", C.c_void_p),
+                ("dhs", C.c_void_p), ("dhs_add", C.c_void_p * 2), ("dgi", C.c_void_p), ("dgh", C.c_void_p),
+                ("rng", C.c_void_p), ("drop_site", C.c_uint32), ("p", C.c_float)]
+
+
 class HeadTailDesc(C.Structure):
     """mser_head_tail_desc (include/mser.h)."""
     _fields_ = [("L", C.c_int32), ("B", C.c_int32), ("D", C.c_int32), ("F", C.c_int32), ("C", C.c_int32),
@@ -130,6 +139,9 @@ SIGNATURES = {
     "mser_logsoftmax_tb_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mser_masked_nll_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "mser_masked_nll_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "mser_gru_speaker_save_bytes": (C.c_size_t, [_i32, _i32, _i32]),
+    "mser_gru_speaker_fwd": (C.c_int, [C.POINTER(GruSpeakerDesc), _vp]),
+    "mser_gru_speaker_bwd": (C.c_int, [C.POINTER(GruSpeakerDesc), _vp]),
     "mser_dropout_apply": (C.c_int, [_vp, _i64, _i32, _i64, _vp, C.c_uint32, _f32, C.c_uint32, _vp]),
     "mser_dropout_scale": (C.c_int, [_vp, _i64, _vp, C.c_uint32, _f32, C.c_uint32, _i32, _vp]),
     "mser_rng_advance": (C.c_int, [_vp, _vp]),

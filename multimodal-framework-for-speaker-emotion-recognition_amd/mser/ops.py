@@ -350,6 +350,43 @@ def masked_nll_bwd(target: Tensor, mask: Tensor, loss_out: Tensor, gscale: Optio
             "masked_nll_bwd")
 
 
+# ---- GRU speaker state (include/mser.h mser_gru_speaker_desc)
+def gru_speaker_desc(T: int, B: int, H: int, gi: Tensor, w_hh: Tensor, b_hh: Tensor, qmask: Tensor, hs: Tensor, save: Tensor,
+                     out: Optional[Tensor] = None, rev: Optional[Tensor] = None, drop=None) -> L.GruSpeakerDesc:
+    for t in (gi, w_hh, b_hh, qmask, hs, save):
+        _f32(t, "gru_speaker")
+        if not t.is_contiguous():
+            raise RuntimeError("gru_speaker: gi, w_hh, b_hh, qmask, hs and save must be contiguous")
+    if save.numel() * 4 < _lib().mser_gru_speaker_save_bytes(T, B, H):
+        raise RuntimeError("gru_speaker: save buffer too small")
+    d = L.GruSpeakerDesc()
+    d.T, d.B, d.H = T, B, H
+    d.gi, d.w_hh, d.b_hh, d.qmask, d.hs, d.save = (_p(t) for t in (gi, w_hh, b_hh, qmask, hs, save))
+    if out is not None:
+        d.out, d.ldo = _p(out), _ld(out)
+    d.rev = _p(rev)
+    if drop is not None:
+        d.rng, d.drop_site, d.p = _p(drop.rng), drop.site, float(drop.p)
+    # the descriptor holds raw pointers: keep the operands referenced for as long as it lives
+    d._keep = (gi, w_hh, b_hh, qmask, hs, save, out, rev, drop.rng if drop is not None else None)
+    return d
+
+
+def gru_speaker_fwd(desc: L.GruSpeakerDesc) -> None:
+    L.check(_lib().mser_gru_speaker_fwd(C.byref(desc), _stream()), "gru_speaker_fwd")
+
+
+def gru_speaker_bwd(desc: L.GruSpeakerDesc, dhs: Tensor, dgi: Tensor, dgh: Tensor, dhs_add: Sequence[Tensor] = ()) -> None:
+    for t in (dhs, dgi, dgh, *dhs_add):
+        if not t.is_contiguous():
+            raise RuntimeError("gru_speaker_bwd: gradient buffers must be contiguous")
+    desc.dhs, desc.dgi, desc.dgh = _p(dhs), _p(dgi), _p(dgh)
+    desc._keep_bwd = (dhs, dgi, dgh, tuple(dhs_add))
+    for i in range(2):
+        desc.dhs_add[i] = _p(dhs_add[i]) if i < len(dhs_add) else None
+    L.check(_lib().mser_gru_speaker_bwd(C.byref(desc), _stream()), "gru_speaker_bwd")
+
+
 # ---- dropout (include/mser.h "Dropout"): rng = int32 tensor {seed, step} on the device
 def dropout_apply_(x: Tensor, rng: Tensor, site: int, p: float, idx0: int = 0) -> None:
     """In place x[r, c] *= keep ? 1/(1-p) : 0 over a 2-D row view (unit column stride) or any contiguous tensor."""

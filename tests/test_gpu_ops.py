@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from gpu_util import maxabs
+
 pytestmark = pytest.mark.gpu
 
 
@@ -361,3 +363,81 @@ def test_confusion_update_matches_numpy(env):
     p_ref = lp.argmax(1)
     assert torch.equal(pred.cpu(), p_ref) and int(pred[5]) == 1
     assert np.array_equal(conf.cpu().numpy(), 2 * confusion_matrix(label.numpy(), p_ref.numpy(), mask.numpy(), C))
+
+
+@pytest.mark.parametrize("T,B,use_drop,use_rev", [(7, 37, False, False), (5, 32, True, True), (3, 1, True, False)])
+def test_gru_speaker_chain_fwd_bwd(env, T, B, use_drop, use_rev):
+    """Speaker state of the GRU-speaker variants (reference model/lsthm_onlysp.py:170-181): one workgroup per
+    32-dialogue block, W_hh register-resident.  Against the same recurrence in torch fp32 on the CPU (autograd for the backward):
+    h_s for every step, the gradients at gi and -- through dgh and the saved qs0 -- at W_hh / b_hh; padded (all-zero qmask) rows,
+    a partial second block, dropout on the carried state, and the optional scatter into the cell's output rows."""
+    ops = env
+    from mser import functional as F_
+    H = 128
+    rs = np.random.RandomState(T * 100 + B)
+    gi = torch.tensor(rs.standard_normal((T * B, 3 * H)).astype(np.float32) * 0.7)
+    w_hh = torch.tensor(rs.uniform(-0.09, 0.09, (3 * H, H)).astype(np.float32))
+    b_hh = torch.tensor(rs.uniform(-0.09, 0.09, (3 * H,)).astype(np.float32))
+    spk = rs.randint(0, 2, (T, B))
+    qmask = np.eye(2, dtype=np.float32)[spk]
+    if T > 2 and B > 2:
+        qmask[T - 2:, 1] = 0                              # padded tail of dialogue 1
+        qmask[:, 2] = np.eye(2, dtype=np.float32)[0]      # one party only
+    qmask = torch.tensor(qmask)
+    rev = None
+    if use_rev:
+        rv = np.tile(np.arange(T - 1, -1, -1, dtype=np.int32)[:, None], (1, B))
+        rv[0, 0] = -1                                     # an output row that must be skipped
+        rev = torch.tensor(rv)
+    drop = None
+    if use_drop:
+        rng = torch.tensor([1234, 5], dtype=torch.int32, device="cuda")
+        drop = F_.DropSite(rng, 77, 0.5)
+    hs = torch.empty(T * B, H, device="cuda")
+    save = torch.empty(T * B, 5 * H, device="cuda")
+    out = torch.zeros(T * B, 4 * H, device="cuda")
+    # (the descriptor holds raw pointers: the device operands must stay referenced for as long as it is used)
+    gi_d, w_d, b_d, qm_d = gi.cuda(), w_hh.cuda(), b_hh.cuda(), qmask.cuda()
+    rev_d = rev.cuda() if rev is not None else None
+    d = ops.gru_speaker_desc(T, B, H, gi_d, w_d, b_d, qm_d, hs, save, out=out[:, 3 * H:], rev=rev_d, drop=drop)
+    ops.gru_speaker_fwd(d)
+    # ---- the same recurrence on the CPU
+    f = drop.scale(T * B * H).cpu().view(T, B, H) if drop is not None else None
+    gi_r, w_r, b_r = gi.clone().requires_grad_(True), w_hh.clone().requires_grad_(True), b_hh.clone().requires_grad_(True)
+    q = torch.zeros(B, 2, H)
+    rows = torch.arange(B)
+    ref = []
+    for t in range(T):
+        idx = torch.argmax(qmask[t], 1)
+        h0 = q[rows, idx]
+        g = gi_r[t * B:(t + 1) * B]
+        gh = h0 @ w_r.t() + b_r
+        r = torch.sigmoid(g[:, :H] + gh[:, :H])
+        z = torch.sigmoid(g[:, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(g[:, 2 * H:] + r * gh[:, 2 * H:])
+        h = (1 - z) * n + z * h0
+        if f is not None:
+            h = h * f[t]
+        m = qmask[t].unsqueeze(2)
+        q = q * (1 - m) + h.unsqueeze(1) * m
+        ref.append(h)
+    ref = torch.cat(ref, 0)
+    assert maxabs(hs, ref) < 2e-6
+    exp_out = torch.zeros(T * B, H)
+    for t in range(T):
+        for b in range(B):
+            tau = int(rev[t, b]) if rev is not None else t
+            if tau >= 0:
+                exp_out[tau * B + b] = ref[t * B + b].detach()
+    assert maxabs(out[:, 3 * H:], exp_out) < 2e-6 and float(out[:, :3 * H].abs().max()) == 0.0
+    # ---- backward
+    w = torch.tensor(rs.standard_normal((T * B, H)).astype(np.float32))
+    w2 = torch.tensor(rs.standard_normal((T * B, H)).astype(np.float32)) * 0.3
+    (ref * (w + w2)).sum().backward()
+    dgi, dgh = torch.empty(T * B, 3 * H, device="cuda"), torch.empty(T * B, 3 * H, device="cuda")
+    w_dev, w2_dev = w.cuda(), w2.cuda()
+    ops.gru_speaker_bwd(d, w_dev, dgi, dgh, dhs_add=[w2_dev])
+    assert maxabs(dgi, gi_r.grad) < 3e-5 * max(1.0, float(gi_r.grad.abs().max()))
+    dW = dgh.cpu().t() @ save[:, :H].cpu()
+    assert maxabs(dW, w_r.grad) < 3e-4 * max(1e-3, float(w_r.grad.norm()))
+    assert maxabs(dgh.cpu().sum(0), b_r.grad) < 3e-4 * max(1e-3, float(b_r.grad.norm()))
