@@ -244,6 +244,14 @@ typedef struct mser_cell_desc {
   uint32_t drop_site[2];
   float p_state[2];
   float p_attn[2];
+  /* External speaker state (the GRU-speaker variants; NULL: the cell's own LSTM speaker chain).  ext_hq[i]
+   * [T*B, H] (direction i's time order, complete before MSER_PHASE_LSTHM_FWD; e.g. mser_gru_speaker_fwd's hs, which can also fill
+   * the h_q quarter of `out`) replaces h_q[t] as the LSTHM streams' speaker input (copied into the workspace by
+   * MSER_PHASE_LSTHM_FWD, so the buffer may be reused afterwards): the speaker phases launch nothing, the speaker
+   * parameters of `p` / `g` may be NULL and the p_state dropout of the h_q site is the caller's.  The backward's
+   * MSER_PHASE_SPEAKER_BWD then writes ext_dhq[i] [T*B, H] = the total gradient at ext_hq[i] (output quarter included). */
+  const float* ext_hq[2];
+  float* ext_dhq[2];
 } mser_cell_desc;
 
 size_t mser_marn_cell_workspace_bytes(int32_t T, int32_t B, int32_t D, int32_t H, int32_t ndir);

@@ -68,6 +68,7 @@ struct CellK {
   int stats_wgs;       // cell_fwd_fused: workgroups that compute the BPTT's softmax statistics beside the chains (0: the row phase does)
   int place;           // fused launches: roles are claimed by physical XCD (claim_role); the grid then covers every CU
   short place_base[8], place_cap[8];   // XCD x hosts logical workgroups place_base[x] .. place_base[x] + place_cap[x] - 1
+  int ext_spk;         // the speaker state h_q[t] comes from the caller (mser_cell_desc::ext_hq): no speaker roles in the launches
   const uint32_t* rng; // dropout generator words {seed, step} (nullptr: every dropout site of the cell is the identity)
   int ksplit;          // BPTT matvec phase: every product's K = 4H reduction is split over `ksplit` workgroups (1 or 2); the
                        // partial results live in consecutive copies of dA / dHQp / dxc and the consumers add them
@@ -1888,7 +1889,7 @@ __global__ __launch_bounds__(NT) void cell_bwd_fused(CellK P, unsigned bwd_nwg) 
   const WS ws = make_ws(P.wsbase, P.wsbytes);
   const int n_l = (int)bwd_nwg * P.ndir;
   const int gx = P.H / 32, gy = 4;
-  const int n_s = gx * gy * P.nmb * P.ndir;
+  const int n_s = P.ext_spk ? 0 : gx * gy * P.nmb * P.ndir;
   int id = blockIdx.x;
   if (P.place) {          // LSTHM BPTT groups on two XCDs each, each speaker group on one, the wgrad roles on the rest
     id = claim_role(P.sync + SYNC_PLACE_BWD, P.place_base, P.place_cap, (int*)smem);
@@ -1992,6 +1993,16 @@ static int colsum4(const float* X, long rows, int n, long ld, float* o0, float* 
 
 // dx_l / dx_a (contiguous [T*B, D]) += up to four contiguous addends each, both modalities in one launch (blockIdx.y):
 // the BPTT launch's dx products of the two directions and the caller's partial sums (sequence-level attention branches).
+// ext_dhq = dHQ + its per-product partials: the total gradient at an externally supplied speaker state (mser_cell_desc::ext_hq)
+__global__ void dhq_total_kernel(float* dst, const float* a, const float* p0, const float* p1, const float* p2, const float* p3, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = a[i];
+  if (p0) v += p0[i] + p1[i];
+  if (p2) v += p2[i] + p3[i];
+  dst[i] = v;
+}
+
 struct SumArgs { float* out[2]; const float* src[2][6]; long n; };
 template <int VEC>
 __global__ void sum_into_kernel(SumArgs a) {
@@ -2113,7 +2124,7 @@ static int validate(const mser_cell_desc& d, bool bwd) {
     const mser_cell_params& p = r.p;
     for (int m = 0; m < 2; ++m)
       MSER_REQUIRE(p.lsthm_W[m] && p.lsthm_Wb[m] && p.lsthm_U[m] && p.lsthm_Ub[m] && p.lsthm_V[m] && p.lsthm_Vb[m] &&
-                       p.lsthm_S[m] && p.lsthm_Sb[m] && p.q_Wih[m] && p.q_Whh[m] && p.q_bih[m] && p.q_bhh[m],
+                       p.lsthm_S[m] && p.lsthm_Sb[m] && (d.ext_hq[0] || (p.q_Wih[m] && p.q_Whh[m] && p.q_bih[m] && p.q_bhh[m])),
                    "marn_cell: dir %d null parameter", i);
     MSER_REQUIRE(p.att_Wq && p.att_Wk, "marn_cell: dir %d null attention vector", i);
     if (bwd) MSER_REQUIRE(r.dout, "marn_cell_bwd: dir %d null dout", i);
@@ -2203,12 +2214,20 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   const long TB = (long)T * B, SB = (long)B * H;
   for (int i = 0; i < d.ndir; ++i) fill_params(K.d[i], d.dir[i]);
   fill_dropout(K, d);
+  // External speaker state (the GRU-speaker variants): h_q[t] = ext_hq rows, complete before this call.  The LSTHM
+  // chain then runs as its own persistent launch (the form MSER_PHASE_SEPARATE_SPEAKER uses) with the speaker's step counter preset.
+  // (The rows are COPIED into the workspace's HQ array: the chains address everything they share through one buffer descriptor
+  // over the workspace, an outside pointer would read as zeros, and the backward wants them saved there anyway.)
+  const bool ext = d.ext_hq[0] != nullptr;
+  K.ext_spk = ext ? 1 : 0;
   const size_t mm_lds = (RED_FLOATS + 1024) * sizeof(float);
   const long fwd_wgs = (long)(H / 8) * 2 * d.ndir * K.nmb;
-  const bool persist = persist_ok(H, 2 * fwd_wgs);        // speaker and LSTHM chains share one launch: all workgroups co-resident
+  const bool persist = persist_ok(H, ext ? fwd_wgs : 2 * fwd_wgs);        // speaker and LSTHM chains share one launch: all workgroups co-resident
   const size_t p_lds = persist_lds(mm_lds + (2 * (size_t)H + 16) * sizeof(float) + 64);
   if (phases & MSER_PHASE_FWD_PREP) {
   MSER_CHECK_HIP(hipMemsetAsync(h.sync, 0, SYNC_WORDS * sizeof(unsigned), s));
+  if (ext)      // "every h_q[t] is published": the LSTHM chain's waits on the speaker counter fall through
+    MSER_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)(h.sync + SYNC_SPK_FWD), 0x3fffffff, 2 * SYNC_DIR, s));
   for (int i = 0; i < d.ndir; ++i) {
     DirP& k = K.d[i];
     MSER_TRY(mser_build_slot_tables(d.dir[i].qmask, k.rev, T, B, k.party, k.perm, k.n0, k.qm, s));
@@ -2218,7 +2237,7 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       MSER_CHECK_HIP(hipMemset2DAsync(k.out, d.ldo * sizeof(float), 0, 4 * (size_t)H * sizeof(float), TB, s));
   }
   }
-  const bool separate = persist && (phases & MSER_PHASE_SEPARATE_SPEAKER);
+  const bool separate = persist && ((phases & MSER_PHASE_SEPARATE_SPEAKER) || ext);
   // XCD placement of the fused launch: needs 32-workgroup chain groups (H = 128, B <= 32) and a launch over every CU
   K.place = (persist && !separate && g_opt_xcd_place && (H / 8) * 2 * K.nmb == 32 && num_cus() == 256) ? 1 : 0;
   if (K.place) {          // groups (LSTHM d0, [LSTHM d1,] speaker d0 [, speaker d1]) = logical ids 32 g .. 32 g + 31 -> XCDs 2g, 2g + 1
@@ -2228,7 +2247,7 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       K.place_base[x] = (short)(g * 32 + (x & 1) * 16);
     }
   }
-  if ((phases & MSER_PHASE_SPEAKER_FWD) && separate) {
+  if ((phases & MSER_PHASE_SPEAKER_FWD) && separate && !ext) {
     ProfScope ps(MSER_PROF_SPK_FWD, s);
     if (H == 128) {
       MSER_TRY(allow_lds((const void*)spk_fwd_persist<2>, p_lds));
@@ -2239,7 +2258,7 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
     }
     MSER_TRY(check_launch("spk_fwd_persist"));
   }
-  if ((phases & MSER_PHASE_SPEAKER_FWD) && !persist) {
+  if ((phases & MSER_PHASE_SPEAKER_FWD) && !persist && !ext) {
     // ---- speaker chain as per-step launches (the persistent mode runs it inside the fused launch of the LSTHM phase)
     MSER_TRY(allow_lds((const void*)spk_fwd_step, mm_lds));
     for (int t = 0; t < T; ++t) {
@@ -2249,6 +2268,9 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
     MSER_TRY(check_launch("spk_fwd"));
   }
   if (!(phases & MSER_PHASE_LSTHM_FWD)) return 0;
+  if (ext)
+    for (int i = 0; i < d.ndir; ++i)
+      MSER_CHECK_HIP(hipMemcpyAsync(K.d[i].HQ, d.ext_hq[i], (size_t)TB * H * sizeof(float), hipMemcpyDeviceToDevice, s));
   // ---- hoisted pre-activations: pre_m = xdir W_m^T + W.bias + HQ S_m^T + S.bias.  The x W^T products of both streams and
   // directions are independent: ONE grouped launch (they sit on the critical path right in front of the chain).
   std::vector<mser_gemm_desc> pg;
@@ -2332,15 +2354,18 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   const long TB = (long)T * B, SB = (long)B * H;
   for (int i = 0; i < d.ndir; ++i) fill_params(K.d[i], d.dir[i]);
   fill_dropout(K, d);
+  const bool ext = d.ext_hq[0] != nullptr;                   // external speaker state: no speaker chain, ext_dhq = the gradient at it
+  K.ext_spk = ext ? 1 : 0;
+  if (ext) MSER_REQUIRE(d.ext_dhq[0] && (d.ndir == 1 || d.ext_dhq[1]), "marn_cell_bwd: ext_hq needs ext_dhq");
   const size_t mm_lds = (RED_FLOATS + 1024) * sizeof(float);
   const size_t row_lds = row_lds_bytes(H);
-  const int spk_wgs = (H / 32) * 4 * K.nmb;                  // speaker BPTT: 4 products
+  const int spk_wgs = ext ? 0 : (H / 32) * 4 * K.nmb;        // speaker BPTT: 4 products
   const int mat_wgs1 = ((H / 32) * 6 + ((D + 31) / 32) * 2) * K.nmb;  // LSTHM BPTT matvec roles: 4 carries + 2 speaker-gradient + 2 dx products
   // K-split of the matvec phase (the longest phase of a BPTT step, MFMA-paced: 8 waves x 32 MFMAs on 4 SIMDs): two workgroups per
   // product halve it when the doubled grid still fits beside the speaker chain
   // XCD placement (claim_role) wants one 32-workgroup LSTHM group per XCD, which excludes the K-split (64 per direction); the
   // placement is worth more (-0.45 us per hand-off against -12 us per launch)
-  const bool place_ok = g_opt_persistent && g_opt_xcd_place && H == 128 && mat_wgs1 <= 32 && num_cus() == 256;
+  const bool place_ok = g_opt_persistent && g_opt_xcd_place && H == 128 && mat_wgs1 <= 32 && num_cus() == 256 && !ext;
   const int ksplit = (!place_ok && g_opt_persistent && g_opt_ksplit && H == 128 && ((long)2 * mat_wgs1 + spk_wgs) * d.ndir <= num_cus()) ? 2 : 1;
   K.ksplit = ksplit;
   const int mat_wgs = mat_wgs1 * ksplit;
@@ -2351,12 +2376,12 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   const int SPLITK = 16;
   // Weight gradients inside the fused BPTT launch (wgrad_role): needs the persistent launch, the H = 128 tiling (16 / 8 column
   // tiles per row tile), D <= H, every gradient tensor present and room for its workgroups beside the chains.
-  const int wgrad_wgs = d.ndir * 2 * ((4 * H / 32) / 2 + (4 * H / 32) / 4);
+  const int wgrad_wgs = d.ndir * 2 * ((4 * H / 32) / 2 + (ext ? 0 : (4 * H / 32) / 4));
   bool wgrad_in = persist && H == 128 && D <= H && ((long)bwd_nwg + spk_wgs) * d.ndir + wgrad_wgs <= num_cus() && g_opt_wgrad_inkernel;
   for (int i = 0; i < d.ndir && wgrad_in; ++i) {
     const mser_cell_params& G = d.dir[i].g;
     for (int m = 0; m < 2; ++m)
-      wgrad_in = wgrad_in && G.lsthm_W[m] && G.lsthm_U[m] && G.lsthm_V[m] && G.lsthm_S[m] && G.q_Wih[m] && G.q_Whh[m];
+      wgrad_in = wgrad_in && G.lsthm_W[m] && G.lsthm_U[m] && G.lsthm_V[m] && G.lsthm_S[m] && (ext || (G.q_Wih[m] && G.q_Whh[m]));
   }
   K.wgrad_wgs = wgrad_in ? wgrad_wgs : 0;
   if (wgrad_in) {
@@ -2518,6 +2543,20 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   MSER_TRY(gemm_group(wg.data(), (int)wg.size(), s));
   wg.clear();
   if (!(phases & MSER_PHASE_SPEAKER_BWD)) return 0;
+  if (ext) {
+    // no speaker chain of our own: hand the total gradient at the external speaker state to the caller.  Persistent mode left the
+    // two (K-split: four) per-product parts dgates_m S_m in dHQp; the per-step mode accumulated them into dHQ already (DX phase).
+    MSER_TRY(gemm_group(wg.data(), (int)wg.size(), s));
+    for (int i = 0; i < d.ndir; ++i) {
+      DirP& k = K.d[i];
+      const long n = TB * H;
+      const float* p0 = persist ? k.dHQp : nullptr;
+      const float* p2 = (persist && ksplit == 2) ? k.dHQp + 2 * n : nullptr;
+      hipLaunchKernelGGL(dhq_total_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, d.ext_dhq[i], k.dHQ, p0, p0 ? p0 + n : nullptr, p2,
+                         p2 ? p2 + n : nullptr, n);
+    }
+    return check_launch("dhq_total");
+  }
   // ---- speaker chain, reverse time
   const size_t spk_lds = spk_bwd_lds_floats(H) * sizeof(float) + 64;
   if (!persist) {      // persistent mode: the speaker BPTT chain already ran inside the fused launch of the LSTHM_BWD phase

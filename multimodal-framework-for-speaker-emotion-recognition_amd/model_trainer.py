@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from loss import MaskedLoss
+from models.lsthm_onlysp import MARN1_onlysp
 from models.lsthm_sps import MARN1_sps
 from mser import ops
 from mser.dist import FlatAllReduce
@@ -24,7 +25,7 @@ from mser.metrics import accuracy_and_weighted_f1
 from mser.optim import FlatAdam, StepLR
 
 _OUT_OF_SCOPE = ("DialogueRNN", "MARN", "BiLSTM", "MARN1_newz", "MARN1_azs", "MARN1_mf", "MARN1_la", "MARN1_cf", "MARN1_sp",
-                 "MARN1_nsps", "MARN1_onlysp", "MARN1_no_en")
+                 "MARN1_nsps", "MARN1_no_en")
 
 
 class ModelTrainer(nn.Module):
@@ -37,8 +38,13 @@ class ModelTrainer(nn.Module):
             self.model = MARN1_sps(n_classes, d_r=kwargs.get("d_r", 1024), hidden=kwargs.get("hidden", 128)).to(self.device)
             if not kwargs.get("dropout", True):       # extension: dropout=False sets every Dropout p to 0 (parity configuration)
                 zero_dropout(self.model)
+        elif model == 'MARN1_onlysp':          # the reference CLI's default (train.py:126); SURVEY.md 8(f) row f1
+            self.model = MARN1_onlysp(n_classes, d_r=kwargs.get("d_r", 1024)).to(self.device)
+            if not kwargs.get("dropout", True):
+                zero_dropout(self.model)
         elif model in _OUT_OF_SCOPE:
-            raise NotImplementedError(f"model '{model}' is outside the accelerated hot path (SURVEY.md 8(f)); only 'MARN1_sps' is built")
+            raise NotImplementedError(f"model '{model}' is outside the accelerated hot path (SURVEY.md 8(f)); 'MARN1_sps' and "
+                                      "'MARN1_onlysp' are built")
         else:
             raise ValueError(f"unknown model '{model}'")
         if loss == 'CrossEntropy':

@@ -52,6 +52,7 @@ class CellDesc(C.Structure):
         ("dir", CellDir * 2), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("dx_l_add", _P2), ("dx_a_add", _P2),
         ("rng", C.c_void_p), ("drop_site", C.c_uint32 * 2), ("p_state", C.c_float * 2), ("p_attn", C.c_float * 2),
+        ("ext_hq", _P2), ("ext_dhq", _P2),
     ]
 
 

@@ -532,7 +532,8 @@ def cell_workspace_bytes(T: int, B: int, D: int, H: int, ndir: int) -> int:
 
 def make_cell_desc(T: int, B: int, D: int, H: int, x_l: Tensor, x_a: Tensor, dirs: Sequence[dict], ldo: int,
                    workspace: Tensor, dx_l: Optional[Tensor] = None, dx_a: Optional[Tensor] = None,
-                   dx_l_add: Sequence[Tensor] = (), dx_a_add: Sequence[Tensor] = (), drop=None) -> L.CellDesc:
+                   dx_l_add: Sequence[Tensor] = (), dx_a_add: Sequence[Tensor] = (), drop=None,
+                   ext_hq: Sequence[Tensor] = (), ext_dhq: Sequence[Tensor] = ()) -> L.CellDesc:
     """dirs: list of dicts with keys p (CellParams), g (CellParams or None), qmask, rev (or None), out, dout (or None).
     drop: None or (rng int32[2] tensor, [site per direction], [p_state per direction], [p_attn per direction])."""
     d = L.CellDesc()
@@ -564,6 +565,12 @@ def make_cell_desc(T: int, B: int, D: int, H: int, x_l: Tensor, x_a: Tensor, dir
         d.rng = _p(rng)
         for i in range(len(dirs)):
             d.drop_site[i], d.p_state[i], d.p_attn[i] = int(sites[i]), float(p_state[i]), float(p_attn[i])
+    for i, t in enumerate(ext_hq):          # external speaker state per direction ([T*B, H] contiguous) and its gradient buffer
+        if not t.is_contiguous() or (i < len(ext_dhq) and not ext_dhq[i].is_contiguous()):
+            raise RuntimeError("ext_hq / ext_dhq must be contiguous")
+        d.ext_hq[i] = _p(t)
+        if i < len(ext_dhq):
+            d.ext_dhq[i] = _p(ext_dhq[i])
     return d
 
 

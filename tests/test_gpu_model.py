@@ -751,3 +751,71 @@ def test_dropout_step_inside_a_captured_graph_draws_fresh_masks(O):
         losses[dropout] = vals
     assert len(set(losses[True])) == 3, losses[True]
     assert len(set(losses[False])) == 1, losses[False]
+
+
+# ------------------------------------------------------------------------------------------------- MARN1_onlysp
+def test_onlysp_model_vs_reference_golden(golden_dir):
+    """MARN1_onlysp (the reference CLI's default model, GRU speaker state): log-probs, loss and gradients against the reference's OWN
+    eval-mode forward/backward (tests/golden/model_onlysp.npz)."""
+    from oracle import ref_cpu as O
+    from models.lsthm_onlysp import MARN1_onlysp
+    from loss import MaskedLoss
+    g = _g(golden_dir, "model_onlysp.npz")
+    B, L, d_r, seed = int(g["B"]), int(g["L"]), int(g["d_r"]), int(g["seed"])
+    net = MARN1_onlysp(6, d_r=d_r).cuda().eval()
+    load_params(net, O.seeded_params(seed=seed, d_r=d_r, variant="onlysp"))
+    x, qmask, umask, label = O.seeded_batch(B, L, d_r=d_r, seed=seed + 1, ragged=True)
+    lp, x_l, _ = net(x.cuda(), qmask.cuda(), umask.cuda())
+    loss = MaskedLoss(torch.nn.NLLLoss)(lp, label.cuda().view(-1), umask.cuda())
+    loss.backward()
+    assert maxabs(lp, g["logits"]) < LOGIT_TOL
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-5
+    _check_grads(g, list(net.named_parameters()))
+
+
+@pytest.mark.parametrize("B,L,train,persistent", [(5, 7, False, 1), (5, 7, True, 1), (37, 6, True, 1), (4, 9, True, 0)])
+def test_onlysp_model_vs_oracle(O, B, L, train, persistent):
+    """MARN1_onlysp against the oracle (itself pinned by the reference golden): eval mode, and train mode mask for mask with every
+    dropout site live (h_s on the GRU's carried state included); a batch with a partial second 32-dialogue block; per-step launches."""
+    from models.lsthm_onlysp import MARN1_onlysp
+    from loss import MaskedLoss
+    from mser import functional as F_, ops
+    d_r, H = 768, 128
+    P = O.seeded_params(seed=81, d_r=d_r, variant="onlysp")
+    net = MARN1_onlysp(6, d_r=d_r).cuda()
+    net.train(train)
+    load_params(net, P)
+    x, qmask, umask, label = O.seeded_batch(B, L, d_r=d_r, seed=83 + B, ragged=True)
+    captured = {}
+    orig = net._drop_cfg
+    net._drop_cfg = lambda dev: captured.setdefault("cfg", orig(dev))
+    ops.set_option(ops.MSER_OPT_PERSISTENT, persistent)
+    try:
+        lp, _, _ = net(x.cuda(), qmask.cuda(), umask.cuda())
+        loss = MaskedLoss(torch.nn.NLLLoss)(lp, label.cuda().view(-1), umask.cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_option(ops.MSER_OPT_PERSISTENT, 1)
+        net._drop_cfg = orig
+    dr = None
+    if train:
+        cfg = captured["cfg"]
+        dr = _dropout_factors(net, cfg, L, B, H)
+        for i in range(2):          # the GRU variant drops h_s [T,B,H] where the LSTM variant dropped h_q0 / h_q1 by slot
+            dr.pop(f"cell{i}.hq")
+            dr[f"cell{i}.hs"] = cfg.site(F_.SITE_CELL + 4 * i, cfg.p_cell[i]).scale(L * B * H).cpu().view(L, B, H)
+        assert "fc" not in dr and len(dr) == 12 + 4 + 1 + 2 + 6
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    lp_ref, _, _ = O.marn1_onlysp_forward(Pr, x, qmask, umask, d_r=d_r, drops=dr)
+    loss_ref = O.masked_nll(lp_ref, label.view(-1), umask)
+    loss_ref.backward()
+    assert maxabs(lp, lp_ref) < LOGIT_TOL
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 2e-5
+    for n, p in net.named_parameters():
+        r = Pr[n].grad
+        if r is None:
+            assert p.grad is None or float(p.grad.abs().sum()) == 0.0, f"{n} must stay dead"
+            continue
+        assert p.grad is not None, n
+        assert maxabs(p.grad, r) < 3e-4 * max(1e-3, float(r.norm())), n
