@@ -332,6 +332,21 @@ def main():
         del trd
         variants["dropout_on"] = {"ms_per_step": round(ms_d, 4), "utterances_per_s": round(B * L / (ms_d * 1e-3), 1),
                                   "note": "all 13 sites live; counter-based masks, re-evaluated in the backward instead of stored; eager launches"}
+        # MARN1_onlysp, the reference CLI's default model (GRU speaker state per dialogue), same batch
+        for tag, dp in (("marn1_onlysp", False), ("marn1_onlysp_dropout_on", True)):
+            tro = ModelTrainer(device, lr=1e-3, test_step=1, lr_decay=0.98, model="MARN1_onlysp", loss="NLL", n_classes=NCLS,
+                               dataset="IEMOCAP", d_r=D_R, quiet=True, dropout=dp)
+            init_attention_weights(tro.model)
+            tro.train()
+            tro.scheduler.step(0)
+            tr_main, tr = tr, tro
+            try:
+                ms_o2 = time_steps((x, qmask, umask, label))
+            finally:
+                tr = tr_main
+            del tro
+            variants[tag] = {"ms_per_step": round(ms_o2, 4), "utterances_per_s": round(B * L / (ms_o2 * 1e-3), 1),
+                             "note": "first version: one stream, GRU speaker chains before / after the LSTHM chains; eager launches"}
         log("variants done")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

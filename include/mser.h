@@ -370,8 +370,9 @@ typedef struct mser_gru_speaker_desc {
 } mser_gru_speaker_desc;
 
 size_t mser_gru_speaker_save_bytes(int32_t T, int32_t B, int32_t H);
-int mser_gru_speaker_fwd(const mser_gru_speaker_desc* d, mser_stream_t stream);
-int mser_gru_speaker_bwd(const mser_gru_speaker_desc* d, mser_stream_t stream);
+/* d: array of n (1 or 2) descriptors with the same T and B -- the two directions of a bidirectional cell share one launch */
+int mser_gru_speaker_fwd(const mser_gru_speaker_desc* d, int32_t n, mser_stream_t stream);
+int mser_gru_speaker_bwd(const mser_gru_speaker_desc* d, int32_t n, mser_stream_t stream);
 
 /* Dropout.  A site's mask is a pure function of (rng[0] = seed, rng[1] = step, site, element index): nothing is stored between
  * the forward and the backward, both evaluate keep(idx) = mix32(idx ^ key(seed, step, site)) >= p * 2^32 (a full-avalanche

@@ -29,8 +29,11 @@ struct GruArgs {
   const uint32_t* rng; uint32_t site; float p;
 };
 
-__global__ __launch_bounds__(GNT) void gru_speaker_fwd_kernel(GruArgs a) {
+struct GruArgs2 { GruArgs d[2]; };        // blockIdx.y selects the chain (the two directions of a bidirectional cell share a launch)
+
+__global__ __launch_bounds__(GNT) void gru_speaker_fwd_kernel(GruArgs2 aa) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  const GruArgs& a = aa.d[blockIdx.y];
   float* q = sm;                   // [32][QS]
   float* gh = q + 32 * QS;         // [32][TS]
   int* party = (int*)(gh + 32 * TS);      // [32]
@@ -40,12 +43,13 @@ __global__ __launch_bounds__(GNT) void gru_speaker_fwd_kernel(GruArgs a) {
   const int r = lane & 31, half = lane >> 5;
   const int g = wave >> 2, s = wave & 3;
   const int b0 = blockIdx.x * 32;
-  // W_hh slice of this wave: B[k][n] = W_hh[g*H + s*32 + n][k], k = 2j + half
+  // W_hh slice of this wave: B[k][n] = W_hh[g*H + s*32 + n][k].  The order in which the reduction index is fed to the MFMAs is free
+  // as long as A and B agree: lane half h takes k = 64 h + j (contiguous), so its A values are consecutive LDS words.
   float breg[64];
   {
-    const float* w = a.w_hh + (long)(g * H + s * 32 + r) * H + half;
+    const float* w = a.w_hh + (long)(g * H + s * 32 + r) * H + half * 64;
 #pragma unroll
-    for (int j = 0; j < 64; ++j) breg[j] = w[2 * j];
+    for (int j = 0; j < 64; ++j) breg[j] = w[j];
   }
   const float bias = a.b_hh[g * H + s * 32 + r];
   for (int e = tid; e < 32 * QS; e += GNT) q[e] = 0.f;
@@ -75,10 +79,10 @@ __global__ __launch_bounds__(GNT) void gru_speaker_fwd_kernel(GruArgs a) {
     __syncthreads();
     // gh tile = qs0 W_hh^T: A[r][k] = q[r][party_r][k]
     {
-      const float* arow = q + r * QS + party[r] * H + half;
+      const float* arow = q + r * QS + party[r] * H + half * 64;
       f32x16 acc = {0};
 #pragma unroll
-      for (int j = 0; j < 64; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * j], breg[j], acc, 0, 0, 0);
+      for (int j = 0; j < 64; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[j], breg[j], acc, 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
@@ -118,8 +122,9 @@ __global__ __launch_bounds__(GNT) void gru_speaker_fwd_kernel(GruArgs a) {
   }
 }
 
-__global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs a) {
+__global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs2 aa) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  const GruArgs& a = aa.d[blockIdx.y];
   float* dq = sm;                  // [32][QS]   gradient at the party states
   float* dg = dq + 32 * QS;        // [32][TS]   gradient at gh (A operand of dqs0 = dgh W_hh)
   float* part = dg + 32 * TS;      // [3][32][H + 1] partial products per gate third
@@ -130,12 +135,12 @@ __global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs a) {
   const int r = lane & 31, half = lane >> 5;
   const int g = wave >> 2, s = wave & 3;
   const int b0 = blockIdx.x * 32;
-  // B[k][n] = W_hh[g*H + k][s*32 + n], k = 2j + half
+  // B[k][n] = W_hh[g*H + k][s*32 + n], k = 64 half + j (see the forward)
   float breg[64];
   {
-    const float* w = a.w_hh + (long)(g * H + half) * H + s * 32 + r;
+    const float* w = a.w_hh + (long)(g * H + half * 64) * H + s * 32 + r;
 #pragma unroll
-    for (int j = 0; j < 64; ++j) breg[j] = w[(long)2 * j * H];
+    for (int j = 0; j < 64; ++j) breg[j] = w[(long)j * H];
   }
   for (int e = tid; e < 32 * QS; e += GNT) dq[e] = 0.f;
   for (int e = tid; e < 32 * TS; e += GNT) dg[e] = 0.f;
@@ -184,10 +189,10 @@ __global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs a) {
     }
     __syncthreads();
     {
-      const float* arow = dg + r * TS + g * H + half;
+      const float* arow = dg + r * TS + g * H + half * 64;
       f32x16 acc = {0};
 #pragma unroll
-      for (int j = 0; j < 64; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * j], breg[j], acc, 0, 0, 0);
+      for (int j = 0; j < 64; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[j], breg[j], acc, 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
@@ -251,24 +256,29 @@ extern "C" {
 
 size_t mser_gru_speaker_save_bytes(int32_t T, int32_t B, int32_t H) { return (size_t)T * B * 5 * H * sizeof(float); }
 
-int mser_gru_speaker_fwd(const mser_gru_speaker_desc* d, mser_stream_t stream) {
-  if (!d) { set_error("mser_gru_speaker_fwd: null descriptor"); return -1; }
-  MSER_TRY(gru_validate(*d, false));
-  const GruArgs a = gru_args(*d);
-  const size_t lds = gru_lds_bytes(false);
-  MSER_TRY(allow_gru((const void*)gru_speaker_fwd_kernel, lds));
-  hipLaunchKernelGGL(gru_speaker_fwd_kernel, dim3(cdiv(d->B, 32)), dim3(GNT), lds, (hipStream_t)stream, a);
-  return check_launch("gru_speaker_fwd_kernel");
+static int gru_launch(const mser_gru_speaker_desc* d, int32_t n, bool bwd, hipStream_t s) {
+  const char* what = bwd ? "mser_gru_speaker_bwd" : "mser_gru_speaker_fwd";
+  if (!d) { set_error("%s: null descriptor", what); return -1; }
+  MSER_REQUIRE(n == 1 || n == 2, "%s: n=%d chains per launch (1 or 2)", what, n);
+  GruArgs2 aa;
+  for (int i = 0; i < n; ++i) {
+    MSER_TRY(gru_validate(d[i], bwd));
+    MSER_REQUIRE(d[i].T == d[0].T && d[i].B == d[0].B, "%s: the chains of one launch must share T and B", what);
+    aa.d[i] = gru_args(d[i]);
+  }
+  if (n == 1) aa.d[1] = aa.d[0];
+  const size_t lds = gru_lds_bytes(bwd);
+  if (bwd) {
+    MSER_TRY(allow_gru((const void*)gru_speaker_bwd_kernel, lds));
+    hipLaunchKernelGGL(gru_speaker_bwd_kernel, dim3(cdiv(d->B, 32), n), dim3(GNT), lds, s, aa);
+  } else {
+    MSER_TRY(allow_gru((const void*)gru_speaker_fwd_kernel, lds));
+    hipLaunchKernelGGL(gru_speaker_fwd_kernel, dim3(cdiv(d->B, 32), n), dim3(GNT), lds, s, aa);
+  }
+  return check_launch(what);
 }
 
-int mser_gru_speaker_bwd(const mser_gru_speaker_desc* d, mser_stream_t stream) {
-  if (!d) { set_error("mser_gru_speaker_bwd: null descriptor"); return -1; }
-  MSER_TRY(gru_validate(*d, true));
-  const GruArgs a = gru_args(*d);
-  const size_t lds = gru_lds_bytes(true);
-  MSER_TRY(allow_gru((const void*)gru_speaker_bwd_kernel, lds));
-  hipLaunchKernelGGL(gru_speaker_bwd_kernel, dim3(cdiv(d->B, 32)), dim3(GNT), lds, (hipStream_t)stream, a);
-  return check_launch("gru_speaker_bwd_kernel");
-}
+int mser_gru_speaker_fwd(const mser_gru_speaker_desc* d, int32_t n, mser_stream_t stream) { return gru_launch(d, n, false, (hipStream_t)stream); }
+int mser_gru_speaker_bwd(const mser_gru_speaker_desc* d, int32_t n, mser_stream_t stream) { return gru_launch(d, n, true, (hipStream_t)stream); }
 
 }  // extern "C"

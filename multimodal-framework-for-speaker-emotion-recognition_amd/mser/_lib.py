@@ -141,8 +141,8 @@ SIGNATURES = {
     "mser_masked_nll_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "mser_masked_nll_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "mser_gru_speaker_save_bytes": (C.c_size_t, [_i32, _i32, _i32]),
-    "mser_gru_speaker_fwd": (C.c_int, [C.POINTER(GruSpeakerDesc), _vp]),
-    "mser_gru_speaker_bwd": (C.c_int, [C.POINTER(GruSpeakerDesc), _vp]),
+    "mser_gru_speaker_fwd": (C.c_int, [C.POINTER(GruSpeakerDesc), _i32, _vp]),
+    "mser_gru_speaker_bwd": (C.c_int, [C.POINTER(GruSpeakerDesc), _i32, _vp]),
     "mser_dropout_apply": (C.c_int, [_vp, _i64, _i32, _i64, _vp, C.c_uint32, _f32, C.c_uint32, _vp]),
     "mser_dropout_scale": (C.c_int, [_vp, _i64, _vp, C.c_uint32, _f32, C.c_uint32, _i32, _vp]),
     "mser_rng_advance": (C.c_int, [_vp, _vp]),

@@ -66,13 +66,12 @@ def gru_speaker_dir_fwd(P: Getter, x_l: Tensor, x_a: Tensor, qmask: Tensor, rev:
     return c
 
 
-def gru_speaker_dir_bwd(c: GruDirCtx, P: Getter, G: Getter, dhs: Tensor, dx_l: Tensor, dx_a: Tensor, T: int, B: int, H: int) -> None:
-    """dhs [T*B, H]: total gradient at h_s.  Accumulates the GRU parameter gradients into G and the input gradients into dx_l / dx_a
-    (natural order)."""
+def gru_speaker_dir_bwd(c: GruDirCtx, P: Getter, G: Getter, dgi: Tensor, dgh: Tensor, dx_l: Tensor, dx_a: Tensor, T: int, B: int,
+                        H: int) -> None:
+    """After the chain's BPTT (ops.gru_speaker_bwd) has produced dgi / dgh: accumulates the GRU parameter gradients into G and the
+    input gradients into dx_l / dx_a (natural order)."""
     D = c.xl.shape[1]
-    dev = dhs.device
-    dgi, dgh = torch.empty(T * B, 3 * H, device=dev), torch.empty(T * B, 3 * H, device=dev)
-    ops.gru_speaker_bwd(c.desc, dhs, dgi, dgh)
+    dev = dgi.device
     gWih = G("gru_s.weight_ih")
     ops.grad_weight(dgi, c.xl, gWih[:, :D])
     ops.grad_weight(dgi, c.xa, gWih[:, D:])
@@ -173,8 +172,7 @@ def onlysp_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mod
     # FWD_PREP zeroes the reversed direction's output rows (h_s quarter included: rows at and beyond len_b stay zero), so the
     # speaker chains, which write that quarter, go after it
     ops.marn_cell_run(desc, ops.PHASE_FWD_PREP)
-    for g in c.gru:
-        ops.gru_speaker_fwd(g.desc)
+    ops.gru_speaker_fwd([g.desc for g in c.gru])                 # both directions' chains in one launch
     ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD)
 
     # ---- sequence-level cross-modal attention (:277-283)
@@ -255,8 +253,12 @@ def onlysp_backward(c: OnlyspCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: O
                                   ext_hq=[g.hs for g in c.gru], ext_dhq=dhq)
         ops.marn_cell_run(desc, ops.PHASE_BWD_PREP | ops.PHASE_LSTHM_BWD)
         ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD_DX | ops.PHASE_LSTHM_WGRAD | ops.PHASE_SPEAKER_BWD)
+        dgs = [(torch.empty(N, 3 * H, device=dev), torch.empty(N, 3 * H, device=dev)) for _ in range(2)]
+        for i in range(2):
+            ops.gru_speaker_set_grads(c.gru[i].desc, dhq[i], dgs[i][0], dgs[i][1])
+        ops.gru_speaker_bwd([g.desc for g in c.gru])              # both directions' BPTT in one launch
         for i, pre in enumerate(("marn_cell_f.", "marn_cell_b.")):
-            gru_speaker_dir_bwd(c.gru[i], _sub(P, pre), _sub(G, pre), dhq[i], dx_l, dx_a, Ln, B, H)
+            gru_speaker_dir_bwd(c.gru[i], _sub(P, pre), _sub(G, pre), dgs[i][0], dgs[i][1], dx_l, dx_a, Ln, B, H)
         # ---- encoders and linear_in
         Pl, Pa, Gl, Ga = _sub(P, "encoder_l."), _sub(P, "encoder_a."), _sub(G, "encoder_l."), _sub(G, "encoder_a.")
         d1 = F_.encoder_layer_bwd(c.enc[0], F_.encoder_layer_bwd(c.enc[1], dx_l, Pl, Gl), Pl, Gl)

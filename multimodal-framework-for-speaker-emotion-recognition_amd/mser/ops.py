@@ -372,11 +372,21 @@ def gru_speaker_desc(T: int, B: int, H: int, gi: Tensor, w_hh: Tensor, b_hh: Ten
     return d
 
 
-def gru_speaker_fwd(desc: L.GruSpeakerDesc) -> None:
-    L.check(_lib().mser_gru_speaker_fwd(C.byref(desc), _stream()), "gru_speaker_fwd")
+def _gru_array(descs):
+    descs = list(descs) if isinstance(descs, (list, tuple)) else [descs]
+    if len(descs) not in (1, 2):
+        raise RuntimeError("gru_speaker: one or two chains per launch")
+    arr = (L.GruSpeakerDesc * len(descs))(*descs)      # (copies the structs: the tensors stay referenced by the originals' _keep)
+    return arr, len(descs)
 
 
-def gru_speaker_bwd(desc: L.GruSpeakerDesc, dhs: Tensor, dgi: Tensor, dgh: Tensor, dhs_add: Sequence[Tensor] = ()) -> None:
+def gru_speaker_fwd(descs) -> None:
+    """descs: one descriptor or a list of two (same T, B): the chains share one launch."""
+    arr, n = _gru_array(descs)
+    L.check(_lib().mser_gru_speaker_fwd(arr, n, _stream()), "gru_speaker_fwd")
+
+
+def gru_speaker_set_grads(desc: L.GruSpeakerDesc, dhs: Tensor, dgi: Tensor, dgh: Tensor, dhs_add: Sequence[Tensor] = ()) -> None:
     for t in (dhs, dgi, dgh, *dhs_add):
         if not t.is_contiguous():
             raise RuntimeError("gru_speaker_bwd: gradient buffers must be contiguous")
@@ -384,7 +394,16 @@ def gru_speaker_bwd(desc: L.GruSpeakerDesc, dhs: Tensor, dgi: Tensor, dgh: Tenso
     desc._keep_bwd = (dhs, dgi, dgh, tuple(dhs_add))
     for i in range(2):
         desc.dhs_add[i] = _p(dhs_add[i]) if i < len(dhs_add) else None
-    L.check(_lib().mser_gru_speaker_bwd(C.byref(desc), _stream()), "gru_speaker_bwd")
+
+
+def gru_speaker_bwd(descs, dhs: Optional[Tensor] = None, dgi: Optional[Tensor] = None, dgh: Optional[Tensor] = None,
+                    dhs_add: Sequence[Tensor] = ()) -> None:
+    """One descriptor with its gradient buffers given here, or a list of (one or two) descriptors prepared with
+    gru_speaker_set_grads."""
+    if dhs is not None:
+        gru_speaker_set_grads(descs, dhs, dgi, dgh, dhs_add)
+    arr, n = _gru_array(descs)
+    L.check(_lib().mser_gru_speaker_bwd(arr, n, _stream()), "gru_speaker_bwd")
 
 
 # ---- dropout (include/mser.h "Dropout"): rng = int32 tensor {seed, step} on the device

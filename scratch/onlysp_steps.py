@@ -1,0 +1,17 @@
+"""A few eager training steps of MARN1_onlysp on the bench batch (scratch: profile with rocprofv3 --kernel-trace --stats)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "multimodal-framework-for-speaker-emotion-recognition_amd")]
+import torch
+import bench
+from model_trainer import ModelTrainer
+dev = torch.device("cuda:0")
+tr = ModelTrainer(dev, lr=1e-3, test_step=1, lr_decay=0.98, model="MARN1_onlysp", loss="NLL", n_classes=6, dataset="IEMOCAP", d_r=768,
+                  quiet=True, dropout=("--dropout" in sys.argv))
+bench.init_attention_weights(tr.model)
+tr.train(); tr.scheduler.step(0)
+x, qmask, umask, label = bench.synth_batch(1000, dev)
+for i in range(12):
+    loss, _ = tr.train_step(x, qmask, umask, label)
+torch.cuda.synchronize()
+print("loss", float(loss))
