@@ -55,14 +55,18 @@ __global__ __launch_bounds__(GNT) void gru_speaker_fwd_kernel(GruArgs2 aa) {
   for (int e = tid; e < 32 * QS; e += GNT) q[e] = 0.f;
   DropKey dk;
   if (a.rng) dk = drop_key(a.rng, a.site, a.p);
+  // the step's qmask row is fetched one step ahead (threads 0..31 hold it): a dependent global load would sit on every step's path
+  float nm0 = 0.f, nm1 = 0.f;
+  if (tid < 32 && b0 + tid < B) { nm0 = a.qmask[(long)(b0 + tid) * 2]; nm1 = a.qmask[(long)(b0 + tid) * 2 + 1]; }
   __syncthreads();
   for (int t = 0; t < a.T; ++t) {
     if (tid < 32) {
-      const int b = b0 + tid;
-      float m0 = 0.f, m1 = 0.f;
-      if (b < B) { m0 = a.qmask[((long)t * B + b) * 2]; m1 = a.qmask[((long)t * B + b) * 2 + 1]; }
+      const float m0 = nm0, m1 = nm1;
       qmv[tid * 2] = m0; qmv[tid * 2 + 1] = m1;
       party[tid] = m1 > m0 ? 1 : 0;          // argmax(qmask[t], 1): ties and padded (all-zero) rows -> party 0 (:175)
+      if (t + 1 < a.T && b0 + tid < B) {
+        nm0 = a.qmask[((long)(t + 1) * B + b0 + tid) * 2]; nm1 = a.qmask[((long)(t + 1) * B + b0 + tid) * 2 + 1];
+      }
     }
     // this step's input-side pre-activations: in flight during the product
     float gi3[NEL][3];
@@ -146,14 +150,39 @@ __global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs2 aa) {
   for (int e = tid; e < 32 * TS; e += GNT) dg[e] = 0.f;
   DropKey dk;
   if (a.rng) dk = drop_key(a.rng, a.site, a.p);
+  float nm0 = 0.f, nm1 = 0.f;
+  if (tid < 32 && b0 + tid < B) {
+    nm0 = a.qmask[((long)(a.T - 1) * B + b0 + tid) * 2]; nm1 = a.qmask[((long)(a.T - 1) * B + b0 + tid) * 2 + 1];
+  }
+  // The step's saved forward values and incoming gradient (6 words per element) are fetched one step ahead, while the previous
+  // step's product runs: loaded at the top of the step they would be a memory round trip on every step's path.
+  float pv[NEL][6];
+  auto fetch = [&](int t) {
+#pragma unroll
+    for (int k = 0; k < NEL; ++k) {
+      const int e = tid + k * GNT;
+      const int row = e / H, u = e - row * H;
+      if (e < 32 * H && b0 + row < B) {
+        const long rowt = (long)t * B + b0 + row;
+        const float* sv = a.save + rowt * 5 * H + u;
+        pv[k][0] = sv[0]; pv[k][1] = sv[H]; pv[k][2] = sv[2 * H]; pv[k][3] = sv[3 * H]; pv[k][4] = sv[4 * H];
+        float dh = a.dhs[rowt * H + u];
+        if (a.dhs2) dh += a.dhs2[rowt * H + u];
+        if (a.dhs3) dh += a.dhs3[rowt * H + u];
+        pv[k][5] = dh;
+      }
+    }
+  };
+  fetch(a.T - 1);
   __syncthreads();
   for (int t = a.T - 1; t >= 0; --t) {
     if (tid < 32) {
-      const int b = b0 + tid;
-      float m0 = 0.f, m1 = 0.f;
-      if (b < B) { m0 = a.qmask[((long)t * B + b) * 2]; m1 = a.qmask[((long)t * B + b) * 2 + 1]; }
+      const float m0 = nm0, m1 = nm1;
       qmv[tid * 2] = m0; qmv[tid * 2 + 1] = m1;
       party[tid] = m1 > m0 ? 1 : 0;
+      if (t > 0 && b0 + tid < B) {
+        nm0 = a.qmask[((long)(t - 1) * B + b0 + tid) * 2]; nm1 = a.qmask[((long)(t - 1) * B + b0 + tid) * 2 + 1];
+      }
     }
     __syncthreads();
     float direct[NEL];
@@ -167,14 +196,11 @@ __global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs2 aa) {
         const long rowt = (long)t * B + b;
         const float m0 = qmv[row * 2], m1 = qmv[row * 2 + 1];
         float* q0 = dq + row * QS + u;
-        float dh = a.dhs[rowt * H + u] + q0[0] * m0 + q0[H] * m1;            // every consumer of h_s[t]: the cell, and the party states
-        if (a.dhs2) dh += a.dhs2[rowt * H + u];
-        if (a.dhs3) dh += a.dhs3[rowt * H + u];
+        float dh = pv[k][5] + q0[0] * m0 + q0[H] * m1;                       // every consumer of h_s[t]: the cell, and the party states
         q0[0] *= (1.f - m0);
         q0[H] *= (1.f - m1);
         if (a.rng) dh *= drop_scale(dk, (uint32_t)(rowt * H + u));
-        const float* sv = a.save + rowt * 5 * H + u;
-        const float hprev = sv[0], rg = sv[H], zg = sv[2 * H], ng = sv[3 * H], ghn = sv[4 * H];
+        const float hprev = pv[k][0], rg = pv[k][1], zg = pv[k][2], ng = pv[k][3], ghn = pv[k][4];
         const float dan = dh * (1.f - zg) * (1.f - ng * ng);
         const float daz = dh * (hprev - ng) * zg * (1.f - zg);
         const float dar = dan * ghn * rg * (1.f - rg);
@@ -187,6 +213,7 @@ __global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs2 aa) {
         direct[k] = dh * zg;
       }
     }
+    if (t > 0) fetch(t - 1);
     __syncthreads();
     {
       const float* arow = dg + r * TS + g * H + half * 64;

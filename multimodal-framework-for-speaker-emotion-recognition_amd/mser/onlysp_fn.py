@@ -8,7 +8,8 @@ row f1) as explicit kernel sequences, built from the same pieces as ``mser.model
 * the second encoder pass takes the first pass's output without the residual add (:262-266);
 * the head is ``nn_out`` = Linear(10H -> 32) + ReLU + Dropout + Linear(32 -> C) on cat[h_f, h_b, attn1, attn2] (:287).
 
-First version: one stream, no hipGraph-specific choreography; the GRU chains run before / after the LSTHM chains.
+First version of the schedule: the GRU chains run before / after the LSTHM chains (not yet counter-linked to them); the audio
+encoder branch and the sequence-level attention modules run on side streams beside the text branch and the recurrent chains.
 """
 from __future__ import annotations
 
@@ -20,7 +21,7 @@ import torch
 from . import functional as F_
 from . import ops
 from .functional import Layout
-from .model_fn import DropCfg, Getter, ModelDims, _sub
+from .model_fn import DropCfg, Getter, ModelDims, _Streams, _sub
 
 Tensor = torch.Tensor
 
@@ -144,17 +145,42 @@ def onlysp_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mod
     c.x_l, c.x_a = torch.empty(N, D, device=dev), torch.empty(N, D, device=dev)
     c.enc = [None] * 4
     Pl, Pa = _sub(P, "encoder_l."), _sub(P, "encoder_a.")
+    cur = torch.cuda.current_stream()
+    s_audio, s_x = _Streams.get(dev)[:2]
+    s_audio.wait_stream(cur)
+    with torch.cuda.stream(s_audio):
+        e1a, c.enc[2] = F_.encoder_layer_fwd(xa0, None, Pa, lay, d.n_head, d.d_k, d.d_v, drops=enc_drops(2), need_attn=False)
+        _, c.enc[3] = F_.encoder_layer_fwd(e1a, None, Pa, lay, d.n_head, d.d_k, d.d_v, out=c.x_a, drops=enc_drops(3), need_attn=False)
     ops.linear(c.x2d[:, :d.d_r], P("linear_in.weight"), c.xl0, bias=P("linear_in.bias"))
     e1, c.enc[0] = F_.encoder_layer_fwd(c.xl0, None, Pl, lay, d.n_head, d.d_k, d.d_v, drops=enc_drops(0), need_attn=False)
     _, c.enc[1] = F_.encoder_layer_fwd(e1, None, Pl, lay, d.n_head, d.d_k, d.d_v, out=c.x_l, drops=enc_drops(1), need_attn=False)
-    e1a, c.enc[2] = F_.encoder_layer_fwd(xa0, None, Pa, lay, d.n_head, d.d_k, d.d_v, drops=enc_drops(2), need_attn=False)
-    _, c.enc[3] = F_.encoder_layer_fwd(e1a, None, Pa, lay, d.n_head, d.d_k, d.d_v, out=c.x_a, drops=enc_drops(3), need_attn=False)
+    cur.wait_stream(s_audio)                     # x_l and x_a are final
+
+    c.Hcat = torch.empty(N, 10 * H, device=dev)
+    # ---- sequence-level cross-modal attention (:277-283): needs only the encoder outputs -- issued on a side stream, it runs beside
+    # the recurrent chains (which leave most of the chip idle); it writes the last two H-wide column blocks of Hcat
+    w, v, v1, v2 = P("w"), P("v"), P("v1"), P("v2")
+    c.A1, c.A2 = torch.empty(N, H, device=dev), torch.empty(N, H, device=dev)
+    c.xa = [None] * 4
+
+    def xa_drop(i):
+        return drop.site(F_.SITE_XATTN + i, drop.p_xattn[i]) if drop is not None else None
+
+    s_x.wait_stream(cur)
+    with torch.cuda.stream(s_x):
+        c.xa[0] = F_.xattn_fwd(c.x_l, w, c.x_a, v, P("crossatt_l2a.Wq"), P("crossatt_l2a.Wk"), P("crossatt_l2a.Wv"), lay, lay, c.A1, 1,
+                               drop=xa_drop(0))
+        c.xa[2] = F_.xattn_fwd(c.x_a, v, c.A1, v1, P("crossatt_l2a_1.Wq"), P("crossatt_l2a_1.Wk"), P("crossatt_l2a_1.Wv"), lay, lay,
+                               c.Hcat[:, 8 * H:9 * H], 1, drop=xa_drop(2))
+        c.xa[1] = F_.xattn_fwd(c.x_a, v, c.x_l, w, P("crossatt_a2l.Wq"), P("crossatt_a2l.Wk"), P("crossatt_a2l.Wv"), lay, lay, c.A2, 1,
+                               drop=xa_drop(1))
+        c.xa[3] = F_.xattn_fwd(c.x_l, w, c.A2, v2, P("crossatt_a2l_1.Wq"), P("crossatt_a2l_1.Wk"), P("crossatt_a2l_1.Wv"), lay, lay,
+                               c.Hcat[:, 9 * H:10 * H], 1, drop=xa_drop(3))
 
     # ---- the two cells: GRU speaker chains, then the LSTHM chains of both directions in one launch
     lens = torch.empty(B, device=dev, dtype=torch.int32)
     c.rev = torch.empty(Ln, B, device=dev, dtype=torch.int32)
     ops.build_reverse_index(umask, lens, c.rev)
-    c.Hcat = torch.empty(N, 10 * H, device=dev)
     c.gru = []
     for i, (pre, rev) in enumerate((("marn_cell_f.", None), ("marn_cell_b.", c.rev))):
         site = drop.site(F_.SITE_CELL + 4 * i, drop.p_cell[i]) if drop is not None else None
@@ -174,21 +200,7 @@ def onlysp_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mod
     ops.marn_cell_run(desc, ops.PHASE_FWD_PREP)
     ops.gru_speaker_fwd([g.desc for g in c.gru])                 # both directions' chains in one launch
     ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD)
-
-    # ---- sequence-level cross-modal attention (:277-283)
-    w, v, v1, v2 = P("w"), P("v"), P("v1"), P("v2")
-    c.A1, c.A2 = torch.empty(N, H, device=dev), torch.empty(N, H, device=dev)
-    c.xa = [None] * 4
-
-    def xa_drop(i):
-        return drop.site(F_.SITE_XATTN + i, drop.p_xattn[i]) if drop is not None else None
-
-    c.xa[0] = F_.xattn_fwd(c.x_l, w, c.x_a, v, P("crossatt_l2a.Wq"), P("crossatt_l2a.Wk"), P("crossatt_l2a.Wv"), lay, lay, c.A1, 1, drop=xa_drop(0))
-    c.xa[2] = F_.xattn_fwd(c.x_a, v, c.A1, v1, P("crossatt_l2a_1.Wq"), P("crossatt_l2a_1.Wk"), P("crossatt_l2a_1.Wv"), lay, lay,
-                           c.Hcat[:, 8 * H:9 * H], 1, drop=xa_drop(2))
-    c.xa[1] = F_.xattn_fwd(c.x_a, v, c.x_l, w, P("crossatt_a2l.Wq"), P("crossatt_a2l.Wk"), P("crossatt_a2l.Wv"), lay, lay, c.A2, 1, drop=xa_drop(1))
-    c.xa[3] = F_.xattn_fwd(c.x_l, w, c.A2, v2, P("crossatt_a2l_1.Wq"), P("crossatt_a2l_1.Wk"), P("crossatt_a2l_1.Wv"), lay, lay,
-                           c.Hcat[:, 9 * H:10 * H], 1, drop=xa_drop(3))
+    cur.wait_stream(s_x)
     if drop is not None and drop.p_rec > 0:
         for i in range(2):
             drop.site(F_.SITE_REC + i, drop.p_rec).apply_(c.Hcat[:, 4 * H * i:4 * H * (i + 1)])
@@ -231,19 +243,24 @@ def onlysp_backward(c: OnlyspCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: O
         if drop is not None and drop.p_rec > 0:
             for i in range(2):
                 drop.site(F_.SITE_REC + i, drop.p_rec).apply_(dH[:, 4 * H * i:4 * H * (i + 1)])
-        # ---- sequence-level attention modules
+        # ---- sequence-level attention modules: on a side stream beside the recurrent chains, into accumulators of their own
+        cur = torch.cuda.current_stream()
+        s_audio, s_x = _Streams.get(dev)[:2]
         dx_l = torch.zeros(N, D, device=dev) if dx_l_out is None else dx_l_out.reshape(N, D).clone()
         dx_a = torch.zeros(N, D, device=dev) if dx_a_out is None else dx_a_out.reshape(N, D).clone()
+        dxl_x, dxa_x = torch.zeros(N, D, device=dev), torch.zeros(N, D, device=dev)
         dA1, dA2 = torch.zeros(N, H, device=dev), torch.zeros(N, H, device=dev)
 
         def xb(i, name, dout, dx1, dx2, ga1, ga2):
             F_.xattn_bwd(c.xa[i], dout, P(name + ".Wq"), P(name + ".Wk"), P(name + ".Wv"), G(name + ".Wq"), G(name + ".Wk"),
                          G(name + ".Wv"), dx1, dx2, ga1, ga2)
 
-        xb(2, "crossatt_l2a_1", dH[:, 8 * H:9 * H], dx_a, dA1, G("v"), G("v1"))
-        xb(0, "crossatt_l2a", dA1, dx_l, dx_a, G("w"), G("v"))
-        xb(3, "crossatt_a2l_1", dH[:, 9 * H:10 * H], dx_l, dA2, G("w"), G("v2"))
-        xb(1, "crossatt_a2l", dA2, dx_a, dx_l, G("v"), G("w"))
+        s_x.wait_stream(cur)
+        with torch.cuda.stream(s_x):
+            xb(2, "crossatt_l2a_1", dH[:, 8 * H:9 * H], dxa_x, dA1, G("v"), G("v1"))
+            xb(0, "crossatt_l2a", dA1, dxl_x, dxa_x, G("w"), G("v"))
+            xb(3, "crossatt_a2l_1", dH[:, 9 * H:10 * H], dxl_x, dA2, G("w"), G("v2"))
+            xb(1, "crossatt_a2l", dA2, dxa_x, dxl_x, G("v"), G("w"))
         # ---- LSTHM chains of both directions (ext speaker state), then the GRU chains
         dhq = [torch.empty(N, H, device=dev) for _ in range(2)]
         for r, pre, sl in ((c.cell_dirs[0], "marn_cell_f.", slice(0, 4 * H)), (c.cell_dirs[1], "marn_cell_b.", slice(4 * H, 8 * H))):
@@ -259,9 +276,15 @@ def onlysp_backward(c: OnlyspCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: O
         ops.gru_speaker_bwd([g.desc for g in c.gru])              # both directions' BPTT in one launch
         for i, pre in enumerate(("marn_cell_f.", "marn_cell_b.")):
             gru_speaker_dir_bwd(c.gru[i], _sub(P, pre), _sub(G, pre), dgs[i][0], dgs[i][1], dx_l, dx_a, Ln, B, H)
-        # ---- encoders and linear_in
+        # ---- encoders (audio branch on a side stream) and linear_in
+        cur.wait_stream(s_x)
+        ops.add_rows(dx_l, dx_l, dxl_x)
+        ops.add_rows(dx_a, dx_a, dxa_x)
         Pl, Pa, Gl, Ga = _sub(P, "encoder_l."), _sub(P, "encoder_a."), _sub(G, "encoder_l."), _sub(G, "encoder_a.")
+        s_audio.wait_stream(cur)
+        with torch.cuda.stream(s_audio):
+            F_.encoder_layer_bwd(c.enc[2], F_.encoder_layer_bwd(c.enc[3], dx_a, Pa, Ga), Pa, Ga)
         d1 = F_.encoder_layer_bwd(c.enc[0], F_.encoder_layer_bwd(c.enc[1], dx_l, Pl, Gl), Pl, Gl)
         ops.grad_weight(d1, c.x2d[:, :d.d_r], G("linear_in.weight"))
         ops.colsum_acc(d1, G("linear_in.bias"))
-        F_.encoder_layer_bwd(c.enc[2], F_.encoder_layer_bwd(c.enc[3], dx_a, Pa, Ga), Pa, Ga)
+        cur.wait_stream(s_audio)
