@@ -171,12 +171,16 @@ def load():
         raise RuntimeError(
             f"libmser.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback on the product path.")
+    # torch first: its wheel carries the HIP runtime of the process (libamdhip64 of its own ROCm).  libmser.so dlopen-ed BEFORE torch
+    # would pull in /opt/rocm's copy instead, the process would hold two runtimes and libmser's launches fail with "no ROCm-capable
+    # device is detected" (seen when build() and smoke() ran in one process).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.mser_version() < 110:
+    if lib.mser_version() < 112:
         raise RuntimeError("libmser.so is older than this binding")
     _lib = lib
     return lib
