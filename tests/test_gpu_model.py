@@ -819,3 +819,29 @@ def test_onlysp_model_vs_oracle(O, B, L, train, persistent):
             continue
         assert p.grad is not None, n
         assert maxabs(p.grad, r) < 3e-4 * max(1e-3, float(r.norm())), n
+
+
+def test_onlysp_trainer_runs_the_reference_loop(O, tmp_path):
+    """ModelTrainer(model="MARN1_onlysp") -- the reference CLI's default (train.py:126): train_network / eval_network / checkpoint
+    round trip with the reference's key names; the loss of a memorisable batch falls."""
+    from model_trainer import ModelTrainer
+    tr = ModelTrainer(torch.device("cuda:0"), 1e-3, 1, 0.98, "MARN1_onlysp", "NLL", 6, "IEMOCAP", quiet=True)
+    load_params(tr.model, O.seeded_params(seed=91, d_r=1024, variant="onlysp"))
+    B, L = 4, 8
+    x, qmask, umask, label = O.seeded_batch(B, L, d_r=1024, seed=92, ragged=True)
+    r = x[:, :, :1024]
+    batch = [r, r, r, r, torch.zeros(L, B, 4), x[:, :, 1024:], qmask, umask, label, ["v"] * B]
+    losses = [tr.train_network(ep, [batch] * 6)[1] for ep in (1, 2, 3)]
+    assert losses[-1] < losses[0], losses
+    acc, f1, extra = tr.eval_network([batch])
+    assert 0.0 <= acc <= 100.0 and 0.0 <= f1 <= 100.0 and extra == {}
+    path = str(tmp_path / "model_0001.model")
+    tr.save_parameters(path)
+    keys = list(torch.load(path, weights_only=True).keys())
+    assert keys[0] == "model.w" and "model.marn_cell_f.gru_s.weight_ih" in keys and len(keys) == 128
+    tr2 = ModelTrainer(torch.device("cuda:0"), 1e-3, 1, 0.98, "MARN1_onlysp", "NLL", 6, "IEMOCAP", quiet=True)
+    tr2.load_parameters(path)
+    tr.eval(); tr2.eval()
+    xs = (x.cuda(), qmask.cuda(), umask.cuda())
+    with torch.no_grad():
+        assert torch.equal(tr.model(*xs)[0], tr2.model(*xs)[0])
