@@ -16,8 +16,8 @@ namespace {
 
 constexpr int GH = 128;            // the reference's dh_s
 constexpr int GNT = 768;           // 12 waves
-constexpr int QS = 2 * GH + 1;     // LDS row stride of the party states [32][2][H] (odd: the 32 rows of an A fragment hit 32 banks)
-constexpr int TS = 3 * GH + 1;     // LDS row stride of the gate tiles [32][3H]
+constexpr int QS = 2 * GH + 4;     // LDS row stride of the party states [32][2][H]: +4 words, so that the 16-byte A reads of eight
+constexpr int TS = 3 * GH + 4;     // consecutive rows cover all 32 banks; likewise for the gate tiles [32][3H]
 constexpr int NEL = (32 * GH + GNT - 1) / GNT;     // (row, unit) elements per thread and step
 
 struct GruArgs {
@@ -28,6 +28,23 @@ struct GruArgs {
   const float* dhs; const float* dhs2; const float* dhs3; float* dgi; float* dgh;
   const uint32_t* rng; uint32_t site; float p;
 };
+
+// 32 x 32 x 128 product of one wave: A row r of this lane from LDS (64 consecutive words: its half of the reduction index, read
+// 16 bytes at a time), B from registers; two independent accumulator chains (the first version chained all 64 MFMAs through one
+// accumulator: the pipe was busy 13 % of the kernel, the waves stood 41 % of the time in issue stalls).  The order of the fp32
+// additions differs from a single chain by the final acc0 + acc1; the parity gates hold.
+__device__ __forceinline__ f32x16 wave_mm_k128(const float* arow, const float (&breg)[64]) {
+  f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const float4 av = *reinterpret_cast<const float4*>(arow + 4 * c);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, breg[4 * c + 0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, breg[4 * c + 1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, breg[4 * c + 2], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, breg[4 * c + 3], acc1, 0, 0, 0);
+  }
+  return acc0 + acc1;
+}
 
 struct GruArgs2 { GruArgs d[2]; };        // blockIdx.y selects the chain (the two directions of a bidirectional cell share a launch)
 
@@ -68,25 +85,10 @@ __global__ __launch_bounds__(GNT) void gru_speaker_fwd_kernel(GruArgs2 aa) {
         nm0 = a.qmask[((long)(t + 1) * B + b0 + tid) * 2]; nm1 = a.qmask[((long)(t + 1) * B + b0 + tid) * 2 + 1];
       }
     }
-    // this step's input-side pre-activations: in flight during the product
-    float gi3[NEL][3];
-#pragma unroll
-    for (int k = 0; k < NEL; ++k) {
-      const int e = tid + k * GNT;
-      const int row = e / H, u = e - row * H;
-      gi3[k][0] = gi3[k][1] = gi3[k][2] = 0.f;
-      if (e < 32 * H && b0 + row < B) {
-        const float* p = a.gi + ((long)t * B + b0 + row) * 3 * H + u;
-        gi3[k][0] = p[0]; gi3[k][1] = p[H]; gi3[k][2] = p[2 * H];
-      }
-    }
     __syncthreads();
     // gh tile = qs0 W_hh^T: A[r][k] = q[r][party_r][k]
     {
-      const float* arow = q + r * QS + party[r] * H + half * 64;
-      f32x16 acc = {0};
-#pragma unroll
-      for (int j = 0; j < 64; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[j], breg[j], acc, 0, 0, 0);
+      const f32x16 acc = wave_mm_k128(q + r * QS + party[r] * H + half * 64, breg);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
@@ -94,18 +96,21 @@ __global__ __launch_bounds__(GNT) void gru_speaker_fwd_kernel(GruArgs2 aa) {
       }
     }
     __syncthreads();
-#pragma unroll
+    // (the register budget of a 12-wave workgroup does not allow the loop to be unrolled NEL times with the W_hh values live)
+#pragma unroll 2
     for (int k = 0; k < NEL; ++k) {
       const int e = tid + k * GNT;
       const int row = e / H, u = e - row * H;
       const int b = b0 + row;
       if (e < 32 * H && b < B) {
+        const float* gp = a.gi + ((long)t * B + b) * 3 * H + u;
+        const float gi0 = gp[0], gi1 = gp[H], gi2 = gp[2 * H];
         const float* gr = gh + row * TS + u;
         const float hprev = q[row * QS + party[row] * H + u];
-        const float rg = sigmoidf_(gi3[k][0] + gr[0]);
-        const float zg = sigmoidf_(gi3[k][1] + gr[H]);
+        const float rg = sigmoidf_(gi0 + gr[0]);
+        const float zg = sigmoidf_(gi1 + gr[H]);
         const float ghn = gr[2 * H];
-        const float ng = tanhf(gi3[k][2] + rg * ghn);
+        const float ng = tanhf(gi2 + rg * ghn);
         float hv = (1.f - zg) * ng + zg * hprev;
         const long rowt = (long)t * B + b;
         if (a.rng) hv *= drop_scale(dk, (uint32_t)(rowt * H + u));         // :177 dropout(gru_s(U, qs_0)): the dropped value is the state
@@ -131,8 +136,8 @@ __global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs2 aa) {
   const GruArgs& a = aa.d[blockIdx.y];
   float* dq = sm;                  // [32][QS]   gradient at the party states
   float* dg = dq + 32 * QS;        // [32][TS]   gradient at gh (A operand of dqs0 = dgh W_hh)
-  float* part = dg + 32 * TS;      // [3][32][H + 1] partial products per gate third
-  int* party = (int*)(part + 3 * 32 * (GH + 1));
+  float* part = dg + 32 * TS;      // [4][32][H + 1]: partial products per gate third, and the direct path dh' z of the step
+  int* party = (int*)(part + 4 * 32 * (GH + 1));
   float* qmv = (float*)(party + 32);
   const int H = GH, B = a.B, PS = GH + 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -154,26 +159,6 @@ __global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs2 aa) {
   if (tid < 32 && b0 + tid < B) {
     nm0 = a.qmask[((long)(a.T - 1) * B + b0 + tid) * 2]; nm1 = a.qmask[((long)(a.T - 1) * B + b0 + tid) * 2 + 1];
   }
-  // The step's saved forward values and incoming gradient (6 words per element) are fetched one step ahead, while the previous
-  // step's product runs: loaded at the top of the step they would be a memory round trip on every step's path.
-  float pv[NEL][6];
-  auto fetch = [&](int t) {
-#pragma unroll
-    for (int k = 0; k < NEL; ++k) {
-      const int e = tid + k * GNT;
-      const int row = e / H, u = e - row * H;
-      if (e < 32 * H && b0 + row < B) {
-        const long rowt = (long)t * B + b0 + row;
-        const float* sv = a.save + rowt * 5 * H + u;
-        pv[k][0] = sv[0]; pv[k][1] = sv[H]; pv[k][2] = sv[2 * H]; pv[k][3] = sv[3 * H]; pv[k][4] = sv[4 * H];
-        float dh = a.dhs[rowt * H + u];
-        if (a.dhs2) dh += a.dhs2[rowt * H + u];
-        if (a.dhs3) dh += a.dhs3[rowt * H + u];
-        pv[k][5] = dh;
-      }
-    }
-  };
-  fetch(a.T - 1);
   __syncthreads();
   for (int t = a.T - 1; t >= 0; --t) {
     if (tid < 32) {
@@ -185,22 +170,25 @@ __global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs2 aa) {
       }
     }
     __syncthreads();
-    float direct[NEL];
-#pragma unroll
+    // (partially unrolled: with the 64 W_hh values live a 12-wave workgroup has ~100 registers left per lane; fully unrolled, this
+    // loop spilled 55 of them to scratch in every step)
+#pragma unroll 2
     for (int k = 0; k < NEL; ++k) {
       const int e = tid + k * GNT;
       const int row = e / H, u = e - row * H;
       const int b = b0 + row;
-      direct[k] = 0.f;
       if (e < 32 * H && b < B) {
         const long rowt = (long)t * B + b;
         const float m0 = qmv[row * 2], m1 = qmv[row * 2 + 1];
         float* q0 = dq + row * QS + u;
-        float dh = pv[k][5] + q0[0] * m0 + q0[H] * m1;                       // every consumer of h_s[t]: the cell, and the party states
+        float dh = a.dhs[rowt * H + u] + q0[0] * m0 + q0[H] * m1;            // every consumer of h_s[t]: the cell, and the party states
+        if (a.dhs2) dh += a.dhs2[rowt * H + u];
+        if (a.dhs3) dh += a.dhs3[rowt * H + u];
         q0[0] *= (1.f - m0);
         q0[H] *= (1.f - m1);
         if (a.rng) dh *= drop_scale(dk, (uint32_t)(rowt * H + u));
-        const float hprev = pv[k][0], rg = pv[k][1], zg = pv[k][2], ng = pv[k][3], ghn = pv[k][4];
+        const float* sv = a.save + rowt * 5 * H + u;
+        const float hprev = sv[0], rg = sv[H], zg = sv[2 * H], ng = sv[3 * H], ghn = sv[4 * H];
         const float dan = dh * (1.f - zg) * (1.f - ng * ng);
         const float daz = dh * (hprev - ng) * zg * (1.f - zg);
         const float dar = dan * ghn * rg * (1.f - rg);
@@ -210,16 +198,12 @@ __global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs2 aa) {
         o2[0] = dar; o2[H] = daz; o2[2 * H] = dan * rg;
         float* l = dg + row * TS + u;
         l[0] = dar; l[H] = daz; l[2 * H] = dan * rg;
-        direct[k] = dh * zg;
+        part[(96 + row) * PS + u] = dh * zg;
       }
     }
-    if (t > 0) fetch(t - 1);
     __syncthreads();
     {
-      const float* arow = dg + r * TS + g * H + half * 64;
-      f32x16 acc = {0};
-#pragma unroll
-      for (int j = 0; j < 64; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[j], breg[j], acc, 0, 0, 0);
+      const f32x16 acc = wave_mm_k128(dg + r * TS + g * H + half * 64, breg);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
@@ -227,12 +211,12 @@ __global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs2 aa) {
       }
     }
     __syncthreads();
-#pragma unroll
+#pragma unroll 2
     for (int k = 0; k < NEL; ++k) {
       const int e = tid + k * GNT;
       const int row = e / H, u = e - row * H;
       if (e < 32 * H && b0 + row < B) {
-        const float v = part[row * PS + u] + part[(32 + row) * PS + u] + part[(64 + row) * PS + u] + direct[k];
+        const float v = part[row * PS + u] + part[(32 + row) * PS + u] + part[(64 + row) * PS + u] + part[(96 + row) * PS + u];
         dq[row * QS + party[row] * H + u] += v;                              // gradient at qs0 = q[b, party_t[b]] (:176)
       }
     }
@@ -241,7 +225,7 @@ __global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs2 aa) {
 }
 
 size_t gru_lds_bytes(bool bwd) {
-  return ((size_t)32 * QS + 32 * TS + (bwd ? 3 * 32 * (GH + 1) : 0) + 32 + 64) * sizeof(float);
+  return ((size_t)32 * QS + 32 * TS + (bwd ? 4 * 32 * (GH + 1) : 0) + 32 + 64) * sizeof(float);
 }
 
 int gru_validate(const mser_gru_speaker_desc& d, bool bwd) {
