@@ -30,9 +30,10 @@ struct GruArgs {
 };
 
 // 32 x 32 x 128 product of one wave: A row r of this lane from LDS (64 consecutive words: its half of the reduction index, read
-// 16 bytes at a time), B from registers; two independent accumulator chains (the first version chained all 64 MFMAs through one
-// accumulator: the pipe was busy 13 % of the kernel, the waves stood 41 % of the time in issue stalls).  The order of the fp32
-// additions differs from a single chain by the final acc0 + acc1; the parity gates hold.
+// 16 bytes at a time), B from registers, two accumulators (the order of the fp32 additions differs from a single chain by the final
+// acc0 + acc1; the parity gates hold).  v_mfma_f32_32x32x2_f32 issues once per 64 cycles per SIMD and a dependent accumulator is
+// ready after 64, so the chain itself does not stall; what bounds the step is the CU's fp32 MFMA rate: 768 MFMAs per step over
+// 4 SIMDs = 12,288 cycles = 5.2 us of the ~11 us step.
 __device__ __forceinline__ f32x16 wave_mm_k128(const float* arow, const float (&breg)[64]) {
   f32x16 acc0 = {0}, acc1 = {0};
 #pragma unroll
