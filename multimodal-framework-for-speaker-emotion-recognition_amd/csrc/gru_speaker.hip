@@ -1,10 +1,12 @@
 // Speaker state of the GRU-speaker variants (reference model/lsthm_onlysp.py:170-181, the CLI's default model):
 //   U_t = [x_l[t] | x_a[t]],  qs0 = q[b, party_t[b]],  h_s = dropout(GRUCell(U_t, qs0)),  q[b, p] = q[b, p] (1 - qmask_t[b, p]) + h_s qmask_t[b, p]
 // There is no slot compaction: every dialogue carries its own two party states, so the recurrence is batch-independent and ONE
-// workgroup owns a 32-dialogue block for the whole sequence -- no inter-workgroup hand-off at all.  The input product
+// workgroup owns a 16-dialogue block for the whole sequence -- no inter-workgroup hand-off at all.  (16, not 32: the step is bound
+// by the CU's fp32 MFMA rate, and with v_mfma_f32_16x16x4_f32 a block of 16 rows costs half the MFMA cycles of a 32-row block, so
+// a batch of 32 dialogues runs on two CUs per direction at half the step time.)  The input product
 // gi = U W_ih^T + b_ih is one GEMM before the chain (caller); only W_hh [3H, H] sits in the loop, register-resident: 12 waves,
-// wave w = (gate g = w / 4, unit slice s = w % 4) owns the 32 x 32 tile gh[:, g*H + s*32 ..] = qs0 W_hh[g*H + s*32 .., :]^T
-// (64 MFMA 32x32x2 per step, its 64 B values per lane loaded once).  The party states live in LDS.
+// wave w = (gate g = w / 4, unit slice s = w % 4) owns the 16 x 32 piece gh[:, g*H + s*32 ..] = qs0 W_hh[g*H + s*32 .., :]^T as two
+// 16 x 16 tiles (2 x 32 MFMA 16x16x4 per step, its 64 B values per lane loaded once).  The party states live in LDS.
 // The backward is the same structure in reverse time: dqs0 = dgh W_hh (wave = (unit slice, gate third of K)), the three partial
 // tiles meet in LDS.  Weight gradients (dW_ih = dgi^T U, dW_hh = dgh^T qs0), bias sums and dU = dgi W_ih are GEMMs after the chain
 // (caller).  gfx950 only; H = 128.
@@ -16,9 +18,10 @@ namespace {
 
 constexpr int GH = 128;            // the reference's dh_s
 constexpr int GNT = 768;           // 12 waves
-constexpr int QS = 2 * GH + 4;     // LDS row stride of the party states [32][2][H]: +4 words, so that the 16-byte A reads of eight
-constexpr int TS = 3 * GH + 4;     // consecutive rows cover all 32 banks; likewise for the gate tiles [32][3H]
-constexpr int NEL = (32 * GH + GNT - 1) / GNT;     // (row, unit) elements per thread and step
+constexpr int QS = 2 * GH + 4;     // LDS row stride of the party states [RB][2][H]: +4 words, so that the 16-byte A reads of eight
+constexpr int TS = 3 * GH + 4;     // consecutive rows cover all 32 banks; likewise for the gate tiles [RB][3H]
+constexpr int RB = 16;             // dialogues per workgroup
+constexpr int NEL = (RB * GH + GNT - 1) / GNT;     // (row, unit) elements per thread and step
 
 struct GruArgs {
   int T, B;
@@ -29,22 +32,22 @@ struct GruArgs {
   const uint32_t* rng; uint32_t site; float p;
 };
 
-// 32 x 32 x 128 product of one wave: A row r of this lane from LDS (64 consecutive words: its half of the reduction index, read
-// 16 bytes at a time), B from registers, two accumulators (the order of the fp32 additions differs from a single chain by the final
-// acc0 + acc1; the parity gates hold).  v_mfma_f32_32x32x2_f32 issues once per 64 cycles per SIMD and a dependent accumulator is
-// ready after 64, so the chain itself does not stall; what bounds the step is the CU's fp32 MFMA rate: 768 MFMAs per step over
-// 4 SIMDs = 12,288 cycles = 5.2 us of the ~11 us step.
-__device__ __forceinline__ f32x16 wave_mm_k128(const float* arow, const float (&breg)[64]) {
-  f32x16 acc0 = {0}, acc1 = {0};
+// 16 x 32 x 128 product of one wave as two 16 x 16 tiles: A row (lane & 15) from LDS, B from registers.  v_mfma_f32_16x16x4_f32
+// takes A[l&15][k = l>>4] and B[k = l>>4][l&15]; the order in which the reduction index is fed is free as long as A and B agree,
+// so lane quarter h = l >> 4 takes k = 32 h + j, j = 0..31: its A values are 32 consecutive LDS words (16-byte reads).
+__device__ __forceinline__ void wave_mm16(const float* arow, const float (&b0)[32], const float (&b1)[32], f32x4& acc0, f32x4& acc1) {
 #pragma unroll
-  for (int c = 0; c < 16; ++c) {
+  for (int c = 0; c < 8; ++c) {
     const float4 av = *reinterpret_cast<const float4*>(arow + 4 * c);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, breg[4 * c + 0], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, breg[4 * c + 1], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, breg[4 * c + 2], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, breg[4 * c + 3], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0[4 * c + 0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b1[4 * c + 0], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b0[4 * c + 1], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b1[4 * c + 1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b0[4 * c + 2], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b1[4 * c + 2], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b0[4 * c + 3], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b1[4 * c + 3], acc1, 0, 0, 0);
   }
-  return acc0 + acc1;
 }
 
 struct GruArgs2 { GruArgs d[2]; };        // blockIdx.y selects the chain (the two directions of a bidirectional cell share a launch)
@@ -52,33 +55,32 @@ struct GruArgs2 { GruArgs d[2]; };        // blockIdx.y selects the chain (the t
 __global__ __launch_bounds__(GNT) void gru_speaker_fwd_kernel(GruArgs2 aa) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const GruArgs& a = aa.d[blockIdx.y];
-  float* q = sm;                   // [32][QS]
-  float* gh = q + 32 * QS;         // [32][TS]
-  int* party = (int*)(gh + 32 * TS);      // [32]
-  float* qmv = (float*)(party + 32);      // [32][2]
+  float* q = sm;                   // [RB][QS]
+  float* gh = q + RB * QS;         // [RB][TS]
+  int* party = (int*)(gh + RB * TS);      // [RB]
+  float* qmv = (float*)(party + 32);      // [RB][2]
   const int H = GH, B = a.B;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, half = lane >> 5;
+  const int r = lane & 15, h4 = lane >> 4;
   const int g = wave >> 2, s = wave & 3;
-  const int b0 = blockIdx.x * 32;
-  // W_hh slice of this wave: B[k][n] = W_hh[g*H + s*32 + n][k].  The order in which the reduction index is fed to the MFMAs is free
-  // as long as A and B agree: lane half h takes k = 64 h + j (contiguous), so its A values are consecutive LDS words.
-  float breg[64];
+  const int b0 = blockIdx.x * RB;
+  // W_hh slices of this wave, two 16-column tiles: B[k][n] = W_hh[g*H + s*32 + 16 i + n][k], k = 32 h4 + j
+  float breg[32], breg1[32];
   {
-    const float* w = a.w_hh + (long)(g * H + s * 32 + r) * H + half * 64;
+    const float* w = a.w_hh + (long)(g * H + s * 32 + r) * H + h4 * 32;
 #pragma unroll
-    for (int j = 0; j < 64; ++j) breg[j] = w[j];
+    for (int j = 0; j < 32; ++j) { breg[j] = w[j]; breg1[j] = w[(long)16 * H + j]; }
   }
-  const float bias = a.b_hh[g * H + s * 32 + r];
-  for (int e = tid; e < 32 * QS; e += GNT) q[e] = 0.f;
+  const float bias = a.b_hh[g * H + s * 32 + r], bias1 = a.b_hh[g * H + s * 32 + 16 + r];
+  for (int e = tid; e < RB * QS; e += GNT) q[e] = 0.f;
   DropKey dk;
   if (a.rng) dk = drop_key(a.rng, a.site, a.p);
-  // the step's qmask row is fetched one step ahead (threads 0..31 hold it): a dependent global load would sit on every step's path
+  // the step's qmask row is fetched one step ahead (threads 0..RB-1 hold it): a dependent global load would sit on every step's path
   float nm0 = 0.f, nm1 = 0.f;
-  if (tid < 32 && b0 + tid < B) { nm0 = a.qmask[(long)(b0 + tid) * 2]; nm1 = a.qmask[(long)(b0 + tid) * 2 + 1]; }
+  if (tid < RB && b0 + tid < B) { nm0 = a.qmask[(long)(b0 + tid) * 2]; nm1 = a.qmask[(long)(b0 + tid) * 2 + 1]; }
   __syncthreads();
   for (int t = 0; t < a.T; ++t) {
-    if (tid < 32) {
+    if (tid < RB) {
       const float m0 = nm0, m1 = nm1;
       qmv[tid * 2] = m0; qmv[tid * 2 + 1] = m1;
       party[tid] = m1 > m0 ? 1 : 0;          // argmax(qmask[t], 1): ties and padded (all-zero) rows -> party 0 (:175)
@@ -87,13 +89,15 @@ __global__ __launch_bounds__(GNT) void gru_speaker_fwd_kernel(GruArgs2 aa) {
       }
     }
     __syncthreads();
-    // gh tile = qs0 W_hh^T: A[r][k] = q[r][party_r][k]
+    // gh piece = qs0 W_hh^T: A[r][k] = q[r][party_r][k]; C: column = lane & 15, row = 4 (lane >> 4) + register
     {
-      const f32x16 acc = wave_mm_k128(q + r * QS + party[r] * H + half * 64, breg);
+      f32x4 acc0 = {0}, acc1 = {0};
+      wave_mm16(q + r * QS + party[r] * H + h4 * 32, breg, breg1, acc0, acc1);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
-        gh[row * TS + g * H + s * 32 + r] = acc[i] + bias;
+      for (int i = 0; i < 4; ++i) {
+        float* o = gh + (4 * h4 + i) * TS + g * H + s * 32 + r;
+        o[0] = acc0[i] + bias;
+        o[16] = acc1[i] + bias1;
       }
     }
     __syncthreads();
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(GNT) void gru_speaker_fwd_kernel(GruArgs2 aa) {
       const int e = tid + k * GNT;
       const int row = e / H, u = e - row * H;
       const int b = b0 + row;
-      if (e < 32 * H && b < B) {
+      if (e < RB * H && b < B) {
         const float* gp = a.gi + ((long)t * B + b) * 3 * H + u;
         const float gi0 = gp[0], gi1 = gp[H], gi2 = gp[2 * H];
         const float* gr = gh + row * TS + u;
@@ -135,34 +139,34 @@ __global__ __launch_bounds__(GNT) void gru_speaker_fwd_kernel(GruArgs2 aa) {
 __global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs2 aa) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const GruArgs& a = aa.d[blockIdx.y];
-  float* dq = sm;                  // [32][QS]   gradient at the party states
-  float* dg = dq + 32 * QS;        // [32][TS]   gradient at gh (A operand of dqs0 = dgh W_hh)
-  float* part = dg + 32 * TS;      // [4][32][H + 1]: partial products per gate third, and the direct path dh' z of the step
-  int* party = (int*)(part + 4 * 32 * (GH + 1));
+  float* dq = sm;                  // [RB][QS]   gradient at the party states
+  float* dg = dq + RB * QS;        // [RB][TS]   gradient at gh (A operand of dqs0 = dgh W_hh)
+  float* part = dg + RB * TS;      // [4][RB][H + 1]: partial products per gate third, and the direct path dh' z of the step
+  int* party = (int*)(part + 4 * RB * (GH + 1));
   float* qmv = (float*)(party + 32);
   const int H = GH, B = a.B, PS = GH + 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, half = lane >> 5;
+  const int r = lane & 15, h4 = lane >> 4;
   const int g = wave >> 2, s = wave & 3;
-  const int b0 = blockIdx.x * 32;
-  // B[k][n] = W_hh[g*H + k][s*32 + n], k = 64 half + j (see the forward)
-  float breg[64];
+  const int b0 = blockIdx.x * RB;
+  // two 16-column tiles of slice s, gate third g of the reduction: B[k][n] = W_hh[g*H + k][s*32 + 16 i + n], k = 32 h4 + j
+  float breg[32], breg1[32];
   {
-    const float* w = a.w_hh + (long)(g * H + half * 64) * H + s * 32 + r;
+    const float* w = a.w_hh + (long)(g * H + h4 * 32) * H + s * 32 + r;
 #pragma unroll
-    for (int j = 0; j < 64; ++j) breg[j] = w[(long)j * H];
+    for (int j = 0; j < 32; ++j) { breg[j] = w[(long)j * H]; breg1[j] = w[(long)j * H + 16]; }
   }
-  for (int e = tid; e < 32 * QS; e += GNT) dq[e] = 0.f;
-  for (int e = tid; e < 32 * TS; e += GNT) dg[e] = 0.f;
+  for (int e = tid; e < RB * QS; e += GNT) dq[e] = 0.f;
+  for (int e = tid; e < RB * TS; e += GNT) dg[e] = 0.f;
   DropKey dk;
   if (a.rng) dk = drop_key(a.rng, a.site, a.p);
   float nm0 = 0.f, nm1 = 0.f;
-  if (tid < 32 && b0 + tid < B) {
+  if (tid < RB && b0 + tid < B) {
     nm0 = a.qmask[((long)(a.T - 1) * B + b0 + tid) * 2]; nm1 = a.qmask[((long)(a.T - 1) * B + b0 + tid) * 2 + 1];
   }
   __syncthreads();
   for (int t = a.T - 1; t >= 0; --t) {
-    if (tid < 32) {
+    if (tid < RB) {
       const float m0 = nm0, m1 = nm1;
       qmv[tid * 2] = m0; qmv[tid * 2 + 1] = m1;
       party[tid] = m1 > m0 ? 1 : 0;
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs2 aa) {
       const int e = tid + k * GNT;
       const int row = e / H, u = e - row * H;
       const int b = b0 + row;
-      if (e < 32 * H && b < B) {
+      if (e < RB * H && b < B) {
         const long rowt = (long)t * B + b;
         const float m0 = qmv[row * 2], m1 = qmv[row * 2 + 1];
         float* q0 = dq + row * QS + u;
@@ -199,16 +203,18 @@ __global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs2 aa) {
         o2[0] = dar; o2[H] = daz; o2[2 * H] = dan * rg;
         float* l = dg + row * TS + u;
         l[0] = dar; l[H] = daz; l[2 * H] = dan * rg;
-        part[(96 + row) * PS + u] = dh * zg;
+        part[(3 * RB + row) * PS + u] = dh * zg;
       }
     }
     __syncthreads();
     {
-      const f32x16 acc = wave_mm_k128(dg + r * TS + g * H + half * 64, breg);
+      f32x4 acc0 = {0}, acc1 = {0};
+      wave_mm16(dg + r * TS + g * H + h4 * 32, breg, breg1, acc0, acc1);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * half;
-        part[(g * 32 + row) * PS + s * 32 + r] = acc[i];
+      for (int i = 0; i < 4; ++i) {
+        float* o = part + (g * RB + 4 * h4 + i) * PS + s * 32 + r;
+        o[0] = acc0[i];
+        o[16] = acc1[i];
       }
     }
     __syncthreads();
@@ -216,8 +222,8 @@ __global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs2 aa) {
     for (int k = 0; k < NEL; ++k) {
       const int e = tid + k * GNT;
       const int row = e / H, u = e - row * H;
-      if (e < 32 * H && b0 + row < B) {
-        const float v = part[row * PS + u] + part[(32 + row) * PS + u] + part[(64 + row) * PS + u] + part[(96 + row) * PS + u];
+      if (e < RB * H && b0 + row < B) {
+        const float v = part[row * PS + u] + part[(RB + row) * PS + u] + part[(2 * RB + row) * PS + u] + part[(3 * RB + row) * PS + u];
         dq[row * QS + party[row] * H + u] += v;                              // gradient at qs0 = q[b, party_t[b]] (:176)
       }
     }
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs2 aa) {
 }
 
 size_t gru_lds_bytes(bool bwd) {
-  return ((size_t)32 * QS + 32 * TS + (bwd ? 4 * 32 * (GH + 1) : 0) + 32 + 64) * sizeof(float);
+  return ((size_t)RB * QS + RB * TS + (bwd ? 4 * RB * (GH + 1) : 0) + 32 + 64) * sizeof(float);
 }
 
 int gru_validate(const mser_gru_speaker_desc& d, bool bwd) {
@@ -282,10 +288,10 @@ static int gru_launch(const mser_gru_speaker_desc* d, int32_t n, bool bwd, hipSt
   const size_t lds = gru_lds_bytes(bwd);
   if (bwd) {
     MSER_TRY(allow_gru((const void*)gru_speaker_bwd_kernel, lds));
-    hipLaunchKernelGGL(gru_speaker_bwd_kernel, dim3(cdiv(d->B, 32), n), dim3(GNT), lds, s, aa);
+    hipLaunchKernelGGL(gru_speaker_bwd_kernel, dim3(cdiv(d->B, RB), n), dim3(GNT), lds, s, aa);
   } else {
     MSER_TRY(allow_gru((const void*)gru_speaker_fwd_kernel, lds));
-    hipLaunchKernelGGL(gru_speaker_fwd_kernel, dim3(cdiv(d->B, 32), n), dim3(GNT), lds, s, aa);
+    hipLaunchKernelGGL(gru_speaker_fwd_kernel, dim3(cdiv(d->B, RB), n), dim3(GNT), lds, s, aa);
   }
   return check_launch(what);
 }
