@@ -484,16 +484,18 @@ def param_shapes(n_classes: int = 6, d_r: int = 1024, D: int = 100, H: int = 128
             for nm, k in (("W", D), ("U", H), ("V", H), ("S", H)):
                 S[cell + st + nm + ".weight"] = (4 * H, k)
                 S[cell + st + nm + ".bias"] = (4 * H,)
-        for lc in ("lstm_q0.", "lstm_q1.", "lstm_s."):
+        for lc in ("lstm_q0.", "lstm_q1.", "gru_s.", "lstm_s."):
+            if lc == "gru_s.":                       # model/lsthm_onlysp.py:152 registers it between lstm_q1 and lstm_s
+                if variant == "onlysp":
+                    S[cell + "gru_s.weight_ih"] = (3 * H, 2 * D)
+                    S[cell + "gru_s.weight_hh"] = (3 * H, H)
+                    S[cell + "gru_s.bias_ih"] = (3 * H,)
+                    S[cell + "gru_s.bias_hh"] = (3 * H,)
+                continue
             S[cell + lc + "weight_ih"] = (4 * H, H)
             S[cell + lc + "weight_hh"] = (4 * H, H)
             S[cell + lc + "bias_ih"] = (4 * H,)
             S[cell + lc + "bias_hh"] = (4 * H,)
-        if variant == "onlysp":
-            S[cell + "gru_s.weight_ih"] = (3 * H, 2 * D)
-            S[cell + "gru_s.weight_hh"] = (3 * H, H)
-            S[cell + "gru_s.bias_ih"] = (3 * H,)
-            S[cell + "gru_s.bias_hh"] = (3 * H,)
     if variant == "onlysp":
         S["linear.weight"] = (h_out, 10 * H)
         S["linear.bias"] = (h_out,)

@@ -133,3 +133,17 @@ def test_metrics_from_confusion_match_sklearn():
         assert abs(acc - accuracy_score(labels, preds, sample_weight=masks)) < 1e-12
         assert abs(wf1 - f1_score(labels, preds, sample_weight=masks, average="weighted")) < 1e-12
     assert accuracy_and_weighted_f1(np.zeros((4, 4))) == (0.0, 0.0)
+
+
+def test_mirror_state_dict_order_matches_the_oracle_tables():
+    """The module mirrors register their parameters in the reference's order (checkpoints interchange, and the same seed draws the
+    same initial weights); oracle.param_shapes restates that order for both model variants.  CPU only: constructing the mirrors
+    needs no GPU (the flat store attaches on the first forward)."""
+    from oracle import ref_cpu as O
+    from models.lsthm_onlysp import MARN1_onlysp
+    from models.lsthm_sps import MARN1_sps
+    for cls, variant, n in ((MARN1_sps, "sps", 120), (MARN1_onlysp, "onlysp", 128)):
+        sd = cls(6).state_dict()
+        shapes = O.param_shapes(variant=variant)
+        assert list(sd.keys()) == list(shapes.keys()) and len(sd) == n
+        assert all(tuple(sd[k].shape) == shapes[k] for k in shapes)
