@@ -252,6 +252,12 @@ typedef struct mser_cell_desc {
    * MSER_PHASE_SPEAKER_BWD then writes ext_dhq[i] [T*B, H] = the total gradient at ext_hq[i] (output quarter included). */
   const float* ext_hq[2];
   float* ext_dhq[2];
+  /* ext_linked != 0 (forward, persistent launch only): the rows are not complete when MSER_PHASE_LSTHM_FWD is issued -- a producer
+   * kernel of the caller, already enqueued on ANOTHER stream and therefore running concurrently, writes them into the workspace
+   * rows and advances the step counter that mser_marn_cell_ext_link returns (MSER_PHASE_FWD_PREP must precede that producer: it
+   * zeroes the counter).  Never inside stream capture (a graph executor may start the consumer first; its waits are bounded but it
+   * would give up).  ext_hq must still be non-NULL (it selects the mode); it is not read. */
+  int32_t ext_linked;
 } mser_cell_desc;
 
 size_t mser_marn_cell_workspace_bytes(int32_t T, int32_t B, int32_t D, int32_t H, int32_t ndir);
@@ -270,6 +276,11 @@ enum { MSER_PHASE_SPEAKER_FWD = 1, MSER_PHASE_LSTHM_FWD = 2, MSER_PHASE_LSTHM_BW
        /* modifier for SPEAKER_FWD and LSTHM_FWD (pass it to both): keep the forward chains as two persistent launches so that the
         * speaker chain, issued on another REAL stream, starts before the encoders finish.  Never inside stream capture. */
        MSER_PHASE_SEPARATE_SPEAKER = 256 };
+/* Where a linked producer publishes direction `dir`'s speaker rows (hq_rows [T*B, H], inside the workspace) and the counter it
+ * advances by per_step after each step (replicas x replica_stride words).  Returns 1 if the persistent LSTHM launch will be used
+ * for these sizes (a link is possible), 0 if not, < 0 on error. */
+int mser_marn_cell_ext_link(const mser_cell_desc* d, int32_t dir, float** hq_rows, uint32_t** counter, int32_t* replicas,
+                            int32_t* replica_stride, uint32_t* per_step);
 int mser_marn_cell_pipelined(int32_t B, int32_t H, int32_t ndir);
 int mser_marn_cell_run(const mser_cell_desc* d, int32_t phases, mser_stream_t stream);
 
@@ -367,6 +378,10 @@ typedef struct mser_gru_speaker_desc {
   const float* dhs_add[2];     /* optional further addends of the same shape */
   float* dgi; float* dgh;      /* [T*B, 3H] written */
   const uint32_t* rng; uint32_t drop_site; float p;      /* dropout on h_s (:177), element (t*B + b)*H + u; NULL: identity */
+  /* Forward link to a consumer that runs CONCURRENTLY (mser_cell_desc::ext_linked; values from mser_marn_cell_ext_link, hs then
+   * being that call's hq_rows): after every step, once the step's hs rows are visible device-wide, each of pub_replicas counters
+   * (pub_replica_stride words apart) is advanced so that the chain's workgroups together add pub_per_step.  NULL: no link. */
+  uint32_t* pub_counter; uint32_t pub_per_step; int32_t pub_replicas; int32_t pub_replica_stride;
 } mser_gru_speaker_desc;
 
 size_t mser_gru_speaker_save_bytes(int32_t T, int32_t B, int32_t H);

@@ -30,6 +30,9 @@ struct GruArgs {
   float* save;           // [T*B][5H]: qs0 | r | z | n | gh_n
   const float* dhs; const float* dhs2; const float* dhs3; float* dgi; float* dgh;
   const uint32_t* rng; uint32_t site; float p;
+  // forward link to a consumer kernel (mser_cell_desc::ext_linked): after every step, once this block's rows of hs are visible
+  // device-wide, every replica of `pub_cnt` receives this block's share of `pub_inc` (the shares of a chain's blocks sum to it)
+  unsigned* pub_cnt; unsigned pub_inc; int pub_rep, pub_stride;
 };
 
 // 16 x 32 x 128 product of one wave as two 16 x 16 tiles: A row (lane & 15) from LDS, B from registers.  v_mfma_f32_16x16x4_f32
@@ -132,7 +135,13 @@ __global__ __launch_bounds__(GNT) void gru_speaker_fwd_kernel(GruArgs2 aa) {
         q0[H] = q0[H] * (1.f - m1) + hv * m1;
       }
     }
+    if (a.pub_cnt) __threadfence();          // release: this thread's hs rows of step t are visible device-wide before the counter moves
     __syncthreads();
+    if (a.pub_cnt && tid < a.pub_rep) {
+      const unsigned nblk = gridDim.x;
+      const unsigned share = a.pub_inc / nblk + (blockIdx.x < a.pub_inc % nblk ? 1u : 0u);
+      __hip_atomic_fetch_add(a.pub_cnt + tid * a.pub_stride, share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -241,6 +250,8 @@ int gru_validate(const mser_gru_speaker_desc& d, bool bwd) {
   MSER_REQUIRE(d.gi && d.w_hh && d.b_hh && d.qmask && d.hs && d.save, "mser_gru_speaker: null pointer");
   MSER_REQUIRE(!d.out || d.ldo >= d.H, "mser_gru_speaker: ldo=%ld < H", (long)d.ldo);
   MSER_REQUIRE(!d.rng || (d.p >= 0.f && d.p < 1.f), "mser_gru_speaker: dropout p=%f", d.p);
+  MSER_REQUIRE(!d.pub_counter || (d.pub_replicas > 0 && d.pub_replicas <= 64 && d.pub_replica_stride > 0 && d.pub_per_step > 0),
+               "mser_gru_speaker: bad publish fields");
   if (bwd) MSER_REQUIRE(d.dhs && d.dgi && d.dgh, "mser_gru_speaker_bwd: null gradient buffer");
   return 0;
 }
@@ -252,6 +263,7 @@ GruArgs gru_args(const mser_gru_speaker_desc& d) {
   a.hs = d.hs; a.out = d.out; a.ldo = d.ldo; a.rev = d.rev; a.save = d.save;
   a.dhs = d.dhs; a.dhs2 = d.dhs_add[0]; a.dhs3 = d.dhs_add[1]; a.dgi = d.dgi; a.dgh = d.dgh;
   a.rng = (d.rng && d.p > 0.f) ? d.rng : nullptr; a.site = d.drop_site; a.p = d.p;
+  a.pub_cnt = d.pub_counter; a.pub_inc = d.pub_per_step; a.pub_rep = d.pub_replicas; a.pub_stride = d.pub_replica_stride;
   return a;
 }
 

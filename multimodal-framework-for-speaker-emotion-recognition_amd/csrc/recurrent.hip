@@ -2226,7 +2226,7 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   const size_t p_lds = persist_lds(mm_lds + (2 * (size_t)H + 16) * sizeof(float) + 64);
   if (phases & MSER_PHASE_FWD_PREP) {
   MSER_CHECK_HIP(hipMemsetAsync(h.sync, 0, SYNC_WORDS * sizeof(unsigned), s));
-  if (ext)      // "every h_q[t] is published": the LSTHM chain's waits on the speaker counter fall through
+  if (ext && !d.ext_linked)      // "every h_q[t] is published": the LSTHM chain's waits on the speaker counter fall through
     MSER_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)(h.sync + SYNC_SPK_FWD), 0x3fffffff, 2 * SYNC_DIR, s));
   for (int i = 0; i < d.ndir; ++i) {
     DirP& k = K.d[i];
@@ -2268,9 +2268,14 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
     MSER_TRY(check_launch("spk_fwd"));
   }
   if (!(phases & MSER_PHASE_LSTHM_FWD)) return 0;
-  if (ext)
+  if (ext && d.ext_linked) {
+    // the producer (a concurrently running kernel of the caller, on another stream) writes the rows straight into the workspace and
+    // bumps the speaker counter per step (mser_marn_cell_ext_link): the LSTHM chain follows it through its ordinary per-step waits
+    MSER_REQUIRE(persist, "marn_cell_fwd: ext_linked needs the persistent launch (all LSTHM workgroups co-resident)");
+  } else if (ext) {
     for (int i = 0; i < d.ndir; ++i)
       MSER_CHECK_HIP(hipMemcpyAsync(K.d[i].HQ, d.ext_hq[i], (size_t)TB * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
   // ---- hoisted pre-activations: pre_m = xdir W_m^T + W.bias + HQ S_m^T + S.bias.  The x W^T products of both streams and
   // directions are independent: ONE grouped launch (they sit on the critical path right in front of the chain).
   std::vector<mser_gemm_desc> pg;
@@ -2821,6 +2826,23 @@ int mser_marn_cell_fwd(const mser_cell_desc* d, mser_stream_t stream) {
 int mser_marn_cell_bwd(const mser_cell_desc* d, mser_stream_t stream) {
   if (!d) { set_error("mser_marn_cell_bwd: null descriptor"); return -1; }
   return marn_cell_bwd(*d, (hipStream_t)stream, MSER_PHASE_BWD_PREP | MSER_PHASE_LSTHM_BWD | MSER_PHASE_LSTHM_BWD_DX | MSER_PHASE_LSTHM_WGRAD | MSER_PHASE_SPEAKER_BWD);
+}
+
+int mser_marn_cell_ext_link(const mser_cell_desc* d, int32_t dir, float** hq_rows, uint32_t** counter, int32_t* replicas,
+                            int32_t* replica_stride, uint32_t* per_step) {
+  if (!d || dir < 0 || dir >= d->ndir || !hq_rows || !counter || !replicas || !replica_stride || !per_step) {
+    set_error("mser_marn_cell_ext_link: bad arguments");
+    return -1;
+  }
+  CellHost h;
+  carve_all((char*)d->workspace, *d, &h);
+  const long fwd_wgs = (long)(d->H / 8) * 2 * d->ndir * h.k.nmb;
+  *hq_rows = h.k.d[dir].HQ;
+  *counter = h.sync + SYNC_SPK_FWD + dir * SYNC_DIR;
+  *replicas = SYNC_REP;
+  *replica_stride = SYNC_LINE;
+  *per_step = (unsigned)((d->H / 8) * 2 * h.k.nmb);          // what the LSTHM chain expects per published step (its nwg_spk)
+  return persist_ok(d->H, fwd_wgs) ? 1 : 0;                   // 1: the persistent LSTHM launch will run (a link is possible)
 }
 
 int mser_marn_cell_pipelined(int32_t B, int32_t H, int32_t ndir) {

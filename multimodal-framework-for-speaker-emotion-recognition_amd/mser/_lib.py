@@ -52,7 +52,7 @@ class CellDesc(C.Structure):
         ("dir", CellDir * 2), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("dx_l_add", _P2), ("dx_a_add", _P2),
         ("rng", C.c_void_p), ("drop_site", C.c_uint32 * 2), ("p_state", C.c_float * 2), ("p_attn", C.c_float * 2),
-        ("ext_hq", _P2), ("ext_dhq", _P2),
+        ("ext_hq", _P2), ("ext_dhq", _P2), ("ext_linked", C.c_int32),
     ]
 
 
@@ -84,7 +84,9 @@ class GruSpeakerDesc(C.Structure):
                 ("gi", C.c_void_p), ("w_hh", C.c_void_p), ("b_hh", C.c_void_p), ("qmask", C.c_void_p),
                 ("hs", C.c_void_p), ("out", C.c_void_p), ("ldo", C.c_int64), ("rev", C.c_void_p), ("save", C.c_void_p),
                 ("dhs", C.c_void_p), ("dhs_add", C.c_void_p * 2), ("dgi", C.c_void_p), ("dgh", C.c_void_p),
-                ("rng", C.c_void_p), ("drop_site", C.c_uint32), ("p", C.c_float)]
+                ("rng", C.c_void_p), ("drop_site", C.c_uint32), ("p", C.c_float),
+                ("pub_counter", C.c_void_p), ("pub_per_step", C.c_uint32), ("pub_replicas", C.c_int32),
+                ("pub_replica_stride", C.c_int32)]
 
 
 class HeadTailDesc(C.Structure):
@@ -140,6 +142,8 @@ SIGNATURES = {
     "mser_logsoftmax_tb_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mser_masked_nll_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "mser_masked_nll_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "mser_marn_cell_ext_link": (C.c_int, [C.POINTER(CellDesc), _i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
     "mser_gru_speaker_save_bytes": (C.c_size_t, [_i32, _i32, _i32]),
     "mser_gru_speaker_fwd": (C.c_int, [C.POINTER(GruSpeakerDesc), _i32, _vp]),
     "mser_gru_speaker_bwd": (C.c_int, [C.POINTER(GruSpeakerDesc), _i32, _vp]),

@@ -39,8 +39,14 @@ class GruDirCtx:
     drop: object = None
 
 
+# The GRU forward chains run CONCURRENTLY with the LSTHM forward chains (eager mode, persistent launches): they write the speaker
+# rows straight into the cell's workspace and advance the step counter the LSTHM chain already waits on (mser_cell_desc::ext_linked).
+# False, stream capture, or sizes without the persistent launch: the GRU chains finish first and the rows are copied.
+LINK_GRU_FWD = True
+
+
 def gru_speaker_dir_fwd(P: Getter, x_l: Tensor, x_a: Tensor, qmask: Tensor, rev: Optional[Tensor], out_q: Tensor, T: int, B: int,
-                        H: int, drop, launch: bool = True) -> GruDirCtx:
+                        H: int, drop, launch: bool = True, hs: Optional[Tensor] = None) -> GruDirCtx:
     """One direction's speaker chain.  x_l / x_a [T*B, D] natural order; ``rev`` (int32 [T, B]) selects the reversed direction;
     ``out_q`` is the h_s quarter of the cell output rows (natural order).  P: names relative to the MARN_cell.  ``launch=False``
     prepares everything (input product included) and leaves the chain launch (ops.gru_speaker_fwd(ctx.desc)) to the caller."""
@@ -58,7 +64,7 @@ def gru_speaker_dir_fwd(P: Getter, x_l: Tensor, x_a: Tensor, qmask: Tensor, rev:
     c.gi = torch.empty(T * B, 3 * H, device=x_l.device)
     ops.linear(c.xl, Wih[:, :D], c.gi, bias=P("gru_s.bias_ih"))                 # gi = [x_l | x_a] W_ih^T + b_ih  (:172,:177)
     ops.linear(c.xa, Wih[:, D:], c.gi, accum=True)
-    c.hs = torch.empty(T * B, H, device=x_l.device)
+    c.hs = hs if hs is not None else torch.empty(T * B, H, device=x_l.device)
     c.save = torch.empty(T * B, 5 * H, device=x_l.device)
     c.desc = ops.gru_speaker_desc(T, B, H, c.gi, P("gru_s.weight_hh"), P("gru_s.bias_hh"), c.qm, c.hs, c.save, out=out_q, rev=rev,
                                   drop=drop)
@@ -181,11 +187,6 @@ def onlysp_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mod
     lens = torch.empty(B, device=dev, dtype=torch.int32)
     c.rev = torch.empty(Ln, B, device=dev, dtype=torch.int32)
     ops.build_reverse_index(umask, lens, c.rev)
-    c.gru = []
-    for i, (pre, rev) in enumerate((("marn_cell_f.", None), ("marn_cell_b.", c.rev))):
-        site = drop.site(F_.SITE_CELL + 4 * i, drop.p_cell[i]) if drop is not None else None
-        c.gru.append(gru_speaker_dir_fwd(_sub(P, pre), c.x_l, c.x_a, qmask, rev, c.Hcat[:, 4 * H * i + 3 * H:4 * H * (i + 1)], Ln, B,
-                                         H, site, launch=False))
     c.cell_ws = torch.empty(ops.cell_workspace_bytes(Ln, B, D, H, 2), device=dev, dtype=torch.uint8)
     c.cell_dirs = [
         dict(p=ops.cell_param_struct(_sub(P, "marn_cell_f.")), qmask=qmask, rev=None, out=c.Hcat[:, 0:4 * H]),
@@ -193,13 +194,40 @@ def onlysp_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mod
     ]
     if drop is not None and (any(p_ > 0 for p_ in drop.p_cell) or any(p_ > 0 for p_ in drop.p_cell_attn)):
         c.cell_drop = (drop.rng, [F_.SITE_CELL, F_.SITE_CELL + 4], drop.p_cell, drop.p_cell_attn)
+    # linked mode: where the producer publishes (workspace rows + step counter), asked of a descriptor without ext fields
+    links = None
+    if LINK_GRU_FWD and not torch.cuda.is_current_stream_capturing():
+        probe = ops.make_cell_desc(Ln, B, D, H, c.x_l, c.x_a, c.cell_dirs, 10 * H, c.cell_ws)
+        links = [ops.cell_ext_link(probe, i) for i in range(2)]
+        if not all(lk[5] for lk in links):
+            links = None
+    c.gru = []
+    for i, (pre, rev) in enumerate((("marn_cell_f.", None), ("marn_cell_b.", c.rev))):
+        site = drop.site(F_.SITE_CELL + 4 * i, drop.p_cell[i]) if drop is not None else None
+        hs = None
+        if links is not None:      # the chain's output rows ARE the workspace's h_q rows
+            off = links[i][0] - c.cell_ws.data_ptr()
+            hs = c.cell_ws[off:off + N * H * 4].view(torch.float32).view(N, H)
+        g = gru_speaker_dir_fwd(_sub(P, pre), c.x_l, c.x_a, qmask, rev, c.Hcat[:, 4 * H * i + 3 * H:4 * H * (i + 1)], Ln, B, H, site,
+                                launch=False, hs=hs)
+        if links is not None:
+            g.desc.pub_counter, g.desc.pub_replicas, g.desc.pub_replica_stride, g.desc.pub_per_step = links[i][1:5]
+        c.gru.append(g)
     desc = ops.make_cell_desc(Ln, B, D, H, c.x_l, c.x_a, c.cell_dirs, 10 * H, c.cell_ws, drop=c.cell_drop,
-                              ext_hq=[g.hs for g in c.gru])
-    # FWD_PREP zeroes the reversed direction's output rows (h_s quarter included: rows at and beyond len_b stay zero), so the
-    # speaker chains, which write that quarter, go after it
+                              ext_hq=[g.hs for g in c.gru], ext_linked=links is not None)
+    # FWD_PREP zeroes the reversed direction's output rows (h_s quarter included: rows at and beyond len_b stay zero) and the step
+    # counters, so the speaker chains, which write that quarter and advance a counter, go after it
     ops.marn_cell_run(desc, ops.PHASE_FWD_PREP)
-    ops.gru_speaker_fwd([g.desc for g in c.gru])                 # both directions' chains in one launch
-    ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD)
+    if links is not None:
+        s_g = _Streams.get(dev)[2]
+        s_g.wait_stream(cur)
+        with torch.cuda.stream(s_g):
+            ops.gru_speaker_fwd([g.desc for g in c.gru])             # producer: both directions' chains, one launch, its own stream
+        ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD)                 # consumer: follows the producer step by step
+        cur.wait_stream(s_g)
+    else:
+        ops.gru_speaker_fwd([g.desc for g in c.gru])                 # both directions' chains in one launch
+        ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD)
     cur.wait_stream(s_x)
     if drop is not None and drop.p_rec > 0:
         for i in range(2):

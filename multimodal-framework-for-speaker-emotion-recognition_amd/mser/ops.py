@@ -552,7 +552,7 @@ def cell_workspace_bytes(T: int, B: int, D: int, H: int, ndir: int) -> int:
 def make_cell_desc(T: int, B: int, D: int, H: int, x_l: Tensor, x_a: Tensor, dirs: Sequence[dict], ldo: int,
                    workspace: Tensor, dx_l: Optional[Tensor] = None, dx_a: Optional[Tensor] = None,
                    dx_l_add: Sequence[Tensor] = (), dx_a_add: Sequence[Tensor] = (), drop=None,
-                   ext_hq: Sequence[Tensor] = (), ext_dhq: Sequence[Tensor] = ()) -> L.CellDesc:
+                   ext_hq: Sequence[Tensor] = (), ext_dhq: Sequence[Tensor] = (), ext_linked: bool = False) -> L.CellDesc:
     """dirs: list of dicts with keys p (CellParams), g (CellParams or None), qmask, rev (or None), out, dout (or None).
     drop: None or (rng int32[2] tensor, [site per direction], [p_state per direction], [p_attn per direction])."""
     d = L.CellDesc()
@@ -584,6 +584,7 @@ def make_cell_desc(T: int, B: int, D: int, H: int, x_l: Tensor, x_a: Tensor, dir
         d.rng = _p(rng)
         for i in range(len(dirs)):
             d.drop_site[i], d.p_state[i], d.p_attn[i] = int(sites[i]), float(p_state[i]), float(p_attn[i])
+    d.ext_linked = 1 if ext_linked else 0
     for i, t in enumerate(ext_hq):          # external speaker state per direction ([T*B, H] contiguous) and its gradient buffer
         if not t.is_contiguous() or (i < len(ext_dhq) and not ext_dhq[i].is_contiguous()):
             raise RuntimeError("ext_hq / ext_dhq must be contiguous")
@@ -591,6 +592,17 @@ def make_cell_desc(T: int, B: int, D: int, H: int, x_l: Tensor, x_a: Tensor, dir
         if i < len(ext_dhq):
             d.ext_dhq[i] = _p(ext_dhq[i])
     return d
+
+
+def cell_ext_link(desc: L.CellDesc, direction: int):
+    """(hq_rows pointer, counter pointer, replicas, replica stride, per-step increment, persistent?) for a linked producer of
+    direction ``direction``'s speaker rows (include/mser.h mser_marn_cell_ext_link)."""
+    hq, cnt = C.c_void_p(), C.c_void_p()
+    rep, stride, inc = C.c_int32(), C.c_int32(), C.c_uint32()
+    rc = _lib().mser_marn_cell_ext_link(C.byref(desc), direction, C.byref(hq), C.byref(cnt), C.byref(rep), C.byref(stride), C.byref(inc))
+    if rc < 0:
+        L.check(rc, "marn_cell_ext_link")
+    return hq.value, cnt.value, rep.value, stride.value, inc.value, rc == 1
 
 
 def marn_cell_fwd(desc: L.CellDesc) -> None:

@@ -845,3 +845,35 @@ def test_onlysp_trainer_runs_the_reference_loop(O, tmp_path):
     xs = (x.cuda(), qmask.cuda(), umask.cuda())
     with torch.no_grad():
         assert torch.equal(tr.model(*xs)[0], tr2.model(*xs)[0])
+
+
+def test_onlysp_linked_forward_chains_bit_identical_to_sequential(O):
+    """The GRU forward chains as a concurrent producer of the LSTHM chains (rows written into the cell workspace, step counter
+    advanced after a device-wide release; mser_cell_desc::ext_linked) against the sequential schedule (chains one after the other,
+    rows copied): the arithmetic is the same, so log-probs and every gradient must agree BIT FOR BIT -- any stale or early read of a
+    speaker row would show.  Bench-sized batch, repeated."""
+    from models.lsthm_onlysp import MARN1_onlysp
+    from loss import MaskedLoss
+    import mser.onlysp_fn as ofn
+    d_r = 768
+    net = MARN1_onlysp(6, d_r=d_r).cuda().eval()
+    load_params(net, O.seeded_params(seed=95, d_r=d_r, variant="onlysp"))
+    x, qmask, umask, label = (t.cuda() for t in O.seeded_batch(32, 96, d_r=d_r, seed=96, ragged=True))
+
+    def run(linked):
+        ofn.LINK_GRU_FWD = linked
+        try:
+            net.zero_grad(set_to_none=True)
+            lp, _, _ = net(x, qmask, umask)
+            MaskedLoss(torch.nn.NLLLoss)(lp, label.view(-1), umask).backward()
+            torch.cuda.synchronize()
+            return lp.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+        finally:
+            ofn.LINK_GRU_FWD = True
+
+    lp_seq, g_seq = run(False)
+    for _ in range(5):
+        lp_lnk, g_lnk = run(True)
+        assert torch.equal(lp_lnk, lp_seq)
+        for n in ("marn_cell_f.gru_s.weight_hh", "marn_cell_b.lsthm_l.S.weight", "linear_in.weight", "nn_out.0.weight"):
+            assert maxabs(g_lnk[n], g_seq[n]) <= 1e-6 * max(1.0, float(g_seq[n].abs().max())), n      # (split-K atomics: not bitwise)
