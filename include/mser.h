@@ -281,6 +281,12 @@ enum { MSER_PHASE_SPEAKER_FWD = 1, MSER_PHASE_LSTHM_FWD = 2, MSER_PHASE_LSTHM_BW
  * for these sizes (a link is possible), 0 if not, < 0 on error. */
 int mser_marn_cell_ext_link(const mser_cell_desc* d, int32_t dir, float** hq_rows, uint32_t** counter, int32_t* replicas,
                             int32_t* replica_stride, uint32_t* per_step);
+/* The backward counterpart: where the BPTT launch leaves the gradient at the external speaker state while it runs -- *dhq [T*B, H]
+ * (output quarter) plus *n_parts arrays at *dhq_parts, *part_stride floats apart -- and the counter that reaches
+ * per_step * (T - t) when step t's rows are complete.  Returns 1 if the persistent BPTT launch will be used, 0 if not, < 0 on error.
+ * A linked consumer must be enqueued on another stream after MSER_PHASE_BWD_PREP (which zeroes the counter); never inside capture. */
+int mser_marn_cell_ext_link_bwd(const mser_cell_desc* d, int32_t dir, const float** dhq, const float** dhq_parts, int32_t* n_parts,
+                                int64_t* part_stride, uint32_t** counter, int32_t* replicas, int32_t* replica_stride, uint32_t* per_step);
 int mser_marn_cell_pipelined(int32_t B, int32_t H, int32_t ndir);
 int mser_marn_cell_run(const mser_cell_desc* d, int32_t phases, mser_stream_t stream);
 
@@ -382,6 +388,12 @@ typedef struct mser_gru_speaker_desc {
    * being that call's hq_rows): after every step, once the step's hs rows are visible device-wide, each of pub_replicas counters
    * (pub_replica_stride words apart) is advanced so that the chain's workgroups together add pub_per_step.  NULL: no link. */
   uint32_t* pub_counter; uint32_t pub_per_step; int32_t pub_replicas; int32_t pub_replica_stride;
+  /* Backward link to a producer that runs CONCURRENTLY (the cell's BPTT launch; values from mser_marn_cell_ext_link_bwd): step t
+   * starts once *sub_counter >= sub_per_step * (T - t); its incoming gradient is then dhs + the sub_nparts arrays at sub_parts
+   * (sub_part_stride floats apart), read with device-coherent loads; dhs_add is ignored.  The wait is bounded: on a time-out the
+   * kernel sets *status (optional, device int) to 1 and carries on.  NULL: no link (dhs / dhs_add are complete at launch). */
+  const uint32_t* sub_counter; uint32_t sub_per_step; const float* sub_parts; int32_t sub_nparts; int64_t sub_part_stride;
+  int32_t* status;
 } mser_gru_speaker_desc;
 
 size_t mser_gru_speaker_save_bytes(int32_t T, int32_t B, int32_t H);

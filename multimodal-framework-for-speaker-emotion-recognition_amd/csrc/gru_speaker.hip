@@ -29,6 +29,9 @@ struct GruArgs {
   float* hs; float* out; long ldo; const int* rev;
   float* save;           // [T*B][5H]: qs0 | r | z | n | gh_n
   const float* dhs; const float* dhs2; const float* dhs3; float* dgi; float* dgh;
+  // backward link to a producer kernel that runs concurrently: step t may start once *sub_cnt >= sub_per_step * (T - t); its
+  // gradient rows (dhs and sub_nparts parts, sub_stride floats apart) are then read with device-coherent loads
+  const unsigned* sub_cnt; unsigned sub_per_step; const float* sub_parts; int sub_nparts; long sub_stride; int* status;
   const uint32_t* rng; uint32_t site; float p;
   // forward link to a consumer kernel (mser_cell_desc::ext_linked): after every step, once this block's rows of hs are visible
   // device-wide, every replica of `pub_cnt` receives this block's share of `pub_inc` (the shares of a chain's blocks sum to it)
@@ -183,6 +186,15 @@ __global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs2 aa) {
         nm0 = a.qmask[((long)(t - 1) * B + b0 + tid) * 2]; nm1 = a.qmask[((long)(t - 1) * B + b0 + tid) * 2 + 1];
       }
     }
+    if (a.sub_cnt && tid == 64) {      // (one lane of the second wave) wait for the producer's step t; bounded: a producer that never
+      const unsigned target = a.sub_per_step * (unsigned)(a.T - t);          // comes leaves wrong numbers and a status flag, not a hang
+      unsigned spins = 0;
+      while (__hip_atomic_load(a.sub_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 22)) { if (a.status) *a.status = 1; break; }
+      }
+      __threadfence();                 // acquire: the rows read below were published before the counter value seen here
+    }
     __syncthreads();
     // (partially unrolled: with the 64 W_hh values live a 12-wave workgroup has ~100 registers left per lane; fully unrolled, this
     // loop spilled 55 of them to scratch in every step)
@@ -195,9 +207,16 @@ __global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs2 aa) {
         const long rowt = (long)t * B + b;
         const float m0 = qmv[row * 2], m1 = qmv[row * 2 + 1];
         float* q0 = dq + row * QS + u;
-        float dh = a.dhs[rowt * H + u] + q0[0] * m0 + q0[H] * m1;            // every consumer of h_s[t]: the cell, and the party states
-        if (a.dhs2) dh += a.dhs2[rowt * H + u];
-        if (a.dhs3) dh += a.dhs3[rowt * H + u];
+        float dh = q0[0] * m0 + q0[H] * m1;                                 // every consumer of h_s[t]: the party states, and the cell
+        if (a.sub_cnt) {       // rows a concurrently running producer has just written: device-coherent loads (no stale cache line)
+          dh += __hip_atomic_load(a.dhs + rowt * H + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int pi = 0; pi < a.sub_nparts; ++pi)
+            dh += __hip_atomic_load(a.sub_parts + pi * a.sub_stride + rowt * H + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          dh += a.dhs[rowt * H + u];
+          if (a.dhs2) dh += a.dhs2[rowt * H + u];
+          if (a.dhs3) dh += a.dhs3[rowt * H + u];
+        }
         q0[0] *= (1.f - m0);
         q0[H] *= (1.f - m1);
         if (a.rng) dh *= drop_scale(dk, (uint32_t)(rowt * H + u));
@@ -264,6 +283,8 @@ GruArgs gru_args(const mser_gru_speaker_desc& d) {
   a.dhs = d.dhs; a.dhs2 = d.dhs_add[0]; a.dhs3 = d.dhs_add[1]; a.dgi = d.dgi; a.dgh = d.dgh;
   a.rng = (d.rng && d.p > 0.f) ? d.rng : nullptr; a.site = d.drop_site; a.p = d.p;
   a.pub_cnt = d.pub_counter; a.pub_inc = d.pub_per_step; a.pub_rep = d.pub_replicas; a.pub_stride = d.pub_replica_stride;
+  a.sub_cnt = d.sub_counter; a.sub_per_step = d.sub_per_step; a.sub_parts = d.sub_parts; a.sub_nparts = d.sub_nparts;
+  a.sub_stride = d.sub_part_stride; a.status = d.status;
   return a;
 }
 

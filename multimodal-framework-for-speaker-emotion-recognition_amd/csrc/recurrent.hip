@@ -2845,6 +2845,33 @@ int mser_marn_cell_ext_link(const mser_cell_desc* d, int32_t dir, float** hq_row
   return persist_ok(d->H, fwd_wgs) ? 1 : 0;                   // 1: the persistent LSTHM launch will run (a link is possible)
 }
 
+int mser_marn_cell_ext_link_bwd(const mser_cell_desc* d, int32_t dir, const float** dhq, const float** dhq_parts, int32_t* n_parts,
+                                int64_t* part_stride, uint32_t** counter, int32_t* replicas, int32_t* replica_stride, uint32_t* per_step) {
+  if (!d || dir < 0 || dir >= d->ndir || !dhq || !dhq_parts || !n_parts || !part_stride || !counter || !replicas || !replica_stride ||
+      !per_step) {
+    set_error("mser_marn_cell_ext_link_bwd: bad arguments");
+    return -1;
+  }
+  CellHost h;
+  carve_all((char*)d->workspace, *d, &h);
+  // the same plan as marn_cell_bwd makes for an external speaker state (no speaker workgroups)
+  const int H = d->H, D = d->D;
+  const int mat_wgs1 = ((H / 32) * 6 + ((D + 31) / 32) * 2) * h.k.nmb;
+  const int ksplit = (g_opt_persistent && g_opt_ksplit && H == 128 && ((long)2 * mat_wgs1) * d->ndir <= num_cus()) ? 2 : 1;
+  const int mat_wgs = mat_wgs1 * ksplit;
+  const int bwd_nwg = mat_wgs > 32 ? mat_wgs : 32;
+  *dhq = h.k.d[dir].dHQ;
+  *dhq_parts = h.k.d[dir].dHQp;
+  *n_parts = 2 * ksplit;
+  *part_stride = (int64_t)d->T * d->B * H;
+  *counter = h.sync + SYNC_LSTHM_BWD + dir * SYNC_DIR;
+  *replicas = SYNC_REP;
+  *replica_stride = SYNC_LINE;
+  *per_step = 2u * (unsigned)bwd_nwg;           // the BPTT chain passes two barriers per step: dHQ[t] and its parts are complete at
+                                               // counter >= per_step * (T - t)
+  return persist_ok(H, (long)bwd_nwg * d->ndir) ? 1 : 0;
+}
+
 int mser_marn_cell_pipelined(int32_t B, int32_t H, int32_t ndir) {
   // Since the chains of a pass share ONE fused launch, the caller never has to overlap phases itself: always 0 (kept for ABI
   // stability; the phases may simply be issued in their listed order).

@@ -86,7 +86,9 @@ class GruSpeakerDesc(C.Structure):
                 ("dhs", C.c_void_p), ("dhs_add", C.c_void_p * 2), ("dgi", C.c_void_p), ("dgh", C.c_void_p),
                 ("rng", C.c_void_p), ("drop_site", C.c_uint32), ("p", C.c_float),
                 ("pub_counter", C.c_void_p), ("pub_per_step", C.c_uint32), ("pub_replicas", C.c_int32),
-                ("pub_replica_stride", C.c_int32)]
+                ("pub_replica_stride", C.c_int32),
+                ("sub_counter", C.c_void_p), ("sub_per_step", C.c_uint32), ("sub_parts", C.c_void_p), ("sub_nparts", C.c_int32),
+                ("sub_part_stride", C.c_int64), ("status", C.c_void_p)]
 
 
 class HeadTailDesc(C.Structure):
@@ -144,6 +146,9 @@ SIGNATURES = {
     "mser_masked_nll_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "mser_marn_cell_ext_link": (C.c_int, [C.POINTER(CellDesc), _i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
+    "mser_marn_cell_ext_link_bwd": (C.c_int, [C.POINTER(CellDesc), _i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                              C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
+                                              C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
     "mser_gru_speaker_save_bytes": (C.c_size_t, [_i32, _i32, _i32]),
     "mser_gru_speaker_fwd": (C.c_int, [C.POINTER(GruSpeakerDesc), _i32, _vp]),
     "mser_gru_speaker_bwd": (C.c_int, [C.POINTER(GruSpeakerDesc), _i32, _vp]),

@@ -43,6 +43,9 @@ class GruDirCtx:
 # rows straight into the cell's workspace and advance the step counter the LSTHM chain already waits on (mser_cell_desc::ext_linked).
 # False, stream capture, or sizes without the persistent launch: the GRU chains finish first and the rows are copied.
 LINK_GRU_FWD = True
+# Likewise the GRU BPTT runs concurrently with the LSTHM BPTT as its consumer: step t starts when the cell's BPTT counter shows that
+# the gradient rows of h_s[t] are complete (bounded wait), and reads them from the workspace with device-coherent loads.
+LINK_GRU_BWD = True
 
 
 def gru_speaker_dir_fwd(P: Getter, x_l: Tensor, x_a: Tensor, qmask: Tensor, rev: Optional[Tensor], out_q: Tensor, T: int, B: int,
@@ -121,6 +124,7 @@ class OnlyspCtx:
     lp: Tensor = None
     drop: DropCfg = None
     qmask: Tensor = None
+    gru_status: Tensor = None
 
 
 def onlysp_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: ModelDims, drop: Optional[DropCfg] = None):
@@ -296,12 +300,30 @@ def onlysp_backward(c: OnlyspCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: O
             r["dout"] = dH[:, sl]
         desc = ops.make_cell_desc(Ln, B, D, H, c.x_l, c.x_a, c.cell_dirs, 10 * H, c.cell_ws, dx_l=dx_l, dx_a=dx_a, drop=c.cell_drop,
                                   ext_hq=[g.hs for g in c.gru], ext_dhq=dhq)
-        ops.marn_cell_run(desc, ops.PHASE_BWD_PREP | ops.PHASE_LSTHM_BWD)
-        ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD_DX | ops.PHASE_LSTHM_WGRAD | ops.PHASE_SPEAKER_BWD)
         dgs = [(torch.empty(N, 3 * H, device=dev), torch.empty(N, 3 * H, device=dev)) for _ in range(2)]
-        for i in range(2):
-            ops.gru_speaker_set_grads(c.gru[i].desc, dhq[i], dgs[i][0], dgs[i][1])
-        ops.gru_speaker_bwd([g.desc for g in c.gru])              # both directions' BPTT in one launch
+        blinks = None
+        if LINK_GRU_BWD and not torch.cuda.is_current_stream_capturing():
+            blinks = [ops.cell_ext_link_bwd(desc, i) for i in range(2)]
+            if not all(lk[6] for lk in blinks):
+                blinks = None
+        ops.marn_cell_run(desc, ops.PHASE_BWD_PREP)                # zeroes the BPTT step counters: before producer AND consumer
+        if blinks is not None:
+            c.gru_status = torch.zeros(1, device=dev, dtype=torch.int32)
+            for i in range(2):
+                ops.gru_speaker_link_bwd(c.gru[i].desc, blinks[i], dgs[i][0], dgs[i][1], c.gru_status)
+            s_g = _Streams.get(dev)[2]
+            s_g.wait_stream(cur)
+            ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD)            # producer (main stream)
+            with torch.cuda.stream(s_g):
+                ops.gru_speaker_bwd([g.desc for g in c.gru])        # consumer: both directions' BPTT, one launch, its own stream
+            ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD_DX | ops.PHASE_LSTHM_WGRAD)
+            cur.wait_stream(s_g)
+        else:
+            ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD)
+            ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD_DX | ops.PHASE_LSTHM_WGRAD | ops.PHASE_SPEAKER_BWD)
+            for i in range(2):
+                ops.gru_speaker_set_grads(c.gru[i].desc, dhq[i], dgs[i][0], dgs[i][1])
+            ops.gru_speaker_bwd([g.desc for g in c.gru])              # both directions' BPTT in one launch
         for i, pre in enumerate(("marn_cell_f.", "marn_cell_b.")):
             gru_speaker_dir_bwd(c.gru[i], _sub(P, pre), _sub(G, pre), dgs[i][0], dgs[i][1], dx_l, dx_a, Ln, B, H)
         # ---- encoders (audio branch on a side stream) and linear_in

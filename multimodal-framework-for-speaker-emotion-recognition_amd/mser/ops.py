@@ -391,9 +391,20 @@ def gru_speaker_set_grads(desc: L.GruSpeakerDesc, dhs: Tensor, dgi: Tensor, dgh:
         if not t.is_contiguous():
             raise RuntimeError("gru_speaker_bwd: gradient buffers must be contiguous")
     desc.dhs, desc.dgi, desc.dgh = _p(dhs), _p(dgi), _p(dgh)
+    desc.sub_counter = None                     # (not a linked consumer)
     desc._keep_bwd = (dhs, dgi, dgh, tuple(dhs_add))
     for i in range(2):
         desc.dhs_add[i] = _p(dhs_add[i]) if i < len(dhs_add) else None
+
+
+def gru_speaker_link_bwd(desc: L.GruSpeakerDesc, link, dgi: Tensor, dgh: Tensor, status: Optional[Tensor] = None) -> None:
+    """Prepare a chain's BPTT as a linked consumer of the cell's BPTT launch (``link`` = cell_ext_link_bwd(...))."""
+    dhq, parts, n_parts, part_stride, cnt, per_step, _ = link
+    desc.dhs, desc.dgi, desc.dgh = dhq, _p(dgi), _p(dgh)
+    desc.dhs_add[0] = desc.dhs_add[1] = None
+    desc.sub_counter, desc.sub_per_step, desc.sub_parts, desc.sub_nparts, desc.sub_part_stride = cnt, per_step, parts, n_parts, part_stride
+    desc.status = _p(status)
+    desc._keep_bwd = (dgi, dgh, status)
 
 
 def gru_speaker_bwd(descs, dhs: Optional[Tensor] = None, dgi: Optional[Tensor] = None, dgh: Optional[Tensor] = None,
@@ -603,6 +614,18 @@ def cell_ext_link(desc: L.CellDesc, direction: int):
     if rc < 0:
         L.check(rc, "marn_cell_ext_link")
     return hq.value, cnt.value, rep.value, stride.value, inc.value, rc == 1
+
+
+def cell_ext_link_bwd(desc: L.CellDesc, direction: int):
+    """(dhq pointer, parts pointer, n_parts, part stride, counter pointer, per-step count, persistent?) for a linked consumer of
+    direction ``direction``'s speaker-state gradient (include/mser.h mser_marn_cell_ext_link_bwd)."""
+    dhq, parts, cnt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    n, rep, stride, inc, ps = C.c_int32(), C.c_int32(), C.c_int32(), C.c_uint32(), C.c_int64()
+    rc = _lib().mser_marn_cell_ext_link_bwd(C.byref(desc), direction, C.byref(dhq), C.byref(parts), C.byref(n), C.byref(ps),
+                                            C.byref(cnt), C.byref(rep), C.byref(stride), C.byref(inc))
+    if rc < 0:
+        L.check(rc, "marn_cell_ext_link_bwd")
+    return dhq.value, parts.value, n.value, ps.value, cnt.value, inc.value, rc == 1
 
 
 def marn_cell_fwd(desc: L.CellDesc) -> None:

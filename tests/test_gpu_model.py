@@ -848,10 +848,11 @@ def test_onlysp_trainer_runs_the_reference_loop(O, tmp_path):
 
 
 def test_onlysp_linked_forward_chains_bit_identical_to_sequential(O):
-    """The GRU forward chains as a concurrent producer of the LSTHM chains (rows written into the cell workspace, step counter
-    advanced after a device-wide release; mser_cell_desc::ext_linked) against the sequential schedule (chains one after the other,
-    rows copied): the arithmetic is the same, so log-probs and every gradient must agree BIT FOR BIT -- any stale or early read of a
-    speaker row would show.  Bench-sized batch, repeated."""
+    """The GRU chains linked to the LSTHM chains -- forward: a concurrent producer (rows written into the cell workspace, step counter
+    advanced after a device-wide release; mser_cell_desc::ext_linked); BPTT: a concurrent bounded-wait consumer of the cell's BPTT
+    counter with device-coherent loads -- against the sequential schedule (chains one after the other, rows copied / summed): the
+    arithmetic is the same, so log-probs must agree BIT FOR BIT and the gradients to the split-K atomics' rounding; any stale or early
+    read of a row would show.  Bench-sized batch, repeated."""
     from models.lsthm_onlysp import MARN1_onlysp
     from loss import MaskedLoss
     import mser.onlysp_fn as ofn
@@ -861,19 +862,37 @@ def test_onlysp_linked_forward_chains_bit_identical_to_sequential(O):
     x, qmask, umask, label = (t.cuda() for t in O.seeded_batch(32, 96, d_r=d_r, seed=96, ragged=True))
 
     def run(linked):
-        ofn.LINK_GRU_FWD = linked
+        ofn.LINK_GRU_FWD = ofn.LINK_GRU_BWD = linked
         try:
             net.zero_grad(set_to_none=True)
             lp, _, _ = net(x, qmask, umask)
             MaskedLoss(torch.nn.NLLLoss)(lp, label.view(-1), umask).backward()
             torch.cuda.synchronize()
             return lp.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+            if linked:
+                assert int(net_status()) == 0, "the linked GRU BPTT gave up waiting for the cell's BPTT"
         finally:
-            ofn.LINK_GRU_FWD = True
+            ofn.LINK_GRU_FWD = ofn.LINK_GRU_BWD = True
+
+    last = {}
+    orig_bwd = ofn.onlysp_backward
+
+    def spy(c, *a, **k):
+        last["c"] = c
+        return orig_bwd(c, *a, **k)
+
+    import models.lsthm_onlysp as mo
+    mo.onlysp_backward = spy
+
+    def net_status():
+        st = last["c"].gru_status
+        return st.item() if st is not None else 0
 
     lp_seq, g_seq = run(False)
     for _ in range(5):
         lp_lnk, g_lnk = run(True)
         assert torch.equal(lp_lnk, lp_seq)
-        for n in ("marn_cell_f.gru_s.weight_hh", "marn_cell_b.lsthm_l.S.weight", "linear_in.weight", "nn_out.0.weight"):
+        for n in ("marn_cell_f.gru_s.weight_hh", "marn_cell_b.gru_s.weight_ih", "marn_cell_b.lsthm_l.S.weight", "linear_in.weight",
+                  "nn_out.0.weight"):
             assert maxabs(g_lnk[n], g_seq[n]) <= 1e-6 * max(1.0, float(g_seq[n].abs().max())), n      # (split-K atomics: not bitwise)
+    mo.onlysp_backward = orig_bwd
