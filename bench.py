@@ -346,7 +346,7 @@ def main():
                 tr = tr_main
             del tro
             variants[tag] = {"ms_per_step": round(ms_o2, 4), "utterances_per_s": round(B * L / (ms_o2 * 1e-3), 1),
-                             "note": "first version: one stream, GRU speaker chains before / after the LSTHM chains; eager launches"}
+                             "note": "GRU speaker chains counter-linked to the LSTHM chains (concurrent launches on two streams); eager launches"}
         log("variants done")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -8,8 +8,9 @@ row f1) as explicit kernel sequences, built from the same pieces as ``mser.model
 * the second encoder pass takes the first pass's output without the residual add (:262-266);
 * the head is ``nn_out`` = Linear(10H -> 32) + ReLU + Dropout + Linear(32 -> C) on cat[h_f, h_b, attn1, attn2] (:287).
 
-First version of the schedule: the GRU chains run before / after the LSTHM chains (not yet counter-linked to them); the audio
-encoder branch and the sequence-level attention modules run on side streams beside the text branch and the recurrent chains.
+Schedule: in eager mode the GRU chains run CONCURRENTLY with the LSTHM chains, linked through the cell's step counters
+(LINK_GRU_FWD / LINK_GRU_BWD below); under stream capture they run before / after them.  The audio encoder branch and the
+sequence-level attention modules run on side streams beside the text branch and the recurrent chains.
 """
 from __future__ import annotations
 
