@@ -386,8 +386,9 @@ typedef struct mser_gru_speaker_desc {
   const uint32_t* rng; uint32_t drop_site; float p;      /* dropout on h_s (:177), element (t*B + b)*H + u; NULL: identity */
   /* Forward link to a consumer that runs CONCURRENTLY (mser_cell_desc::ext_linked; values from mser_marn_cell_ext_link, hs then
    * being that call's hq_rows): after every step, once the step's hs rows are visible device-wide, each of pub_replicas counters
-   * (pub_replica_stride words apart) is advanced so that the chain's workgroups together add pub_per_step.  NULL: no link. */
-  uint32_t* pub_counter; uint32_t pub_per_step; int32_t pub_replicas; int32_t pub_replica_stride;
+   * (pub_replica_stride words apart) is raised to pub_per_step * (number of steps that EVERY workgroup of the chain has
+   * published); pub_progress: ceil(B / 16) words of scratch per chain, zeroed by the caller before the launch.  NULL: no link. */
+  uint32_t* pub_counter; uint32_t pub_per_step; int32_t pub_replicas; int32_t pub_replica_stride; uint32_t* pub_progress;
   /* Backward link to a producer that runs CONCURRENTLY (the cell's BPTT launch; values from mser_marn_cell_ext_link_bwd): step t
    * starts once *sub_counter >= sub_per_step * (T - t); its incoming gradient is then dhs + the sub_nparts arrays at sub_parts
    * (sub_part_stride floats apart), read with device-coherent loads; dhs_add is ignored.  The wait is bounded: on a time-out the

@@ -33,9 +33,13 @@ struct GruArgs {
   // gradient rows (dhs and sub_nparts parts, sub_stride floats apart) are then read with device-coherent loads
   const unsigned* sub_cnt; unsigned sub_per_step; const float* sub_parts; int sub_nparts; long sub_stride; int* status;
   const uint32_t* rng; uint32_t site; float p;
-  // forward link to a consumer kernel (mser_cell_desc::ext_linked): after every step, once this block's rows of hs are visible
-  // device-wide, every replica of `pub_cnt` receives this block's share of `pub_inc` (the shares of a chain's blocks sum to it)
-  unsigned* pub_cnt; unsigned pub_inc; int pub_rep, pub_stride;
+  // forward link to a consumer kernel (mser_cell_desc::ext_linked).  The consumer waits for counter >= pub_inc * (t + 1) = "EVERY
+  // block of this chain has published step t".  The blocks run without a barrier among themselves, so they must not simply add
+  // shares to the counter (a block two steps ahead would stand in for one that is behind): each block keeps its own progress word
+  // (pub_progress[block], zeroed by the caller) and, after a step, raises every counter replica to pub_inc * min over the blocks'
+  // progress words with atomicMax -- a lower bound of the true minimum at any later time, and the slowest block's own update makes
+  // it exact.
+  unsigned* pub_cnt; unsigned pub_inc; int pub_rep, pub_stride; unsigned* pub_progress;
 };
 
 // 16 x 32 x 128 product of one wave as two 16 x 16 tiles: A row (lane & 15) from LDS, B from registers.  v_mfma_f32_16x16x4_f32
@@ -141,9 +145,11 @@ __global__ __launch_bounds__(GNT) void gru_speaker_fwd_kernel(GruArgs2 aa) {
     if (a.pub_cnt) __threadfence();          // release: this thread's hs rows of step t are visible device-wide before the counter moves
     __syncthreads();
     if (a.pub_cnt && tid < a.pub_rep) {
-      const unsigned nblk = gridDim.x;
-      const unsigned share = a.pub_inc / nblk + (blockIdx.x < a.pub_inc % nblk ? 1u : 0u);
-      __hip_atomic_fetch_add(a.pub_cnt + tid * a.pub_stride, share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) __hip_atomic_store(a.pub_progress + blockIdx.x, (unsigned)(t + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned mn = (unsigned)(t + 1);
+      for (unsigned bi = 0; bi < gridDim.x; ++bi)
+        if (bi != blockIdx.x) mn = min(mn, __hip_atomic_load(a.pub_progress + bi, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
+      __hip_atomic_fetch_max(a.pub_cnt + tid * a.pub_stride, a.pub_inc * mn, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -269,7 +275,8 @@ int gru_validate(const mser_gru_speaker_desc& d, bool bwd) {
   MSER_REQUIRE(d.gi && d.w_hh && d.b_hh && d.qmask && d.hs && d.save, "mser_gru_speaker: null pointer");
   MSER_REQUIRE(!d.out || d.ldo >= d.H, "mser_gru_speaker: ldo=%ld < H", (long)d.ldo);
   MSER_REQUIRE(!d.rng || (d.p >= 0.f && d.p < 1.f), "mser_gru_speaker: dropout p=%f", d.p);
-  MSER_REQUIRE(!d.pub_counter || (d.pub_replicas > 0 && d.pub_replicas <= 64 && d.pub_replica_stride > 0 && d.pub_per_step > 0),
+  MSER_REQUIRE(!d.pub_counter || (d.pub_replicas > 0 && d.pub_replicas <= 64 && d.pub_replica_stride > 0 && d.pub_per_step > 0 &&
+                                  d.pub_progress),
                "mser_gru_speaker: bad publish fields");
   if (bwd) MSER_REQUIRE(d.dhs && d.dgi && d.dgh, "mser_gru_speaker_bwd: null gradient buffer");
   return 0;
@@ -283,6 +290,7 @@ GruArgs gru_args(const mser_gru_speaker_desc& d) {
   a.dhs = d.dhs; a.dhs2 = d.dhs_add[0]; a.dhs3 = d.dhs_add[1]; a.dgi = d.dgi; a.dgh = d.dgh;
   a.rng = (d.rng && d.p > 0.f) ? d.rng : nullptr; a.site = d.drop_site; a.p = d.p;
   a.pub_cnt = d.pub_counter; a.pub_inc = d.pub_per_step; a.pub_rep = d.pub_replicas; a.pub_stride = d.pub_replica_stride;
+  a.pub_progress = d.pub_progress;
   a.sub_cnt = d.sub_counter; a.sub_per_step = d.sub_per_step; a.sub_parts = d.sub_parts; a.sub_nparts = d.sub_nparts;
   a.sub_stride = d.sub_part_stride; a.status = d.status;
   return a;

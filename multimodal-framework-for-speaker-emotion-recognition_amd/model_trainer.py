@@ -111,6 +111,8 @@ class ModelTrainer(nn.Module):
             num += loss.double() * n.double()
             den += n.double()
         avg_loss = round(float(num / den), 4)
+        if hasattr(self.model, "check_links"):       # (the float() above has synchronised already)
+            self.model.check_links()
         return lr, avg_loss
 
     def eval_network(self, loader, return_predictions=False):

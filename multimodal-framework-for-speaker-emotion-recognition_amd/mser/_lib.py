@@ -86,7 +86,7 @@ class GruSpeakerDesc(C.Structure):
                 ("dhs", C.c_void_p), ("dhs_add", C.c_void_p * 2), ("dgi", C.c_void_p), ("dgh", C.c_void_p),
                 ("rng", C.c_void_p), ("drop_site", C.c_uint32), ("p", C.c_float),
                 ("pub_counter", C.c_void_p), ("pub_per_step", C.c_uint32), ("pub_replicas", C.c_int32),
-                ("pub_replica_stride", C.c_int32),
+                ("pub_replica_stride", C.c_int32), ("pub_progress", C.c_void_p),
                 ("sub_counter", C.c_void_p), ("sub_per_step", C.c_uint32), ("sub_parts", C.c_void_p), ("sub_nparts", C.c_int32),
                 ("sub_part_stride", C.c_int64), ("status", C.c_void_p)]
 

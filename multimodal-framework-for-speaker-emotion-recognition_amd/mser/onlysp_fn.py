@@ -38,6 +38,7 @@ class GruDirCtx:
     save: Tensor = None
     gi: Tensor = None
     drop: object = None
+    progress: Tensor = None
 
 
 # The GRU forward chains run CONCURRENTLY with the LSTHM forward chains (eager mode, persistent launches): they write the speaker
@@ -217,6 +218,8 @@ def onlysp_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mod
                                 launch=False, hs=hs)
         if links is not None:
             g.desc.pub_counter, g.desc.pub_replicas, g.desc.pub_replica_stride, g.desc.pub_per_step = links[i][1:5]
+            g.progress = torch.zeros((B + 15) // 16, device=dev, dtype=torch.int32)      # per-block progress words of the chain
+            g.desc.pub_progress = g.progress.data_ptr()
         c.gru.append(g)
     desc = ops.make_cell_desc(Ln, B, D, H, c.x_l, c.x_a, c.cell_dirs, 10 * H, c.cell_ws, drop=c.cell_drop,
                               ext_hq=[g.hs for g in c.gru], ext_linked=links is not None)
@@ -252,8 +255,9 @@ def onlysp_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mod
 
 
 def onlysp_backward(c: OnlyspCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: Optional[Tensor] = None,
-                    dx_a_out: Optional[Tensor] = None) -> None:
-    """Accumulates every parameter gradient into G(name)."""
+                    dx_a_out: Optional[Tensor] = None, status: Optional[Tensor] = None) -> None:
+    """Accumulates every parameter gradient into G(name).  ``status`` (int32 [1] on the device, optional): set to 1 by a linked GRU
+    BPTT that gave up waiting for the cell's BPTT (never cleared here: a caller may keep one across steps and look at it rarely)."""
     d = c.dims
     Ln, B, N, D, H = c.L, c.B, c.L * c.B, c.dims.D, c.dims.H
     dev = dlp.device
@@ -309,7 +313,7 @@ def onlysp_backward(c: OnlyspCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: O
                 blinks = None
         ops.marn_cell_run(desc, ops.PHASE_BWD_PREP)                # zeroes the BPTT step counters: before producer AND consumer
         if blinks is not None:
-            c.gru_status = torch.zeros(1, device=dev, dtype=torch.int32)
+            c.gru_status = status if status is not None else torch.zeros(1, device=dev, dtype=torch.int32)
             for i in range(2):
                 ops.gru_speaker_link_bwd(c.gru[i].desc, blinks[i], dgs[i][0], dgs[i][1], c.gru_status)
             s_g = _Streams.get(dev)[2]

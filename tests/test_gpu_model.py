@@ -838,6 +838,7 @@ def test_onlysp_trainer_runs_the_reference_loop(O, tmp_path):
     path = str(tmp_path / "model_0001.model")
     tr.save_parameters(path)
     keys = list(torch.load(path, weights_only=True).keys())
+    tr.model.check_links()                               # the linked launches never timed out (train_network checks it per epoch too)
     assert keys[0] == "model.w" and "model.marn_cell_f.gru_s.weight_ih" in keys and len(keys) == 128
     tr2 = ModelTrainer(torch.device("cuda:0"), 1e-3, 1, 0.98, "MARN1_onlysp", "NLL", 6, "IEMOCAP", quiet=True)
     tr2.load_parameters(path)
@@ -889,7 +890,7 @@ def test_onlysp_linked_forward_chains_bit_identical_to_sequential(O):
         return st.item() if st is not None else 0
 
     lp_seq, g_seq = run(False)
-    for _ in range(5):
+    for _ in range(12):         # (the chain's two 16-dialogue blocks run without a barrier between them: their relative speed varies)
         lp_lnk, g_lnk = run(True)
         assert torch.equal(lp_lnk, lp_seq)
         for n in ("marn_cell_f.gru_s.weight_hh", "marn_cell_b.gru_s.weight_ih", "marn_cell_b.lsthm_l.S.weight", "linear_in.weight",
