@@ -80,6 +80,19 @@ def lsthm_step_bytes(backward):
                 + 2 * 2 * B * 4 * H + 4 * B * H + B * H + 2 * B * H)
 
 
+def lsthm_step_bytes_survey(backward):
+    """SURVEY.md 8(d)'s streaming model of one LSTHM + speaker step of one direction (the contract's per-unit figure):
+    forward  s * [P_step + B*(2D+2) + B*4H],  P_step = 2*(4H*(D+2H+Hs) + 4*4H) + 2*(4Hs*2Hs + 8Hs) + 2H parameters (every weight of the
+    step streamed once, W and S and the speaker LSTMs included); backward = the same weights once more + the saved-gate reads
+    B*(2*4H + 2*4Hs + 6H)*s.  H = Hs = 128, D = 100, B = 32, fp32: 3,148,032 / 3,508,480 bytes."""
+    D, Hs = 100, H
+    p_step = 2 * (4 * H * (D + 2 * H + Hs) + 4 * 4 * H) + 2 * (4 * Hs * 2 * Hs + 8 * Hs) + 2 * H
+    by = 4 * (p_step + B * (2 * D + 2) + B * 4 * H)
+    if backward:
+        by += 4 * B * (2 * 4 * H + 2 * 4 * Hs + 6 * H)
+    return by
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE
     rocprofv3 passes over this same command, FETCH_SIZE doubled per the gfx950 correction).  PMC collection serialises kernels,
@@ -96,7 +109,26 @@ def pmc_traffic(kernel):
     return None
 
 
-def cpu_baseline(steps=3):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline(steps=5):
+    """The CPU oracle (oracle/ref_cpu.py, kind "port": the restatement pinned against the reference's own outputs) timed on this
+    host's cores on the full B x L batch: 1 warm-up + `steps` timed passes per leg, median.  Legs:
+      eval_fwd_bwd    -- every Dropout the identity, forward + MaskedLoss + backward   (the parity configuration; this is `value`,
+                         the FASTEST of the three, i.e. the most conservative GPU/CPU ratio)
+      train_fwd_bwd   -- all 13 dropout sites live, masks drawn inside the timed region with torch's CPU generator, as the
+                         reference's nn.Dropout modules do
+      trainer_step    -- batch ingest (textf = (r1+r2+r3+r4)/4, cat), train-mode forward + loss + backward, Adam(wd=2e-5) over the
+                         100 live tensors: what ModelTrainer.train_network does per batch (model_trainer.py:96-120)"""
     from oracle import ref_cpu as O
     # the GPU box hands a 1-GPU job a 16-core CPU share (cgroup), while os.cpu_count() reports the whole host
     try:
@@ -107,18 +139,81 @@ def cpu_baseline(steps=3):
     torch.set_num_threads(ncores)
     P = {k: v.clone().requires_grad_(True) for k, v in O.seeded_params(seed=0, d_r=D_R).items()}
     x, qmask, umask, label = O.seeded_batch(B, L, d_r=D_R, seed=1)
-    times = []
-    for i in range(steps + 1):
-        for p in P.values():
-            p.grad = None
+    r = [x[:, :, :D_R] + 0.01 * i for i in range(4)]          # four RoBERTa layers of the reference's batch tuple
+    acouf = x[:, :, D_R:].contiguous()
+    shapes = {k: tuple(v.shape) for k, v in O.seeded_drops(1, 1).items()}          # site keys only
+    pk = O.DEFAULT_DROPOUT
+
+    def draw_drops():
+        full = {}
+        for k in shapes:
+            if k.startswith("enc"):
+                shp = (B, 8, L, L) if k.endswith("attn") else (B, L, 100)
+                p_ = pk["enc"]
+            elif k.startswith("xattn"):
+                shp, p_ = (B, L, L), pk["xattn"]
+            elif k == "fc":
+                shp, p_ = (L, B, 100), pk["fc"]
+            elif k == "out":
+                shp, p_ = (L, B, 32), pk["out"]
+            elif k.startswith("rec"):
+                shp, p_ = (L, B, 4 * H), pk["rec"]
+            elif k.endswith("attn"):
+                shp, p_ = (L, B, H, H), pk["cell_attn"]
+            else:
+                shp, p_ = (L, 2, B, H), pk["cell"]
+            full[k] = torch.nn.functional.dropout(torch.ones(shp), p_, True)
+        return full
+
+    state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in P.items()}
+    step_no = [0]
+
+    def leg(mode):
+        for p_ in P.values():
+            p_.grad = None
         t0 = time.perf_counter()
-        lp, _, _ = O.marn1_sps_forward(P, x, qmask, umask, d_r=D_R)
+        xx = x
+        if mode == "trainer":
+            xx = torch.cat([(r[0] + r[1] + r[2] + r[3]) / 4, acouf], dim=-1)
+        drops = draw_drops() if mode != "eval" else None
+        lp, _, _ = O.marn1_sps_forward(P, xx, qmask, umask, d_r=D_R, drops=drops)
         O.masked_nll(lp, label.view(-1), umask).backward()
-        times.append(time.perf_counter() - t0)
-    t = float(np.median(times[1:]))
-    return dict(value=B * L / t, unit="utterances/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{steps} timed eval-mode fwd+bwd steps (+1 warm-up) of the full B={B},L={L},d_t={D_R} batch, median; "
-                       f"{t:.3f} s/step; torch {torch.__version__} CPU fp32")
+        if mode == "trainer":
+            step_no[0] += 1
+            with torch.no_grad():
+                for k, p_ in P.items():
+                    if p_.grad is not None:
+                        O.adam_step(p_, p_.grad, state[k][0], state[k][1], step_no[0], 1e-3)
+        return time.perf_counter() - t0
+
+    legs = {}
+    for name, mode in (("eval_fwd_bwd", "eval"), ("train_fwd_bwd", "train"), ("trainer_step", "trainer")):
+        ts = [leg(mode) for _ in range(steps + 1)][1:]
+        t = float(np.median(ts))
+        legs[name] = {"s_per_step": round(t, 4), "utterances_per_s": round(B * L / t, 1)}
+        log(f"cpu baseline {name}: {t:.3f} s/step")
+    t = legs["eval_fwd_bwd"]["s_per_step"]
+    return dict(value=legs["eval_fwd_bwd"]["utterances_per_s"], unit="utterances/s", cores=torch.get_num_threads(), kind="port",
+                cpu_model=cpu_model(), legs=legs,
+                sample=f"{steps} timed steps (+1 warm-up) per leg of the full B={B},L={L},d_t={D_R} batch, median; value = eval-mode "
+                       f"fwd+bwd ({t:.3f} s/step), the fastest leg; torch {torch.__version__} CPU fp32, {torch.get_num_threads()} threads")
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same flags>`
+    as a CHILD process (never exec: the parent has not touched the GPU, but a child is the safe form everywhere), stream its
+    output through, return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] launching {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
 
 
 def log(msg):
@@ -142,8 +237,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # Invoked directly as `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU over RCCL), BEFORE this
+            # process makes any GPU call, relay rank 0's JSON line and leave with the children's exit code.
+            raise SystemExit(self_launch(args.gpus))
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -238,6 +335,14 @@ def main():
         dist.all_reduce(ms, op=dist.ReduceOp.MAX)
     ms_per_step = float(ms)
     log(f"timed region done: {ms_per_step:.3f} ms/step")
+    # a persistent chain that gave up at a bounded wait would have made the steps FASTER and wrong: the sticky fault word says so
+    # (Adam skipped those updates on the device), and the loss of one more step must be finite
+    from mser import fault
+    fault.check(device, "bench.py timed region")
+    loss_chk, _ = tr.train_step(x, qmask, umask, label)
+    if not bool(torch.isfinite(loss_chk)):
+        raise SystemExit(f"bench.py: non-finite loss after the timed region ({float(loss_chk)})")
+    fault.check(device, "bench.py check step")
 
     # ---- live roofline measurement: HIP events around every launch of the LSTHM chain kernels (eager pass, same inputs)
     roofline = None
@@ -256,8 +361,16 @@ def main():
             steps_per_launch = 2 * L if us > 200 else 2                 # persistent launch = T steps x 2 directions
             by = lsthm_step_bytes(backward) * steps_per_launch
             ach = by / (us * 1e-6) / 1e9
+            # `achieved` / `frac` follow SURVEY.md 8(d)'s formula (every weight of the step streamed once per step); the narrower model
+            # (`*_touched`: only what this kernel actually touches per step -- U, V, states, gates; W, S and the speaker LSTM weights
+            # are hoisted or belong to other roles) is printed beside it
+            by_t = by
+            by = lsthm_step_bytes_survey(backward) * steps_per_launch
+            ach_t = by_t / (us * 1e-6) / 1e9
+            ach = by / (us * 1e-6) / 1e9
             return dict(bound="hbm", kernel=name, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(ach / HBM_PEAK_GBS, 4), traffic=pmc_traffic(name), bytes_per_launch=by, avg_launch_us=round(us, 2),
+                        achieved_touched=round(ach_t, 1), frac_touched=round(ach_t / HBM_PEAK_GBS, 4), bytes_per_launch_touched=by_t,
                         launches_timed=launches, steps_per_launch=steps_per_launch,
                         note="dependency-latency bound recurrence (2 inter-workgroup hand-offs per time step); weights are "
                              "register-resident, so real HBM traffic is far below this streaming model")

@@ -22,10 +22,16 @@ extern "C" {
 
 typedef void* mser_stream_t; /* hipStream_t */
 
-#define MSER_VERSION 112   /* 110: + encoder layer, grouped GEMM, head tail, ingest, confusion, cell desc addends */
+#define MSER_VERSION 120   /* 110: + encoder layer, grouped GEMM, head tail, ingest, confusion, cell desc addends */
 
 int mser_version(void);
 const char* mser_last_error(void);
+
+/* Bits of the caller-owned sticky fault word (uint32 in device memory) that kernels OR into when something went wrong that
+ * cannot be reported through a return code (the launch is asynchronous): see mser_cell_desc::fault, mser_gru_speaker_desc::status,
+ * mser_masked_loss_fwd, mser_adam_flat_dev.  The reference raises in the corresponding situations (an out-of-range label makes
+ * NLLLoss / CrossEntropyLoss raise, loss.py:19-24); a persistent chain has no counterpart there. */
+enum { MSER_FAULT_CHAIN_TIMEOUT = 1, MSER_FAULT_LINK_TIMEOUT = 2, MSER_FAULT_BAD_LABEL = 4 };
 
 /* ------------------------------------------------------------------------------------------------
  * Generic strided batched fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chains).
@@ -258,6 +264,10 @@ typedef struct mser_cell_desc {
    * zeroes the counter).  Never inside stream capture (a graph executor may start the consumer first; its waits are bounded but it
    * would give up).  ext_hq must still be non-NULL (it selects the mode); it is not read. */
   int32_t ext_linked;
+  /* Sticky fault word in device memory (may be NULL): a persistent launch that gives up at a bounded wait ORs
+   * MSER_FAULT_CHAIN_TIMEOUT into it.  Unlike the abort word inside the workspace (cleared by the next MSER_PHASE_FWD_PREP) it
+   * stays set until the caller clears it; mser_adam_flat_dev skips its update while it is non-zero. */
+  uint32_t* fault;
 } mser_cell_desc;
 
 size_t mser_marn_cell_workspace_bytes(int32_t T, int32_t B, int32_t D, int32_t H, int32_t ndir);
@@ -277,16 +287,19 @@ enum { MSER_PHASE_SPEAKER_FWD = 1, MSER_PHASE_LSTHM_FWD = 2, MSER_PHASE_LSTHM_BW
         * speaker chain, issued on another REAL stream, starts before the encoders finish.  Never inside stream capture. */
        MSER_PHASE_SEPARATE_SPEAKER = 256 };
 /* Where a linked producer publishes direction `dir`'s speaker rows (hq_rows [T*B, H], inside the workspace) and the counter it
- * advances by per_step after each step (replicas x replica_stride words).  Returns 1 if the persistent LSTHM launch will be used
- * for these sizes (a link is possible), 0 if not, < 0 on error. */
-int mser_marn_cell_ext_link(const mser_cell_desc* d, int32_t dir, float** hq_rows, uint32_t** counter, int32_t* replicas,
-                            int32_t* replica_stride, uint32_t* per_step);
+ * advances by per_step after each step (replicas x replica_stride words).  partner_wgs = the workgroups of the producer launch:
+ * both kernels must be co-resident for the hand-off to progress.  Returns 1 if the persistent LSTHM launch will be used for these
+ * sizes and partner_wgs further workgroups fit on the chip beside it (a link is possible), 0 if not, < 0 on error. */
+int mser_marn_cell_ext_link(const mser_cell_desc* d, int32_t dir, int32_t partner_wgs, float** hq_rows, uint32_t** counter,
+                            int32_t* replicas, int32_t* replica_stride, uint32_t* per_step);
 /* The backward counterpart: where the BPTT launch leaves the gradient at the external speaker state while it runs -- *dhq [T*B, H]
  * (output quarter) plus *n_parts arrays at *dhq_parts, *part_stride floats apart -- and the counter that reaches
- * per_step * (T - t) when step t's rows are complete.  Returns 1 if the persistent BPTT launch will be used, 0 if not, < 0 on error.
+ * per_step * (T - t) when step t's rows are complete.  Returns 1 if the persistent BPTT launch will be used and partner_wgs further
+ * workgroups (the consumer launch) fit beside it, 0 if not, < 0 on error.
  * A linked consumer must be enqueued on another stream after MSER_PHASE_BWD_PREP (which zeroes the counter); never inside capture. */
-int mser_marn_cell_ext_link_bwd(const mser_cell_desc* d, int32_t dir, const float** dhq, const float** dhq_parts, int32_t* n_parts,
-                                int64_t* part_stride, uint32_t** counter, int32_t* replicas, int32_t* replica_stride, uint32_t* per_step);
+int mser_marn_cell_ext_link_bwd(const mser_cell_desc* d, int32_t dir, int32_t partner_wgs, const float** dhq, const float** dhq_parts,
+                                int32_t* n_parts, int64_t* part_stride, uint32_t** counter, int32_t* replicas, int32_t* replica_stride,
+                                uint32_t* per_step);
 int mser_marn_cell_pipelined(int32_t B, int32_t H, int32_t ndir);
 int mser_marn_cell_run(const mser_cell_desc* d, int32_t phases, mser_stream_t stream);
 
@@ -348,7 +361,10 @@ int mser_masked_nll_fwd(const float* pred, const int64_t* target, const float* m
  *   row adds weight[y]*log(C) to the numerator (the reference's default --loss CrossEntropy reports that on padded batches).
  * loss_out[0] = loss, loss_out[1] = D.  bwd: dpred = (*gscale_dev) * d loss / d pred (all columns written). */
 int mser_masked_loss_fwd(const float* pred, const int64_t* target, const float* mask, const float* weight, int32_t is_ce,
-                         int64_t rows, int32_t C, float* loss_out, mser_stream_t stream);
+                         int64_t rows, int32_t C, float* loss_out, uint32_t* fault, mser_stream_t stream);
+/* (fault: optional sticky fault word.  A target of -100 without class weights is torch's ignore_index: no term, no gradient, the
+ * row still counts in sum(mask).  Any other target outside [0, C) -- where NLLLoss / CrossEntropyLoss raise -- is skipped and ORs
+ * MSER_FAULT_BAD_LABEL into *fault.  bwd: an empty shard (D == 0) yields a zero gradient, not NaN.) */
 int mser_masked_loss_bwd(const float* pred, const int64_t* target, const float* mask, const float* weight, int32_t is_ce,
                          const float* loss_out, const float* gscale_dev, float* dpred, int64_t rows, int32_t C,
                          mser_stream_t stream);
@@ -392,9 +408,10 @@ typedef struct mser_gru_speaker_desc {
   /* Backward link to a producer that runs CONCURRENTLY (the cell's BPTT launch; values from mser_marn_cell_ext_link_bwd): step t
    * starts once *sub_counter >= sub_per_step * (T - t); its incoming gradient is then dhs + the sub_nparts arrays at sub_parts
    * (sub_part_stride floats apart), read with device-coherent loads; dhs_add is ignored.  The wait is bounded: on a time-out the
-   * kernel sets *status (optional, device int) to 1 and carries on.  NULL: no link (dhs / dhs_add are complete at launch). */
+   * kernel ORs MSER_FAULT_LINK_TIMEOUT into *status (optional sticky fault word in device memory) and carries on.  NULL: no link
+   * (dhs / dhs_add are complete at launch). */
   const uint32_t* sub_counter; uint32_t sub_per_step; const float* sub_parts; int32_t sub_nparts; int64_t sub_part_stride;
-  int32_t* status;
+  uint32_t* status;
 } mser_gru_speaker_desc;
 
 size_t mser_gru_speaker_save_bytes(int32_t T, int32_t B, int32_t H);
@@ -450,11 +467,14 @@ int mser_prof_collect(float* total_ms, int32_t* launches);
  * (gscale_div_dev may be NULL): after the data-parallel all-reduce *gscale_div_dev is the global mask count. */
 int mser_adam_flat_dev(float* p, const float* g, float* m, float* v, const uint8_t* live, int64_t n, int32_t* step_dev,
                        const float* hp_dev, float* sched_dev, float eps, float wd, const float* gscale_div_dev, float gscale,
-                       mser_stream_t stream);
+                       const uint32_t* fault, const float* gfault, mser_stream_t stream);
+/* (fault, gfault: optional.  While the sticky fault word *fault is non-zero, or the all-reduced fault flag *gfault is, the update
+ * -- step counter included -- is skipped: a training step whose kernels reported a fault never reaches the weights.) */
 /* Pack for the single data-parallel all-reduce (new: the reference has no distributed code):
- * buf[0..n) = g * (*cnt_dev), buf[n] = *cnt_dev, so that after a SUM all-reduce buf[0..n)/buf[n] is the gradient of the
- * globally mask-weighted loss (loss.py:21 divides by the local mask count). */
-int mser_dp_pack(float* buf, const float* g, const float* cnt_dev, int64_t n, mser_stream_t stream);
+ * buf[0..n) = g * (*cnt_dev), buf[n] = *cnt_dev, buf[n+1] = (*fault != 0) (fault may be NULL), so that after a SUM all-reduce
+ * buf[0..n)/buf[n] is the gradient of the globally mask-weighted loss (loss.py:21 divides by the local mask count) and buf[n+1]
+ * counts the ranks whose step faulted (every rank then skips the update together). */
+int mser_dp_pack(float* buf, const float* g, const float* cnt_dev, int64_t n, const uint32_t* fault, mser_stream_t stream);
 
 #ifdef __cplusplus
 }

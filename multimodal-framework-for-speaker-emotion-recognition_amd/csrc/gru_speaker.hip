@@ -31,7 +31,7 @@ struct GruArgs {
   const float* dhs; const float* dhs2; const float* dhs3; float* dgi; float* dgh;
   // backward link to a producer kernel that runs concurrently: step t may start once *sub_cnt >= sub_per_step * (T - t); its
   // gradient rows (dhs and sub_nparts parts, sub_stride floats apart) are then read with device-coherent loads
-  const unsigned* sub_cnt; unsigned sub_per_step; const float* sub_parts; int sub_nparts; long sub_stride; int* status;
+  const unsigned* sub_cnt; unsigned sub_per_step; const float* sub_parts; int sub_nparts; long sub_stride; unsigned* status;
   const uint32_t* rng; uint32_t site; float p;
   // forward link to a consumer kernel (mser_cell_desc::ext_linked).  The consumer waits for counter >= pub_inc * (t + 1) = "EVERY
   // block of this chain has published step t".  The blocks run without a barrier among themselves, so they must not simply add
@@ -145,10 +145,19 @@ __global__ __launch_bounds__(GNT) void gru_speaker_fwd_kernel(GruArgs2 aa) {
     if (a.pub_cnt) __threadfence();          // release: this thread's hs rows of step t are visible device-wide before the counter moves
     __syncthreads();
     if (a.pub_cnt && tid < a.pub_rep) {
-      if (tid == 0) __hip_atomic_store(a.pub_progress + blockIdx.x, (unsigned)(t + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned mn = (unsigned)(t + 1);
+      // "Publish my progress, then read the others'" is the store-buffering pattern: with release/acquire alone two blocks that
+      // finish a step together may both read the other's OLD word and both publish the smaller value -- harmless mid-sequence (the
+      // next step republishes) but at the last step nothing would ever raise the counter to T * pub_inc.  Hence: (1) the progress
+      // word is written with a RETURNING read-modify-write (performed at the memory side before its value comes back) and the
+      // loads are sequentially consistent, so at least one of two racing blocks sees the other's new word; (2) independently of
+      // that argument the host raises every replica to T * pub_inc with a stream-ordered fill right behind this kernel
+      // (gru_launch), when every block has published everything.
+      unsigned mine = 0;
+      if (tid == 0) mine = __hip_atomic_exchange(a.pub_progress + blockIdx.x, (unsigned)(t + 1), __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_AGENT);
+      mine = __shfl(mine, 0, 64);            // every publishing lane orders its loads behind the exchange's return
+      unsigned mn = (unsigned)(t + 1) + (mine & 0u);
       for (unsigned bi = 0; bi < gridDim.x; ++bi)
-        if (bi != blockIdx.x) mn = min(mn, __hip_atomic_load(a.pub_progress + bi, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
+        if (bi != blockIdx.x) mn = min(mn, __hip_atomic_load(a.pub_progress + bi, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_AGENT));
       __hip_atomic_fetch_max(a.pub_cnt + tid * a.pub_stride, a.pub_inc * mn, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs2 aa) {
       unsigned spins = 0;
       while (__hip_atomic_load(a.sub_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1u << 22)) { if (a.status) *a.status = 1; break; }
+        if (++spins > (1u << 22)) { if (a.status) atomicOr(a.status, (unsigned)MSER_FAULT_LINK_TIMEOUT); break; }
       }
       __threadfence();                 // acquire: the rows read below were published before the counter value seen here
     }
@@ -263,6 +272,10 @@ __global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs2 aa) {
     }
     __syncthreads();
   }
+}
+
+__global__ void gru_publish_all_kernel(unsigned* cnt, int replicas, int stride, unsigned value) {
+  if ((int)threadIdx.x < replicas) __hip_atomic_fetch_max(cnt + threadIdx.x * stride, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 size_t gru_lds_bytes(bool bwd) {
@@ -333,6 +346,15 @@ static int gru_launch(const mser_gru_speaker_desc* d, int32_t n, bool bwd, hipSt
   } else {
     MSER_TRY(allow_gru((const void*)gru_speaker_fwd_kernel, lds));
     hipLaunchKernelGGL(gru_speaker_fwd_kernel, dim3(cdiv(d->B, RB), n), dim3(GNT), lds, s, aa);
+    // stream-ordered final publication of a linked chain: behind the kernel every block has written every row, so the counter
+    // replicas (consecutive words pub_replica_stride apart) are simply filled with T * per_step.  The consumer polls with
+    // device-coherent loads; whatever the in-kernel min/max protocol left behind at the last step, this makes it exact.
+    for (int i = 0; i < n; ++i)
+      if (d[i].pub_counter) {
+        hipLaunchKernelGGL(gru_publish_all_kernel, dim3(1), dim3(64), 0, s, d[i].pub_counter, d[i].pub_replicas, d[i].pub_replica_stride,
+                           d[i].pub_per_step * (unsigned)d[i].T);
+        MSER_TRY(check_launch("gru_publish_all"));
+      }
   }
   return check_launch(what);
 }

@@ -1,21 +1,30 @@
 // MARN_cell on gfx950: speaker-state recurrence + LSTHM recurrence + per-step rank-1 cross-modal attention,
 // forward and backward (BPTT).  Replaces model/lsthm_sps.py:132-221, :28-44, :59-72, :238-259 of the reference.
 //
-// Structure (DESIGN.md "recurrent path"):
-//  * The speaker recurrence (two per-party nn.LSTMCell states indexed by compaction slot) depends on qmask only, so
-//    it runs as its own chain first and its outputs h_q[t] are folded, together with W x[t], into one big
-//    pre-activation GEMM outside the time loop.  Only  U h + V z  remains inside the loop.
-//  * Every time step is an all-to-all seam between workgroups (each workgroup owns a slice of hidden units but needs
-//    every unit of h/z for the next step).  On MI355X a dependent kernel boundary (~1.5 us) is cheaper than an
-//    in-launch grid barrier (~4-7 us) or an all-gather hand-off (~2.4-4 us) -- MI355X_MICROARCH.md price list, rows
-//    "boundary", "barrier-xcd", "allgather" -- so the chain is cut into per-step launches (captured into one hipGraph
-//    by the host) and both directions share each launch.
-//  * A step's matvec is a 32(rows) x 32(cols) x K tile per workgroup: 16 waves split K, each wave runs a short chain of
-//    v_mfma_f32_32x32x2_f32 with operands loaded straight from L2 (weights stay L2-resident per XCD because the
-//    blockIdx -> weight-slice mapping is static), partials are reduced through LDS in a fixed order (deterministic),
-//    and the gate non-linearities run as the epilogue of the same workgroup.
+// Structure:
+//  * Every time step is an all-to-all seam between workgroups: a workgroup owns 8 hidden units of one stream (x 4 gates = 32
+//    gate columns) for a block of 32 dialogues and needs every unit of h / z / c_a for its next phase.  Measured on the box
+//    (scratch/ubench*.hip): a dependent kernel boundary costs 1.56 us in a hipGraph and 2.5 us eager, a counter barrier among 32
+//    co-resident workgroups with a 4 KB write-through payload 1.8 us.  With two seams per step the chains are therefore
+//    PERSISTENT launches: the time loop runs inside the kernel, the workgroup's weight slice stays in registers for the whole
+//    sequence, and a seam is a monotonic per-direction counter (8 replicas on separate 128-byte lines) plus `sc1` (write-through /
+//    L1-bypassing) payload accesses through one buffer descriptor over the workspace.  Every spin is bounded: a workgroup that
+//    waits too long sets the abort word (and the caller's sticky fault word) and every workgroup leaves the kernel.
+//  * One fused launch per pass: cell_fwd_fused = LSTHM chain roles + speaker chain roles + softmax-statistics roles,
+//    cell_bwd_fused = LSTHM BPTT roles + speaker BPTT roles + in-launch weight-gradient roles -- one residency guarantee for
+//    every party of every hand-off, and capturable into a hipGraph.
+//  * The speaker recurrence (two per-party nn.LSTMCell states indexed by compaction slot) depends on qmask only; its chain runs
+//    ahead of the LSTHM chain inside the same launch and  S h_q[t]  joins the step's early product.  W x[t] for all t is hoisted
+//    into one GEMM before the launch; [U | S] [h_{t-1} | h_q[t]] is formed in the shadow of the barrier that publishes z_{t-1},
+//    only  V z_{t-1}  is on the critical path.
+//  * A step's product is a 32(rows) x 32(gate columns) x K tile per workgroup: the 8 waves split K, each runs a short chain of
+//    v_mfma_f32_32x32x2_f32 (bit-exact fp32 fmaf chains) with its B fragments in registers, the 8 partial tiles meet in LDS in a
+//    fixed order (deterministic), the gate non-linearities are the epilogue of the same workgroup.
 //  * The rank-1 attention never materialises the reference's [B,H,H] tensors: logits[i,j] = c_l[i] * s * Wk[j] with
-//    s = <Wq, c_a>/sqrt(H); the row maximum is analytic (u * max(Wk) or u * min(Wk)), so one pass suffices.
+//    s = <Wq, c_a>/sqrt(H); the row maximum is analytic (u * max(Wk) or u * min(Wk)), so one exp2 pass suffices.
+//  * The per-step launches (spk_fwd_step, lsthm_fwd_gates, lsthm_fwd_z, lsthm_bwd_row, lsthm_bwd_mat, spk_bwd_step) remain as the
+//    fallback for shapes whose workgroups cannot all be co-resident (H not in {128,256}, or more workgroups than CUs) and as the
+//    cross-check of the persistent path (tests/test_gpu_model.py::test_persistent_vs_per_step_launches).
 #include "common.h"
 #include "../../include/mser.h"
 #include <cstring>
@@ -70,6 +79,7 @@ struct CellK {
   short place_base[8], place_cap[8];   // XCD x hosts logical workgroups place_base[x] .. place_base[x] + place_cap[x] - 1
   int ext_spk;         // the speaker state h_q[t] comes from the caller (mser_cell_desc::ext_hq): no speaker roles in the launches
   const uint32_t* rng; // dropout generator words {seed, step} (nullptr: every dropout site of the cell is the identity)
+  unsigned* fault;     // sticky fault word (mser_cell_desc::fault) or nullptr
   int ksplit;          // BPTT matvec phase: every product's K = 4H reduction is split over `ksplit` workgroups (1 or 2); the
                        // partial results live in consecutive copies of dA / dHQp / dxc and the consumers add them
   DirP d[2];
@@ -233,9 +243,17 @@ __device__ __forceinline__ void barrier_arrive(unsigned* cnt) {
 // The fused launches assign roles by physical XCD (claim_role), so a workgroup's logical id is not its blockIdx: every persistent
 // kernel publishes it here first (the separate-launch kernels store blockIdx.x + y + z).
 __shared__ unsigned s_logical_wg;
-__device__ __forceinline__ void set_logical_wg(unsigned id) {
-  if (threadIdx.x == 0) s_logical_wg = id;
+// Sticky fault word of the caller (mser_cell_desc::fault, may be null): unlike the abort word in the workspace, which the next
+// FWD_PREP clears, it survives until the host reads it, so a timed-out chain can never pass unnoticed (the optimiser skips its
+// update while the word is set, the trainer raises at its next synchronisation).
+__shared__ unsigned* s_fault;
+__device__ __forceinline__ void set_logical_wg(unsigned id, unsigned* fault = nullptr) {
+  if (threadIdx.x == 0) { s_logical_wg = id; s_fault = fault; }
   __syncthreads();
+}
+__device__ __forceinline__ void raise_abort(unsigned* abortw) {
+  __hip_atomic_store((gu32*)abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (s_fault) __hip_atomic_fetch_or((gu32*)s_fault, (unsigned)MSER_FAULT_CHAIN_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ unsigned sync_replica() { return (s_logical_wg % SYNC_REP) * SYNC_LINE; }
 // One early look at this workgroup's replica (all lanes load the same word: uniform code, the value comes back while the
@@ -264,7 +282,7 @@ __device__ __forceinline__ bool barrier_wait(const unsigned* cnt, unsigned* abor
         }
       }
     }
-    if (!ok) __hip_atomic_store((gu32*)abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!ok) raise_abort(abortw);
     *lds_ok = ok;
   }
   __syncthreads();
@@ -287,7 +305,7 @@ __device__ __forceinline__ bool lazy_wait(const unsigned* cnt, unsigned* abortw,
         }
       }
     }
-    if (!ok) __hip_atomic_store((gu32*)abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!ok) raise_abort(abortw);
     *lds_ok = ok;
   }
   __syncthreads();
@@ -320,7 +338,7 @@ __device__ __forceinline__ bool dir_barrier(unsigned* cnt, unsigned* abortw, uns
         }
       }
     }
-    if (!ok) __hip_atomic_store((gu32*)abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!ok) raise_abort(abortw);
     *lds_ok = ok;
   }
   __syncthreads();
@@ -1725,7 +1743,7 @@ __global__ __launch_bounds__(NT) void cell_fwd_fused(CellK P) {
     id = claim_role(P.sync + SYNC_PLACE_FWD, P.place_base, P.place_cap, (int*)smem);
     if (id < 0) return;
   }
-  set_logical_wg((unsigned)id);
+  set_logical_wg((unsigned)id, P.fault);
   if (id >= 2 * n_l) {        // statistics roles (P.stats_wgs > 0): off both chains
     constexpr int JCT = (128 * NPL / 3) * (128 * NPL / 3) / NT;      // = H*H/NT, as in lsthm_fwd_role
     stats_fwd_role<JCT>(P, id - 2 * n_l, P.stats_wgs / P.ndir, smem, ws, (unsigned)(gx * gy * P.nmb));
@@ -1750,14 +1768,14 @@ template <int NP>
 __global__ __launch_bounds__(NT) void spk_fwd_persist(CellK P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const WS ws = make_ws(P.wsbase, P.wsbytes);
-  set_logical_wg(blockIdx.x + blockIdx.y + blockIdx.z);
+  set_logical_wg(blockIdx.x + blockIdx.y + blockIdx.z, P.fault);
   spk_fwd_role<NP>(P, Role{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, smem, ws);
 }
 template <int NP>
 __global__ __launch_bounds__(NT) void lsthm_fwd_persist(CellK P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const WS ws = make_ws(P.wsbase, P.wsbytes);
-  set_logical_wg(blockIdx.x + blockIdx.y + blockIdx.z);
+  set_logical_wg(blockIdx.x + blockIdx.y + blockIdx.z, P.fault);
   lsthm_fwd_role<NP>(P, Role{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, smem, ws);
 }
 
@@ -1895,7 +1913,7 @@ __global__ __launch_bounds__(NT) void cell_bwd_fused(CellK P, unsigned bwd_nwg) 
     id = claim_role(P.sync + SYNC_PLACE_BWD, P.place_base, P.place_cap, (int*)smem);
     if (id < 0) return;
   }
-  set_logical_wg((unsigned)id);
+  set_logical_wg((unsigned)id, P.fault);
   if (id < n_l) {
     const Role R{id % (int)bwd_nwg, 0, id / (int)bwd_nwg, (int)bwd_nwg, 1};
     lsthm_bwd_role<NPL, KSPLIT>(P, R, smem, ws);
@@ -2144,6 +2162,7 @@ static void fill_params(DirP& k, const mser_cell_dir& r) {
 }
 static void fill_dropout(CellK& K, const mser_cell_desc& d) {
   K.rng = d.rng;
+  K.fault = d.fault;
   for (int i = 0; i < d.ndir; ++i) {
     K.d[i].drop_site = d.drop_site[i];
     K.d[i].p_state = d.rng ? d.p_state[i] : 0.f;
@@ -2828,8 +2847,8 @@ int mser_marn_cell_bwd(const mser_cell_desc* d, mser_stream_t stream) {
   return marn_cell_bwd(*d, (hipStream_t)stream, MSER_PHASE_BWD_PREP | MSER_PHASE_LSTHM_BWD | MSER_PHASE_LSTHM_BWD_DX | MSER_PHASE_LSTHM_WGRAD | MSER_PHASE_SPEAKER_BWD);
 }
 
-int mser_marn_cell_ext_link(const mser_cell_desc* d, int32_t dir, float** hq_rows, uint32_t** counter, int32_t* replicas,
-                            int32_t* replica_stride, uint32_t* per_step) {
+int mser_marn_cell_ext_link(const mser_cell_desc* d, int32_t dir, int32_t partner_wgs, float** hq_rows, uint32_t** counter,
+                            int32_t* replicas, int32_t* replica_stride, uint32_t* per_step) {
   if (!d || dir < 0 || dir >= d->ndir || !hq_rows || !counter || !replicas || !replica_stride || !per_step) {
     set_error("mser_marn_cell_ext_link: bad arguments");
     return -1;
@@ -2842,11 +2861,14 @@ int mser_marn_cell_ext_link(const mser_cell_desc* d, int32_t dir, float** hq_row
   *replicas = SYNC_REP;
   *replica_stride = SYNC_LINE;
   *per_step = (unsigned)((d->H / 8) * 2 * h.k.nmb);          // what the LSTHM chain expects per published step (its nwg_spk)
-  return persist_ok(d->H, fwd_wgs) ? 1 : 0;                   // 1: the persistent LSTHM launch will run (a link is possible)
+  // 1: the persistent LSTHM launch will run AND the partner's workgroups fit beside it (a consumer that filled every CU before the
+  // producer was dispatched would spin to its bound): one CU per workgroup of either kernel
+  return (partner_wgs >= 0 && persist_ok(d->H, fwd_wgs) && fwd_wgs + partner_wgs <= num_cus()) ? 1 : 0;
 }
 
-int mser_marn_cell_ext_link_bwd(const mser_cell_desc* d, int32_t dir, const float** dhq, const float** dhq_parts, int32_t* n_parts,
-                                int64_t* part_stride, uint32_t** counter, int32_t* replicas, int32_t* replica_stride, uint32_t* per_step) {
+int mser_marn_cell_ext_link_bwd(const mser_cell_desc* d, int32_t dir, int32_t partner_wgs, const float** dhq, const float** dhq_parts,
+                                int32_t* n_parts, int64_t* part_stride, uint32_t** counter, int32_t* replicas, int32_t* replica_stride,
+                                uint32_t* per_step) {
   if (!d || dir < 0 || dir >= d->ndir || !dhq || !dhq_parts || !n_parts || !part_stride || !counter || !replicas || !replica_stride ||
       !per_step) {
     set_error("mser_marn_cell_ext_link_bwd: bad arguments");
@@ -2869,7 +2891,10 @@ int mser_marn_cell_ext_link_bwd(const mser_cell_desc* d, int32_t dir, const floa
   *replica_stride = SYNC_LINE;
   *per_step = 2u * (unsigned)bwd_nwg;           // the BPTT chain passes two barriers per step: dHQ[t] and its parts are complete at
                                                // counter >= per_step * (T - t)
-  return persist_ok(H, (long)bwd_nwg * d->ndir) ? 1 : 0;
+  // the BPTT launch also carries the in-launch weight-gradient roles when they fit (marn_cell_bwd's plan): count them
+  const long wgrad_wgs = (long)d->ndir * 2 * ((4 * H / 32) / 2);
+  const long cell_wgs = (long)bwd_nwg * d->ndir + ((g_opt_wgrad_inkernel && H == 128 && D <= H) ? wgrad_wgs : 0);
+  return (partner_wgs >= 0 && persist_ok(H, (long)bwd_nwg * d->ndir) && cell_wgs + partner_wgs <= num_cus()) ? 1 : 0;
 }
 
 int mser_marn_cell_pipelined(int32_t B, int32_t H, int32_t ndir) {

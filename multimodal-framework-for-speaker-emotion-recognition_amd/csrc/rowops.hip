@@ -402,13 +402,28 @@ __global__ __launch_bounds__(1024) void masked_nll_fwd_kernel(const float* pred,
 // divided by sum(mask) (w == null) or sum(w[target] * mask).  CrossEntropyLoss re-applies log_softmax to pred * mask: on the
 // log-probabilities of a valid row that is the identity, but a masked row (pred * 0) contributes w[y] * log(C) to the numerator --
 // the reference's reported loss on padded batches with its default --loss CrossEntropy (train.py:117) includes that term.
+// Labels: torch's lossers skip rows whose target is ignore_index (-100: no term in the sum; the reference's denominator
+// sum(mask) still counts the row) and raise on any other target outside [0, C).  A launch cannot raise: such a row is skipped and
+// MSER_FAULT_BAD_LABEL is ORed into *fault (the trainer raises at its next synchronisation); with class weights an ignored row
+// would make the reference index weight[-100], so it counts as a bad label there.
+__device__ __forceinline__ bool label_ok(long y, int C, bool weighted, unsigned* fault) {
+  if (y >= 0 && y < C) return true;
+  if (!(y == -100 && !weighted) && fault) atomicOr(fault, (unsigned)MSER_FAULT_BAD_LABEL);
+  return false;
+}
+
 __global__ __launch_bounds__(1024) void masked_loss_fwd_kernel(const float* pred, const long* target, const float* mask,
-                                                               const float* weight, int is_ce, long rows, int C, float* loss_out) {
+                                                               const float* weight, int is_ce, long rows, int C, float* loss_out,
+                                                               unsigned* fault) {
   __shared__ float s_num[16], s_den[16];
   float num = 0.f, den = 0.f;
   for (long r = threadIdx.x; r < rows; r += 1024) {
     const float m = mask[r];
     const long y = target[r];
+    if (!label_ok(y, C, weight != nullptr, fault)) {
+      if (!weight) den += m;
+      continue;
+    }
     const float w = weight ? weight[y] : 1.f;
     const float* p = pred + r * C;
     if (is_ce) {
@@ -440,9 +455,15 @@ __global__ void masked_loss_bwd_kernel(const float* pred, const long* target, co
   if (r >= rows) return;
   const float m = mask[r];
   const long y = target[r];
+  float* d = dpred + r * C;
+  // an empty shard (sum(mask) == 0: the forward reports 0/0 like the reference) contributes a ZERO gradient, so that the
+  // data-parallel sum n_r * g_r over the ranks stays finite; ignored / out-of-range labels contribute nothing either
+  if (!(y >= 0 && y < C) || loss_out[1] == 0.f) {
+    for (int c = 0; c < C; ++c) d[c] = 0.f;
+    return;
+  }
   const float k = (gscale_dev ? *gscale_dev : 1.f) * (weight ? weight[y] : 1.f) / loss_out[1];
   const float* p = pred + r * C;
-  float* d = dpred + r * C;
   if (is_ce) {
     float mx = -INFINITY;
     for (int c = 0; c < C; ++c) mx = fmaxf(mx, m * p[c]);
@@ -482,7 +503,8 @@ __global__ void adam_flat_kernel(float* p, const float* g, float* m, float* v, c
 
 // Graph-capturable Adam: the step counter and learning rate live on the device, so a captured launch stays valid for every
 // replay.  hp = {lr, beta1, beta2}; sched (2 floats of scratch) receives lr/(1-beta1^t) and 1/sqrt(1-beta2^t).
-__global__ void adam_sched_kernel(int* step, const float* hp, float* sched) {
+__global__ void adam_sched_kernel(int* step, const float* hp, float* sched, const unsigned* fault, const float* gfault) {
+  if ((fault && *fault != 0u) || (gfault && *gfault != 0.f)) return;        // a faulted step is not applied (see adam_flat_dev_kernel): it does not count either
   const int t = *step + 1;
   *step = t;
   const double bc1 = 1.0 - pow((double)hp[1], (double)t), bc2 = 1.0 - pow((double)hp[2], (double)t);
@@ -491,9 +513,13 @@ __global__ void adam_sched_kernel(int* step, const float* hp, float* sched) {
 }
 
 __global__ void adam_flat_dev_kernel(float* p, const float* g, float* m, float* v, const uint8_t* live, long n, const float* sched,
-                                     const float* hp, float eps, float wd, const float* gscale_dev, float gscale) {
+                                     const float* hp, float eps, float wd, const float* gscale_dev, float gscale,
+                                     const unsigned* fault, const float* gfault) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  // the sticky fault word of this step's kernels is set (a persistent chain gave up at a bounded wait, a label was out of range):
+  // the gradients are not to be trusted, leave parameters and moments untouched; the host raises when it next reads the word
+  if ((fault && *fault != 0u) || (gfault && *gfault != 0.f)) return;     // gfault: the ranks' fault flags, summed by the all-reduce
   if (live && !live[i]) return;
   const float b1 = hp[1], b2 = hp[2];
   const float gs = gscale_dev ? gscale / *gscale_dev : gscale;
@@ -506,12 +532,12 @@ __global__ void adam_flat_dev_kernel(float* p, const float* g, float* m, float* 
   p[i] = pi - sched[0] * mi / (sqrtf(vi) * sched[1] + eps);
 }
 
-// buf[0..n) = g[0..n) * (*cnt) ; buf[n] = *cnt       (pack for the single data-parallel all-reduce)
-__global__ void dp_pack_kernel(float* buf, const float* g, const float* cnt, long n) {
+// buf[0..n) = g[0..n) * (*cnt) ; buf[n] = *cnt ; buf[n+1] = (*fault != 0)      (pack for the single data-parallel all-reduce)
+__global__ void dp_pack_kernel(float* buf, const float* g, const float* cnt, long n, const unsigned* fault) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const float c = *cnt;
   if (i < n) buf[i] = g[i] * c;
-  if (i == 0) buf[n] = c;
+  if (i == 0) { buf[n] = c; buf[n + 1] = (fault && *fault != 0u) ? 1.f : 0.f; }
 }
 
 
@@ -728,10 +754,10 @@ int mser_masked_nll_bwd(const int64_t* target, const float* mask, const float* l
 }
 
 int mser_masked_loss_fwd(const float* pred, const int64_t* target, const float* mask, const float* weight, int32_t is_ce,
-                         int64_t rows, int32_t C, float* loss_out, mser_stream_t stream) {
+                         int64_t rows, int32_t C, float* loss_out, uint32_t* fault, mser_stream_t stream) {
   MSER_REQUIRE(pred && target && mask && loss_out && rows > 0 && C > 0, "mser_masked_loss_fwd: bad arguments");
   hipLaunchKernelGGL(masked_loss_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, (const long*)target, mask, weight,
-                     is_ce, (long)rows, C, loss_out);
+                     is_ce, (long)rows, C, loss_out, (unsigned*)fault);
   return check_launch("mser_masked_loss_fwd");
 }
 
@@ -756,18 +782,18 @@ int mser_adam_flat(float* p, const float* g, float* m, float* v, const uint8_t* 
 
 int mser_adam_flat_dev(float* p, const float* g, float* m, float* v, const uint8_t* live, int64_t n, int32_t* step_dev,
                        const float* hp_dev, float* sched_dev, float eps, float wd, const float* gscale_div_dev, float gscale,
-                       mser_stream_t stream) {
+                       const uint32_t* fault, const float* gfault, mser_stream_t stream) {
   MSER_REQUIRE(p && g && m && v && step_dev && hp_dev && sched_dev, "mser_adam_flat_dev: bad arguments");
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(adam_sched_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, hp_dev, sched_dev);
+  hipLaunchKernelGGL(adam_sched_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, hp_dev, sched_dev, (const unsigned*)fault, gfault);
   hipLaunchKernelGGL(adam_flat_dev_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, live, (long)n, sched_dev,
-                     hp_dev, eps, wd, gscale_div_dev, gscale);
+                     hp_dev, eps, wd, gscale_div_dev, gscale, (const unsigned*)fault, gfault);
   return check_launch("mser_adam_flat_dev");
 }
 
-int mser_dp_pack(float* buf, const float* g, const float* cnt_dev, int64_t n, mser_stream_t stream) {
+int mser_dp_pack(float* buf, const float* g, const float* cnt_dev, int64_t n, const uint32_t* fault, mser_stream_t stream) {
   MSER_REQUIRE(buf && g && cnt_dev && n > 0, "mser_dp_pack: bad arguments");
-  hipLaunchKernelGGL(dp_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, buf, g, cnt_dev, (long)n);
+  hipLaunchKernelGGL(dp_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, buf, g, cnt_dev, (long)n, (const unsigned*)fault);
   return check_launch("mser_dp_pack");
 }
 

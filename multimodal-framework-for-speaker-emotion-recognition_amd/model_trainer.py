@@ -18,8 +18,8 @@ import torch.nn as nn
 from loss import MaskedLoss
 from models.lsthm_onlysp import MARN1_onlysp
 from models.lsthm_sps import MARN1_sps
-from mser import ops
-from mser.dist import FlatAllReduce
+from mser import fault, ops
+from mser.dist import FlatAllReduce, broadcast_replica
 from mser.functional import zero_dropout
 from mser.metrics import accuracy_and_weighted_f1
 from mser.optim import FlatAdam, StepLR
@@ -57,6 +57,7 @@ class ModelTrainer(nn.Module):
         self.optim = FlatAdam(self.model.flat_store, lr=lr, weight_decay=2e-5)
         self.scheduler = StepLR(self.optim, step_size=test_step, gamma=lr_decay)
         self._allreduce = None
+        self._replicated = False
         if not kwargs.get("quiet", False):
             print(time.strftime("%m-%d %H:%M:%S") + " Model para number = %.2f" % (
                 sum(param.numel() for param in self.model.parameters()) / 1024 / 1024))
@@ -72,6 +73,12 @@ class ModelTrainer(nn.Module):
 
     def forward_backward(self, x, qmask, umask, label):
         """zero_grad + forward + MaskedLoss + backward (graph-capturable: no host sync, no host-dependent scalars)."""
+        if not self._replicated and self._world() > 1:
+            # identical replicas before the first data-parallel step, whatever each rank's initialiser drew (outside any capture)
+            self.model._ensure_attached(x.device)
+            self.optim._ensure_state()
+            broadcast_replica(self.model.flat_store, self.optim)
+            self._replicated = True
         self.optim.zero_grad()
         lp_, x_a, x_l = self.model(x, qmask, umask)
         loss = self.loss(lp_, label.view(-1), umask)
@@ -87,9 +94,10 @@ class ModelTrainer(nn.Module):
         if self._world() > 1:
             store = self.model.flat_store
             if self._allreduce is None:
-                self._allreduce = FlatAllReduce(store.total, store.grad.device)
+                self._allreduce = FlatAllReduce(store.total, store.grad.device,
+                                                host_staging=torch.distributed.get_backend() == "gloo")
             self._allreduce.reduce(store.grad, umask.sum())
-            self.optim.step(sync_hp=sync_hp, grad=self._allreduce.grad, grad_div=self._allreduce.count)
+            self.optim.step(sync_hp=sync_hp, grad=self._allreduce.grad, grad_div=self._allreduce.count, gfault=self._allreduce.faults)
         else:
             self.optim.step(sync_hp=sync_hp)
 
@@ -110,9 +118,14 @@ class ModelTrainer(nn.Module):
             loss, n = self.train_step(self._features(r1, r2, r3, r4, acouf), qmask, umask, label)
             num += loss.double() * n.double()
             den += n.double()
+        if self._world() > 1:                        # the epoch's loss over ALL ranks' utterances (one tiny collective per epoch)
+            nd = torch.stack([num, den])
+            torch.distributed.all_reduce(nd)
+            num, den = nd[0], nd[1]
         avg_loss = round(float(num / den), 4)
-        if hasattr(self.model, "check_links"):       # (the float() above has synchronised already)
-            self.model.check_links()
+        # (the float() above has synchronised) any persistent chain that gave up, linked launch that timed out or label out of range
+        # during this epoch left the device's sticky fault word set -- and Adam skipped those steps on the device
+        fault.check(self.device, "ModelTrainer.train_network")
         return lr, avg_loss
 
     def eval_network(self, loader, return_predictions=False):
@@ -132,6 +145,7 @@ class ModelTrainer(nn.Module):
                 if return_predictions:
                     cols.append((pred, label.view(-1), umask.reshape(-1)))
         acc, wf1 = accuracy_and_weighted_f1(conf.cpu().numpy())
+        fault.check(self.device, "ModelTrainer.eval_network")
         avg_accuracy, avg_fscore = round(acc * 100, 2), round(wf1 * 100, 2)
         if return_predictions:
             table = {k: np.concatenate([c[i].cpu().numpy() for c in cols]) for i, k in enumerate(("preds", "labels", "masks"))}

@@ -10,7 +10,7 @@ encoder pass takes the first pass's output; the head is ``nn_out`` on the concat
 import torch
 import torch.nn as nn
 
-from mser import ops
+from mser import fault, ops
 from mser.autograd import require_gpu
 from mser.flat import FlatStore
 from mser.model_fn import DropCfg, ModelDims
@@ -65,10 +65,7 @@ class _OnlyspFn(torch.autograd.Function):
             store.zero_grad()
         if dlp is None:
             dlp = torch.zeros_like(c.lp)
-        if model._link_status is None or model._link_status.device != dlp.device:
-            model._link_status = torch.zeros(1, device=dlp.device, dtype=torch.int32)
-        onlysp_backward(c, store.p, store.g, dlp, dxl, dxa, status=model._link_status)
-        model._last_cell = (c.cell_ws, c.L, c.B)
+        onlysp_backward(c, store.p, store.g, dlp, dxl, dxa)
         store.publish_grads()
         ctx.c = None
         return None, None, None, None, None
@@ -115,8 +112,6 @@ class MARN1_onlysp(nn.Module):
         self.dropout_seed = 0x5EED
         self.dropout_enabled = True
         self._rng = None
-        self._link_status = None             # device flag of the linked (concurrent) GRU BPTT launches, see check_links()
-        self._last_cell = None
         dead = [c + n for c in ("marn_cell_f.", "marn_cell_b.") for n in _CELL_DEAD]
         dead += [e + n for e in ("encoder_l.", "encoder_a.") for n in ("pos_ffn.fc.weight", "pos_ffn.fc.bias")]
         dead += ["linear.weight", "linear.bias"]
@@ -161,11 +156,10 @@ class MARN1_onlysp(nn.Module):
         return cfg
 
     def check_links(self) -> None:
-        """Synchronising health check of the counter-linked concurrent launches (mser.onlysp_fn LINK_GRU_*): raises if a GRU BPTT
-        ever gave up its bounded wait for the cell's BPTT since the model was created.  Cheap enough for once per epoch."""
-        if self._link_status is not None and int(self._link_status.item()) != 0:
-            raise RuntimeError("MARN1_onlysp: a linked GRU BPTT launch timed out waiting for the LSTHM BPTT (the two launches were not "
-                               "co-resident); gradients of that step are wrong.  Set mser.onlysp_fn.LINK_GRU_BWD = False.")
+        """Synchronising health check of every persistent / counter-linked launch issued on this device since the last check (the
+        cell's own barriers, the linked GRU launches, label range): raises if the device's sticky fault word is set (mser.fault).
+        ``ModelTrainer`` calls ``mser.fault.check`` itself once per epoch; kept as a method for callers of the bare model."""
+        fault.check(self._store.data.device if self._store.data is not None else "cuda", "MARN1_onlysp")
 
     def forward(self, x, qmask, umask):
         require_gpu(x, qmask, umask)

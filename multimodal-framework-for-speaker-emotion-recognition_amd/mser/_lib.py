@@ -52,7 +52,7 @@ class CellDesc(C.Structure):
         ("dir", CellDir * 2), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("dx_l_add", _P2), ("dx_a_add", _P2),
         ("rng", C.c_void_p), ("drop_site", C.c_uint32 * 2), ("p_state", C.c_float * 2), ("p_attn", C.c_float * 2),
-        ("ext_hq", _P2), ("ext_dhq", _P2), ("ext_linked", C.c_int32),
+        ("ext_hq", _P2), ("ext_dhq", _P2), ("ext_linked", C.c_int32), ("fault", C.c_void_p),
     ]
 
 
@@ -105,6 +105,7 @@ class HeadTailDesc(C.Structure):
 
 MSER_GEMM_RELU = 1
 MSER_GEMM_ACCUM = 2
+MSER_FAULT_CHAIN_TIMEOUT, MSER_FAULT_LINK_TIMEOUT, MSER_FAULT_BAD_LABEL = 1, 2, 4
 
 _i32, _i64, _f32, _vp, _sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
@@ -144,9 +145,9 @@ SIGNATURES = {
     "mser_logsoftmax_tb_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mser_masked_nll_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "mser_masked_nll_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
-    "mser_marn_cell_ext_link": (C.c_int, [C.POINTER(CellDesc), _i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+    "mser_marn_cell_ext_link": (C.c_int, [C.POINTER(CellDesc), _i32, _i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
-    "mser_marn_cell_ext_link_bwd": (C.c_int, [C.POINTER(CellDesc), _i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+    "mser_marn_cell_ext_link_bwd": (C.c_int, [C.POINTER(CellDesc), _i32, _i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                               C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                               C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
     "mser_gru_speaker_save_bytes": (C.c_size_t, [_i32, _i32, _i32]),
@@ -157,11 +158,11 @@ SIGNATURES = {
     "mser_rng_advance": (C.c_int, [_vp, _vp]),
     "mser_ingest_features": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "mser_confusion_update": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
-    "mser_masked_loss_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp]),
+    "mser_masked_loss_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     "mser_masked_loss_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp]),
     "mser_adam_flat": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
-    "mser_adam_flat_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _f32, _vp, _f32, _vp]),
-    "mser_dp_pack": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "mser_adam_flat_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _f32, _vp, _f32, _vp, _vp, _vp]),
+    "mser_dp_pack": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "mser_set_option": (C.c_int, [_i32, _i32]),
     "mser_marn_cell_status": (C.c_int, [C.POINTER(CellDesc), _vp]),
     "mser_prof_enable": (C.c_int, [_i32, _i32]),
@@ -189,7 +190,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.mser_version() < 112:
+    if lib.mser_version() < 120:
         raise RuntimeError("libmser.so is older than this binding")
     _lib = lib
     return lib

@@ -20,7 +20,7 @@ from typing import Optional
 import torch
 
 from . import functional as F_
-from . import ops
+from . import fault, ops
 from .functional import Layout
 from .model_fn import DropCfg, Getter, ModelDims, _Streams, _sub
 
@@ -204,7 +204,8 @@ def onlysp_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mod
     links = None
     if LINK_GRU_FWD and not torch.cuda.is_current_stream_capturing():
         probe = ops.make_cell_desc(Ln, B, D, H, c.x_l, c.x_a, c.cell_dirs, 10 * H, c.cell_ws)
-        links = [ops.cell_ext_link(probe, i) for i in range(2)]
+        gru_wgs = 2 * ((B + 15) // 16)            # the producer launch: both directions' chains, one 16-dialogue block per workgroup
+        links = [ops.cell_ext_link(probe, i, gru_wgs) for i in range(2)]
         if not all(lk[5] for lk in links):
             links = None
     c.gru = []
@@ -308,12 +309,12 @@ def onlysp_backward(c: OnlyspCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: O
         dgs = [(torch.empty(N, 3 * H, device=dev), torch.empty(N, 3 * H, device=dev)) for _ in range(2)]
         blinks = None
         if LINK_GRU_BWD and not torch.cuda.is_current_stream_capturing():
-            blinks = [ops.cell_ext_link_bwd(desc, i) for i in range(2)]
+            blinks = [ops.cell_ext_link_bwd(desc, i, 2 * ((B + 15) // 16)) for i in range(2)]
             if not all(lk[6] for lk in blinks):
                 blinks = None
         ops.marn_cell_run(desc, ops.PHASE_BWD_PREP)                # zeroes the BPTT step counters: before producer AND consumer
         if blinks is not None:
-            c.gru_status = status if status is not None else torch.zeros(1, device=dev, dtype=torch.int32)
+            c.gru_status = status if status is not None else fault.word(dev)
             for i in range(2):
                 ops.gru_speaker_link_bwd(c.gru[i].desc, blinks[i], dgs[i][0], dgs[i][1], c.gru_status)
             s_g = _Streams.get(dev)[2]

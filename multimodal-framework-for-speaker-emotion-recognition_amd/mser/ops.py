@@ -13,6 +13,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib as L
+from . import fault
 
 Tensor = torch.Tensor
 
@@ -403,6 +404,8 @@ def gru_speaker_link_bwd(desc: L.GruSpeakerDesc, link, dgi: Tensor, dgh: Tensor,
     desc.dhs, desc.dgi, desc.dgh = dhq, _p(dgi), _p(dgh)
     desc.dhs_add[0] = desc.dhs_add[1] = None
     desc.sub_counter, desc.sub_per_step, desc.sub_parts, desc.sub_nparts, desc.sub_part_stride = cnt, per_step, parts, n_parts, part_stride
+    if status is None:
+        status = fault.word(dgi.device)
     desc.status = _p(status)
     desc._keep_bwd = (dgi, dgh, status)
 
@@ -473,8 +476,8 @@ def confusion_update(lp: Tensor, label: Tensor, mask: Tensor, conf: Tensor, pred
 
 def masked_loss_fwd(pred: Tensor, target: Tensor, mask: Tensor, weight: Optional[Tensor], is_ce: bool, loss_out: Tensor) -> None:
     rows, Cn = pred.shape
-    L.check(_lib().mser_masked_loss_fwd(_p(pred), _p(target), _p(mask), _p(weight), int(is_ce), rows, Cn, _p(loss_out), _stream()),
-            "masked_loss_fwd")
+    L.check(_lib().mser_masked_loss_fwd(_p(pred), _p(target), _p(mask), _p(weight), int(is_ce), rows, Cn, _p(loss_out),
+                                          _p(fault.word(pred.device)), _stream()), "masked_loss_fwd")
 
 
 def masked_loss_bwd(pred: Tensor, target: Tensor, mask: Tensor, weight: Optional[Tensor], is_ce: bool, loss_out: Tensor,
@@ -492,13 +495,17 @@ def adam_flat(p: Tensor, g: Tensor, m: Tensor, v: Tensor, live: Optional[Tensor]
 
 def adam_flat_dev(p: Tensor, g: Tensor, m: Tensor, v: Tensor, live: Optional[Tensor], step_dev: Tensor, hp_dev: Tensor,
                   sched_dev: Tensor, eps: float = 1e-8, wd: float = 0.0, gscale_div_dev: Optional[Tensor] = None,
-                  gscale: float = 1.0) -> None:
+                  gscale: float = 1.0, gfault: Optional[Tensor] = None) -> None:
+    """The update is skipped on the device while this device's sticky fault word (mser.fault) is set, or while ``gfault`` (float
+    [1]: the ranks' fault flags summed by the data-parallel all-reduce) is non-zero."""
     L.check(_lib().mser_adam_flat_dev(_p(p), _p(g), _p(m), _p(v), _p(live), p.numel(), _p(step_dev), _p(hp_dev), _p(sched_dev),
-                                        eps, wd, _p(gscale_div_dev), gscale, _stream()), "adam_flat_dev")
+                                        eps, wd, _p(gscale_div_dev), gscale, _p(fault.word(p.device)), _p(gfault), _stream()),
+            "adam_flat_dev")
 
 
 def dp_pack(buf: Tensor, g: Tensor, cnt_dev: Tensor) -> None:
-    L.check(_lib().mser_dp_pack(_p(buf), _p(g), _p(cnt_dev), g.numel(), _stream()), "dp_pack")
+    """buf [n + 2] = g * cnt | cnt | (this device's fault word != 0)."""
+    L.check(_lib().mser_dp_pack(_p(buf), _p(g), _p(cnt_dev), g.numel(), _p(fault.word(g.device)), _stream()), "dp_pack")
 
 
 def lsthm_step_fwd(x, c, h, z, s, W, Wb, U, Ub, V, Vb, S, Sb, c_out, h_out, gates=None) -> None:
@@ -596,6 +603,7 @@ def make_cell_desc(T: int, B: int, D: int, H: int, x_l: Tensor, x_a: Tensor, dir
         for i in range(len(dirs)):
             d.drop_site[i], d.p_state[i], d.p_attn[i] = int(sites[i]), float(p_state[i]), float(p_attn[i])
     d.ext_linked = 1 if ext_linked else 0
+    d.fault = _p(fault.word(workspace.device))
     for i, t in enumerate(ext_hq):          # external speaker state per direction ([T*B, H] contiguous) and its gradient buffer
         if not t.is_contiguous() or (i < len(ext_dhq) and not ext_dhq[i].is_contiguous()):
             raise RuntimeError("ext_hq / ext_dhq must be contiguous")
@@ -605,23 +613,24 @@ def make_cell_desc(T: int, B: int, D: int, H: int, x_l: Tensor, x_a: Tensor, dir
     return d
 
 
-def cell_ext_link(desc: L.CellDesc, direction: int):
-    """(hq_rows pointer, counter pointer, replicas, replica stride, per-step increment, persistent?) for a linked producer of
-    direction ``direction``'s speaker rows (include/mser.h mser_marn_cell_ext_link)."""
+def cell_ext_link(desc: L.CellDesc, direction: int, partner_wgs: int):
+    """(hq_rows pointer, counter pointer, replicas, replica stride, per-step increment, link possible?) for a linked producer of
+    direction ``direction``'s speaker rows whose launch has ``partner_wgs`` workgroups (include/mser.h mser_marn_cell_ext_link)."""
     hq, cnt = C.c_void_p(), C.c_void_p()
     rep, stride, inc = C.c_int32(), C.c_int32(), C.c_uint32()
-    rc = _lib().mser_marn_cell_ext_link(C.byref(desc), direction, C.byref(hq), C.byref(cnt), C.byref(rep), C.byref(stride), C.byref(inc))
+    rc = _lib().mser_marn_cell_ext_link(C.byref(desc), direction, int(partner_wgs), C.byref(hq), C.byref(cnt), C.byref(rep),
+                                        C.byref(stride), C.byref(inc))
     if rc < 0:
         L.check(rc, "marn_cell_ext_link")
     return hq.value, cnt.value, rep.value, stride.value, inc.value, rc == 1
 
 
-def cell_ext_link_bwd(desc: L.CellDesc, direction: int):
-    """(dhq pointer, parts pointer, n_parts, part stride, counter pointer, per-step count, persistent?) for a linked consumer of
-    direction ``direction``'s speaker-state gradient (include/mser.h mser_marn_cell_ext_link_bwd)."""
+def cell_ext_link_bwd(desc: L.CellDesc, direction: int, partner_wgs: int):
+    """(dhq pointer, parts pointer, n_parts, part stride, counter pointer, per-step count, link possible?) for a linked consumer
+    (``partner_wgs`` workgroups) of direction ``direction``'s speaker-state gradient (include/mser.h mser_marn_cell_ext_link_bwd)."""
     dhq, parts, cnt = C.c_void_p(), C.c_void_p(), C.c_void_p()
     n, rep, stride, inc, ps = C.c_int32(), C.c_int32(), C.c_int32(), C.c_uint32(), C.c_int64()
-    rc = _lib().mser_marn_cell_ext_link_bwd(C.byref(desc), direction, C.byref(dhq), C.byref(parts), C.byref(n), C.byref(ps),
+    rc = _lib().mser_marn_cell_ext_link_bwd(C.byref(desc), direction, int(partner_wgs), C.byref(dhq), C.byref(parts), C.byref(n), C.byref(ps),
                                             C.byref(cnt), C.byref(rep), C.byref(stride), C.byref(inc))
     if rc < 0:
         L.check(rc, "marn_cell_ext_link_bwd")

@@ -53,16 +53,18 @@ class FlatAdam:
             self.hp_dev.copy_(torch.tensor(hp, dtype=torch.float32))
             self._hp_host = hp
 
-    def step(self, sync_hp: bool = True, grad: Optional[torch.Tensor] = None, grad_div: Optional[torch.Tensor] = None) -> None:
+    def step(self, sync_hp: bool = True, grad: Optional[torch.Tensor] = None, grad_div: Optional[torch.Tensor] = None,
+             gfault: Optional[torch.Tensor] = None) -> None:
         """``grad`` / ``grad_div`` (device tensors) override the flat gradient: the data-parallel path passes the all-reduced
-        buffer and the global mask count so that no copy-back or separate scaling pass is needed."""
+        buffer and the global mask count so that no copy-back or separate scaling pass is needed.  The launch skips the update on the
+        device while the device's fault word (mser.fault) or ``gfault`` (the all-reduced fault flags) is non-zero."""
         if self.store.data is None:
             raise RuntimeError("FlatAdam.step() before the first forward/backward")
         if sync_hp:
             self.sync_hyperparams()
         g = self.param_groups[0]
         ops.adam_flat_dev(self.store.data, self.store.grad if grad is None else grad, self.m, self.v, self.store.live,
-                          self.step_dev, self.hp_dev, self.sched_dev, g["eps"], g["weight_decay"], grad_div, 1.0)
+                          self.step_dev, self.hp_dev, self.sched_dev, g["eps"], g["weight_decay"], grad_div, 1.0, gfault)
 
     def state_dict(self):
         return dict(step=self.step_count, m=self.m, v=self.v, param_groups=self.param_groups)

@@ -33,7 +33,7 @@ for (B, L) in ((32, 128), (48, 40), (17, 64), (64, 32), (32, 16)):
         lp1, g1 = run(True)
         mism += int(not torch.equal(lp1, lp0))
         gmax = max(gmax, float((g1 - g0).abs().max()) / max(1e-9, float(g0.abs().max())))
-    net.check_links()
+    net.check_links()          # raises if the sticky fault word is set (mser.fault)
     print(f"B={B} L={L}: {mism} / {reps} forward mismatches, worst relative gradient difference {gmax:.2e}", flush=True)
     bad += mism + int(gmax > 1e-5)
 ofn.LINK_GRU_FWD = ofn.LINK_GRU_BWD = True

@@ -1,0 +1,239 @@
+"""GPU side of the data-parallel step and of the sticky fault word (run with -m gpu):
+
+* world 1: ``FlatAllReduce.reduce`` on CUDA tensors (``mser_dp_pack``) + ``FlatAdam.step(grad=, grad_div=, gfault=)`` against the
+  plain step and against ``oracle.adam_step``;
+* world 2 on ONE GPU (two processes, gloo through a pinned host copy): shard -> the product's forward/backward per rank -> dp_pack ->
+  all-reduce -> fused Adam with the global count, against the same two shards run in one process and combined by hand;
+* world 2 over RCCL ("nccl") when the box has two GPUs (skipped otherwise);
+* the fault word: a set word makes the fused Adam skip on the device and the trainer raise; out-of-range labels set it; an
+  empty shard yields zero gradients, not NaN.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import load_params, maxabs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import ref_cpu
+    return ref_cpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_dp_pack_and_adam_grad_div_world1(O):
+    """The device branch of FlatAllReduce.reduce (mser_dp_pack) and the grad / grad_div / gfault branch of the fused Adam."""
+    from mser import fault
+    from mser.dist import FlatAllReduce
+    from mser.flat import FlatStore
+    from mser.optim import FlatAdam
+    fault.word("cuda:0").zero_()
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.Linear(19, 5)).cuda()
+    lin2 = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.Linear(19, 5)).cuda()
+    lin2.load_state_dict(lin.state_dict())
+    sa, sb = FlatStore(lin), FlatStore(lin2)
+    sa.attach(torch.device("cuda:0"))
+    sb.attach(torch.device("cuda:0"))
+    oa, ob = FlatAdam(sa, 1e-3, weight_decay=2e-5), FlatAdam(sb, 1e-3, weight_decay=2e-5)
+    ar = FlatAllReduce(sa.total, "cuda:0")
+    ref = {n: (sa.p(n).detach().cpu().clone(), torch.zeros(sa.shapes[n]), torch.zeros(sa.shapes[n])) for n in sa.names}
+    for step in (1, 2, 3):
+        g = torch.tensor(np.random.RandomState(step).standard_normal(sa.total).astype(np.float32)).cuda()
+        n_local = torch.tensor(7.0 + step, device="cuda")
+        sa.grad.copy_(g)
+        sb.grad.copy_(g)
+        ar.reduce(sa.grad, n_local)                                   # buf = g * n | n | 0
+        assert torch.equal(ar.grad, g * n_local) and float(ar.count) == 7.0 + step and float(ar.faults) == 0.0
+        oa.step(grad=ar.grad, grad_div=ar.count, gfault=ar.faults)    # (g * n) / n
+        ob.step()
+        for name in sa.names:
+            off, shp = sa.offsets[name], sa.shapes[name]
+            numel = int(np.prod(shp))
+            O.adam_step(ref[name][0], g[off:off + numel].cpu().view(shp), ref[name][1], ref[name][2], step, 1e-3, wd=2e-5)
+    assert maxabs(sa.data, sb.data) < 2e-7                            # g*n/n rounds once more than g
+    for name in sa.names:
+        assert maxabs(sa.p(name), ref[name][0]) < 1e-6, name
+    assert oa.step_count == 3
+
+
+def test_fault_word_skips_adam_and_trainer_raises(O):
+    """A set fault word: the fused Adam leaves parameters, moments and the step counter untouched (on the device, no host round trip),
+    dp_pack forwards the flag, and ModelTrainer.train_network raises at its epoch-end synchronisation."""
+    from model_trainer import ModelTrainer
+    from mser import fault
+    from mser.dist import FlatAllReduce
+    dev = torch.device("cuda:0")
+    w = fault.word(dev)
+    w.zero_()
+    tr = ModelTrainer(dev, 1e-3, 1, 0.98, "MARN1_sps", "NLL", 6, "IEMOCAP", d_r=64, quiet=True, dropout=False)
+    load_params(tr.model, O.seeded_params(seed=5, d_r=64))
+    x, qmask, umask, label = (t.cuda() for t in O.seeded_batch(3, 5, d_r=64, seed=6, ragged=True))
+    tr.train()
+    tr.scheduler.step(0)
+    tr.train_step(x, qmask, umask, label)
+    before = tr.model.flat_store.data.clone()
+    m_before = tr.optim.m.clone()
+    assert tr.optim.step_count == 1
+    w.fill_(1)                                           # as a timed-out chain would leave it
+    tr.train_step(x, qmask, umask, label)
+    assert torch.equal(tr.model.flat_store.data, before) and torch.equal(tr.optim.m, m_before) and tr.optim.step_count == 1
+    ar = FlatAllReduce(8, dev)
+    ar.reduce(torch.ones(8, device=dev), torch.tensor(2.0, device=dev))
+    assert float(ar.faults) == 1.0
+    r = x[:, :, :64]
+    batch = [r, r, r, r, torch.zeros(5, 3, 4), x[:, :, 64:], qmask, umask, label, ["v"] * 3]
+    with pytest.raises(RuntimeError, match="device fault"):
+        tr.train_network(1, [batch])
+    assert fault.peek(dev) == 0                          # check() cleared it: the next epoch trains again
+    tr.train_network(1, [batch])
+    assert not torch.equal(tr.model.flat_store.data, before)
+    # all-reduced flag alone (another rank faulted): this rank skips too
+    snap = tr.model.flat_store.data.clone()
+    tr.optim.step(gfault=torch.ones(1, device=dev))
+    assert torch.equal(tr.model.flat_store.data, snap)
+
+
+def test_bad_label_sets_fault_and_ignore_index(O):
+    """loss.py:19-24: torch's lossers raise on a target outside [0, C) and skip ignore_index = -100.  Here: the row is skipped and the
+    fault word says so / the row is skipped silently but still counts in sum(mask)."""
+    from loss import MaskedLoss
+    from mser import fault
+    dev = torch.device("cuda:0")
+    fault.word(dev).zero_()
+    rs = np.random.RandomState(3)
+    pred = torch.log_softmax(torch.tensor(rs.standard_normal((12, 6)).astype(np.float32)), 1)
+    target = torch.tensor(rs.randint(0, 6, 12))
+    mask = torch.ones(3, 4)
+    mask[2, 3] = 0
+    for is_ce, losser in ((False, torch.nn.NLLLoss), (True, torch.nn.CrossEntropyLoss)):
+        t2 = target.clone()
+        t2[1] = -100
+        p = pred.clone().cuda().requires_grad_(True)
+        out = MaskedLoss(losser)(p, t2.cuda(), mask.cuda())
+        out.backward()
+        pr = pred.clone().requires_grad_(True)
+        ref = losser(reduction="sum")(pr * mask.view(-1, 1), t2) / mask.sum()
+        ref.backward()
+        assert abs(float(out) - float(ref)) < 1e-6 and maxabs(p.grad, pr.grad) < 1e-7
+        assert fault.peek(dev) == 0
+    t3 = target.clone()
+    t3[5] = 6
+    p = pred.clone().cuda().requires_grad_(True)
+    out = MaskedLoss(torch.nn.NLLLoss)(p, t3.cuda(), mask.cuda())
+    out.backward()
+    assert bool(torch.isfinite(out)) and float(p.grad[5].abs().sum()) == 0.0
+    with pytest.raises(RuntimeError, match="label"):
+        fault.check(dev, "test")
+    assert fault.peek(dev) == 0
+
+
+def test_empty_shard_contributes_zero_gradient(O):
+    """A rank whose shard has no valid utterance: the loss is 0/0 like the reference's, its gradient must be zeros (n_r * g_r
+    rides the all-reduce), not NaN."""
+    from loss import MaskedLoss
+    pred = torch.log_softmax(torch.randn(8, 6), 1).cuda().requires_grad_(True)
+    target = torch.randint(0, 6, (8,)).cuda()
+    out = MaskedLoss(torch.nn.NLLLoss)(pred, target, torch.zeros(2, 4).cuda())
+    out.backward()
+    assert not bool(torch.isfinite(out)) and float(pred.grad.abs().sum()) == 0.0
+
+
+# ---- two ranks -------------------------------------------------------------------------------------------------------------
+def _dp_worker(rank, world, port, backend, out_path, d_r, Bg, Ln):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", rank % ndev)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import ref_cpu as O
+    from model_trainer import ModelTrainer
+    from mser.dist import shard_batch
+    torch.manual_seed(100 + rank)                        # DIFFERENT initial draws per rank: the trainer must broadcast rank 0's
+    tr = ModelTrainer(dev, 1e-3, 1, 0.98, "MARN1_sps", "NLL", 6, "IEMOCAP", d_r=d_r, quiet=True, dropout=False)
+    if rank == 0:
+        load_params(tr.model, O.seeded_params(seed=31, d_r=d_r))
+    x, qmask, umask, label = O.seeded_batch(Bg, Ln, d_r=d_r, seed=32, ragged=True)
+    xs, qs, us, ls = (t.to(dev) for t in shard_batch(x, qmask, umask, label, rank, world))
+    tr.train()
+    tr.scheduler.step(0)
+    for _ in range(2):
+        tr.train_step(xs, qs, us, ls)
+    torch.cuda.synchronize()
+    flat = tr.model.flat_store.data.detach().cpu()
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        torch.save(dict(flat=flat, same=bool(all(torch.equal(g, flat) for g in gathered))), out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _dp_reference(O, d_r, Bg, Ln, world):
+    """The same two steps in ONE process: the product's forward/backward on each shard separately, gradients combined by hand with
+    the mask counts (sum_r n_r g_r / sum_r n_r), ONE fused Adam step on the combination."""
+    from model_trainer import ModelTrainer
+    from mser.dist import shard_batch
+    dev = torch.device("cuda:0")
+    tr = ModelTrainer(dev, 1e-3, 1, 0.98, "MARN1_sps", "NLL", 6, "IEMOCAP", d_r=d_r, quiet=True, dropout=False)
+    load_params(tr.model, O.seeded_params(seed=31, d_r=d_r))
+    x, qmask, umask, label = O.seeded_batch(Bg, Ln, d_r=d_r, seed=32, ragged=True)
+    shards = [[t.to(dev) for t in shard_batch(x, qmask, umask, label, r, world)] for r in range(world)]
+    tr.train()
+    tr.scheduler.step(0)
+    for _ in range(2):
+        acc, cnt = None, 0.0
+        for xs, qs, us, ls in shards:
+            tr.forward_backward(xs, qs, us, ls)
+            n = float(us.sum())
+            g = tr.model.flat_store.grad.clone() * n
+            acc = g if acc is None else acc + g
+            cnt += n
+        tr.optim.step(grad=acc, grad_div=torch.tensor([cnt], device=dev))
+    torch.cuda.synchronize()
+    return tr.model.flat_store.data.detach().cpu()
+
+
+def _run_two_ranks(O, tmp_path, backend):
+    import torch.multiprocessing as mp
+    d_r, Bg, Ln, world = 64, 6, 7, 2
+    out = str(tmp_path / f"dp_{backend}.pt")
+    mp.spawn(_dp_worker, args=(world, _free_port(), backend, out, d_r, Bg, Ln), nprocs=world, join=True)
+    res = torch.load(out, weights_only=True)
+    assert res["same"], "replicas diverged"
+    ref = _dp_reference(O, d_r, Bg, Ln, world)
+    # (the weight-gradient GEMMs accumulate split-K partials with float atomics: equal to rounding, not bitwise)
+    assert maxabs(res["flat"], ref) < 2e-6, maxabs(res["flat"], ref)
+
+
+def test_data_parallel_two_ranks_one_gpu_gloo(O, tmp_path):
+    """Two processes share cuda:0; the collective itself runs over gloo through a pinned host copy (FlatAllReduce host_staging), every
+    device-side piece of the step -- per-shard slot tables and chains, mser_dp_pack, the fused Adam with grad_div / gfault, the initial
+    replica broadcast -- is the product's."""
+    _run_two_ranks(O, tmp_path, "gloo")
+
+
+def test_data_parallel_two_ranks_rccl(O, tmp_path):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the driver's multi-GPU tier); the one-GPU gloo test above covers the device path")
+    _run_two_ranks(O, tmp_path, "nccl")
