@@ -412,6 +412,13 @@ typedef struct mser_gru_speaker_desc {
    * (dhs / dhs_add are complete at launch). */
   const uint32_t* sub_counter; uint32_t sub_per_step; const float* sub_parts; int32_t sub_nparts; int64_t sub_part_stride;
   uint32_t* status;
+  /* listener_blend != 0: the state update of model/lsthm_nsps.py:188-191 (MARN1_nsps / MARN1_no_en): both party states become
+   * ql_0 (1 - qmask[t,b,p]) + h_s qmask[t,b,p] with ql_0 = q[b, 1 - argmax(qmask[t,b])], the state of the party NOT speaking --
+   * identical to the default for a one-hot qmask row, different on padded (all-zero) rows.  hli (optional, [T*B, H]) receives the
+   * ql_0 rows (the cell's h_li output), dhli (optional) is their incoming gradient in the backward. */
+  int32_t listener_blend;
+  float* hli;
+  const float* dhli;
 } mser_gru_speaker_desc;
 
 size_t mser_gru_speaker_save_bytes(int32_t T, int32_t B, int32_t H);

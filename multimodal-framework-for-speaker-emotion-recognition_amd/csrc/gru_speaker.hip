@@ -33,6 +33,9 @@ struct GruArgs {
   // gradient rows (dhs and sub_nparts parts, sub_stride floats apart) are then read with device-coherent loads
   const unsigned* sub_cnt; unsigned sub_per_step; const float* sub_parts; int sub_nparts; long sub_stride; unsigned* status;
   const uint32_t* rng; uint32_t site; float p;
+  // lblend (model/lsthm_nsps.py:188-191): q[b,p] = ql_0 (1 - m_p) + h_s m_p with ql_0 = the state of the party NOT speaking, instead of
+  // q[b,p] (1 - m_p) + h_s m_p; hli / dhli (optional): the ql_0 rows [T*B, H] as an output (the cell's h_li) and their gradient
+  int lblend; float* hli; const float* dhli;
   // forward link to a consumer kernel (mser_cell_desc::ext_linked).  The consumer waits for counter >= pub_inc * (t + 1) = "EVERY
   // block of this chain has published step t".  The blocks run without a barrier among themselves, so they must not simply add
   // shares to the counter (a block two steps ahead would stand in for one that is behind): each block keeps its own progress word
@@ -138,8 +141,15 @@ __global__ __launch_bounds__(GNT) void gru_speaker_fwd_kernel(GruArgs2 aa) {
         sv[0] = hprev; sv[H] = rg; sv[2 * H] = zg; sv[3 * H] = ng; sv[4 * H] = ghn;
         const float m0 = qmv[row * 2], m1 = qmv[row * 2 + 1];
         float* q0 = q + row * QS + u;
-        q0[0] = q0[0] * (1.f - m0) + hv * m0;                                // :179-181
-        q0[H] = q0[H] * (1.f - m1) + hv * m1;
+        if (a.lblend) {                                                      // model/lsthm_nsps.py:188-191
+          const float ql = q0[(1 - party[row]) * H];
+          if (a.hli) a.hli[rowt * H + u] = ql;
+          q0[0] = ql * (1.f - m0) + hv * m0;
+          q0[H] = ql * (1.f - m1) + hv * m1;
+        } else {
+          q0[0] = q0[0] * (1.f - m0) + hv * m0;                              // model/lsthm_onlysp.py:179-181
+          q0[H] = q0[H] * (1.f - m1) + hv * m1;
+        }
       }
     }
     if (a.pub_cnt) __threadfence();          // release: this thread's hs rows of step t are visible device-wide before the counter moves
@@ -232,8 +242,16 @@ __global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs2 aa) {
           if (a.dhs2) dh += a.dhs2[rowt * H + u];
           if (a.dhs3) dh += a.dhs3[rowt * H + u];
         }
-        q0[0] *= (1.f - m0);
-        q0[H] *= (1.f - m1);
+        if (a.lblend) {        // both new party states took (1 - m_p) of ql_0 = q_old[1 - party]; q_old[party] is reached through qs0 only
+          float dl = q0[0] * (1.f - m0) + q0[H] * (1.f - m1);
+          if (a.dhli) dl += a.dhli[rowt * H + u];
+          const int pr = party[row];
+          q0[(1 - pr) * H] = dl;
+          q0[pr * H] = 0.f;
+        } else {
+          q0[0] *= (1.f - m0);
+          q0[H] *= (1.f - m1);
+        }
         if (a.rng) dh *= drop_scale(dk, (uint32_t)(rowt * H + u));
         const float* sv = a.save + rowt * 5 * H + u;
         const float hprev = sv[0], rg = sv[H], zg = sv[2 * H], ng = sv[3 * H], ghn = sv[4 * H];
@@ -306,6 +324,7 @@ GruArgs gru_args(const mser_gru_speaker_desc& d) {
   a.pub_progress = d.pub_progress;
   a.sub_cnt = d.sub_counter; a.sub_per_step = d.sub_per_step; a.sub_parts = d.sub_parts; a.sub_nparts = d.sub_nparts;
   a.sub_stride = d.sub_part_stride; a.status = d.status;
+  a.lblend = d.listener_blend; a.hli = d.hli; a.dhli = d.dhli;
   return a;
 }
 

@@ -16,6 +16,8 @@ import torch
 import torch.nn as nn
 
 from loss import MaskedLoss
+from models.lsthm_no_en import MARN1_no_en
+from models.lsthm_nsps import MARN1_nsps
 from models.lsthm_onlysp import MARN1_onlysp
 from models.lsthm_sps import MARN1_sps
 from mser import fault, ops
@@ -24,8 +26,7 @@ from mser.functional import zero_dropout
 from mser.metrics import accuracy_and_weighted_f1
 from mser.optim import FlatAdam, StepLR
 
-_OUT_OF_SCOPE = ("DialogueRNN", "MARN", "BiLSTM", "MARN1_newz", "MARN1_azs", "MARN1_mf", "MARN1_la", "MARN1_cf", "MARN1_sp",
-                 "MARN1_nsps", "MARN1_no_en")
+_OUT_OF_SCOPE = ("DialogueRNN", "MARN", "BiLSTM", "MARN1_newz", "MARN1_azs", "MARN1_mf", "MARN1_la", "MARN1_cf", "MARN1_sp")
 
 
 class ModelTrainer(nn.Module):
@@ -42,9 +43,14 @@ class ModelTrainer(nn.Module):
             self.model = MARN1_onlysp(n_classes, d_r=kwargs.get("d_r", 1024)).to(self.device)
             if not kwargs.get("dropout", True):
                 zero_dropout(self.model)
+        elif model in ('MARN1_nsps', 'MARN1_no_en'):   # reference :67-68, :71-72: these two take the dataset name (and ignore it)
+            cls = MARN1_nsps if model == 'MARN1_nsps' else MARN1_no_en
+            self.model = cls(n_classes, dataset, d_r=kwargs.get("d_r", 1024)).to(self.device)
+            if not kwargs.get("dropout", True):
+                zero_dropout(self.model)
         elif model in _OUT_OF_SCOPE:
-            raise NotImplementedError(f"model '{model}' is outside the accelerated hot path (SURVEY.md 8(f)); 'MARN1_sps' and "
-                                      "'MARN1_onlysp' are built")
+            raise NotImplementedError(f"model '{model}' is outside the accelerated hot path (SURVEY.md 8(f)); 'MARN1_sps', "
+                                      "'MARN1_onlysp', 'MARN1_nsps' and 'MARN1_no_en' are built")
         else:
             raise ValueError(f"unknown model '{model}'")
         if loss == 'CrossEntropy':

@@ -11,11 +11,13 @@ import torch
 import torch.nn as nn
 
 from mser import fault, ops
-from mser.autograd import require_gpu
+from mser import functional as F_
+from mser.autograd import ModuleFn, require_gpu
+from mser.gru_cell_fn import GRU_CELL_LIVE, gru_cell_backward, gru_cell_forward
 from mser.flat import FlatStore
 from mser.model_fn import DropCfg, ModelDims
 from mser.onlysp_fn import onlysp_backward, onlysp_forward
-from models.encoder import EncoderLayer
+from models.encoder import EncoderLayer, _Grads
 from models.lsthm_sps import LSTHM1, CrossAttention, CrossAttention2, CrossAttention3  # noqa: F401  (same classes in the reference file)
 
 # parameters that never receive a gradient in the reference: the LSTM cells kept from the sps variant, the unused attention modules
@@ -24,8 +26,9 @@ _CELL_DEAD = ["crossatt_l2a.Wv", "crossatt_a2l.Wq", "crossatt_a2l.Wk", "crossatt
 
 
 class MARN_cell(nn.Module):
-    """Reference model/lsthm_onlysp.py:131-206.  Holds the cell's parameters in the reference's layout; the arithmetic of both
-    directions runs inside ``MARN1_onlysp`` (one launch for the two LSTHM chains), so the cell has no forward of its own yet."""
+    """Reference model/lsthm_onlysp.py:131-206.  forward(x, x_l, x_a, qmask) -> h [T,N,4*128] = cat(h_l, h_a, z_l, h_s) (:158-197;
+    ``x`` only supplies the shape, as in the reference).  Inside ``MARN1_onlysp`` both directions share the launches
+    (mser.onlysp_fn); this forward is the same kernels for one direction (mser.gru_cell_fn)."""
 
     def __init__(self, dh_l, dh_a, d_l, d_a, dropout=0.5) -> None:
         super(MARN_cell, self).__init__()
@@ -45,7 +48,38 @@ class MARN_cell(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x, x_l, x_a, qmask):
-        raise NotImplementedError("models.lsthm_onlysp.MARN_cell runs inside MARN1_onlysp (both directions share the launches)")
+        require_gpu(x_l, x_a, qmask)
+        if not (self.dh_l == self.dh_a == self.dh_s == 128) or self.d_l != self.d_a:
+            raise RuntimeError("MARN_cell: the reference only runs with dh_l == dh_a == dh_s == 128 and d_l == d_a")
+        H, D = self.dh_l, self.d_l
+        params = dict(self.named_parameters())
+        names = GRU_CELL_LIVE
+        # train mode on its own: sites +8 (h_s), +9 (h_l / h_a), +10 (rank-1 attention) of the module generator
+        ds, da = F_.module_site(self.dropout, x_l.device, 8), F_.module_site(self.crossatt_l2a.dropout, x_l.device, 10)
+        if ds is not None and da is not None:
+            da = F_.DropSite(ds.rng, ds.site + 2, da.p)        # one generator word pair for the whole call
+        self._last_drops = (ds, da)
+
+        class Impl:
+            @staticmethod
+            def fwd(x_l, x_a, qmask, *pv):
+                P = dict(zip(names, pv)).get
+                T, N, _ = x_l.shape
+                xl2, xa2 = x_l.contiguous().view(T * N, D), x_a.contiguous().view(T * N, D)
+                out, _, ctx = gru_cell_forward(P, xl2, xa2, xl2, xa2, qmask.contiguous().float(), T, N, D, H, False, ds, da)
+                return out.view(T, N, 4 * H), (ctx, T, N)
+
+            @staticmethod
+            def bwd(saved, tensors, dout):
+                ctx, T, N = saved
+                P = dict(zip(names, [params[n].detach() for n in names])).get
+                G = _Grads({n: params[n] for n in names})
+                dx_l, dx_a, du_l, du_a = gru_cell_backward(ctx, P, G.g.get, dout.contiguous().view(T * N, 4 * H), None, True)
+                ops.add_rows(dx_l, dx_l, du_l)                 # U = cat(x_l[t], x_a[t]) (:172): the GRU reads the same rows
+                ops.add_rows(dx_a, dx_a, du_a)
+                return (dx_l.view(tensors[0].shape), dx_a.view(tensors[1].shape), None, *[G(n) for n in names])
+
+        return ModuleFn.apply(Impl, x_l, x_a, qmask, *[params[n] for n in names])
 
 
 class _OnlyspFn(torch.autograd.Function):

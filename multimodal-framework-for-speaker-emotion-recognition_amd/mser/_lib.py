@@ -88,7 +88,8 @@ class GruSpeakerDesc(C.Structure):
                 ("pub_counter", C.c_void_p), ("pub_per_step", C.c_uint32), ("pub_replicas", C.c_int32),
                 ("pub_replica_stride", C.c_int32), ("pub_progress", C.c_void_p),
                 ("sub_counter", C.c_void_p), ("sub_per_step", C.c_uint32), ("sub_parts", C.c_void_p), ("sub_nparts", C.c_int32),
-                ("sub_part_stride", C.c_int64), ("status", C.c_void_p)]
+                ("sub_part_stride", C.c_int64), ("status", C.c_void_p),
+                ("listener_blend", C.c_int32), ("hli", C.c_void_p), ("dhli", C.c_void_p)]
 
 
 class HeadTailDesc(C.Structure):

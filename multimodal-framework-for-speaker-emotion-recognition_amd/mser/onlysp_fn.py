@@ -50,8 +50,9 @@ LINK_GRU_FWD = True
 LINK_GRU_BWD = True
 
 
-def gru_speaker_dir_fwd(P: Getter, x_l: Tensor, x_a: Tensor, qmask: Tensor, rev: Optional[Tensor], out_q: Tensor, T: int, B: int,
-                        H: int, drop, launch: bool = True, hs: Optional[Tensor] = None) -> GruDirCtx:
+def gru_speaker_dir_fwd(P: Getter, x_l: Tensor, x_a: Tensor, qmask: Tensor, rev: Optional[Tensor], out_q: Optional[Tensor], T: int,
+                        B: int, H: int, drop, launch: bool = True, hs: Optional[Tensor] = None, lblend: bool = False,
+                        hli: Optional[Tensor] = None) -> GruDirCtx:
     """One direction's speaker chain.  x_l / x_a [T*B, D] natural order; ``rev`` (int32 [T, B]) selects the reversed direction;
     ``out_q`` is the h_s quarter of the cell output rows (natural order).  P: names relative to the MARN_cell.  ``launch=False``
     prepares everything (input product included) and leaves the chain launch (ops.gru_speaker_fwd(ctx.desc)) to the caller."""
@@ -72,16 +73,16 @@ def gru_speaker_dir_fwd(P: Getter, x_l: Tensor, x_a: Tensor, qmask: Tensor, rev:
     c.hs = hs if hs is not None else torch.empty(T * B, H, device=x_l.device)
     c.save = torch.empty(T * B, 5 * H, device=x_l.device)
     c.desc = ops.gru_speaker_desc(T, B, H, c.gi, P("gru_s.weight_hh"), P("gru_s.bias_hh"), c.qm, c.hs, c.save, out=out_q, rev=rev,
-                                  drop=drop)
+                                  drop=drop, lblend=lblend, hli=hli)
     if launch:
         ops.gru_speaker_fwd(c.desc)
     return c
 
 
-def gru_speaker_dir_bwd(c: GruDirCtx, P: Getter, G: Getter, dgi: Tensor, dgh: Tensor, dx_l: Tensor, dx_a: Tensor, T: int, B: int,
-                        H: int) -> None:
+def gru_speaker_dir_bwd(c: GruDirCtx, P: Getter, G: Getter, dgi: Tensor, dgh: Tensor, dx_l: Optional[Tensor], dx_a: Optional[Tensor],
+                        T: int, B: int, H: int) -> None:
     """After the chain's BPTT (ops.gru_speaker_bwd) has produced dgi / dgh: accumulates the GRU parameter gradients into G and the
-    input gradients into dx_l / dx_a (natural order)."""
+    input gradients into dx_l / dx_a (natural order; None: that input needs no gradient)."""
     D = c.xl.shape[1]
     dev = dgi.device
     gWih = G("gru_s.weight_ih")
@@ -92,6 +93,8 @@ def gru_speaker_dir_bwd(c: GruDirCtx, P: Getter, G: Getter, dgi: Tensor, dgh: Te
     ops.colsum_acc(dgh, G("gru_s.bias_hh"))
     Wih = P("gru_s.weight_ih")
     for X, Wp, dx in ((c.xl, Wih[:, :D], dx_l), (c.xa, Wih[:, D:], dx_a)):
+        if dx is None:
+            continue
         if c.rev is None:
             ops.matmul(dgi, Wp, dx, accum=True)
         else:

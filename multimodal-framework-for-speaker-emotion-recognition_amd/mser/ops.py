@@ -353,7 +353,8 @@ def masked_nll_bwd(target: Tensor, mask: Tensor, loss_out: Tensor, gscale: Optio
 
 # ---- GRU speaker state (include/mser.h mser_gru_speaker_desc)
 def gru_speaker_desc(T: int, B: int, H: int, gi: Tensor, w_hh: Tensor, b_hh: Tensor, qmask: Tensor, hs: Tensor, save: Tensor,
-                     out: Optional[Tensor] = None, rev: Optional[Tensor] = None, drop=None) -> L.GruSpeakerDesc:
+                     out: Optional[Tensor] = None, rev: Optional[Tensor] = None, drop=None, lblend: bool = False,
+                     hli: Optional[Tensor] = None) -> L.GruSpeakerDesc:
     for t in (gi, w_hh, b_hh, qmask, hs, save):
         _f32(t, "gru_speaker")
         if not t.is_contiguous():
@@ -368,8 +369,10 @@ def gru_speaker_desc(T: int, B: int, H: int, gi: Tensor, w_hh: Tensor, b_hh: Ten
     d.rev = _p(rev)
     if drop is not None:
         d.rng, d.drop_site, d.p = _p(drop.rng), drop.site, float(drop.p)
+    d.listener_blend = 1 if lblend else 0            # model/lsthm_nsps.py:188-191 (see include/mser.h)
+    d.hli = _p(hli)
     # the descriptor holds raw pointers: keep the operands referenced for as long as it lives
-    d._keep = (gi, w_hh, b_hh, qmask, hs, save, out, rev, drop.rng if drop is not None else None)
+    d._keep = (gi, w_hh, b_hh, qmask, hs, save, out, rev, drop.rng if drop is not None else None, hli)
     return d
 
 
@@ -554,10 +557,18 @@ def cell_param_struct(get) -> L.CellParams:
         "q_Wih": ("lstm_q0.weight_ih", "lstm_q1.weight_ih"), "q_Whh": ("lstm_q0.weight_hh", "lstm_q1.weight_hh"),
         "q_bih": ("lstm_q0.bias_ih", "lstm_q1.bias_ih"), "q_bhh": ("lstm_q0.bias_hh", "lstm_q1.bias_hh"),
     }
+    def opt(n):           # the speaker LSTM cells are absent from the GRU-speaker variants' cells (ext_hq mode: may be NULL)
+        try:
+            return get(n)
+        except KeyError:
+            if n.startswith("lstm_q"):
+                return None
+            raise
+
     for field, (n0, n1) in names.items():
         arr = getattr(cp, field)
-        arr[0] = _p(get(n0))
-        arr[1] = _p(get(n1))
+        arr[0] = _p(opt(n0))
+        arr[1] = _p(opt(n1))
     cp.att_Wq = _p(get("crossatt_l2a.Wq"))
     cp.att_Wk = _p(get("crossatt_l2a.Wk"))
     return cp

@@ -351,6 +351,111 @@ def marn1_onlysp_forward(P: Params, x: Tensor, qmask: Tensor, umask: Tensor, d_r
     return lp.reshape(-1, lp.shape[-1]), x_l, x_a
 
 
+# --------------------------------------------------------------------------------------
+# GRU-speaker variants with the LayerNorm'd sequence attention and the softmax-weighted fusion:
+# model/lsthm_nsps.py (MARN1_nsps) and model/lsthm_no_en.py (MARN1_no_en: the same without the text encoder)
+# --------------------------------------------------------------------------------------
+def cross_attention_seq_ln(P: Params, pre: str, x1: Tensor, x2: Tensor, drop: Optional[Tensor] = None, eps: float = 1e-6) -> Tensor:
+    """CrossAttention2 of model/lsthm_nsps.py:75-108: single-head attention across the utterance axis with dh = dk = dv (100 in
+    MARN1_nsps, :287-288), then ``output += residual`` (x_1) and LayerNorm(dh, eps=1e-6).  x1, x2 [L,B,D] -> [L,B,D]."""
+    Wq, Wk, Wv = P[pre + "Wq"], P[pre + "Wk"], P[pre + "Wv"]
+    a, b = x1.permute(1, 0, 2), x2.permute(1, 0, 2)
+    Q, K, V = a @ Wq, b @ Wk, b @ Wv                                         # :96-98
+    attn = torch.softmax((Q / (Wq.shape[1] ** 0.5)) @ K.transpose(1, 2), -1)  # :100
+    if drop is not None:
+        attn = attn * drop                                                   # :101
+    out = (attn @ V).permute(1, 0, 2) + x1                                   # :102-105
+    return F.layer_norm(out, (out.shape[-1],), P[pre + "layer_norm.weight"], P[pre + "layer_norm.bias"], eps)
+
+
+def marn_cell_nsps(P: Params, pre: str, x: Tensor, x_l: Tensor, x_a: Tensor, qmask: Tensor, H: int = 128,
+                   drops: Optional[Dict[str, Tensor]] = None):
+    """MARN_cell.forward of model/lsthm_nsps.py:158-216.  Against marn_cell_onlysp: the speaker GRU is fed ``x[t]`` (the caller's
+    cat[linear_in(text) | audio], i.e. the PRE-encoder features, :305,:177), the new party states are
+    q[b,p] = ql_0[b] (1 - m[b,p]) + h_s[b] m[b,p] with ql_0 = the state of the party NOT speaking (:183-191; ``gru_l`` is
+    constructed but its update is commented out, h_l_ = ql_0) -- for a one-hot qmask row that is the onlysp update, for a padded
+    (all-zero) row both party states become the listener's -- and the output rows are cat(h_l, h_a, z_l) (:202).
+    Returns (h [T,B,3H], h_l, h_a, h_sp, h_li [T,B,H]).  ``drops``: "hs" [T,B,H] (:182), "h" [T,2,B,H] (:195,:197), "attn" [T,B,H,H]."""
+    drops = drops or {}
+    T, B, _ = x_l.shape
+    dt, dev = x_l.dtype, x_l.device
+    qm = qmask.to(dt)
+    q = torch.zeros(B, 2, H, dtype=dt, device=dev)
+    h_l = torch.zeros(B, H, dtype=dt, device=dev)
+    h_a, c_l, c_a, z = (torch.zeros_like(h_l) for _ in range(4))
+    rows = torch.arange(B, device=dev)
+    outs, hl, ha, hsp, hli = [], [], [], [], []
+    for t in range(T):
+        idx = torch.argmax(qm[t], 1)                                        # :178
+        qs_0, ql_0 = q[rows, idx], q[rows, 1 - idx]                         # :180, :231-239
+        h_s = gru_cell(P, pre + "gru_s.", x[t], qs_0)                       # :182
+        if "hs" in drops:
+            h_s = h_s * drops["hs"][t]
+        m = qm[t].unsqueeze(2)
+        q = ql_0.unsqueeze(1) * (1 - m) + h_s.unsqueeze(1) * m              # :188-191
+        c_l, h_l = lsthm1(P, pre + "lsthm_l.", x_l[t], c_l, h_l, z, h_s)     # :194
+        c_a, h_a = lsthm1(P, pre + "lsthm_a.", x_a[t], c_a, h_a, z, h_s)     # :196
+        if "h" in drops:
+            h_l, h_a = h_l * drops["h"][t, 0], h_a * drops["h"][t, 1]
+        z = cross_attention(P, pre + "crossatt_l2a.", c_l, c_a, drops["attn"][t] if "attn" in drops else None)   # :199
+        outs.append(torch.cat([h_l, h_a, z], 1))
+        hl.append(h_l); ha.append(h_a); hsp.append(h_s); hli.append(ql_0)
+    return tuple(torch.stack(v, 0) for v in (outs, hl, ha, hsp, hli))
+
+
+def marn1_nsps_forward(P: Params, x: Tensor, qmask: Tensor, umask: Tensor, d_r: int = 1024, d_a: int = 100, H: int = 128,
+                       n_head: int = 8, d_k: int = 40, d_v: int = 40, no_en: bool = False,
+                       drops: Optional[Dict[str, Tensor]] = None):
+    """MARN1_nsps.forward -- model/lsthm_nsps.py:300-360; ``no_en=True``: MARN1_no_en.forward -- model/lsthm_no_en.py:300-360 (the
+    text stream skips its encoder, :306,:309).  Encoder passes as in MARN1_sps (second pass on x + first pass); the cells are
+    marn_cell_nsps on x = cat[linear_in(text), audio]; only h_l and h_a of the cells reach the head (h, h_sp are computed and never
+    used, :335-339); CrossAttention2 is the LayerNorm'd form on the unscaled encoder outputs (:341-342); the fusion weights are
+    softmax(p) (:347-348); head = nn_out(cat[w1 [h_l | attn2], w2 [h_a | attn1]] + fc(x_l)) (:350-355; fc2(x_a) is computed and
+    never used).  ``drops``: "enc{k}.*" as in marn1_sps_forward ("enc0"/"enc1" absent with no_en), "xattn0"/"xattn1",
+    "cell{k}.{hs,h,attn}", "rec{k}.{l,a}" [L,B,H] (dropout_rec on hf_l, hf_a / hb_l, hb_a, :317-318,:330-331), "fc" [L,B,712], "out"."""
+    dr = drops or {}
+
+    def enc_dr(k):
+        return tuple(dr.get(f"enc{k}.{n}") for n in ("attn", "fc", "ffn"))
+
+    def cell_dr(k):
+        return {n: dr[f"cell{k}.{n}"] for n in ("hs", "h", "attn") if f"cell{k}.{n}" in dr}
+
+    x_l = x[:, :, :d_r].permute(1, 0, 2)
+    x_a = x[:, :, d_r:d_r + d_a].permute(1, 0, 2)
+    x_l = linear(x_l, P["linear_in.weight"], P["linear_in.bias"])
+    xin = torch.cat([x_l, x_a], 2).permute(1, 0, 2)                           # :305  [L,B,2D]
+    if not no_en:
+        x_l_1, _ = encoder_layer(P, "encoder_l.", x_l, n_head, d_k, d_v, drops=enc_dr(0))
+    x_a_1, _ = encoder_layer(P, "encoder_a.", x_a, n_head, d_k, d_v, drops=enc_dr(2))
+    if not no_en:
+        x_l, _ = encoder_layer(P, "encoder_l.", x_l + x_l_1, n_head, d_k, d_v, drops=enc_dr(1))
+    x_a, _ = encoder_layer(P, "encoder_a.", x_a + x_a_1, n_head, d_k, d_v, drops=enc_dr(3))
+    x_l = x_l.permute(1, 0, 2)
+    x_a = x_a.permute(1, 0, 2)
+    _, hf_l, hf_a, _, _ = marn_cell_nsps(P, "marn_cell_f.", xin, x_l, x_a, qmask, H, cell_dr(0))
+    _, hb_l, hb_a, _, _ = marn_cell_nsps(P, "marn_cell_b.", reverse_seq(xin, umask), reverse_seq(x_l, umask), reverse_seq(x_a, umask),
+                                         reverse_seq(qmask, umask), H, cell_dr(1))
+    hb_l, hb_a = reverse_seq(hb_l, umask), reverse_seq(hb_a, umask)
+    if "rec0.l" in dr:
+        hf_l, hf_a, hb_l, hb_a = hf_l * dr["rec0.l"], hf_a * dr["rec0.a"], hb_l * dr["rec1.l"], hb_a * dr["rec1.a"]
+    attn1 = cross_attention_seq_ln(P, "crossatt_l2a.", x_l, x_a, dr.get("xattn0"))
+    attn2 = cross_attention_seq_ln(P, "crossatt_a2l.", x_a, x_l, dr.get("xattn1"))
+    wsm = torch.softmax(P["p"], 0)                                            # :347-348
+    resid = F.relu(linear(x_l, P["fc.0.weight"], P["fc.0.bias"]))             # :350
+    if "fc" in dr:
+        resid = resid * dr["fc"]
+    l = torch.cat([hf_l, hb_l, attn2], 2)                                     # :352
+    a = torch.cat([hf_a, hb_a, attn1], 2)                                     # :353
+    out = torch.cat([wsm[0] * l, wsm[1] * a], -1) + resid                     # :355
+    out = F.relu(linear(out, P["nn_out.0.weight"], P["nn_out.0.bias"]))
+    if "out" in dr:
+        out = out * dr["out"]
+    out = linear(out, P["nn_out.3.weight"], P["nn_out.3.bias"])
+    lp = F.log_softmax(out, 2).permute(1, 0, 2)
+    return lp.reshape(-1, lp.shape[-1]), x_l, x_a
+
+
 def reverse_seq(X: Tensor, umask: Tensor) -> Tensor:
     """MARN1_sps._reverse_seq -- model/lsthm_sps.py:396-409 (flip the first len_b steps, zero-pad)."""
     L, B = X.shape[0], X.shape[1]
@@ -470,10 +575,16 @@ def param_shapes(n_classes: int = 6, d_r: int = 1024, D: int = 100, H: int = 128
                  d_k: int = 40, d_v: int = 40, d_inner: int = 40, h_out: int = 32, variant: str = "sps") -> Dict[str, Tuple[int, ...]]:
     """state_dict key -> shape, in the reference's registration order.  variant "onlysp": MARN1_onlysp
     (model/lsthm_onlysp.py:209-258): every cell also owns ``gru_s`` = GRUCell(2D, H); the head is ``nn_out`` on the 10H-wide
-    concatenation (plus a dead ``linear``), there is no ``fc``."""
+    concatenation (plus a dead ``linear``), there is no ``fc``.  variant "nsps": MARN1_nsps / MARN1_no_en
+    (model/lsthm_nsps.py:242-298): ``p`` [2] instead of w, v, v1, v2; cells own gru_s and gru_l and no LSTM cells; fc / fc2 =
+    Linear(D, 712); nn_out on 712; CrossAttention2 [D,D] with a LayerNorm; no crossatt_*_1."""
     S: Dict[str, Tuple[int, ...]] = {}
-    for k in ("w", "v", "v1", "v2"):
-        S[k] = (1,)
+    nsps = variant == "nsps"
+    if nsps:
+        S["p"] = (2,)
+    else:
+        for k in ("w", "v", "v1", "v2"):
+            S[k] = (1,)
     S["linear_in.weight"] = (D, d_r)
     S["linear_in.bias"] = (D,)
     for cell in ("marn_cell_f.", "marn_cell_b."):
@@ -484,25 +595,30 @@ def param_shapes(n_classes: int = 6, d_r: int = 1024, D: int = 100, H: int = 128
             for nm, k in (("W", D), ("U", H), ("V", H), ("S", H)):
                 S[cell + st + nm + ".weight"] = (4 * H, k)
                 S[cell + st + nm + ".bias"] = (4 * H,)
-        for lc in ("lstm_q0.", "lstm_q1.", "gru_s.", "lstm_s."):
-            if lc == "gru_s.":                       # model/lsthm_onlysp.py:152 registers it between lstm_q1 and lstm_s
-                if variant == "onlysp":
-                    S[cell + "gru_s.weight_ih"] = (3 * H, 2 * D)
-                    S[cell + "gru_s.weight_hh"] = (3 * H, H)
-                    S[cell + "gru_s.bias_ih"] = (3 * H,)
-                    S[cell + "gru_s.bias_hh"] = (3 * H,)
+        for lc in (("gru_s.", "gru_l.") if nsps else ("lstm_q0.", "lstm_q1.", "gru_s.", "lstm_s.")):
+            if lc.startswith("gru_"):                # model/lsthm_onlysp.py:152 registers gru_s between lstm_q1 and lstm_s
+                if variant in ("onlysp", "nsps"):
+                    S[cell + lc + "weight_ih"] = (3 * H, 2 * D)
+                    S[cell + lc + "weight_hh"] = (3 * H, H)
+                    S[cell + lc + "bias_ih"] = (3 * H,)
+                    S[cell + lc + "bias_hh"] = (3 * H,)
                 continue
             S[cell + lc + "weight_ih"] = (4 * H, H)
             S[cell + lc + "weight_hh"] = (4 * H, H)
             S[cell + lc + "bias_ih"] = (4 * H,)
             S[cell + lc + "bias_hh"] = (4 * H,)
+    final = 2 * (2 * H + D)
     if variant == "onlysp":
         S["linear.weight"] = (h_out, 10 * H)
         S["linear.bias"] = (h_out,)
+    elif nsps:
+        for f in ("fc.0.", "fc2.0."):
+            S[f + "weight"] = (final, D)
+            S[f + "bias"] = (final,)
     else:
         S["fc.0.weight"] = (D, 8 * H + 2 * H)
         S["fc.0.bias"] = (D,)
-    S["nn_out.0.weight"] = (h_out, 10 * H if variant == "onlysp" else D)
+    S["nn_out.0.weight"] = (h_out, 10 * H if variant == "onlysp" else (final if nsps else D))
     S["nn_out.0.bias"] = (h_out,)
     S["nn_out.3.weight"] = (n_classes, h_out)
     S["nn_out.3.bias"] = (n_classes,)
@@ -523,11 +639,15 @@ def param_shapes(n_classes: int = 6, d_r: int = 1024, D: int = 100, H: int = 128
         S[enc + "pos_ffn.fc.bias"] = (100,)
     for ca in ("crossatt_l2a.", "crossatt_a2l."):
         for wn in ("Wq", "Wk", "Wv"):
-            S[ca + wn] = (D, H)
-    for ca in ("crossatt_l2a_1.", "crossatt_a2l_1."):
-        S[ca + "Wq"] = (D, H)
-        S[ca + "Wk"] = (H, H)
-        S[ca + "Wv"] = (H, H)
+            S[ca + wn] = (D, D if nsps else H)
+        if nsps:
+            S[ca + "layer_norm.weight"] = (D,)
+            S[ca + "layer_norm.bias"] = (D,)
+    if not nsps:
+        for ca in ("crossatt_l2a_1.", "crossatt_a2l_1."):
+            S[ca + "Wq"] = (D, H)
+            S[ca + "Wk"] = (H, H)
+            S[ca + "Wv"] = (H, H)
     return S
 
 
@@ -547,6 +667,8 @@ def seeded_params(seed: int = 0, dtype=torch.float32, **dims) -> Params:
         rs = np.random.RandomState((zlib.crc32(name.encode()) + 7919 * seed) % (2 ** 31))
         if name in ("w", "v", "v1", "v2"):
             a = 1.0 + 0.1 * rs.standard_normal(shp)
+        elif name == "p":
+            a = 1.0 + 0.5 * rs.standard_normal(shp)
         elif name.endswith("layer_norm.weight"):
             a = 1.0 + 0.1 * rs.standard_normal(shp)
         elif name.endswith("layer_norm.bias"):

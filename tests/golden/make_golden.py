@@ -250,6 +250,69 @@ def onlysp_case():
     print("onlysp", float(loss.detach()))
 
 
+def nsps_cases():
+    """MARN1_nsps (model/lsthm_nsps.py) and MARN1_no_en (model/lsthm_no_en.py), SURVEY 8(f) row f1: eval-mode forward/backward of the
+    reference on a ragged batch (padded steps exercise the listener blend of :188-191 on all-zero qmask rows)."""
+    from models.lsthm_nsps import MARN1_nsps
+    from models.lsthm_no_en import MARN1_no_en
+
+    B, L, d_r, seed = 3, 9, 1024, 41
+    for tag, cls in (("nsps", MARN1_nsps), ("no_en", MARN1_no_en)):
+        torch.manual_seed(0)
+        net = cls(6, "IEMOCAP").eval()
+        P = O.seeded_params(seed=seed, d_r=d_r, variant="nsps")
+        _load(net, P)
+        x, qmask, umask, label = O.seeded_batch(B, L, d_r=d_r, seed=seed + 1, ragged=True)
+        lp, x_l, x_a = net(x, qmask, umask)
+        m = umask.reshape(-1, 1)
+        loss = torch.nn.functional.nll_loss(lp * m, label.view(-1), reduction="sum") / umask.sum()
+        loss.backward()
+        rec = dict(B=B, L=L, d_r=d_r, seed=seed, logits=lp.detach().numpy(), loss=np.float64(float(loss.detach())),
+                   x_l_sum=np.float64(float(x_l.double().sum())), x_a_sum=np.float64(float(x_a.double().sum())))
+        rec.update(_grad_samples(net.named_parameters()))
+        np.savez_compressed(os.path.join(HERE, f"model_{tag}.npz"), **rec)
+        print(tag, float(loss.detach()))
+
+
+def gru_cell_cases():
+    """MARN_cell.forward of the GRU-speaker variants on its own (model/lsthm_onlysp.py:158-197, model/lsthm_nsps.py:158-216): T = 10,
+    N = 5, padded tails (all-zero qmask rows); outputs and input gradients."""
+    from models.lsthm_onlysp import MARN_cell as CellOnlysp
+    from models.lsthm_nsps import MARN_cell as CellNsps
+
+    T, N = 10, 5
+    rs = np.random.RandomState(51)
+    spk = rs.randint(0, 2, (T, N))
+    qmask = np.eye(2, dtype=np.float32)[spk]
+    qmask[7:, 1] = 0
+    qmask[5:, 3] = 0
+    qmask = torch.tensor(qmask)
+    rec = dict(qmask=qmask.numpy())
+    for tag, cls, variant in (("onlysp", CellOnlysp, "onlysp"), ("nsps", CellNsps, "nsps")):
+        torch.manual_seed(0)
+        cell = cls(128, 128, 100, 100).eval()
+        P = O.seeded_params(seed=52, variant=variant)
+        _load(cell, {k[len("marn_cell_f."):]: v for k, v in P.items() if k.startswith("marn_cell_f.")})
+        x_l = torch.tensor(rs.standard_normal((T, N, 100)).astype(np.float32), requires_grad=True)
+        x_a = torch.tensor(rs.standard_normal((T, N, 100)).astype(np.float32), requires_grad=True)
+        x = torch.tensor(rs.standard_normal((T, N, 200)).astype(np.float32), requires_grad=True)
+        out = cell(x, x_l, x_a, qmask)
+        outs = (out,) if tag == "onlysp" else out
+        ws = [torch.tensor(rs.standard_normal(tuple(o.shape)).astype(np.float32)) for o in outs]
+        sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+        rec.update({f"{tag}/x_l": x_l.detach().numpy(), f"{tag}/x_a": x_a.detach().numpy(), f"{tag}/x": x.detach().numpy(),
+                    f"{tag}/dx_l": x_l.grad.numpy(), f"{tag}/dx_a": x_a.grad.numpy()})
+        if x.grad is not None:
+            rec[f"{tag}/dx"] = x.grad.numpy()
+        for i, (o, w) in enumerate(zip(outs, ws)):
+            rec[f"{tag}/out{i}"] = o.detach().numpy()
+            rec[f"{tag}/w{i}"] = w.numpy()
+        for k, v in _grad_samples(cell.named_parameters()).items():
+            rec[f"{tag}/{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "cell_gru_variants.npz"), **rec)
+    print("gru cells ok")
+
+
 def train_mode_case():
     """The reference in TRAIN mode with its 13 dropout sites fed from known masks: nn.Dropout.forward is replaced, for the duration
     of this case, by a function that multiplies by the next factor tensor of that module's queue (O.seeded_drops, laid out in the
@@ -351,6 +414,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "onlysp":
         onlysp_case()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "nsps":
+        nsps_cases()
+        gru_cell_cases()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "loss":       # regenerate only the loss fixtures
         loss_cases()
         trainer_case(loss="CrossEntropy", epochs=(1,), out="trainer_ce.npz")
@@ -365,3 +432,5 @@ if __name__ == "__main__":
     trainer_case(loss="CrossEntropy", epochs=(1,), out="trainer_ce.npz")
     train_mode_case()
     onlysp_case()
+    nsps_cases()
+    gru_cell_cases()

@@ -917,3 +917,129 @@ def test_onlysp_link_needs_room_for_both_launches(O):
         lp_ref, _, _ = O.marn1_onlysp_forward(Pr, x.cpu(), qmask.cpu(), umask.cpu(), d_r=d_r)
         assert maxabs(lp, lp_ref) < LOGIT_TOL
     assert fault.peek("cuda:0") == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------- f1: nsps / no_en
+@pytest.mark.parametrize("tag", ["nsps", "no_en"])
+def test_nsps_models_vs_reference_golden(O, golden_dir, tag):
+    """MARN1_nsps / MARN1_no_en against the reference's own eval-mode forward/backward
+    (tests/golden/make_golden.py::nsps_cases): log-probs 1e-4, loss, every gradient, the dead parameters."""
+    from models.lsthm_nsps import MARN1_nsps
+    from models.lsthm_no_en import MARN1_no_en
+    from loss import MaskedLoss
+    g = _g(golden_dir, f"model_{tag}.npz")
+    B, L, d_r, seed = int(g["B"]), int(g["L"]), int(g["d_r"]), int(g["seed"])
+    net = (MARN1_nsps if tag == "nsps" else MARN1_no_en)(6, "IEMOCAP", d_r=d_r).cuda().eval()
+    load_params(net, O.seeded_params(seed=seed, d_r=d_r, variant="nsps"))
+    x, qmask, umask, label = O.seeded_batch(B, L, d_r=d_r, seed=seed + 1, ragged=True)
+    lp, x_l, x_a = net(x.cuda(), qmask.cuda(), umask.cuda())
+    loss = MaskedLoss(torch.nn.NLLLoss)(lp, label.cuda().view(-1), umask.cuda())
+    loss.backward()
+    assert maxabs(lp, g["logits"]) < LOGIT_TOL
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-5
+    assert abs(float(x_l.double().sum()) - float(g["x_l_sum"])) < 1e-2 and abs(float(x_a.double().sum()) - float(g["x_a_sum"])) < 1e-2
+    _check_grads(g, list(net.named_parameters()))
+
+
+@pytest.mark.parametrize("no_en,train,B,L", [(False, False, 5, 11), (False, True, 4, 6), (True, True, 3, 7), (True, False, 35, 5)])
+def test_nsps_models_vs_oracle(O, no_en, train, B, L):
+    """The same two models against the oracle (pinned by the goldens above): eval mode and, in train mode, mask for mask with every
+    dropout site live (the four dropout_rec slabs, the fc residual, h_s on the GRU's carried state); a batch with a partial third
+    16-dialogue block."""
+    from models.lsthm_nsps import MARN1_nsps
+    from models.lsthm_no_en import MARN1_no_en
+    from loss import MaskedLoss
+    from mser import functional as F_
+    from mser.nsps_fn import SITE_NSPS_REC
+    d_r, H, D = 96, 128, 100
+    P = O.seeded_params(seed=111, d_r=d_r, variant="nsps")
+    net = (MARN1_no_en if no_en else MARN1_nsps)(6, "IEMOCAP", d_r=d_r).cuda()
+    net.train(train)
+    load_params(net, P)
+    x, qmask, umask, label = O.seeded_batch(B, L, d_r=d_r, seed=113 + B, ragged=True)
+    captured = {}
+    orig = net._drop_cfg
+    net._drop_cfg = lambda dev: captured.setdefault("cfg", orig(dev))
+    try:
+        lp, _, _ = net(x.cuda(), qmask.cuda(), umask.cuda())
+        loss = MaskedLoss(torch.nn.NLLLoss)(lp, label.cuda().view(-1), umask.cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        net._drop_cfg = orig
+    dr = None
+    if train:
+        cfg = captured["cfg"]
+        dr = _dropout_factors(net, cfg, L, B, H)
+        N = L * B
+        for k in ("xattn2", "xattn3", "rec0", "rec1", "fc", "out"):
+            dr.pop(k, None)
+        for i in range(2):
+            dr.pop(f"cell{i}.hq")
+            dr[f"cell{i}.hs"] = cfg.site(F_.SITE_CELL + 4 * i, cfg.p_cell[i]).scale(N * H).cpu().view(L, B, H)
+            dr[f"rec{i}.l"] = cfg.site(SITE_NSPS_REC + 2 * i, cfg.p_rec).scale(N * H).cpu().view(L, B, H)
+            dr[f"rec{i}.a"] = cfg.site(SITE_NSPS_REC + 2 * i + 1, cfg.p_rec).scale(N * H).cpu().view(L, B, H)
+        dr["fc"] = cfg.site(F_.SITE_FC, cfg.p_fc).scale(N * 712).cpu().view(L, B, 712)
+        dr["out"] = cfg.site(F_.SITE_OUT, cfg.p_out).scale(N * 32).cpu().view(L, B, 32)
+        if no_en:
+            assert not any(k.startswith("enc0") or k.startswith("enc1") for k in dr)
+        assert 0.3 < float((dr["rec0.l"] == 0).float().mean()) < 0.7
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    lp_ref, _, _ = O.marn1_nsps_forward(Pr, x, qmask, umask, d_r=d_r, no_en=no_en, drops=dr)
+    loss_ref = O.masked_nll(lp_ref, label.view(-1), umask)
+    loss_ref.backward()
+    assert maxabs(lp, lp_ref) < LOGIT_TOL
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 2e-5
+    for n, p in net.named_parameters():
+        r = Pr[n].grad
+        if r is None:
+            assert p.grad is None or float(p.grad.abs().sum()) == 0.0, f"{n} must stay dead"
+            continue
+        assert p.grad is not None, n
+        assert maxabs(p.grad, r) < 3e-4 * max(1e-3, float(r.norm())), n
+
+
+def test_gru_variant_cells_standalone_vs_reference_golden(O, golden_dir):
+    """MARN_cell.forward of models.lsthm_onlysp (:158-197) and models.lsthm_nsps (:158-216) on their own against the reference's own
+    outputs and gradients (tests/golden/make_golden.py::gru_cell_cases; padded tails exercise the listener blend of :188-191)."""
+    from models.lsthm_onlysp import MARN_cell as CellOnlysp
+    from models.lsthm_nsps import MARN_cell as CellNsps
+    g = _g(golden_dir, "cell_gru_variants.npz")
+    qmask = torch.tensor(g["qmask"]).cuda()
+    for tag, cls, variant in (("onlysp", CellOnlysp, "onlysp"), ("nsps", CellNsps, "nsps")):
+        cell = cls(128, 128, 100, 100).cuda().eval()
+        P = O.seeded_params(seed=52, variant=variant)
+        load_params(cell, {k[len("marn_cell_f."):]: v for k, v in P.items() if k.startswith("marn_cell_f.")})
+        x_l, x_a, x = (torch.tensor(g[f"{tag}/{n}"]).cuda().requires_grad_(True) for n in ("x_l", "x_a", "x"))
+        out = cell(x, x_l, x_a, qmask)
+        outs = (out,) if tag == "onlysp" else out
+        assert len(outs) == (1 if tag == "onlysp" else 5)
+        for i, o in enumerate(outs):
+            assert maxabs(o, g[f"{tag}/out{i}"]) < 2e-5, (tag, i)
+        sum((o * torch.tensor(g[f"{tag}/w{i}"]).cuda()).sum() for i, o in enumerate(outs)).backward()
+        assert maxabs(x_l.grad, g[f"{tag}/dx_l"]) < 1e-4 and maxabs(x_a.grad, g[f"{tag}/dx_a"]) < 1e-4
+        if tag == "nsps":
+            assert maxabs(x.grad, g[f"{tag}/dx"]) < 1e-4
+        gg = {k[len(tag) + 1:]: g[k] for k in g.files if k.startswith(tag + "/g")}
+        _check_grads(gg, list(cell.named_parameters()))
+
+
+def test_nsps_trainer_runs_the_reference_loop(O, tmp_path):
+    """ModelTrainer(model="MARN1_nsps" / "MARN1_no_en") (model_trainer.py:67-68,:71-72): the loss of a memorisable batch falls,
+    eval_network runs, the checkpoint carries the reference's key names."""
+    from model_trainer import ModelTrainer
+    for model in ("MARN1_nsps", "MARN1_no_en"):
+        tr = ModelTrainer(torch.device("cuda:0"), 1e-3, 1, 0.98, model, "NLL", 6, "IEMOCAP", quiet=True)
+        load_params(tr.model, O.seeded_params(seed=121, d_r=1024, variant="nsps"))
+        B, L = 4, 8
+        x, qmask, umask, label = O.seeded_batch(B, L, d_r=1024, seed=122, ragged=True)
+        r = x[:, :, :1024]
+        batch = [r, r, r, r, torch.zeros(L, B, 4), x[:, :, 1024:], qmask, umask, label, ["v"] * B]
+        losses = [tr.train_network(ep, [batch] * 6)[1] for ep in (1, 2, 3)]
+        assert losses[-1] < losses[0], (model, losses)
+        acc, f1, extra = tr.eval_network([batch])
+        assert 0.0 <= acc <= 100.0 and extra == {}
+        path = str(tmp_path / f"{model}.model")
+        tr.save_parameters(path)
+        keys = list(torch.load(path, weights_only=True).keys())
+        assert keys[0] == "model.p" and "model.marn_cell_b.gru_l.bias_hh" in keys and len(keys) == 109

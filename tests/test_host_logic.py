@@ -142,8 +142,40 @@ def test_mirror_state_dict_order_matches_the_oracle_tables():
     from oracle import ref_cpu as O
     from models.lsthm_onlysp import MARN1_onlysp
     from models.lsthm_sps import MARN1_sps
-    for cls, variant, n in ((MARN1_sps, "sps", 120), (MARN1_onlysp, "onlysp", 128)):
+    from models.lsthm_nsps import MARN1_nsps
+    from models.lsthm_no_en import MARN1_no_en
+    for cls, variant, n in ((MARN1_sps, "sps", 120), (MARN1_onlysp, "onlysp", 128), (lambda c: MARN1_nsps(c, "IEMOCAP"), "nsps", 109),
+                            (lambda c: MARN1_no_en(c, "IEMOCAP"), "nsps", 109)):
         sd = cls(6).state_dict()
         shapes = O.param_shapes(variant=variant)
         assert list(sd.keys()) == list(shapes.keys()) and len(sd) == n
         assert all(tuple(sd[k].shape) == shapes[k] for k in shapes)
+
+
+def test_gru_variant_mirrors_follow_the_reference_registration_order(golden_dir):
+    """The fixtures written by the reference itself list its parameters in ``named_parameters()`` order (one "gnorm/<name>" entry
+    each, tests/golden/make_golden.py::_grad_samples): the mirrors of MARN1_onlysp / MARN1_nsps / MARN1_no_en must register the same
+    names in the same order, and mark exactly the reference's gradient-less parameters as dead."""
+    from models.lsthm_nsps import MARN1_nsps
+    from models.lsthm_no_en import MARN1_no_en
+    from models.lsthm_onlysp import MARN1_onlysp
+    for fix, make in (("model_onlysp.npz", lambda: MARN1_onlysp(6)), ("model_nsps.npz", lambda: MARN1_nsps(6, "IEMOCAP")),
+                      ("model_no_en.npz", lambda: MARN1_no_en(6, "IEMOCAP"))):
+        g = np.load(os.path.join(golden_dir, fix))
+        ref_names = [k[len("gnorm/"):] for k in g.files if k.startswith("gnorm/")]
+        net = make()
+        assert [n for n, _ in net.named_parameters()] == ref_names, fix
+        ref_dead = {n for n in ref_names if float(g["gnorm/" + n]) < 0}
+        assert set(net.flat_store.dead) == ref_dead, (fix, set(net.flat_store.dead) ^ ref_dead)
+
+
+def test_nsps_constructor_takes_the_dataset_argument():
+    """model_trainer.py:67-68,:71-72: MARN1_nsps(n_classes, dataset) / MARN1_no_en(n_classes, dataset)."""
+    from models.lsthm_nsps import MARN1_nsps, MARN_cell, CrossAttention2
+    from models.lsthm_no_en import MARN1_no_en
+    for c in (MARN1_nsps, MARN1_no_en):
+        pos = [p.name for p in inspect.signature(c.__init__).parameters.values() if p.kind == p.POSITIONAL_OR_KEYWORD and p.name != "self"]
+        assert pos == ["n_classes", "dataset"]
+    assert list(inspect.signature(MARN_cell.forward).parameters)[1:] == ["x", "x_l", "x_a", "qmask"]
+    ca = CrossAttention2(100, 100, 100)
+    assert tuple(ca.Wq.shape) == (100, 100) and ca.layer_norm.eps == 1e-6 and torch.all(ca.Wv == 1.0)

@@ -131,6 +131,46 @@ def test_onlysp_variant_vs_reference(golden_dir):
     _check_grads(g, list(P.items()))
 
 
+@pytest.mark.parametrize("tag", ["nsps", "no_en"])
+def test_nsps_variants_vs_reference(golden_dir, tag):
+    """the oracle's restatement of MARN1_nsps / MARN1_no_en (speaker GRU on the pre-encoder features with the
+    listener blend, LayerNorm'd CrossAttention2, softmax(p)-weighted fusion + fc residual) against the reference's own eval-mode
+    forward/backward (tests/golden/make_golden.py::nsps_cases), dead parameters included (gru_l, fc2, crossatt_a2l of the cells)."""
+    g = _g(golden_dir, f"model_{tag}.npz")
+    B, L, d_r, seed = int(g["B"]), int(g["L"]), int(g["d_r"]), int(g["seed"])
+    P = {k: v.clone().requires_grad_(True) for k, v in O.seeded_params(seed=seed, d_r=d_r, variant="nsps").items()}
+    x, qmask, umask, label = O.seeded_batch(B, L, d_r=d_r, seed=seed + 1, ragged=True)
+    lp, x_l, x_a = O.marn1_nsps_forward(P, x, qmask, umask, d_r=d_r, no_en=(tag == "no_en"))
+    loss = O.masked_nll(lp, label.view(-1), umask)
+    loss.backward()
+    assert np.abs(lp.detach().numpy() - g["logits"]).max() < 2e-5
+    assert abs(float(loss) - float(g["loss"])) < 2e-6
+    assert abs(float(x_l.double().sum()) - float(g["x_l_sum"])) < 1e-2 and abs(float(x_a.double().sum()) - float(g["x_a_sum"])) < 1e-2
+    _check_grads(g, list(P.items()))
+
+
+def test_gru_variant_cells_vs_reference(golden_dir):
+    """MARN_cell.forward of model/lsthm_onlysp.py:158-197 and model/lsthm_nsps.py:158-216 on their own, padded tails included
+    (tests/golden/make_golden.py::gru_cell_cases): outputs and input gradients of oracle.marn_cell_onlysp / marn_cell_nsps."""
+    g = _g(golden_dir, "cell_gru_variants.npz")
+    qmask = _t(g["qmask"])
+    for tag, variant in (("onlysp", "onlysp"), ("nsps", "nsps")):
+        P = {k: v.clone().requires_grad_(True) for k, v in O.seeded_params(seed=52, variant=variant).items() if k.startswith("marn_cell_f.")}
+        x_l, x_a, x = (_t(g[f"{tag}/{n}"]).requires_grad_(True) for n in ("x_l", "x_a", "x"))
+        if tag == "onlysp":
+            outs = (O.marn_cell_onlysp(P, "marn_cell_f.", x_l, x_a, qmask),)
+        else:
+            outs = O.marn_cell_nsps(P, "marn_cell_f.", x, x_l, x_a, qmask)
+        for i, o in enumerate(outs):
+            assert np.abs(o.detach().numpy() - g[f"{tag}/out{i}"]).max() < 5e-6, (tag, i)
+        sum((o * _t(g[f"{tag}/w{i}"])).sum() for i, o in enumerate(outs)).backward()
+        assert np.abs(x_l.grad.numpy() - g[f"{tag}/dx_l"]).max() < 2e-5 and np.abs(x_a.grad.numpy() - g[f"{tag}/dx_a"]).max() < 2e-5
+        if tag == "nsps":
+            assert np.abs(x.grad.numpy() - g[f"{tag}/dx"]).max() < 2e-5
+        gg = {k[len(tag) + 1:]: g[k] for k in g.files if k.startswith(tag + "/g")}
+        _check_grads(gg, [(k[len("marn_cell_f."):], v) for k, v in P.items()])
+
+
 def test_trainer_lr_schedule(golden_dir):
     g = _g(golden_dir, "trainer.npz")
     assert O.step_lr(1e-3, 0.98, 1, 1) == pytest.approx(float(g["lr1"]), rel=1e-12)
