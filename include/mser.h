@@ -426,6 +426,52 @@ size_t mser_gru_speaker_save_bytes(int32_t T, int32_t B, int32_t H);
 int mser_gru_speaker_fwd(const mser_gru_speaker_desc* d, int32_t n, mser_stream_t stream);
 int mser_gru_speaker_bwd(const mser_gru_speaker_desc* d, int32_t n, mser_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * DialogueRNN (BASELINE configs[3]; model/DialogueRNN.py:80-198 as BiModel :201-277 and model_trainer.py:35-47 use
+ * it: listener_state=True, context_attention='general').  One call runs BOTH DialogueRNNs of a BiModel (dialog_rnn_f on the input
+ * as given, dialog_rnn_r on the per-dialogue reversed input, rev from mser_build_reverse_index) through shared launches and writes
+ * the emotion states e[t] at their natural time rows: out[(tau*B + b)*ldo + dir*De ...], tau = t (dir 0) or rev[t,b] (dir 1, rows
+ * beyond a dialogue's length are not written: the caller zeroes `out` first, pad_sequence semantics).
+ * Per step: global GRU on [U_t | q[b,s_b]], 'general' MatchingAttention of W_att U_t over the history of global states, party GRU
+ * for both parties on [U_t | c], listener GRU on [U_t | qs[b,s_b]], blend by qmask, emotion GRU on q[b,s_b].
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct mser_drnn_params {      /* one DialogueRNN.dialogue_cell; pointers into the parameter (or gradient) storage */
+  float* g_wih; float* g_whh; float* g_bih; float* g_bhh;     /* g_cell GRUCell(Dm+Dp, Dg): [3Dg, Dm+Dp], [3Dg, Dg], [3Dg], [3Dg]  (:92) */
+  float* p_wih; float* p_whh; float* p_bih; float* p_bhh;     /* p_cell GRUCell(Dm+Dg, Dp)                                       (:93) */
+  float* e_wih; float* e_whh; float* e_bih; float* e_bhh;     /* e_cell GRUCell(Dp, De)                                          (:94) */
+  float* l_wih; float* l_whh; float* l_bih; float* l_bhh;     /* l_cell GRUCell(Dm+Dp, Dp)                                       (:96) */
+  float* att_w;                                               /* attention.transform.weight [Dg, Dm] (no bias, :35)              */
+} mser_drnn_params;
+
+typedef struct mser_drnn_desc {
+  int32_t T, B, Dm, Dg, Dp, De;
+  const float* U; int64_t ldu;      /* [T*B, Dm] natural time order */
+  const float* qmask;               /* [T, B, 2] */
+  const int32_t* rev;               /* [T, B] (mser_build_reverse_index) */
+  mser_drnn_params p[2];            /* dialog_rnn_f, dialog_rnn_r.  Corresponding tensors of the two directions may lie anywhere; */
+  mser_drnn_params g[2];            /* gradients (ACCUMULATED), backward only                                                      */
+  float* out; int64_t ldo;          /* [T*B, ldo >= 2 De] */
+  const float* dout;                /* gradient of `out`, same indexing (backward only) */
+  void* workspace; size_t workspace_bytes;      /* mser_drnn_workspace_bytes(); holds everything saved for the backward */
+  /* the cell's nn.Dropout (:98; identity when rng == NULL): direction i draws sites drop_site[i] + {0: g (:136), 1: qs (:146),
+   * 2: ql (:153), 3: e (:161)} with element indices (t*B + b)*Dg + u, ((t*B + b)*2 + party)*Dp + u (qs and ql), (t*B + b)*De + u,
+   * t = the direction's own time index */
+  const uint32_t* rng; uint32_t drop_site[2]; float p_drop;
+} mser_drnn_desc;
+
+size_t mser_drnn_workspace_bytes(int32_t T, int32_t B, int32_t Dm, int32_t Dg, int32_t Dp, int32_t De);
+int mser_drnn_fwd(const mser_drnn_desc* d, mser_stream_t stream);
+int mser_drnn_bwd(const mser_drnn_desc* d, mser_stream_t stream);
+/* alpha_f / alpha_b of BiModel.forward (:196,:240,:250) after mser_drnn_fwd: *alpha = [T][B][T] inside the workspace, row (t, b)
+ * valid in its first t entries (direction `dir`'s own time order). */
+int mser_drnn_alpha(const mser_drnn_desc* d, int32_t dir, const float** alpha);
+/* MatchingAttention(att_type='general2') rows (:61-68): S [rows, n] holds <W x_t + b, M_s>; mask [rows / L, n] (row r uses mask row
+ * r / L): in place  a_ = softmax(S * mask); alpha = a_ mask / sum(a_ mask).  bwd: dS from d alpha (written over dA), given the saved
+ * alpha and the UNNORMALISED a_ is not needed: a_ = alpha * Z with Z recomputed from S -- the backward therefore takes the original
+ * scores S0 as well. */
+int mser_general2_rows_fwd(const float* S0, float* alpha, const float* mask, int64_t rows, int32_t n, int32_t L, mser_stream_t stream);
+int mser_general2_rows_bwd(const float* S0, const float* mask, float* dA, int64_t rows, int32_t n, int32_t L, mser_stream_t stream);
+
 /* Dropout.  A site's mask is a pure function of (rng[0] = seed, rng[1] = step, site, element index): nothing is stored between
  * the forward and the backward, both evaluate keep(idx) = mix32(idx ^ key(seed, step, site)) >= p * 2^32 (a full-avalanche
  * 32-bit mix; the streams of torch's CPU generators cannot be reproduced on a GPU, so train-mode parity is defined mask for

@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from loss import MaskedLoss
+from models.DialogueRNN import BiModel
 from models.lsthm_no_en import MARN1_no_en
 from models.lsthm_nsps import MARN1_nsps
 from models.lsthm_onlysp import MARN1_onlysp
@@ -26,7 +27,7 @@ from mser.functional import zero_dropout
 from mser.metrics import accuracy_and_weighted_f1
 from mser.optim import FlatAdam, StepLR
 
-_OUT_OF_SCOPE = ("DialogueRNN", "MARN", "BiLSTM", "MARN1_newz", "MARN1_azs", "MARN1_mf", "MARN1_la", "MARN1_cf", "MARN1_sp")
+_OUT_OF_SCOPE = ("MARN", "BiLSTM", "MARN1_newz", "MARN1_azs", "MARN1_mf", "MARN1_la", "MARN1_cf", "MARN1_sp")
 
 
 class ModelTrainer(nn.Module):
@@ -46,6 +47,16 @@ class ModelTrainer(nn.Module):
         elif model in ('MARN1_nsps', 'MARN1_no_en'):   # reference :67-68, :71-72: these two take the dataset name (and ignore it)
             cls = MARN1_nsps if model == 'MARN1_nsps' else MARN1_no_en
             self.model = cls(n_classes, dataset, d_r=kwargs.get("d_r", 1024)).to(self.device)
+            if not kwargs.get("dropout", True):
+                zero_dropout(self.model)
+        elif model == 'DialogueRNN':
+            # reference :35-47 (and model_trainer_d.py:23-33): BiModel(D_m 712, D_g = D_p 500, D_e = D_h 300, n_classes=6,
+            # listener_state=True, context_attention='general', dropout_rec = dropout = 0.1).  The widths are keyword extensions.
+            kw = {k: kwargs[k] for k in ("D_m", "D_g", "D_p", "D_e", "D_h") if k in kwargs}
+            dm = dict(D_m=712, D_g=500, D_p=500, D_e=300, D_h=300)
+            dm.update(kw)
+            self.model = BiModel(dm["D_m"], dm["D_g"], dm["D_p"], dm["D_e"], dm["D_h"], n_classes=6, listener_state=True,
+                                 context_attention='general', dropout_rec=0.1, dropout=0.1).to(self.device)
             if not kwargs.get("dropout", True):
                 zero_dropout(self.model)
         elif model in _OUT_OF_SCOPE:
@@ -86,10 +97,20 @@ class ModelTrainer(nn.Module):
             broadcast_replica(self.model.flat_store, self.optim)
             self._replicated = True
         self.optim.zero_grad()
-        lp_, x_a, x_l = self.model(x, qmask, umask)
+        lp_ = self._log_probs(x, qmask, umask)
         loss = self.loss(lp_, label.view(-1), umask)
         loss.backward()
         return loss.detach()
+
+    def _log_probs(self, x, qmask, umask):
+        """[B*L, C] batch-major log-probabilities of the model.  The MARN1 models return them in that layout (with x_l, x_a); the
+        DialogueRNN BiModel returns (log_prob [L,B,C], alpha, alpha_f, alpha_b) and the trainer transposes
+        (model_trainer_d.py:63-64: log_prob.transpose(0,1).contiguous().view(-1, C))."""
+        out = self.model(x, qmask, umask)
+        if isinstance(self.model, BiModel):
+            lp = out[0]
+            return lp.transpose(0, 1).contiguous().view(-1, lp.size()[2])
+        return out[0]
 
     def _world(self):
         d = torch.distributed
@@ -145,7 +166,7 @@ class ModelTrainer(nn.Module):
         with torch.no_grad():
             for _, data in enumerate(loader):
                 r1, r2, r3, r4, acouf, qmask, umask, label = self._unpack(data)
-                lp_, x_a, x_l = self.model(self._features(r1, r2, r3, r4, acouf), qmask, umask)
+                lp_ = self._log_probs(self._features(r1, r2, r3, r4, acouf), qmask, umask)
                 pred = torch.empty(lp_.shape[0], device=self.device, dtype=torch.int64) if return_predictions else None
                 ops.confusion_update(lp_, label.view(-1), umask.reshape(-1), conf, pred)
                 if return_predictions:

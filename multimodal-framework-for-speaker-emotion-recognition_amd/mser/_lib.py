@@ -92,6 +92,21 @@ class GruSpeakerDesc(C.Structure):
                 ("listener_blend", C.c_int32), ("hli", C.c_void_p), ("dhli", C.c_void_p)]
 
 
+class DrnnParams(C.Structure):
+    """mser_drnn_params (include/mser.h): one DialogueRNN.dialogue_cell."""
+    _fields_ = [(n, C.c_void_p) for n in ("g_wih", "g_whh", "g_bih", "g_bhh", "p_wih", "p_whh", "p_bih", "p_bhh",
+                                           "e_wih", "e_whh", "e_bih", "e_bhh", "l_wih", "l_whh", "l_bih", "l_bhh", "att_w")]
+
+
+class DrnnDesc(C.Structure):
+    """mser_drnn_desc (include/mser.h)."""
+    _fields_ = [("T", C.c_int32), ("B", C.c_int32), ("Dm", C.c_int32), ("Dg", C.c_int32), ("Dp", C.c_int32), ("De", C.c_int32),
+                ("U", C.c_void_p), ("ldu", C.c_int64), ("qmask", C.c_void_p), ("rev", C.c_void_p),
+                ("p", DrnnParams * 2), ("g", DrnnParams * 2), ("out", C.c_void_p), ("ldo", C.c_int64), ("dout", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("rng", C.c_void_p), ("drop_site", C.c_uint32 * 2), ("p_drop", C.c_float)]
+
+
 class HeadTailDesc(C.Structure):
     """mser_head_tail_desc (include/mser.h)."""
     _fields_ = [("L", C.c_int32), ("B", C.c_int32), ("D", C.c_int32), ("F", C.c_int32), ("C", C.c_int32),
@@ -164,6 +179,12 @@ SIGNATURES = {
     "mser_adam_flat": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
     "mser_adam_flat_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _f32, _vp, _f32, _vp, _vp, _vp]),
     "mser_dp_pack": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "mser_drnn_workspace_bytes": (C.c_size_t, [_i32] * 6),
+    "mser_drnn_fwd": (C.c_int, [C.POINTER(DrnnDesc), _vp]),
+    "mser_drnn_bwd": (C.c_int, [C.POINTER(DrnnDesc), _vp]),
+    "mser_drnn_alpha": (C.c_int, [C.POINTER(DrnnDesc), _i32, C.POINTER(C.c_void_p)]),
+    "mser_general2_rows_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "mser_general2_rows_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "mser_set_option": (C.c_int, [_i32, _i32]),
     "mser_marn_cell_status": (C.c_int, [C.POINTER(CellDesc), _vp]),
     "mser_prof_enable": (C.c_int, [_i32, _i32]),

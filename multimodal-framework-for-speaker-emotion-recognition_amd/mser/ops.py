@@ -423,6 +423,74 @@ def gru_speaker_bwd(descs, dhs: Optional[Tensor] = None, dgi: Optional[Tensor] =
     L.check(_lib().mser_gru_speaker_bwd(arr, n, _stream()), "gru_speaker_bwd")
 
 
+# ---- DialogueRNN (include/mser.h mser_drnn_*)
+_DRNN_FIELDS = (("g_wih", "g_cell.weight_ih"), ("g_whh", "g_cell.weight_hh"), ("g_bih", "g_cell.bias_ih"), ("g_bhh", "g_cell.bias_hh"),
+                ("p_wih", "p_cell.weight_ih"), ("p_whh", "p_cell.weight_hh"), ("p_bih", "p_cell.bias_ih"), ("p_bhh", "p_cell.bias_hh"),
+                ("e_wih", "e_cell.weight_ih"), ("e_whh", "e_cell.weight_hh"), ("e_bih", "e_cell.bias_ih"), ("e_bhh", "e_cell.bias_hh"),
+                ("l_wih", "l_cell.weight_ih"), ("l_whh", "l_cell.weight_hh"), ("l_bih", "l_cell.bias_ih"), ("l_bhh", "l_cell.bias_hh"),
+                ("att_w", "attention.transform.weight"))
+
+
+def drnn_param_struct(get) -> L.DrnnParams:
+    """``get(name)``: tensor for a parameter name relative to a DialogueRNN's ``dialogue_cell`` (contiguous)."""
+    dp = L.DrnnParams()
+    for field, name in _DRNN_FIELDS:
+        t = get(name)
+        if not t.is_contiguous():
+            raise RuntimeError(f"drnn: parameter {name} must be contiguous")
+        setattr(dp, field, _p(t))
+    return dp
+
+
+def drnn_workspace_bytes(T: int, B: int, Dm: int, Dg: int, Dp: int, De: int) -> int:
+    return int(L.load().mser_drnn_workspace_bytes(T, B, Dm, Dg, Dp, De))
+
+
+def make_drnn_desc(T: int, B: int, dims, U: Tensor, qmask: Tensor, rev: Tensor, params, out: Tensor, workspace: Tensor, grads=None,
+                   dout: Optional[Tensor] = None, drop=None) -> L.DrnnDesc:
+    """dims = (Dm, Dg, Dp, De); params / grads: two DrnnParams (dialog_rnn_f, dialog_rnn_r); drop: None or (rng, [site_f, site_r], p)."""
+    d = L.DrnnDesc()
+    d.T, d.B = T, B
+    d.Dm, d.Dg, d.Dp, d.De = dims
+    d.U, d.ldu = _p(U), _ld(U)
+    d.qmask, d.rev = _p(qmask), _p(rev)
+    for i in range(2):
+        d.p[i] = params[i]
+        if grads is not None:
+            d.g[i] = grads[i]
+    d.out, d.ldo = _p(out), _ld(out)
+    d.dout = _p(dout)
+    d.workspace, d.workspace_bytes = _p(workspace), workspace.numel() * workspace.element_size()
+    if drop is not None:
+        rng, sites, p = drop
+        d.rng, d.p_drop = _p(rng), float(p)
+        d.drop_site[0], d.drop_site[1] = int(sites[0]), int(sites[1])
+    d._keep = (U, qmask, rev, out, workspace, dout)
+    return d
+
+
+def drnn_fwd(desc: L.DrnnDesc) -> None:
+    L.check(_lib().mser_drnn_fwd(C.byref(desc), _stream()), "drnn_fwd")
+
+
+def drnn_bwd(desc: L.DrnnDesc) -> None:
+    L.check(_lib().mser_drnn_bwd(C.byref(desc), _stream()), "drnn_bwd")
+
+
+def drnn_alpha_ptr(desc: L.DrnnDesc, direction: int) -> int:
+    ptr = C.c_void_p()
+    L.check(_lib().mser_drnn_alpha(C.byref(desc), direction, C.byref(ptr)), "drnn_alpha")
+    return ptr.value
+
+
+def general2_rows_fwd(S0: Tensor, alpha: Tensor, mask: Tensor, rows: int, n: int, Ln: int) -> None:
+    L.check(_lib().mser_general2_rows_fwd(_p(S0), _p(alpha), _p(mask), rows, n, Ln, _stream()), "general2_rows_fwd")
+
+
+def general2_rows_bwd(S0: Tensor, mask: Tensor, dA: Tensor, rows: int, n: int, Ln: int) -> None:
+    L.check(_lib().mser_general2_rows_bwd(_p(S0), _p(mask), _p(dA), rows, n, Ln, _stream()), "general2_rows_bwd")
+
+
 # ---- dropout (include/mser.h "Dropout"): rng = int32 tensor {seed, step} on the device
 def dropout_apply_(x: Tensor, rng: Tensor, site: int, p: float, idx0: int = 0) -> None:
     """In place x[r, c] *= keep ? 1/(1-p) : 0 over a 2-D row view (unit column stride) or any contiguous tensor."""

@@ -549,6 +549,155 @@ def masked_loss(pred: Tensor, target: Tensor, mask: Tensor, weight: Optional[Ten
 
 
 # --------------------------------------------------------------------------------------
+# DialogueRNN BiModel (BASELINE configs[3]): model/DialogueRNN.py:24-77 (MatchingAttention), :80-166
+# (DialogueRNNCell), :169-198 (DialogueRNN), :201-277 (BiModel); constructed by model_trainer.py:35-47 with D_m 712, D_g = D_p = 500,
+# D_e = D_h = 300, listener_state=True, context_attention='general', dropout_rec = dropout = 0.1
+# --------------------------------------------------------------------------------------
+def dialogue_rnn(P: Params, pre: str, U: Tensor, qmask: Tensor, drops: Optional[Dict[str, Tensor]] = None):
+    """DialogueRNN.forward (:183-198) with DialogueRNNCell.forward (:119-166), listener_state=True, 'general' MatchingAttention over
+    the growing history of global states.  U [T,B,D_m], qmask [T,B,2] -> (e [T,B,D_e], alphas: list of [B,t] for t = 1..T-1).
+    Per step: g = dropout(GRU_g([U_t | q[b,s_b]], g_{t-1}));  c = sum_s softmax_s(<W_att U_t, g_s>) g_s over s < t (zeros at t = 0);
+    qs = dropout(GRU_p([U_t | c], q[b,p])) for both parties;  ql = dropout(GRU_l([U_t | qs[b,s_b]], q[b,p]));
+    q = ql (1 - qmask) + qs qmask;  e = dropout(GRU_e(q[b,s_b], e_{t-1})).
+    ``drops`` (factors): "g" [T,B,D_g], "qs" / "ql" [T,B,2,D_p], "e" [T,B,D_e]."""
+    dr = drops or {}
+    T, B, _ = U.shape
+    c_pre = pre + "dialogue_cell."
+    Dg = P[c_pre + "g_cell.weight_hh"].shape[1]
+    Dp = P[c_pre + "p_cell.weight_hh"].shape[1]
+    De = P[c_pre + "e_cell.weight_hh"].shape[1]
+    dt, dev = U.dtype, U.device
+    qm = qmask.to(dt)
+    q = torch.zeros(B, 2, Dp, dtype=dt, device=dev)
+    g_prev = torch.zeros(B, Dg, dtype=dt, device=dev)
+    e_prev = torch.zeros(B, De, dtype=dt, device=dev)
+    rows = torch.arange(B, device=dev)
+    ghist, es, alphas = [], [], []
+    Watt = P[c_pre + "attention.transform.weight"]
+    for t in range(T):
+        u = U[t]
+        idx = torch.argmax(qm[t], 1)                                          # :129
+        q0_sel = q[rows, idx]                                                 # :131
+        g = gru_cell(P, c_pre + "g_cell.", torch.cat([u, q0_sel], 1), g_prev)  # :133-135
+        if "g" in dr:
+            g = g * dr["g"][t]
+        if t == 0:
+            c = torch.zeros(B, Dg, dtype=dt, device=dev)                      # :137-139
+        else:
+            M = torch.stack(ghist, 0)                                         # [t,B,Dg]
+            x_ = linear(u, Watt)                                              # :58
+            alpha = torch.softmax(torch.einsum("bd,tbd->bt", x_, M), 1)       # :59
+            c = torch.einsum("bt,tbd->bd", alpha, M)                          # :75
+            alphas.append(alpha)
+        uc = torch.cat([u, c], 1).unsqueeze(1).expand(-1, 2, -1).reshape(B * 2, -1)          # :144
+        qs = gru_cell(P, c_pre + "p_cell.", uc, q.reshape(B * 2, Dp)).view(B, 2, Dp)          # :145
+        if "qs" in dr:
+            qs = qs * dr["qs"][t]
+        ss = qs[rows, idx].unsqueeze(1).expand(-1, 2, -1).reshape(B * 2, Dp)                  # :150
+        u2 = u.unsqueeze(1).expand(-1, 2, -1).reshape(B * 2, -1)
+        ql = gru_cell(P, c_pre + "l_cell.", torch.cat([u2, ss], 1), q.reshape(B * 2, Dp)).view(B, 2, Dp)   # :151-152
+        if "ql" in dr:
+            ql = ql * dr["ql"][t]
+        m = qm[t].unsqueeze(2)
+        q = ql * (1 - m) + qs * m                                             # :157
+        e = gru_cell(P, c_pre + "e_cell.", q[rows, idx], e_prev)              # :160
+        if "e" in dr:
+            e = e * dr["e"][t]
+        ghist.append(g)
+        g_prev, e_prev = g, e
+        es.append(e)
+    return torch.stack(es, 0), alphas
+
+
+def matching_attention_general2(P: Params, pre: str, M: Tensor, x: Tensor, mask: Tensor):
+    """MatchingAttention(att_type='general2').forward (:61-68,:75): M [S,B,D], x [B,D], mask [B,S] ->
+    alpha_ = softmax_s(<W x + b, M_s> * mask_s); alpha = alpha_ mask / sum_s(alpha_ mask); pool = sum_s alpha_s M_s."""
+    x_ = linear(x, P[pre + "transform.weight"], P[pre + "transform.bias"])
+    sc = torch.einsum("bd,sbd->bs", x_, M) * mask
+    a_ = torch.softmax(sc, 1) * mask
+    alpha = a_ / a_.sum(1, keepdim=True)
+    return torch.einsum("bs,sbd->bd", alpha, M), alpha
+
+
+def bimodel_forward(P: Params, U: Tensor, qmask: Tensor, umask: Tensor, drops: Optional[Dict[str, Tensor]] = None):
+    """BiModel.forward(U, qmask, umask, att2=True) (:236-277): forward DialogueRNN, reversed DialogueRNN (``_reverse_seq``), the
+    'general2' matching attention of every position over all positions of the concatenated emotion states, linear + ReLU, smax_fc,
+    log_softmax.  Returns (log_prob [L,B,C], alpha [L][B,L], alpha_f, alpha_b).
+    ``drops``: "f.*" / "b.*" (dialogue_rnn keys per direction), "rec_f" / "rec_b" [L,B,D_e] (:245,:252), "hidden" [L,B,2 D_h] (:268)."""
+    dr = drops or {}
+
+    def sub(k):
+        return {n[len(k) + 1:]: v for n, v in dr.items() if n.startswith(k + ".")}
+    e_f, a_f = dialogue_rnn(P, "dialog_rnn_f.", U, qmask, sub("f"))
+    if "rec_f" in dr:
+        e_f = e_f * dr["rec_f"]
+    e_b, a_b = dialogue_rnn(P, "dialog_rnn_r.", reverse_seq(U, umask), reverse_seq(qmask, umask), sub("b"))
+    e_b = reverse_seq(e_b, umask)
+    if "rec_b" in dr:
+        e_b = e_b * dr["rec_b"]
+    em = torch.cat([e_f, e_b], -1)
+    att, alpha = [], []
+    for t in range(em.shape[0]):
+        pool, a = matching_attention_general2(P, "matchatt.", em, em[t], umask)       # :259
+        att.append(pool)
+        alpha.append(a)
+    att = torch.stack(att, 0)
+    hidden = F.relu(linear(att, P["linear.weight"], P["linear.bias"]))                # :264
+    if "hidden" in dr:
+        hidden = hidden * dr["hidden"]
+    lp = F.log_softmax(linear(hidden, P["smax_fc.weight"], P["smax_fc.bias"]), 2)     # :269
+    return lp, alpha, a_f, a_b
+
+
+def bimodel_param_shapes(D_m: int = 712, D_g: int = 500, D_p: int = 500, D_e: int = 300, D_h: int = 300,
+                         n_classes: int = 6) -> Dict[str, Tuple[int, ...]]:
+    """state_dict key -> shape of BiModel(listener_state=True, context_attention='general') in registration order."""
+    S: Dict[str, Tuple[int, ...]] = {}
+    for d in ("dialog_rnn_f.", "dialog_rnn_r."):
+        c = d + "dialogue_cell."
+        for cell, din, dh in (("g_cell.", D_m + D_p, D_g), ("p_cell.", D_m + D_g, D_p), ("e_cell.", D_p, D_e), ("l_cell.", D_m + D_p, D_p)):
+            S[c + cell + "weight_ih"] = (3 * dh, din)
+            S[c + cell + "weight_hh"] = (3 * dh, dh)
+            S[c + cell + "bias_ih"] = (3 * dh,)
+            S[c + cell + "bias_hh"] = (3 * dh,)
+        S[c + "attention.transform.weight"] = (D_g, D_m)
+    S["linear.weight"] = (2 * D_h, 2 * D_e)
+    S["linear.bias"] = (2 * D_h,)
+    S["smax_fc.weight"] = (n_classes, 2 * D_h)
+    S["smax_fc.bias"] = (n_classes,)
+    S["matchatt.transform.weight"] = (2 * D_e, 2 * D_e)
+    S["matchatt.transform.bias"] = (2 * D_e,)
+    return S
+
+
+def bimodel_seeded_params(seed: int = 0, dtype=torch.float32, **dims) -> Params:
+    """Deterministic BiModel parameters (numpy RandomState per name): U(-1/sqrt(fan_in), +) like nn.Linear / nn.GRUCell; the two
+    attention transforms are scaled up (x3) so that the softmaxes over the history are far from uniform and the tests bite."""
+    import zlib
+
+    import numpy as np
+
+    P: Params = {}
+    for name, shp in bimodel_param_shapes(**dims).items():
+        rs = np.random.RandomState((zlib.crc32(name.encode()) + 104729 * seed) % (2 ** 31))
+        if len(shp) == 2:
+            k = 1.0 / math.sqrt(shp[1])
+            if "transform" in name:
+                k *= 3.0
+            a = rs.uniform(-k, k, shp)
+        else:
+            a = rs.uniform(-0.05, 0.05, shp)
+        P[name] = torch.tensor(a, dtype=dtype)
+    return P
+
+
+def bimodel_seeded_batch(B: int, L: int, D_m: int = 712, seed: int = 1, ragged: bool = False, n_classes: int = 6):
+    """U [L,B,D_m], qmask [L,B,2], umask [B,L], label [B,L] (model_trainer_d.py:62-63: U = cat(textf, acouf, visuf))."""
+    x, qmask, umask, label = seeded_batch(B, L, d_r=D_m, d_a=0, seed=seed, ragged=ragged, n_classes=n_classes)
+    return x, qmask, umask, label
+
+
+# --------------------------------------------------------------------------------------
 # optimiser (model_trainer.py:82-83, :92)
 # --------------------------------------------------------------------------------------
 def step_lr(lr0: float, gamma: float, step_size: int, epoch: int) -> float:

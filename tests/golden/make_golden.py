@@ -313,6 +313,37 @@ def gru_cell_cases():
     print("gru cells ok")
 
 
+def bimodel_cases():
+    """DialogueRNN BiModel (model/DialogueRNN.py:201-277) as model_trainer.py:35-47 constructs it
+    (listener_state=True, context_attention='general'), eval mode, ragged batches: at small widths (full outputs incl. the three
+    attention maps) and at the trainer's widths D_m 712, D_g = D_p = 500, D_e = D_h = 300 (log-probs + gradient samples)."""
+    from models.DialogueRNN import BiModel
+
+    for tag, dims, B, L, seed in (("small", dict(D_m=36, D_g=20, D_p=24, D_e=12, D_h=10), 4, 9, 71),
+                                  ("ref", dict(D_m=712, D_g=500, D_p=500, D_e=300, D_h=300), 3, 6, 73)):
+        torch.manual_seed(0)
+        net = BiModel(dims["D_m"], dims["D_g"], dims["D_p"], dims["D_e"], dims["D_h"], n_classes=6, listener_state=True,
+                      context_attention="general", dropout_rec=0.1, dropout=0.1).eval()
+        P = O.bimodel_seeded_params(seed=seed, **dims)
+        _load(net, P)
+        U, qmask, umask, label = O.bimodel_seeded_batch(B, L, D_m=dims["D_m"], seed=seed + 1, ragged=True)
+        lp, alpha, alpha_f, alpha_b = net(U, qmask, umask, att2=True)
+        lp_ = lp.transpose(0, 1).contiguous().view(-1, lp.size()[2])           # model_trainer_d.py:64
+        m = umask.reshape(-1, 1)
+        loss = torch.nn.functional.nll_loss(lp_ * m, label.view(-1), reduction="sum") / umask.sum()
+        loss.backward()
+        rec = dict(B=B, L=L, seed=seed, logits=lp.detach().numpy(), loss=np.float64(float(loss.detach())),
+                   **{k: np.int64(v) for k, v in dims.items()})
+        if tag == "small":
+            rec["alpha"] = torch.stack(alpha, 0).detach().numpy()                       # [L,B,L]
+            for nm, al in (("alpha_f", alpha_f), ("alpha_b", alpha_b)):
+                for t, a in enumerate(al):
+                    rec[f"{nm}/{t + 1}"] = a.detach().numpy()                           # [B,t+1]
+        rec.update(_grad_samples(net.named_parameters()))
+        np.savez_compressed(os.path.join(HERE, f"bimodel_{tag}.npz"), **rec)
+        print("bimodel", tag, float(loss.detach()))
+
+
 def train_mode_case():
     """The reference in TRAIN mode with its 13 dropout sites fed from known masks: nn.Dropout.forward is replaced, for the duration
     of this case, by a function that multiplies by the next factor tensor of that module's queue (O.seeded_drops, laid out in the
@@ -414,6 +445,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "onlysp":
         onlysp_case()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bimodel":
+        bimodel_cases()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "nsps":
         nsps_cases()
         gru_cell_cases()
@@ -434,3 +468,4 @@ if __name__ == "__main__":
     onlysp_case()
     nsps_cases()
     gru_cell_cases()
+    bimodel_cases()

@@ -1043,3 +1043,108 @@ def test_nsps_trainer_runs_the_reference_loop(O, tmp_path):
         tr.save_parameters(path)
         keys = list(torch.load(path, weights_only=True).keys())
         assert keys[0] == "model.p" and "model.marn_cell_b.gru_l.bias_hh" in keys and len(keys) == 109
+
+
+# ---------------------------------------------------------------------------------------------------------------- f2: DialogueRNN BiModel
+def _bimodel(dims, seed, O, train=False):
+    from models.DialogueRNN import BiModel
+    net = BiModel(dims["D_m"], dims["D_g"], dims["D_p"], dims["D_e"], dims["D_h"], n_classes=6, listener_state=True,
+                  context_attention="general", dropout_rec=0.1, dropout=0.1).cuda()
+    net.train(train)
+    load_params(net, O.bimodel_seeded_params(seed=seed, **dims))
+    return net
+
+
+@pytest.mark.parametrize("tag", ["small", "ref"])
+def test_bimodel_vs_reference_golden(O, golden_dir, tag):
+    """DialogueRNN BiModel against the reference's own eval-mode forward/backward
+    (tests/golden/make_golden.py::bimodel_cases): log-probs 1e-4, loss, the three attention maps, every gradient."""
+    from loss import MaskedLoss
+    g = _g(golden_dir, f"bimodel_{tag}.npz")
+    dims = {k: int(g[k]) for k in ("D_m", "D_g", "D_p", "D_e", "D_h")}
+    B, L, seed = int(g["B"]), int(g["L"]), int(g["seed"])
+    net = _bimodel(dims, seed, O)
+    U, qmask, umask, label = O.bimodel_seeded_batch(B, L, D_m=dims["D_m"], seed=seed + 1, ragged=True)
+    lp, alpha, alpha_f, alpha_b = net(U.cuda(), qmask.cuda(), umask.cuda(), att2=True)
+    lp_ = lp.transpose(0, 1).contiguous().view(-1, lp.size()[2])
+    loss = MaskedLoss(torch.nn.NLLLoss)(lp_, label.cuda().view(-1), umask.cuda())
+    loss.backward()
+    assert tuple(lp.shape) == (L, B, 6) and len(alpha) == L and len(alpha_f) == L - 1 and len(alpha_b) == L - 1
+    assert maxabs(lp, g["logits"]) < LOGIT_TOL
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-5
+    if tag == "small":
+        assert maxabs(torch.stack(alpha, 0), g["alpha"]) < 1e-5
+        for nm, al in (("alpha_f", alpha_f), ("alpha_b", alpha_b)):
+            for t, a in enumerate(al):
+                assert tuple(a.shape) == (B, t + 1) and maxabs(a, g[f"{nm}/{t + 1}"]) < 1e-5, (nm, t)
+    _check_grads(g, list(net.named_parameters()))
+
+
+@pytest.mark.parametrize("train,B,L", [(False, 5, 12), (True, 4, 7), (True, 9, 3), (False, 3, 1)])
+def test_bimodel_vs_oracle(O, train, B, L):
+    """The same model against the oracle (pinned by the goldens above): eval mode and, in train mode, mask for mask with every dropout
+    site live (g, qs, ql, e inside both cells; the two emotion-state slabs; the hidden layer); L = 1 (no history at all)."""
+    from loss import MaskedLoss
+    from mser.bimodel_fn import SITE_DRNN, SITE_DRNN_HID, SITE_DRNN_REC
+    dims = dict(D_m=44, D_g=28, D_p=20, D_e=16, D_h=12)
+    net = _bimodel(dims, 131, O, train)
+    U, qmask, umask, label = O.bimodel_seeded_batch(B, L, D_m=dims["D_m"], seed=133 + B, ragged=True)
+    captured = {}
+    orig = net._drop_cfg
+    net._drop_cfg = lambda dev: captured.setdefault("cfg", orig(dev))
+    try:
+        lp, alpha, _, _ = net(U.cuda(), qmask.cuda(), umask.cuda())
+        lp_ = lp.transpose(0, 1).contiguous().view(-1, 6)
+        loss = MaskedLoss(torch.nn.NLLLoss)(lp_, label.cuda().view(-1), umask.cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        net._drop_cfg = orig
+    dr = None
+    if train:
+        cfg = captured["cfg"]
+        N = L * B
+        dr = {}
+        for i, k in enumerate(("f", "b")):
+            base = SITE_DRNN + 4 * i
+            dr[f"{k}.g"] = cfg.site(base, cfg.p_cell).scale(N * dims["D_g"]).cpu().view(L, B, dims["D_g"])
+            dr[f"{k}.qs"] = cfg.site(base + 1, cfg.p_cell).scale(N * 2 * dims["D_p"]).cpu().view(L, B, 2, dims["D_p"])
+            dr[f"{k}.ql"] = cfg.site(base + 2, cfg.p_cell).scale(N * 2 * dims["D_p"]).cpu().view(L, B, 2, dims["D_p"])
+            dr[f"{k}.e"] = cfg.site(base + 3, cfg.p_cell).scale(N * dims["D_e"]).cpu().view(L, B, dims["D_e"])
+            dr[f"rec_{k}"] = cfg.site(SITE_DRNN_REC + i, cfg.p_rec).scale(N * dims["D_e"]).cpu().view(L, B, dims["D_e"])
+        dr["hidden"] = cfg.site(SITE_DRNN_HID, cfg.p_hid).scale(N * 2 * dims["D_h"]).cpu().view(L, B, 2 * dims["D_h"])
+        assert 0.1 < float((dr["rec_f"] == 0).float().mean()) < 0.45
+    Pr = {k: v.clone().requires_grad_(True) for k, v in O.bimodel_seeded_params(seed=131, **dims).items()}
+    lp_ref, alpha_ref, _, _ = O.bimodel_forward(Pr, U, qmask, umask, drops=dr)
+    loss_ref = O.masked_nll(lp_ref.transpose(0, 1).reshape(-1, 6), label.view(-1), umask)
+    loss_ref.backward()
+    assert maxabs(lp, lp_ref) < LOGIT_TOL
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 2e-5
+    assert maxabs(torch.stack(alpha, 0), torch.stack(alpha_ref, 0)) < 1e-5
+    for n, p in net.named_parameters():
+        r = Pr[n].grad
+        if r is None:            # L = 1: no history, so the global cell and the attention transform are never read
+            assert L == 1 and float(p.grad.abs().sum()) == 0.0, n
+            continue
+        assert p.grad is not None, n
+        assert maxabs(p.grad, r) < 3e-4 * max(1e-3, float(r.norm())), n
+
+
+def test_dialoguernn_trainer_runs_the_reference_loop(O, tmp_path):
+    """ModelTrainer(model="DialogueRNN") (model_trainer.py:35-47): BiModel at the reference's widths on a memorisable batch of 712-wide
+    features: the loss falls, eval_network runs, the checkpoint carries the reference's key names."""
+    from model_trainer import ModelTrainer
+    tr = ModelTrainer(torch.device("cuda:0"), 1e-3, 1, 0.98, "DialogueRNN", "NLL", 6, "IEMOCAP", quiet=True)
+    load_params(tr.model, O.bimodel_seeded_params(seed=141))
+    B, L = 4, 8
+    U, qmask, umask, label = O.bimodel_seeded_batch(B, L, D_m=712, seed=142, ragged=True)
+    r = U[:, :, :612].contiguous()
+    batch = [r, r, r, r, torch.zeros(L, B, 4), U[:, :, 612:].contiguous(), qmask, umask, label, ["v"] * B]     # textf = mean(r1..r4) = r
+    losses = [tr.train_network(ep, [batch] * 6)[1] for ep in (1, 2, 3)]
+    assert losses[-1] < losses[0], losses
+    acc, f1, extra = tr.eval_network([batch])
+    assert 0.0 <= acc <= 100.0 and extra == {}
+    path = str(tmp_path / "drnn.model")
+    tr.save_parameters(path)
+    keys = list(torch.load(path, weights_only=True).keys())
+    assert keys[0] == "model.dialog_rnn_f.dialogue_cell.g_cell.weight_ih" and keys[-1] == "model.matchatt.transform.bias" and len(keys) == 40

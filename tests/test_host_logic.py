@@ -115,7 +115,7 @@ def test_step_lr_closed_form(golden_dir):
 def test_out_of_scope_models_are_refused_loudly():
     from model_trainer import ModelTrainer
     with pytest.raises(NotImplementedError):
-        ModelTrainer("cpu", 1e-3, 1, 0.98, "DialogueRNN", "NLL", 6, "IEMOCAP", quiet=True)
+        ModelTrainer("cpu", 1e-3, 1, 0.98, "MARN1_cf", "NLL", 6, "IEMOCAP", quiet=True)
 
 
 def test_metrics_from_confusion_match_sklearn():
@@ -167,6 +167,25 @@ def test_gru_variant_mirrors_follow_the_reference_registration_order(golden_dir)
         assert [n for n, _ in net.named_parameters()] == ref_names, fix
         ref_dead = {n for n in ref_names if float(g["gnorm/" + n]) < 0}
         assert set(net.flat_store.dead) == ref_dead, (fix, set(net.flat_store.dead) ^ ref_dead)
+
+
+def test_bimodel_mirror_matches_the_oracle_table_and_the_reference_order(golden_dir):
+    """models.DialogueRNN.BiModel as model_trainer.py:42-47 constructs it: parameter names / shapes / order equal the reference's own
+    named_parameters() order (recorded by the reference-written fixture) and oracle.bimodel_param_shapes."""
+    from models.DialogueRNN import BiModel, DialogueRNNCell, MatchingAttention
+    m = BiModel(712, 500, 500, 300, 300, n_classes=6, listener_state=True, context_attention='general', dropout_rec=0.1, dropout=0.1)
+    sd = m.state_dict()
+    shapes = O.bimodel_param_shapes()
+    assert list(sd.keys()) == list(shapes.keys()) and all(tuple(sd[k].shape) == shapes[k] for k in shapes)
+    g = np.load(os.path.join(golden_dir, "bimodel_ref.npz"))
+    assert [n for n, _ in m.named_parameters()] == [k[len("gnorm/"):] for k in g.files if k.startswith("gnorm/")]
+    assert all(float(g[k]) >= 0 for k in g.files if k.startswith("gnorm/"))          # no dead parameters in this model
+    assert m.dropout_rec.p == pytest.approx(0.25) and m.dialog_rnn_f.dialogue_cell.dropout.p == 0.1    # :215, :216-217
+    pos = [p.name for p in inspect.signature(BiModel.__init__).parameters.values() if p.name != "self"]
+    assert pos == ["D_m", "D_g", "D_p", "D_e", "D_h", "n_classes", "listener_state", "context_attention", "D_a", "dropout_rec", "dropout"]
+    assert list(inspect.signature(BiModel.forward).parameters)[1:] == ["U", "qmask", "umask", "att2"]
+    with pytest.raises(NotImplementedError):
+        DialogueRNNCell(10, 8, 8, 4, listener_state=False, context_attention='simple')
 
 
 def test_nsps_constructor_takes_the_dataset_argument():

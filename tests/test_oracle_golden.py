@@ -171,6 +171,31 @@ def test_gru_variant_cells_vs_reference(golden_dir):
         _check_grads(gg, [(k[len("marn_cell_f."):], v) for k, v in P.items()])
 
 
+@pytest.mark.parametrize("tag", ["small", "ref"])
+def test_bimodel_vs_reference(golden_dir, tag):
+    """the oracle's restatement of the DialogueRNN BiModel (global / party / listener / emotion GRUs, 'general'
+    matching attention over the growing history, 'general2' attention over the bidirectional emotion states) against the
+    reference's own eval-mode forward/backward (tests/golden/make_golden.py::bimodel_cases)."""
+    g = _g(golden_dir, f"bimodel_{tag}.npz")
+    dims = {k: int(g[k]) for k in ("D_m", "D_g", "D_p", "D_e", "D_h")}
+    B, L, seed = int(g["B"]), int(g["L"]), int(g["seed"])
+    P = {k: v.clone().requires_grad_(True) for k, v in O.bimodel_seeded_params(seed=seed, **dims).items()}
+    U, qmask, umask, label = O.bimodel_seeded_batch(B, L, D_m=dims["D_m"], seed=seed + 1, ragged=True)
+    lp, alpha, a_f, a_b = O.bimodel_forward(P, U, qmask, umask)
+    lp_ = lp.transpose(0, 1).reshape(-1, lp.shape[2])
+    loss = O.masked_nll(lp_, label.view(-1), umask)
+    loss.backward()
+    assert np.abs(lp.detach().numpy() - g["logits"]).max() < 2e-5
+    assert abs(float(loss) - float(g["loss"])) < 2e-6
+    if tag == "small":
+        assert np.abs(torch.stack(alpha, 0).detach().numpy() - g["alpha"]).max() < 2e-6
+        for nm, al in (("alpha_f", a_f), ("alpha_b", a_b)):
+            assert len(al) == L - 1
+            for t, a in enumerate(al):
+                assert np.abs(a.detach().numpy() - g[f"{nm}/{t + 1}"]).max() < 2e-6, (nm, t)
+    _check_grads(g, list(P.items()))
+
+
 def test_trainer_lr_schedule(golden_dir):
     g = _g(golden_dir, "trainer.npz")
     assert O.step_lr(1e-3, 0.98, 1, 1) == pytest.approx(float(g["lr1"]), rel=1e-12)
