@@ -460,6 +460,31 @@ def main():
             del tro
             variants[tag] = {"ms_per_step": round(ms_o2, 4), "utterances_per_s": round(B * L / (ms_o2 * 1e-3), 1),
                              "note": "GRU speaker chains counter-linked to the LSTHM chains (concurrent launches on two streams); eager launches"}
+        # BASELINE.json configs[3]: DialogueRNN-style global / party / listener / emotion GRUs with attention over the growing history
+        # (model/DialogueRNN.py BiModel as model_trainer.py:35-47 builds it), B = 64 dialogues x L = 200 utterances, D_m = 712
+        trd = ModelTrainer(device, lr=1e-3, test_step=1, lr_decay=0.98, model="DialogueRNN", loss="NLL", n_classes=NCLS,
+                           dataset="IEMOCAP", quiet=True, dropout=False)
+        trd.train()
+        trd.scheduler.step(0)
+        rs = np.random.RandomState(4000)
+        Bd, Ld, Dmd = 64, 200, 712
+        Ud = torch.tensor(rs.standard_normal((Ld, Bd, Dmd)).astype(np.float32)).to(device)
+        qd = torch.tensor(np.eye(2, dtype=np.float32)[rs.randint(0, 2, (Ld, Bd))]).to(device)
+        ud = torch.ones(Bd, Ld, device=device)
+        ld_ = torch.tensor(rs.randint(0, NCLS, (Bd, Ld)).astype(np.int64)).to(device)
+        tr_main, tr = tr, trd
+        try:
+            ms_dr = time_steps((Ud, qd, ud, ld_), n=4)
+        finally:
+            tr = tr_main
+        del trd
+        gflop = 3 * 2 * Ld * 2 * (Bd * (500 * 1500 * 2 + 500 * 1500 + 2 * 500 * 1500 + 500 * 1500 + 2 * 500 * 1500 + 500 * 900 + 300 * 900)
+                                  + Bd * 712 * (3 * 1500 + 500)) / 1e9
+        variants["dialoguernn_bimodel_B64_L200"] = {
+            "ms_per_step": round(ms_dr, 3), "utterances_per_s": round(Bd * Ld / (ms_dr * 1e-3), 1),
+            "fp32_mfma_frac": round(gflop / (ms_dr * 1e-3) / 1e3 / 157.0, 4),
+            "note": f"configs[3]; eager; ~{gflop:.0f} GFLOP of exact-fp32 GEMM work per training step against the 157 TFLOP/s fp32 matrix "
+                    "peak; first version: 13 launches per step and direction pair issued from a C++ host loop"}
         log("variants done")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -241,7 +241,7 @@ __global__ void drnn_e_fwd_kernel(int B, int H, const float* gi, const float* gh
 
 // ---- attention over the history (:56-59,:75): one workgroup per (b, dir) ---------------------------------------------------------------
 // scores_s = <x, g_s>, s = 0..t-1 (g_s = Gh[s+1]); alpha = softmax; c = sum alpha_s g_s.  LDS: x[Dg] | sc[t]
-constexpr int ATT_NT = 256;
+constexpr int ATT_NT = 1024;       // 16 waves: the score pass is a chain of dependent global-load round trips per wave, so many short chains
 __global__ __launch_bounds__(ATT_NT) void drnn_attn_fwd_kernel(int B, int Dg, int T, int t, const float* Xatt_t, long x_ds, const float* Gh,
                                                                long gh_ds, float* alpha_t, long al_ds, float* c_t, long c_ds) {
   extern __shared__ float sm[];
@@ -267,22 +267,38 @@ __global__ __launch_bounds__(ATT_NT) void drnn_attn_fwd_kernel(int B, int Dg, in
   mx = wave_max(mx);
   if (lane == 0) red[wave] = mx;
   __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  mx = red[0];
+#pragma unroll
+  for (int k = 1; k < ATT_NT / 64; ++k) mx = fmaxf(mx, red[k]);
   __syncthreads();
   float z = 0.f;
   for (int s = tid; s < t; s += ATT_NT) { const float ev = expf(sc[s] - mx); sc[s] = ev; z += ev; }
   z = wave_sum(z);
   if (lane == 0) red[wave] = z;
   __syncthreads();
-  z = red[0] + red[1] + red[2] + red[3];
+  z = 0.f;
+#pragma unroll
+  for (int k = 0; k < ATT_NT / 64; ++k) z += red[k];
   const float rz = 1.f / z;
   for (int s = tid; s < t; s += ATT_NT) { const float a = sc[s] * rz; sc[s] = a; alpha_t[(long)dir * al_ds + (long)b * T + s] = a; }
   __syncthreads();
-  for (int u = tid; u < Dg; u += ATT_NT) {
-    float acc = 0.f;
-    for (int s = 0; s < t; ++s) acc = fmaf(sc[s], G[(long)(s + 1) * gs + u], acc);
-    c_t[(long)dir * c_ds + (long)b * Dg + u] = acc;
+  // pooled vector: thread (u, part) sums its quarter of the history (independent loads, unrolled), the parts meet through atomics
+  // on LDS-resident accumulators (x[] is free now)
+  for (int u = tid; u < Dg; u += ATT_NT) x[u] = 0.f;
+  __syncthreads();
+  {
+    const int NP = ATT_NT / 256;                          // history parts
+    const int part = tid / 256, lu = tid % 256;
+    const int s0 = (int)((long)t * part / NP), s1 = (int)((long)t * (part + 1) / NP);
+    for (int u = lu; u < Dg; u += 256) {
+      float acc = 0.f;
+#pragma unroll 8
+      for (int s = s0; s < s1; ++s) acc = fmaf(sc[s], G[(long)(s + 1) * gs + u], acc);
+      atomicAdd(&x[u], acc);
+    }
   }
+  __syncthreads();
+  for (int u = tid; u < Dg; u += ATT_NT) c_t[(long)dir * c_ds + (long)b * Dg + u] = x[u];
 }
 // backward: dalpha_s = <dc, g_s>; ds = alpha (dalpha - sum alpha dalpha); dx = sum ds_s g_s; dGh[s+1] += alpha_s dc + ds_s x
 __global__ __launch_bounds__(ATT_NT) void drnn_attn_bwd_kernel(int B, int Dg, int T, int t, const float* Xatt_t, long x_ds, const float* Gh,
@@ -312,20 +328,33 @@ __global__ __launch_bounds__(ATT_NT) void drnn_attn_bwd_kernel(int B, int Dg, in
   dot = wave_sum(dot);
   if (lane == 0) red[wave] = dot;
   __syncthreads();
-  dot = red[0] + red[1] + red[2] + red[3];
+  dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < ATT_NT / 64; ++k) dot += red[k];
   __syncthreads();
   for (int s = tid; s < t; s += ATT_NT) ds[s] = al[s] * (ds[s] - dot);
   __syncthreads();
-  for (int u = tid; u < Dg; u += ATT_NT) {
-    float acc = 0.f;
-    const float dcu = dcv[u], xu = x[u];
-    for (int s = 0; s < t; ++s) {
-      const long o = (long)(s + 1) * gs + u;
-      acc = fmaf(ds[s], G[o], acc);
-      dG[o] += al[s] * dcu + ds[s] * xu;       // this workgroup owns every (s, b, dir) row it touches
+  float* dxa = al + T;                          // [Dg] accumulator of dx
+  for (int u = tid; u < Dg; u += ATT_NT) dxa[u] = 0.f;
+  __syncthreads();
+  {
+    const int NP = ATT_NT / 256;
+    const int part = tid / 256, lu = tid % 256;
+    const int s0 = (int)((long)t * part / NP), s1 = (int)((long)t * (part + 1) / NP);
+    for (int u = lu; u < Dg; u += 256) {
+      float acc = 0.f;
+      const float dcu = dcv[u], xu = x[u];
+#pragma unroll 4
+      for (int s = s0; s < s1; ++s) {
+        const long o = (long)(s + 1) * gs + u;
+        acc = fmaf(ds[s], G[o], acc);
+        dG[o] += al[s] * dcu + ds[s] * xu;     // this workgroup owns every (s, b, dir) row it touches; each (s, u) has one thread
+      }
+      atomicAdd(&dxa[u], acc);
     }
-    dX_t[(long)dir * x_ds + (long)b * Dg + u] = acc;
   }
+  __syncthreads();
+  for (int u = tid; u < Dg; u += ATT_NT) dX_t[(long)dir * x_ds + (long)b * Dg + u] = dxa[u];
 }
 
 // ---- backward epilogues ------------------------------------------------------------------------------------------------------------------
@@ -497,13 +526,21 @@ int mm_nt(hipStream_t s, const float* A, long lda, long a_ds, const float* W, lo
   return gemm(g, s);
 }
 // C[dir][M, N] (+)= A[dir][M, K] W[dir][K, N]        -- backward data gradient through an nn.Linear weight [K, N] (row-major, ld ldw)
+// The reduction runs over the 3H gate columns (K = 1500 at the reference's widths) while the output is only N <= 500 wide: without a
+// split the grid would be 16 column tiles x 2 directions = 32 workgroups with 24 serial k-tiles each (33 us per product, measured);
+// every such product therefore ACCUMULATES with split-K float atomics into a buffer that is either live (accum) or zeroed first.
 int mm_nn(hipStream_t s, const float* A, long lda, long a_ds, const float* W, long ldw, long w_ds, float* C, long ldc, long c_ds, int M, int N,
           int K, bool accum) {
+  if (!accum) {
+    if (c_ds == (long)M * ldc) MSER_CHECK_HIP(hipMemsetAsync(C, 0, (size_t)2 * M * ldc * sizeof(float), s));
+    else for (int dir = 0; dir < 2; ++dir) MSER_CHECK_HIP(hipMemsetAsync(C + dir * c_ds, 0, (size_t)M * ldc * sizeof(float), s));
+  }
   mser_gemm_desc g = gd();
   g.A = A; g.B = W; g.C = C; g.M = M; g.N = N; g.K = K;
   g.sAm = lda; g.sAk = 1; g.sBk = ldw; g.sBn = 1; g.ldc = ldc;
   g.batch1 = 2; g.sA1 = a_ds; g.sB1 = w_ds; g.sC1 = c_ds;
-  if (accum) g.flags |= MSER_GEMM_ACCUM;
+  g.flags |= MSER_GEMM_ACCUM;
+  g.splitk = 2;                      // "C is initialised, accumulate atomically": mser::gemm picks the split that fills the chip
   return gemm(g, s);
 }
 // dW[N, K] += dY[rows, N]^T X[rows, K]   (one direction; split-K over the rows, float atomics)
@@ -522,7 +559,7 @@ int validate(const mser_drnn_desc& d, bool bwd) {
   MSER_REQUIRE(d.ldu >= d.Dm && d.ldo >= 2 * d.De, "mser_drnn: leading dimension too small");
   MSER_REQUIRE(((uintptr_t)d.workspace & 255) == 0, "mser_drnn: workspace must be 256-byte aligned");
   MSER_REQUIRE(d.workspace_bytes >= mser_drnn_workspace_bytes(d.T, d.B, d.Dm, d.Dg, d.Dp, d.De), "mser_drnn: workspace too small");
-  MSER_REQUIRE((2 * (size_t)d.Dg + 2 * (size_t)d.T) * sizeof(float) <= 64 * 1024, "mser_drnn: D_g / T too large for the attention kernel's LDS");
+  MSER_REQUIRE((3 * (size_t)d.Dg + 2 * (size_t)d.T) * sizeof(float) <= 64 * 1024, "mser_drnn: D_g / T too large for the attention kernel's LDS");
   for (int i = 0; i < 2; ++i) {
     const mser_drnn_params& p = d.p[i];
     MSER_REQUIRE(p.g_wih && p.g_whh && p.g_bih && p.g_bhh && p.p_wih && p.p_whh && p.p_bih && p.p_bhh && p.e_wih && p.e_whh && p.e_bih &&
@@ -689,7 +726,7 @@ int mser_drnn_bwd(const mser_drnn_desc* dp, mser_stream_t stream) {
     MSER_TRY(mm_nn(s, w.dgh_p + (long)t * 2 * B * 3 * Dp, 3 * Dp, TB * 2 * 3 * Dp, d.p[0].p_whh, Dp, DS(p_whh), dQc, Dp, dq_ds, 2 * B, Dp, 3 * Dp, true));
     // -- attention over the history
     if (t > 0) {
-      hipLaunchKernelGGL(drnn_attn_bwd_kernel, dim3(B, 2), dim3(ATT_NT), (size_t)(2 * Dg + 2 * T) * sizeof(float), s, B, Dg, T, t,
+      hipLaunchKernelGGL(drnn_attn_bwd_kernel, dim3(B, 2), dim3(ATT_NT), (size_t)(3 * Dg + 2 * T) * sizeof(float), s, B, Dg, T, t,
                          w.Xatt + (long)t * B * Dg, TB * Dg, w.Gh, w.dGh, g_ds, w.alpha + (long)t * B * T, TB * T, w.dc, (long)B * Dg,
                          w.dXatt + (long)t * B * Dg);
     } else {
