@@ -318,9 +318,12 @@ int mser_marn_cell_run(const mser_cell_desc* d, int32_t phases, mser_stream_t st
  * slower end to end (the concentrated groups starve the kernels that run beside the chains), hence off.
  * MSER_OPT_FWD_STATS_ROLES = 1 (default): in the fused forward launch at H = 128 the softmax statistics of the rank-1 attention
  * rows that the BPTT consumes are computed by extra workgroups following the chain's step counter instead of inside the row
- * phase of the chain. */
+ * phase of the chain.
+ * MSER_OPT_FWD_SENTINEL = 1 (default): the persistent forward chains hand their state from workgroup to workgroup through
+ * self-validating payload (the state arrays start as a sentinel bit pattern, consumers re-load until their words are final)
+ * instead of counter barriers: one store->load trip per seam, no store drain, no atomics.  0: the counter barriers. */
 enum { MSER_OPT_PERSISTENT = 1, MSER_OPT_WGRAD_INKERNEL = 2, MSER_OPT_BPTT_KSPLIT = 3, MSER_OPT_XCD_PLACEMENT = 4,
-       MSER_OPT_FWD_STATS_ROLES = 5 };
+       MSER_OPT_FWD_STATS_ROLES = 5, MSER_OPT_FWD_SENTINEL = 6 };
 int mser_set_option(int32_t key, int32_t value);
 /* Synchronises `stream` and reports whether a persistent kernel of the last fwd/bwd call on this workspace gave up at a
  * barrier (bounded spins; returns -2 and a message in that case).  Diagnostic; not needed on the hot path. */

@@ -80,6 +80,7 @@ struct CellK {
   int ext_spk;         // the speaker state h_q[t] comes from the caller (mser_cell_desc::ext_hq): no speaker roles in the launches
   const uint32_t* rng; // dropout generator words {seed, step} (nullptr: every dropout site of the cell is the identity)
   unsigned* fault;     // sticky fault word (mser_cell_desc::fault) or nullptr
+  int fwd_sentinel;    // forward chain hand-offs through self-validating payload instead of counter barriers (MSER_OPT_FWD_SENTINEL)
   int ksplit;          // BPTT matvec phase: every product's K = 4H reduction is split over `ksplit` workgroups (1 or 2); the
                        // partial results live in consecutive copies of dA / dHQp / dxc and the consumers add them
   DirP d[2];
@@ -343,6 +344,39 @@ __device__ __forceinline__ bool dir_barrier(unsigned* cnt, unsigned* abortw, uns
   }
   __syncthreads();
   return *lds_ok != 0;
+}
+
+// ---- self-validating hand-off (forward chain, MSER_OPT_FWD_SENTINEL) ------------------------------------------------------------
+// The counter barrier above costs a store drain (s_waitcnt vmcnt(0) on write-through stores: a memory-side round trip), a workgroup
+// barrier, the counter adds, a poll, a second workgroup barrier and only THEN the payload loads -- four dependent trips through the
+// memory side per seam.  The chain's state arrays are indexed by the time step and written exactly once per launch, so the payload can
+// validate itself: MSER_PHASE_FWD_PREP fills them with a bit pattern no finite value takes (a quiet NaN with a payload), producers
+// just store (sc1), consumers load (sc1) and re-load until none of their words is the pattern.  Every 4-byte word is written by one
+// store, so a word is either the pattern or final; no ordering between different words is assumed.  One store->load trip per
+// seam, no drain, no atomics, and every wave proceeds as soon as ITS operands are valid (scratch/ubench_ll.hip: 1.67 us per
+// all-to-all exchange among 32 workgroups against 1.97 for the counter form, before counting the barriers' own synchronisation).
+// Every poll is bounded: a wave that gives up raises the abort word (and the caller's sticky fault word), sets s_poll_abort and goes
+// on with garbage; all waves of the workgroup leave together at the next point where they are synchronised anyway.
+constexpr unsigned SENT_BITS = 0x7fc0dead;
+__device__ __forceinline__ bool is_sent(float v) { return __float_as_uint(v) == SENT_BITS; }
+__device__ __forceinline__ bool any_sent8(const float* a) {
+  bool b = false;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) b |= is_sent(a[j]);
+  return b;
+}
+__shared__ int s_poll_abort;
+constexpr unsigned POLL_LIMIT = 1u << 20;          // re-loads (each a memory-side round trip, ~1 us): ~1 s
+// call after a failed validation; returns true when the caller must stop polling
+__device__ __forceinline__ bool poll_giveup(unsigned& spins, unsigned* abortw) {
+  if ((++spins & 31u) == 0u) {
+    if (spins > POLL_LIMIT || __hip_atomic_load((const gu32*)abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+      raise_abort(abortw);
+      s_poll_abort = 1;
+      return true;
+    }
+  }
+  return false;
 }
 
 // ---- XCD-aware role assignment of the fused persistent launches ---------------------------------------------------------------
@@ -744,7 +778,7 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // `after_loads` runs right behind the row's own operand loads: loads issued there are YOUNGER than the row's, so the row phase
 // does not wait for them (vmcnt retires in order) -- used to fetch the next step's early-product operands under the exp2 work.
 // STATS = false: the statistics are left to the stats roles of the fused launch (stats_fwd_role), off the chain.
-template <bool PS, int JCT, class Hook = NoHook, bool STATS = true>       // JCT = keys per thread chunk when known at compile time (fully unrolled loops), 0 = runtime
+template <bool PS, int JCT, class Hook = NoHook, bool STATS = true, bool SV = false>       // JCT = keys per thread chunk when known at compile time (fully unrolled loops), 0 = runtime; SV: sentinel-validated loads
 __device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, const WS& ws, int t, int b, const float* att, float* scr,
                                              Hook after_loads = Hook()) {
   const int H = P.H, B = P.B, T = P.T;
@@ -762,14 +796,24 @@ __device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, cons
   const float* c_a = D.cstate + ((long)1 * (T + 1) + t + 1) * B * H + (long)b * H;
   const int i = tid & (H - 1), q = tid / H;
   float sp = 0.f;
+  float cv = 0.f;
+  if (tid < H) cv = ldx<PS>(ws, c_a + tid);
+  float cli = ldx<PS>(ws, c_l + i);
+  if (SV) {                          // c_l[t], c_a[t] come from the gate epilogues of all workgroups of the direction
+    unsigned spins = 0;
+    while (__builtin_amdgcn_ballot_w64(is_sent(cli) || is_sent(cv)) != 0ull) {
+      if (poll_giveup(spins, P.sync + SYNC_ABORT)) break;
+      if (tid < H) cv = ldx<PS>(ws, c_a + tid);
+      cli = ldx<PS>(ws, c_l + i);
+    }
+  }
   if (tid < H) {
-    const float cv = ldx<PS>(ws, c_a + tid), w = wk[tid];
+    const float w = wk[tid];
     kc[tid] = make_float4(w, cv, cv * w, 0.f);
     sp = wq[tid] * cv;
   }
-  const float cli = ldx<PS>(ws, c_l + i);
   const int tau = D.rev ? D.rev[(long)t * B + b] : t;
-  after_loads();
+  if (!SV) after_loads();            // (SV: the hook runs behind the exp2 loop instead -- see there)
   sp = wave_sum(sp);
   if (lane == 0) sh[wave] = sp;
   __syncthreads();
@@ -813,6 +857,10 @@ __device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, cons
     }
   }
   float* pN3 = pN2 + NT;
+  // SV: h_t of the other workgroups was stored right behind the c_t this row polled for, but nothing orders the two: requested at the
+  // start of the row phase it still read as the sentinel for some producers and had to be polled again AFTER the row phase (a full
+  // round trip on the critical path, 0.8 us measured).  Requested here, one exp2 loop later, it is final and lands under the reduction.
+  if (SV) after_loads();
   if (q > 0) {
     pZ[tid] = Z; pN[tid] = N;
     if (STATS) { pN2[tid] = N2; pN3[tid] = N3; }
@@ -878,6 +926,20 @@ __device__ __forceinline__ void lsthm_early_aload(const CellK& P, const DirP& D,
     for (int p = 0; p < NPE / 2; ++p) zero8(a[PART * NPE / 2 + p]);
   }
 }
+// The same fragments, re-loaded until none of the words is the sentinel (every wave polls for itself)
+template <int NP, int PART>
+__device__ __forceinline__ void lsthm_early_aload_valid(const CellK& P, const DirP& D, const WS& ws, int t, int m, int mb, float (*a)[8]) {
+  constexpr int NPE = FwdSplit<NP>::NPE;
+  unsigned spins = 0;
+  while (true) {
+    bool bad = false;
+#pragma unroll
+    for (int p = PART * NPE / 2; p < (PART + 1) * NPE / 2; ++p) bad |= any_sent8(a[p]);
+    if (__builtin_amdgcn_ballot_w64(bad) == 0ull) break;
+    if (poll_giveup(spins, P.sync + SYNC_ABORT)) break;
+    lsthm_early_aload<NP, PART>(P, D, ws, t, m, mb, a);
+  }
+}
 // PART 0 / 1: h part / h_q part of the early chain
 template <int NP, int PART>
 __device__ __forceinline__ f32x16 lsthm_early_mm(const float (*a)[8], const float (*bpre)[8], f32x16 acc) {
@@ -908,9 +970,19 @@ __device__ __forceinline__ GatePre lsthm_gate_prefetch(const CellK& P, const Dir
   return g;
 }
 
+// Gate non-linearities of the persistent chains on the hardware transcendentals (v_exp_f32, v_rcp_f32: ~1 ulp each): the libm
+// expf / tanhf the per-step launches use cost ~60-80 instructions per value, five values per (row, unit) on the critical path of
+// every step.  Absolute error ~1e-7 per value; through 128 steps the log-probs move by < 2e-6 (the parity tests run this path).
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-LOG2E * x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 2.0f * sigmoid_fast(2.0f * x) - 1.0f; }
+
 // Gates phase of step t: acc (early product, in registers) += z_{t-1} V^T, cross-wave reduction, LSTM epilogue.
 // c_state: this thread's cell state c_{t-1}[b][u] (the same thread owns the same (b, u) every step: it never leaves the register).
-template <int NP>
+#ifndef MSER_FAST_NL
+#define MSER_FAST_NL 0        // measured: no change of the step time (the chain is bound by the hand-off latency, not by the epilogue); the libm forms stay
+#endif
+constexpr bool FASTNL = MSER_FAST_NL != 0;
+template <int NP, bool SV = false>
 __device__ __forceinline__ void lsthm_gates_late(const CellK& P, const DirP& D, const WS& ws, int t, int m, int u0, int mb,
                                                  const float (*bpre)[8], f32x16 acc, const GatePre& gp, float& c_state, float* red,
                                                  float* tile) {
@@ -928,6 +1000,19 @@ __device__ __forceinline__ void lsthm_gates_late(const CellK& P, const DirP& D, 
 #pragma unroll
     for (int p = 0; p < NPL; ++p)
       load8x<true>(ws, D.hz + ((long)t * B + bc) * 3 * H + 2 * H + wave * 16 * NPL + 16 * p + half * 8, a[p]);
+    if (SV && t > 0) {                 // z_{t-1} comes from the other workgroups' row phases: poll until every word is final
+      unsigned spins = 0;
+      while (true) {
+        bool bad = false;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) bad |= any_sent8(a[p]);
+        if (__builtin_amdgcn_ballot_w64(bad) == 0ull) break;
+        if (poll_giveup(spins, P.sync + SYNC_ABORT)) break;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+          load8x<true>(ws, D.hz + ((long)t * B + bc) * 3 * H + 2 * H + wave * 16 * NPL + 16 * p + half * 8, a[p]);
+      }
+    }
     if (b >= B) {
 #pragma unroll
       for (int p = 0; p < NPL; ++p) zero8(a[p]);
@@ -957,12 +1042,12 @@ __device__ __forceinline__ void lsthm_gates_late(const CellK& P, const DirP& D, 
     const int rr = tid >> 3, uu = tid & 7;
     const int b = mb * 32 + rr, u = u0 + uu;
     if (b < B) {
-      const float gf = sigmoidf_(tile[rr * 32 + 0 + uu] + gp.pre4[0]);
-      const float gi = sigmoidf_(tile[rr * 32 + 8 + uu] + gp.pre4[1]);
-      const float go = sigmoidf_(tile[rr * 32 + 16 + uu] + gp.pre4[2]);
-      const float gc = tanhf(tile[rr * 32 + 24 + uu] + gp.pre4[3]);
+      const float gf = FASTNL ? sigmoid_fast(tile[rr * 32 + 0 + uu] + gp.pre4[0]) : sigmoidf_(tile[rr * 32 + 0 + uu] + gp.pre4[0]);
+      const float gi = FASTNL ? sigmoid_fast(tile[rr * 32 + 8 + uu] + gp.pre4[1]) : sigmoidf_(tile[rr * 32 + 8 + uu] + gp.pre4[1]);
+      const float go = FASTNL ? sigmoid_fast(tile[rr * 32 + 16 + uu] + gp.pre4[2]) : sigmoidf_(tile[rr * 32 + 16 + uu] + gp.pre4[2]);
+      const float gc = FASTNL ? tanh_fast(tile[rr * 32 + 24 + uu] + gp.pre4[3]) : tanhf(tile[rr * 32 + 24 + uu] + gp.pre4[3]);
       const float cn = gf * c_state + gi * gc;
-      float hn = tanhf(cn) * go;
+      float hn = (FASTNL ? tanh_fast(cn) : tanhf(cn)) * go;
       if (drop_state_on(P, D)) hn *= drop_h(P, D, t, m, b, u);               // :211 / :213
       c_state = cn;
       stx<true>(ws, c_new + (long)b * H + u, cn);
@@ -994,8 +1079,61 @@ __global__ __launch_bounds__(NT) void lsthm_fwd_z(CellK P, int t) {
 
 // persistent launch: grid (H/8, 2 streams, ndir*nmb); two barriers per step (gates -> z -> next gates).  Runs concurrently with
 // spk_fwd_persist: step t starts only once the speaker counter shows h_q[t] published (checked inside the previous barrier).
+// MSER_OPT_FWD_SENTINEL form of lsthm_fwd_role below: the same step without a single counter -- every operand that another
+// workgroup produces (z_{t-1} for the late product, c_l / c_a for the row phase, h_t and h_q[t+1] for the early product) is loaded
+// with sentinel validation.  The order of the work inside a step is unchanged (late product -> epilogue -> [h_q part of the next
+// early product] -> row phase -> [h part, pre-activation fetch]).
+template <int NP, bool STATS = true>
+__device__ __forceinline__ void lsthm_fwd_role_sv(const CellK& P, const Role R, float* smem, const WS& ws) {
+  float* red = smem;
+  float* tile = smem + RED_FLOATS;
+  float* att = tile + 1024;
+  const int dir = R.z / P.nmb, mb = R.z % P.nmb;
+  const DirP& D = P.d[dir];
+  const int m = R.y, u0 = R.x * 8;
+  const unsigned nwg = R.gx * R.gy * P.nmb;
+  const int w = (mb * R.gy + R.y) * R.gx + R.x;
+  float bpre[NP][8];
+  lsthm_preload_b_split<NP>(D, m, u0, P.H, bpre);
+  if (threadIdx.x == 0) s_poll_abort = 0;
+  att_prepare(D, P.H, att, red);
+  drop_init(P, D);
+  STAMP_INIT();
+  constexpr int JCT = (128 * NP / 3) * (128 * NP / 3) / NT;
+  float a[FwdSplit<NP>::NPE][8];
+  lsthm_early_aload<NP, 0>(P, D, ws, 0, m, mb, a);                  // h_{-1} = 0 (hz[0] is zeroed by FWD_PREP)
+  lsthm_early_aload<NP, 1>(P, D, ws, 0, m, mb, a);                  // h_q[0]
+  lsthm_early_aload_valid<NP, 1>(P, D, ws, 0, m, mb, a);
+  f32x16 acc = lsthm_early_mm<NP, 1>(a, bpre, lsthm_early_mm<NP, 0>(a, bpre, f32x16{0}));
+  GatePre gp = lsthm_gate_prefetch(P, D, 0, m, u0, mb);
+  float c_state = 0.f;
+  for (int t = 0; t < P.T; ++t) {
+    const bool more = t + 1 < P.T;
+    if (more) lsthm_early_aload<NP, 1>(P, D, ws, t + 1, m, mb, a);  // h_q[t+1] (the speaker chain normally runs far ahead): requested now,
+    lsthm_gates_late<NP, true>(P, D, ws, t, m, u0, mb, bpre, acc, gp, c_state, red, tile);           // validated after the gates phase
+    if (s_poll_abort) return;                                       // (read behind the phase's workgroup barriers: uniform)
+    if (more) {
+      lsthm_early_aload_valid<NP, 1>(P, D, ws, t + 1, m, mb, a);
+      acc = lsthm_early_mm<NP, 1>(a, bpre, f32x16{0});
+    }
+    STAMP_ACC(3);
+    bool fetched = !more;
+    auto fetch = [&]() { if (!fetched) { lsthm_early_aload<NP, 0>(P, D, ws, t + 1, m, mb, a); fetched = true; } };
+    for (int b = w; b < P.B; b += (int)nwg) lsthm_z_body<true, JCT, decltype(fetch), STATS, true>(P, D, ws, t, b, att, red, fetch);
+    fetch();
+    STAMP_ACC(4);
+    if (!more) break;
+    gp = lsthm_gate_prefetch(P, D, t + 1, m, u0, mb);
+    lsthm_early_aload_valid<NP, 0>(P, D, ws, t + 1, m, mb, a);      // h_t of every workgroup of the direction
+    acc = lsthm_early_mm<NP, 0>(a, bpre, acc);
+    STAMP_ACC(5);
+  }
+  STAMP_DUMP(P, 24, R.x == 3 && R.y == 1 && R.z == 0);
+}
+
 template <int NP, bool STATS = true>
 __device__ __forceinline__ void lsthm_fwd_role(const CellK& P, const Role R, float* smem, const WS& ws) {
+  if (P.fwd_sentinel) { lsthm_fwd_role_sv<NP, STATS>(P, R, smem, ws); return; }
   float* red = smem;
   float* tile = smem + RED_FLOATS;
   float* att = tile + 1024;
@@ -1278,7 +1416,7 @@ __device__ __forceinline__ void lsthm_bwd_row_part2(const CellK& P, const DirP& 
       float dh = dh2[m];                                   // gradient at the dropped h (:211 / :213): the same factor again
       if (drop_state_on(P, D)) dh *= drop_h(P, D, t, m, b, i);
       const float cc = m ? pre.cav : pre.clv;
-      const float tc = tanhf(cc);
+      const float tc = (PS && FASTNL) ? tanh_fast(cc) : tanhf(cc);
       const float dc = carry[m] + dh * go * (1.f - tc * tc) + (m ? dca_att : dcl_att);
       float* dg = D.dgates + ((long)m * T * B + rowt) * 4 * H + i;
       stx<PS>(ws, dg, dc * pre.cprev[m] * gf * (1.f - gf));
@@ -1678,6 +1816,7 @@ __device__ __forceinline__ void stats_fwd_role(const CellK& P, int id, int nsw, 
   float* scr = smem;
   float* att = smem + RED_FLOATS;
   int* lds_ok = (int*)(att + att_floats(H));
+  if (threadIdx.x == 0) s_poll_abort = 0;
   att_prepare(D, H, att, scr);
   float4* kc = reinterpret_cast<float4*>(scr);
   float* pZ = scr + 4 * H;
@@ -1690,17 +1829,28 @@ __device__ __forceinline__ void stats_fwd_role(const CellK& P, int id, int nsw, 
   const unsigned* cnt = P.sync + SYNC_LSTHM_FWD + dir * SYNC_DIR;
   for (int t = 0; t < T; ++t) {
     // c_l[t], c_a[t] are published behind the barrier that follows the gates phase of step t: barrier 2t + 1 of the chain
-    if (!lazy_wait(cnt, P.sync + SYNC_ABORT, nwg_l * (2u * (unsigned)t + 1u), lds_ok)) return;
+    if (!P.fwd_sentinel && !lazy_wait(cnt, P.sync + SYNC_ABORT, nwg_l * (2u * (unsigned)t + 1u), lds_ok)) return;
     for (int b = w; b < B; b += nsw) {
       const float* c_l = D.cstate + ((long)0 * (T + 1) + t + 1) * B * H + (long)b * H;
       const float* c_a = D.cstate + ((long)1 * (T + 1) + t + 1) * B * H + (long)b * H;
       float sp = 0.f;
+      float cv = 0.f;
+      if (tid < H) cv = ldx<true>(ws, c_a + tid);
+      float cli = ldx<true>(ws, c_l + i);
+      if (P.fwd_sentinel) {            // the chain publishes no counter in this mode: the rows validate themselves (long sleeps between
+        unsigned spins = 0;            // polls: this role is off the chain and must not crowd its requests)
+        while (__builtin_amdgcn_ballot_w64(is_sent(cli) || is_sent(cv)) != 0ull) {
+          __builtin_amdgcn_s_sleep(32);
+          if (poll_giveup(spins, P.sync + SYNC_ABORT)) break;
+          if (tid < H) cv = ldx<true>(ws, c_a + tid);
+          cli = ldx<true>(ws, c_l + i);
+        }
+      }
       if (tid < H) {
-        const float cv = ldx<true>(ws, c_a + tid), wk = att[tid];
+        const float wk = att[tid];
         kc[tid] = make_float4(wk, cv, cv * wk, 0.f);
         sp = att[H + tid] * cv;
       }
-      const float cli = ldx<true>(ws, c_l + i);
       sp = wave_sum(sp);
       if (lane == 0) sh[wave] = sp;
       __syncthreads();
@@ -1728,6 +1878,7 @@ __device__ __forceinline__ void stats_fwd_role(const CellK& P, int id, int nsw, 
         *reinterpret_cast<float4*>(D.rstat + (((long)t * B + b) * H + i) * 4) = make_float4(Z, N2, N3, s);
       }
       __syncthreads();
+      if (s_poll_abort) return;
     }
   }
 }
@@ -2205,6 +2356,7 @@ static int g_opt_wgrad_inkernel = 1;  // MSER_OPT_WGRAD_INKERNEL
 static int g_opt_ksplit = 1;          // MSER_OPT_BPTT_KSPLIT
 static int g_opt_stats_roles = 1;     // MSER_OPT_FWD_STATS_ROLES
 static int g_opt_xcd_place = 0;       // MSER_OPT_XCD_PLACEMENT (off: measured slower end to end)
+static int g_opt_fwd_sentinel = 1;    // MSER_OPT_FWD_SENTINEL
 static int g_num_cus = 0;
 constexpr size_t PERSIST_MIN_LDS = 84 * 1024;     // > half of the 160 KiB LDS: at most ONE persistent workgroup per CU
 
@@ -2243,8 +2395,20 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   const long fwd_wgs = (long)(H / 8) * 2 * d.ndir * K.nmb;
   const bool persist = persist_ok(H, ext ? fwd_wgs : 2 * fwd_wgs);        // speaker and LSTHM chains share one launch: all workgroups co-resident
   const size_t p_lds = persist_lds(mm_lds + (2 * (size_t)H + 16) * sizeof(float) + 64);
+  K.fwd_sentinel = (persist && g_opt_fwd_sentinel) ? 1 : 0;
   if (phases & MSER_PHASE_FWD_PREP) {
   MSER_CHECK_HIP(hipMemsetAsync(h.sync, 0, SYNC_WORDS * sizeof(unsigned), s));
+  if (K.fwd_sentinel) {
+    // every word the forward chains hand from workgroup to workgroup starts as the sentinel: h | h | z rows, the two cell states,
+    // the speaker rows.  (cell_prep_kernel, below, then zeroes the index-0 states; an external speaker state is copied over HQ by
+    // MSER_PHASE_LSTHM_FWD, a linked producer writes its rows while the chain polls them.)
+    for (int i = 0; i < d.ndir; ++i) {
+      DirP& k = K.d[i];
+      MSER_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)k.hz, SENT_BITS, (size_t)(T + 1) * B * 3 * H, s));
+      MSER_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)k.cstate, SENT_BITS, (size_t)2 * (T + 1) * SB, s));
+      MSER_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)k.HQ, SENT_BITS, (size_t)TB * H, s));
+    }
+  }
   if (ext && !d.ext_linked)      // "every h_q[t] is published": the LSTHM chain's waits on the speaker counter fall through
     MSER_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)(h.sync + SYNC_SPK_FWD), 0x3fffffff, 2 * SYNC_DIR, s));
   for (int i = 0; i < d.ndir; ++i) {
@@ -2773,6 +2937,7 @@ int mser_set_option(int32_t key, int32_t value) {
     case MSER_OPT_BPTT_KSPLIT: g_opt_ksplit = value ? 1 : 0; return 0;
     case MSER_OPT_XCD_PLACEMENT: g_opt_xcd_place = value ? 1 : 0; return 0;
     case MSER_OPT_FWD_STATS_ROLES: g_opt_stats_roles = value ? 1 : 0; return 0;
+    case MSER_OPT_FWD_SENTINEL: g_opt_fwd_sentinel = value ? 1 : 0; return 0;
     default: set_error("mser_set_option: unknown key %d", key); return -1;
   }
 }

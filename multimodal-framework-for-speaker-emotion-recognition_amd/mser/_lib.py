@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmser.so")
+LIB_PATH = os.environ.get("MSER_LIB") or os.path.join(_HERE, "libmser.so")      # MSER_LIB: a diagnostic build (scratch/diag_stamps.py)
 
 c_float_p = C.c_void_p   # raw device pointers travel as integers
 
@@ -215,6 +215,11 @@ def load():
     if lib.mser_version() < 120:
         raise RuntimeError("libmser.so is older than this binding")
     _lib = lib
+    # A/B switch for measurements: MSER_OPTIONS="6=0,3=1" applies mser_set_option(key, value) pairs once at load
+    for kv in filter(None, os.environ.get("MSER_OPTIONS", "").split(",")):
+        k, v = kv.split("=")
+        if lib.mser_set_option(int(k), int(v)) != 0:
+            raise RuntimeError(f"MSER_OPTIONS: bad pair {kv}")
     return lib
 
 

@@ -6,6 +6,7 @@
 //   V1: self-validating payload -- slabs are indexed by the exchange number and pre-filled with a sentinel bit pattern that no
 //       finite value takes; producers just store (sc1), consumers load (sc1) and re-load until none of their words is the
 //       sentinel.  No counter, no drain wait, no barrier on the critical path.
+//   V3 / V4: V1 / V0 with the slab stored by ONE wave instruction of 16-byte stores instead of 256 scalar stores.
 //   V2: 8-byte {value, tag} pairs (tag = exchange number), slabs ping-pong by parity: no pre-fill needed, twice the bytes.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -51,12 +52,21 @@ __global__ __launch_bounds__(512) void k_ex(unsigned* sync, float* buf, unsigned
         u32x2 v; v.x = __float_as_uint(carry + tid * 1e-6f); v.y = (unsigned)(it + 1);
         __builtin_amdgcn_raw_buffer_store_b64(v, r, (((it & 1) * slab_f + w * 256 + tid) * 8), 0, ST_AUX);
       }
+    } else if (V == 3 || V == 4) {
+      // the same 1 KB slab as ONE wave instruction of 16-byte stores (a scalar sc1 store is one fabric write each)
+      const unsigned base = (V == 3 ? (unsigned)it : (unsigned)(it & 1)) * slab_f;
+      if (tid < 64) {
+        u32x4 v;
+        v.x = __float_as_uint(carry + (4 * tid) * 1e-6f); v.y = __float_as_uint(carry + (4 * tid + 1) * 1e-6f);
+        v.z = __float_as_uint(carry + (4 * tid + 2) * 1e-6f); v.w = __float_as_uint(carry + (4 * tid + 3) * 1e-6f);
+        __builtin_amdgcn_raw_buffer_store_b128(v, r, (base + w * 256 + tid * 4) * 4, 0, ST_AUX);
+      }
     } else {
-      const unsigned base = (V == 1 ? (unsigned)it : (unsigned)(it & 1)) * slab_f;
+      const unsigned base = ((V == 1 || V == 5 || V == 6) ? (unsigned)it : (unsigned)(it & 1)) * slab_f;
       if (tid < 256) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(carry + tid * 1e-6f), r, (base + w * 256 + tid) * 4, 0, ST_AUX);
     }
     float acc = 0.f;
-    if (V == 0) {
+    if (V == 0 || V == 4) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       const unsigned gen = (unsigned)(it + 1);
@@ -76,9 +86,25 @@ __global__ __launch_bounds__(512) void k_ex(unsigned* sync, float* buf, unsigned
         const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r, (base + o) * 4 + 16, 0, AUX_SC1);
         acc += __uint_as_float(a.x) + __uint_as_float(a.w) + __uint_as_float(b.y) + __uint_as_float(b.z);
       }
-    } else if (V == 1) {
+    } else if (V == 1 || V == 3 || V == 5 || V == 6) {
       // all of this thread's words are requested at once (NPASS x 32 bytes in flight), then validated together
       const unsigned base = (unsigned)it * slab_f;
+      if (V == 5) {
+        // indicator: wave 0, lane i polls the first 16 bytes of producer i's slab (64 lanes cover up to 64 producers); the slab's other
+        // words are NOT ordered behind it, so the full read below still validates every word -- it just rarely has to retry
+        if (tid < 64) {
+          unsigned spins = 0;
+          while (true) {
+            u32x4 a = {1, 1, 1, 1};
+            if (tid < nwg) a = __builtin_amdgcn_raw_buffer_load_b128(r, (base + tid * 256 + 252) * 4, 0, AUX_SC1);
+            const bool bad = a.x == SENT || a.y == SENT || a.z == SENT || a.w == SENT;
+            if (__builtin_amdgcn_ballot_w64(bad) == 0ull) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 20)) { *fail = 1; break; }
+          }
+        }
+        __syncthreads();
+      }
       constexpr int NPASS = 4;                 // up to 64 workgroups: 16384 floats / (512 threads x 8)
       const int np = (int)(slab_f / (512 * 8));
       u32x4 a[NPASS], b[NPASS];
@@ -97,6 +123,7 @@ __global__ __launch_bounds__(512) void k_ex(unsigned* sync, float* buf, unsigned
             bad |= a[p].x == SENT || a[p].y == SENT || a[p].z == SENT || a[p].w == SENT || b[p].x == SENT || b[p].y == SENT ||
                    b[p].z == SENT || b[p].w == SENT;
         if (__builtin_amdgcn_ballot_w64(bad) == 0ull) break;
+        if (V == 6) __builtin_amdgcn_s_sleep(8);
         if (++spins > (1u << 20)) { *fail = 1; break; }
       }
 #pragma unroll
@@ -139,7 +166,7 @@ int run(unsigned* sync, float* buf, size_t bytes, unsigned long long* ts, float*
     CK(hipMemset(sync, 0, 16384));
     CK(hipMemset(fail, 0, 4));
     CK(hipMemset(tickets, 0, 4));
-    if (V == 1) CK(hipMemsetD32((hipDeviceptr_t)buf, SENT, (size_t)iters * nwg * 256));
+    if (V == 1 || V == 3 || V == 5 || V == 6) CK(hipMemsetD32((hipDeviceptr_t)buf, SENT, (size_t)iters * nwg * 256));
     else CK(hipMemset(buf, 0, bytes));
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
@@ -165,11 +192,17 @@ int main() {
     if (run<0, 0>(sync, buf, bytes, ts, sink, fail, tickets, nwg, iters)) return 1;
     if (run<1, 0>(sync, buf, bytes, ts, sink, fail, tickets, nwg, iters)) return 1;
     if (run<2, 0>(sync, buf, bytes, ts, sink, fail, tickets, nwg, iters)) return 1;
+    if (run<3, 0>(sync, buf, bytes, ts, sink, fail, tickets, nwg, iters)) return 1;
+    if (run<4, 0>(sync, buf, bytes, ts, sink, fail, tickets, nwg, iters)) return 1;
+    if (run<5, 0>(sync, buf, bytes, ts, sink, fail, tickets, nwg, iters)) return 1;
+    if (run<6, 0>(sync, buf, bytes, ts, sink, fail, tickets, nwg, iters)) return 1;
   }
   for (int nwg : {16, 32}) {
     if (run<0, 1>(sync, buf, bytes, ts, sink, fail, tickets, nwg, iters)) return 1;
     if (run<1, 1>(sync, buf, bytes, ts, sink, fail, tickets, nwg, iters)) return 1;
     if (run<2, 1>(sync, buf, bytes, ts, sink, fail, tickets, nwg, iters)) return 1;
+    if (run<5, 1>(sync, buf, bytes, ts, sink, fail, tickets, nwg, iters)) return 1;
+    if (run<6, 1>(sync, buf, bytes, ts, sink, fail, tickets, nwg, iters)) return 1;
   }
   return 0;
 }
