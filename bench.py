@@ -32,6 +32,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: FP32 matrix (v_mfma_f32_32x32x2_f32), dense
 B, L, D_R, D_A, H, NCLS = 32, 128, 768, 100, 128, 6
 
 
@@ -348,7 +349,7 @@ def main():
     roofline = None
     if rank == 0 and not args.no_roofline:
         def timed(kernel_id, steps_prof=5):
-            _lib.check(lib.mser_prof_enable(kernel_id, 4 * L * steps_prof + 16), "prof_enable")
+            _lib.check(lib.mser_prof_enable(kernel_id, 4 * L * steps_prof + 64), "prof_enable")
             for _ in range(steps_prof):
                 tr.forward_backward(x, qmask, umask, label)
             torch.cuda.synchronize()
@@ -380,6 +381,26 @@ def main():
         # speaker BPTT riding in the same grid), the forward launch is cell_fwd_fused (LSTHM chain, speaker chain, statistics roles)
         roofline = entry("cell_bwd_fused" if us_b > 200 else "lsthm_bwd_row", us_b, n_b, True)
         roofline["lsthm_forward"] = entry("cell_fwd_fused" if us_f > 200 else "lsthm_fwd_gates", us_f, n_f, False)
+
+        # ---- MFMA-bound kernels: the batched QK^T and attention.V contractions.  Algorithmic FLOPs per launch
+        # (SURVEY.md 8(d)): sequence-level cross-modal attention 4*B*L^2*Dk forward (QK^T + PV), 10*B*L^2*Dk backward (recomputed
+        # QK^T, dP, dV, dQ, dK); encoder self-attention 4*B*nh*L^2*dk / 10*B*nh*L^2*dk.  Peak = the fp32 matrix rate (exact-fp32
+        # MFMA is what the 1e-4 gate needs): 157.3 TFLOP/s.
+        def mfma_entry(name, pid, flops):
+            us, n = timed(pid, 3)
+            ach = flops / (us * 1e-6) / 1e12 if n else 0.0
+            return dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None, flops_per_launch=flops, avg_launch_us=round(us, 2),
+                        launches_timed=n, note="launches of this kernel run beside the recurrent chains on side streams; a launch is "
+                        "32 x 4 (cross-modal) or 32 x 8 (encoder) workgroups, i.e. at most half the chip, and each is latency-bound "
+                        "(LDS staging, softmax, two dependent MFMA chains of K <= 128)")
+        Dk, nh, dkh = 128, 8, 40
+        roofline["attention_mfma"] = [
+            mfma_entry("xattn_fwd_kernel", 7, 4 * B * L * L * Dk),
+            mfma_entry("xattn_bwd_kernel", 8, 10 * B * L * L * Dk),
+            mfma_entry("attn_fwd_kernel", 9, 4 * B * nh * L * L * dkh),
+            mfma_entry("attn_bwd_kernel", 10, 10 * B * nh * L * L * dkh),
+        ]
 
     log("roofline pass done")
 

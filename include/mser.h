@@ -160,6 +160,31 @@ int mser_encoder_layer_bwd(const mser_encoder_desc* d, int32_t phases, mser_stre
 int mser_encoder_layer_wgrad_descs(const mser_encoder_desc* d, mser_gemm_desc* out, int32_t cap);
 
 /* ------------------------------------------------------------------------------------------------
+ * Sequence-level cross-modal attention core (model/lsthm_sps.py:88-101 CrossAttention2, :116-129 CrossAttention3, after the three
+ * projection products): O = dropout(softmax(scale Q K^T)) V per (dialogue, head), fused: one workgroup per (32-query tile, head,
+ * dialogue), scores and probabilities never leave LDS; the forward saves only the row statistics (max of the scaled logits,
+ * 1 / sum).  The backward recomputes P from them; dk_ / dv are ACCUMULATED with float atomics (zero them first), dq is written.
+ * q / k / v / o / dO / dq / dk_ / dv are row views [rows, ld] with head h in columns h*dk .. h*dk+dk-1 (dk == dv);
+ * row(b, l) = b*sb + l*sl on the query side (sbq, slq) and on the key side (sbk, slk).  Supported: Lk <= 128, dk % 8 == 0,
+ * dk <= 128 (mser_xattn_seq_supported); otherwise compose it from mser_gemm + mser_softmax_rows.
+ * Dropout (:98,:126): element ((b*nh + h)*Lq + i)*Lk + j of site `site`; rng == NULL: identity.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct mser_xattn_desc {
+  int32_t nb, nh, Lq, Lk, dk;
+  const float* q; int64_t ldq; const float* k; int64_t ldk; const float* v; int64_t ldv;
+  int64_t sbq, slq, sbk, slk;
+  float* o; int64_t ldo;                 /* forward: written; backward: read (delta = <dO, O>) */
+  float* stats;                          /* [nb, nh, Lq, 2] */
+  float scale;
+  const uint32_t* rng; uint32_t site; float p;
+  const float* dO; int64_t lddo;         /* backward */
+  float* dq; int64_t lddq; float* dk_; int64_t lddk; float* dv; int64_t lddv;
+} mser_xattn_desc;
+int mser_xattn_seq_supported(const mser_xattn_desc* d);
+int mser_xattn_seq_fwd(const mser_xattn_desc* d, mser_stream_t stream);
+int mser_xattn_seq_bwd(const mser_xattn_desc* d, mser_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Classifier tail of the fusion head (model/lsthm_sps.py:390-393 after `self.fc`): y1r = y1 + x_l + x_a,
  * y2 = relu(nn_out.0(y1r)), y3 = nn_out.3(y2), lp[b*L+t] = log_softmax(y3[t*B+b]) -- one row-tiled launch, and its
  * whole backward (log_softmax, both Linear layers, both ReLUs incl. the one of `fc`, the residual fan-out) as one launch.
@@ -514,7 +539,9 @@ int mser_adam_flat(float* p, const float* g, float* m, float* v, const uint8_t* 
  * launches seen since the last collect.  Not for use inside hipGraph capture.
  * ------------------------------------------------------------------------------------------------ */
 enum { MSER_PROF_SPK_FWD = 1, MSER_PROF_LSTHM_FWD_GATES = 2, MSER_PROF_LSTHM_FWD_Z = 3, MSER_PROF_LSTHM_BWD_ROW = 4,
-       MSER_PROF_LSTHM_BWD_MAT = 5, MSER_PROF_SPK_BWD = 6 };
+       MSER_PROF_LSTHM_BWD_MAT = 5, MSER_PROF_SPK_BWD = 6,
+       MSER_PROF_XATTN_FWD = 7, MSER_PROF_XATTN_BWD = 8,           /* mser_xattn_seq_fwd / bwd (csrc/xattn.hip) */
+       MSER_PROF_ENC_ATTN_FWD = 9, MSER_PROF_ENC_ATTN_BWD = 10 };  /* the encoder's per-head attention launches (csrc/encoder.hip) */
 int mser_prof_enable(int32_t kernel_id, int32_t max_launches);
 int mser_prof_collect(float* total_ms, int32_t* launches);
 

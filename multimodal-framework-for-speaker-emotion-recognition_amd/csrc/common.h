@@ -45,6 +45,26 @@ inline int check_launch(const char* what) {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---- optional per-kernel timing with HIP events (bench.py's live roofline measurement; off by default) ----------------------
+// mser_prof_enable(id, max) arms ONE kernel id (include/mser.h MSER_PROF_*); a ProfScope around a launch of that id records a
+// (start, stop) event pair on the launch stream; mser_prof_collect sums them.  Defined in api.cpp.
+struct Prof {
+  int kernel_id = 0;            // 0 = off
+  int cap = 0, used = 0;
+  hipEvent_t* ev = nullptr;     // 2*cap events: (start, stop) pairs
+};
+extern Prof g_prof;
+struct ProfScope {
+  bool on;
+  hipStream_t s;
+  ProfScope(int id, hipStream_t st) : on(g_prof.kernel_id == id && g_prof.used < g_prof.cap), s(st) {
+    if (on) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
+  }
+  ~ProfScope() {
+    if (on) { (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s); ++g_prof.used; }
+  }
+};
+
 // ---- device helpers -------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

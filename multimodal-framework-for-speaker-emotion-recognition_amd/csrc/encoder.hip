@@ -819,7 +819,10 @@ int encoder_layer_fwd(const mser_encoder_desc& d, hipStream_t s) {
   const AttnArgs a = attn_args(d);
   const size_t lds_a = attn_lds_bytes(d.nl, d.dk, false);
   MSER_TRY(allow((const void*)attn_fwd_kernel, lds_a));
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(d.nh, d.nb), dim3(ET), lds_a, s, a);
+  {
+    ProfScope ps(MSER_PROF_ENC_ATTN_FWD, s);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(d.nh, d.nb), dim3(ET), lds_a, s, a);
+  }
   MSER_TRY(check_launch("attn_fwd_kernel"));
   const PostArgs p = post_args(d);
   const size_t lds_p = post_lds_bytes(d.D, nq, d.dff, false);
@@ -869,7 +872,10 @@ int encoder_layer_bwd(const mser_encoder_desc& d, int phases, hipStream_t s) {
     const AttnArgs a = attn_args(d);
     const size_t lds_a = attn_lds_bytes(d.nl, d.dk, true);
     MSER_TRY(allow((const void*)attn_bwd_kernel, lds_a));
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(d.nh, d.nb), dim3(ET), lds_a, s, a);
+    {
+      ProfScope ps(MSER_PROF_ENC_ATTN_BWD, s);
+      hipLaunchKernelGGL(attn_bwd_kernel, dim3(d.nh, d.nb), dim3(ET), lds_a, s, a);
+    }
     MSER_TRY(check_launch("attn_bwd_kernel"));
     // de0 = dy1 (residual) + dq Wq + dk Wk + dv Wv
     mser_gemm_desc g = gd0();

@@ -122,24 +122,6 @@ enum { SYNC_LINE = 32, SYNC_REP = MSER_SYNC_REP, SYNC_DIR = SYNC_REP * SYNC_LINE
        SYNC_PLACE_FWD = SYNC_STAMPS + 2 * SYNC_LINE, SYNC_WORDS = SYNC_PLACE_FWD + SYNC_PLACE_LINES * SYNC_LINE };
 
 
-// ---- optional per-kernel timing with HIP events (bench.py's live roofline measurement; off by default) ----------------------
-struct Prof {
-  int kernel_id = 0;            // MSER_PROF_* of include/mser.h, 0 = off
-  int cap = 0, used = 0;
-  hipEvent_t* ev = nullptr;     // 2*cap events: (start, stop) pairs
-};
-static Prof g_prof;
-struct ProfScope {
-  bool on;
-  hipStream_t s;
-  ProfScope(int id, hipStream_t st) : on(g_prof.kernel_id == id && g_prof.used < g_prof.cap), s(st) {
-    if (on) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
-  }
-  ~ProfScope() {
-    if (on) { (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s); ++g_prof.used; }
-  }
-};
-
 // ---- cross-workgroup accessors ---------------------------------------------------------------------------------------
 // PS = true inside the persistent kernels: every array that another workgroup wrote (or will read) during the same launch is
 // stored write-through and loaded L1-bypassing (`sc1`: relaxed agent-scope atomics on address-space-1 pointers), which is the
@@ -2965,33 +2947,6 @@ int mser_marn_cell_status(const mser_cell_desc* d, mser_stream_t stream) {
               words[SYNC_LSTHM_BWD + SYNC_DIR], words[SYNC_SPK_BWD], words[SYNC_SPK_BWD + SYNC_DIR]);
     return -2;
   }
-  return 0;
-}
-
-int mser_prof_enable(int32_t kernel_id, int32_t max_launches) {
-  for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
-  delete[] g_prof.ev;
-  g_prof = Prof();
-  if (kernel_id <= 0 || max_launches <= 0) return 0;
-  g_prof.ev = new hipEvent_t[2 * (size_t)max_launches];
-  for (int i = 0; i < 2 * max_launches; ++i) MSER_CHECK_HIP(hipEventCreate(&g_prof.ev[i]));
-  g_prof.cap = max_launches;
-  g_prof.kernel_id = kernel_id;
-  return 0;
-}
-
-int mser_prof_collect(float* total_ms, int32_t* launches) {
-  MSER_REQUIRE(total_ms && launches, "mser_prof_collect: null pointer");
-  float tot = 0.f;
-  for (int i = 0; i < g_prof.used; ++i) {
-    MSER_CHECK_HIP(hipEventSynchronize(g_prof.ev[2 * i + 1]));
-    float ms = 0.f;
-    MSER_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
-    tot += ms;
-  }
-  *total_ms = tot;
-  *launches = g_prof.used;
-  g_prof.used = 0;
   return 0;
 }
 

@@ -107,6 +107,17 @@ class DrnnDesc(C.Structure):
                 ("rng", C.c_void_p), ("drop_site", C.c_uint32 * 2), ("p_drop", C.c_float)]
 
 
+class XAttnDesc(C.Structure):
+    """mser_xattn_desc (include/mser.h)."""
+    _fields_ = [("nb", C.c_int32), ("nh", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32), ("dk", C.c_int32),
+                ("q", C.c_void_p), ("ldq", C.c_int64), ("k", C.c_void_p), ("ldk", C.c_int64), ("v", C.c_void_p), ("ldv", C.c_int64),
+                ("sbq", C.c_int64), ("slq", C.c_int64), ("sbk", C.c_int64), ("slk", C.c_int64),
+                ("o", C.c_void_p), ("ldo", C.c_int64), ("stats", C.c_void_p), ("scale", C.c_float),
+                ("rng", C.c_void_p), ("site", C.c_uint32), ("p", C.c_float),
+                ("dO", C.c_void_p), ("lddo", C.c_int64), ("dq", C.c_void_p), ("lddq", C.c_int64), ("dk_", C.c_void_p), ("lddk", C.c_int64),
+                ("dv", C.c_void_p), ("lddv", C.c_int64)]
+
+
 class HeadTailDesc(C.Structure):
     """mser_head_tail_desc (include/mser.h)."""
     _fields_ = [("L", C.c_int32), ("B", C.c_int32), ("D", C.c_int32), ("F", C.c_int32), ("C", C.c_int32),
@@ -179,6 +190,9 @@ SIGNATURES = {
     "mser_adam_flat": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
     "mser_adam_flat_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _f32, _vp, _f32, _vp, _vp, _vp]),
     "mser_dp_pack": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "mser_xattn_seq_supported": (C.c_int, [C.POINTER(XAttnDesc)]),
+    "mser_xattn_seq_fwd": (C.c_int, [C.POINTER(XAttnDesc), _vp]),
+    "mser_xattn_seq_bwd": (C.c_int, [C.POINTER(XAttnDesc), _vp]),
     "mser_drnn_workspace_bytes": (C.c_size_t, [_i32] * 6),
     "mser_drnn_fwd": (C.c_int, [C.POINTER(DrnnDesc), _vp]),
     "mser_drnn_bwd": (C.c_int, [C.POINTER(DrnnDesc), _vp]),

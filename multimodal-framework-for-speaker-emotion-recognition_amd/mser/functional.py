@@ -14,6 +14,7 @@ from typing import Callable, Dict, Optional
 
 import torch
 
+from . import _lib as L_
 from . import ops
 
 Tensor = torch.Tensor
@@ -447,12 +448,32 @@ class XAttnCtx:
     heads: int = 1
     dk: int = 0
     dv: int = 0
+    fused: object = None       # mser_xattn_desc of the fused core launch (None: composed path)
+    stats: Tensor = None       # [nb, heads, Lq, 2] softmax row statistics saved by the fused forward
+    out: Tensor = None
+
+
+FUSED_XATTN = True          # the fused QK^T-softmax-V launch (csrc/xattn.hip) where the shape allows; False: GEMM + softmax rows + GEMM
+
+
+def _xattn_desc(c: "XAttnCtx", out: Tensor, Dk: int):
+    d = L_.XAttnDesc()
+    d.nb, d.nh, d.Lq, d.Lk, d.dk = c.l1.nb, c.heads, c.l1.nl, c.l2.nl, c.dk
+    K_, V_ = c.KV[:, :Dk], c.KV[:, Dk:]
+    d.q, d.ldq, d.k, d.ldk, d.v, d.ldv = c.Q.data_ptr(), c.Q.stride(0), K_.data_ptr(), K_.stride(0), V_.data_ptr(), V_.stride(0)
+    d.sbq, d.slq, d.sbk, d.slk = c.l1.sb, c.l1.sl, c.l2.sb, c.l2.sl
+    d.o, d.ldo = out.data_ptr(), out.stride(0)
+    d.scale = 1.0 / (c.dk ** 0.5)
+    if c.drop is not None:
+        d.rng, d.site, d.p = c.drop.rng.data_ptr(), c.drop.site, float(c.drop.p)
+    return d
 
 
 def xattn_fwd(x1: Tensor, a1: Optional[Tensor], x2: Tensor, a2: Optional[Tensor], Wq: Tensor, Wk: Tensor, Wv: Tensor,
               l1: Layout, l2: Layout, out: Tensor, heads: int = 1, drop: Optional[DropSite] = None):
     """CrossAttention2/3.forward(a1*x1, a2*x2) -- reference model/lsthm_sps.py:88-101 / :116-129 with the learnable scalars of
-    :377-383 folded into the projection GEMMs.  x1 [rows1,D1], x2 [rows2,D2]; out [rows1,Dv] (any leading dimension)."""
+    :377-383 folded into the projection GEMMs.  x1 [rows1,D1], x2 [rows2,D2]; out [rows1,Dv] (any leading dimension).  The core
+    softmax(Q K^T / sqrt(dk)) V is ONE fused launch (mser_xattn_seq_fwd: no [B, L, L] tensor in HBM) when the shape fits it."""
     c = XAttnCtx(x1=x1, x2=x2, a1=a1, a2=a2, l1=l1, l2=l2, heads=heads, drop=drop)
     Dk, Dv = Wq.shape[1], Wv.shape[1]
     c.dk, c.dv = Dk // heads, Dv // heads
@@ -461,6 +482,14 @@ def xattn_fwd(x1: Tensor, a1: Optional[Tensor], x2: Tensor, a2: Optional[Tensor]
     ops.matmul(x1, Wq, c.Q, alpha_dev=a1)
     ops.matmul(x2, Wk, c.KV[:, :Dk], alpha_dev=a2)
     ops.matmul(x2, Wv, c.KV[:, Dk:], alpha_dev=a2)
+    if FUSED_XATTN and c.dk == c.dv:
+        d = _xattn_desc(c, out, Dk)
+        if ops.xattn_seq_supported(d):
+            c.stats = _empty(l1.nb, heads, l1.nl, 2, like=x1)
+            d.stats = c.stats.data_ptr()
+            ops.xattn_seq_fwd(d)
+            c.fused, c.out = d, out
+            return c
     c.P = attn_core_fwd(c.Q, c.KV[:, :Dk], c.KV[:, Dk:], out, l1, l2, heads, c.dk, c.dv, 1.0 / (c.dk ** 0.5), drop=drop)
     if drop is not None:
         c.P, c.Pd = c.P                                     # :98 / :126 dropout(softmax(.)) before .V
@@ -472,9 +501,20 @@ def xattn_bwd(c: XAttnCtx, dout: Tensor, Wq: Tensor, Wk: Tensor, Wv: Tensor, gWq
     """Accumulates into dx1, dx2 (grads of the UNSCALED inputs), the weight grads and the scalar grads."""
     Dk = Wq.shape[1]
     dQ = torch.empty_like(c.Q)
-    dKV = torch.empty_like(c.KV)
-    attn_core_bwd(dout, c.Q, c.KV[:, :Dk], c.KV[:, Dk:], c.P, dQ, dKV[:, :Dk], dKV[:, Dk:], c.l1, c.l2, c.heads, c.dk, c.dv,
-                  1.0 / (c.dk ** 0.5), drop=c.drop, Pd=c.Pd)
+    if c.fused is not None:
+        dKV = torch.zeros_like(c.KV)                        # dK / dV are accumulated over the query tiles (float atomics)
+        dO = dout if (dout.stride(1) == 1 and dout.stride(0) % 4 == 0 and dout.data_ptr() % 16 == 0) else dout.contiguous()
+        d = c.fused
+        d.dO, d.lddo = dO.data_ptr(), dO.stride(0)
+        d.dq, d.lddq = dQ.data_ptr(), dQ.stride(0)
+        d.dk_, d.lddk = dKV.data_ptr(), dKV.stride(0)
+        d.dv, d.lddv = dKV[:, Dk:].data_ptr(), dKV.stride(0)
+        ops.xattn_seq_bwd(d)
+        c._keep_bwd = dO
+    else:
+        dKV = torch.empty_like(c.KV)
+        attn_core_bwd(dout, c.Q, c.KV[:, :Dk], c.KV[:, Dk:], c.P, dQ, dKV[:, :Dk], dKV[:, Dk:], c.l1, c.l2, c.heads, c.dk, c.dv,
+                      1.0 / (c.dk ** 0.5), drop=c.drop, Pd=c.Pd)
     ops.grad_weight(dQ, c.x1, gWq, transposed=True, alpha_dev=c.a1)
     ops.grad_weight(dKV[:, :Dk], c.x2, gWk, transposed=True, alpha_dev=c.a2)
     ops.grad_weight(dKV[:, Dk:], c.x2, gWv, transposed=True, alpha_dev=c.a2)

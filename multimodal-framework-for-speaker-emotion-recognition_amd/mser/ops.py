@@ -423,6 +423,19 @@ def gru_speaker_bwd(descs, dhs: Optional[Tensor] = None, dgi: Optional[Tensor] =
     L.check(_lib().mser_gru_speaker_bwd(arr, n, _stream()), "gru_speaker_bwd")
 
 
+# ---- fused sequence-level cross-modal attention core (include/mser.h mser_xattn_seq_*)
+def xattn_seq_supported(desc: L.XAttnDesc) -> bool:
+    return bool(_lib().mser_xattn_seq_supported(C.byref(desc)))
+
+
+def xattn_seq_fwd(desc: L.XAttnDesc) -> None:
+    L.check(_lib().mser_xattn_seq_fwd(C.byref(desc), _stream()), "xattn_seq_fwd")
+
+
+def xattn_seq_bwd(desc: L.XAttnDesc) -> None:
+    L.check(_lib().mser_xattn_seq_bwd(C.byref(desc), _stream()), "xattn_seq_bwd")
+
+
 # ---- DialogueRNN (include/mser.h mser_drnn_*)
 _DRNN_FIELDS = (("g_wih", "g_cell.weight_ih"), ("g_whh", "g_cell.weight_hh"), ("g_bih", "g_cell.bias_ih"), ("g_bhh", "g_cell.bias_hh"),
                 ("p_wih", "p_cell.weight_ih"), ("p_whh", "p_cell.weight_hh"), ("p_bih", "p_cell.bias_ih"), ("p_bhh", "p_cell.bias_hh"),

@@ -441,3 +441,52 @@ def test_gru_speaker_chain_fwd_bwd(env, T, B, use_drop, use_rev):
     dW = dgh.cpu().t() @ save[:, :H].cpu()
     assert maxabs(dW, w_r.grad) < 3e-4 * max(1e-3, float(w_r.grad.norm()))
     assert maxabs(dgh.cpu().sum(0), b_r.grad) < 3e-4 * max(1e-3, float(b_r.grad.norm()))
+
+
+@pytest.mark.parametrize("nb,Lq,Lk,nh,dk,p", [(3, 128, 128, 1, 128, 0.0), (2, 37, 50, 1, 128, 0.0), (2, 96, 70, 8, 16, 0.0), (2, 33, 128, 1, 128, 0.3),
+                                               (1, 1, 1, 1, 8, 0.0), (2, 64, 64, 2, 64, 0.25)])
+def test_fused_sequence_cross_attention_core(env, nb, Lq, Lk, nh, dk, p):
+    """mser_xattn_seq_fwd / bwd (csrc/xattn.hip: QK^T -> softmax -> .V per 32-query tile, no [B,L,L] in HBM) against a float64
+    restatement of the core of CrossAttention2/3 (model/lsthm_sps.py:93-99), time-major rows, with and without the dropout of :98
+    (mask for mask: the factors are read back through mser_dropout_scale), ragged tile edges, multi-head."""
+    ops = env
+    from mser import _lib as L_
+    from mser.functional import DropSite
+    rs = np.random.RandomState(nb * 131 + Lq + Lk + dk)
+    D = nh * dk
+    q = torch.tensor(rs.standard_normal((Lq * nb, D)).astype(np.float32)).cuda()
+    kv = torch.tensor(rs.standard_normal((Lk * nb, 2 * D)).astype(np.float32)).cuda()
+    dO = torch.tensor(rs.standard_normal((Lq * nb, D)).astype(np.float32)).cuda()
+    out = torch.zeros(Lq * nb, D, device="cuda")
+    stats = torch.empty(nb, nh, Lq, 2, device="cuda")
+    d = L_.XAttnDesc()
+    d.nb, d.nh, d.Lq, d.Lk, d.dk = nb, nh, Lq, Lk, dk
+    k_, v_ = kv[:, :D], kv[:, D:]
+    d.q, d.ldq, d.k, d.ldk, d.v, d.ldv = q.data_ptr(), D, k_.data_ptr(), 2 * D, v_.data_ptr(), 2 * D
+    d.sbq, d.slq, d.sbk, d.slk = 1, nb, 1, nb                    # time-major rows: row(b, l) = l*nb + b
+    d.o, d.ldo, d.stats, d.scale = out.data_ptr(), D, stats.data_ptr(), 1.0 / np.sqrt(dk)
+    drop = None
+    if p > 0:
+        rng = torch.tensor([1234, 7], dtype=torch.int32, device="cuda")
+        drop = DropSite(rng, 9, p)
+        d.rng, d.site, d.p = rng.data_ptr(), 9, p
+    assert ops.xattn_seq_supported(d)
+    ops.xattn_seq_fwd(d)
+    dq = torch.empty_like(q)
+    dkv = torch.zeros_like(kv)
+    d.dO, d.lddo, d.dq, d.lddq = dO.data_ptr(), D, dq.data_ptr(), D
+    d.dk_, d.lddk, d.dv, d.lddv = dkv.data_ptr(), 2 * D, dkv[:, D:].data_ptr(), 2 * D
+    ops.xattn_seq_bwd(d)
+    # float64 reference with autograd
+    Q = q.cpu().double().view(Lq, nb, nh, dk).permute(1, 2, 0, 3).requires_grad_(True)          # [nb, nh, Lq, dk]
+    K = kv.cpu().double()[:, :D].reshape(Lk, nb, nh, dk).permute(1, 2, 0, 3).requires_grad_(True)
+    V = kv.cpu().double()[:, D:].reshape(Lk, nb, nh, dk).permute(1, 2, 0, 3).requires_grad_(True)
+    P = torch.softmax(Q @ K.transpose(2, 3) / np.sqrt(dk), -1)
+    if drop is not None:
+        P = P * drop.scale(nb * nh * Lq * Lk).cpu().double().view(nb, nh, Lq, Lk)
+    O = (P @ V).permute(2, 0, 1, 3).reshape(Lq * nb, D)
+    (O * dO.cpu().double()).sum().backward()
+    assert float((out.cpu().double() - O.detach()).abs().max()) < 2e-5
+    for got, ref in ((dq, Q.grad.permute(2, 0, 1, 3).reshape(Lq * nb, D)), (dkv[:, :D], K.grad.permute(2, 0, 1, 3).reshape(Lk * nb, D)),
+                     (dkv[:, D:], V.grad.permute(2, 0, 1, 3).reshape(Lk * nb, D))):
+        assert float((got.cpu().double() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
