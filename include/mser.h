@@ -346,9 +346,11 @@ int mser_marn_cell_run(const mser_cell_desc* d, int32_t phases, mser_stream_t st
  * phase of the chain.
  * MSER_OPT_FWD_SENTINEL = 1 (default): the persistent forward chains hand their state from workgroup to workgroup through
  * self-validating payload (the state arrays start as a sentinel bit pattern, consumers re-load until their words are final)
- * instead of counter barriers: one store->load trip per seam, no store drain, no atomics.  0: the counter barriers. */
+ * instead of counter barriers: one store->load trip per seam, no store drain, no atomics.  0: the counter barriers.
+ * MSER_OPT_BWD_SENTINEL = 0 (default; 1 = measured without gain): the second seam of the LSTHM BPTT step and the hand-off to the speaker BPTT (carry
+ * products, speaker-state gradients in step-indexed arrays) self-validating as well; the first seam keeps its counter barrier. */
 enum { MSER_OPT_PERSISTENT = 1, MSER_OPT_WGRAD_INKERNEL = 2, MSER_OPT_BPTT_KSPLIT = 3, MSER_OPT_XCD_PLACEMENT = 4,
-       MSER_OPT_FWD_STATS_ROLES = 5, MSER_OPT_FWD_SENTINEL = 6 };
+       MSER_OPT_FWD_STATS_ROLES = 5, MSER_OPT_FWD_SENTINEL = 6, MSER_OPT_BWD_SENTINEL = 7 };
 int mser_set_option(int32_t key, int32_t value);
 /* Synchronises `stream` and reports whether a persistent kernel of the last fwd/bwd call on this workspace gave up at a
  * barrier (bounded spins; returns -2 and a message in that case).  Diagnostic; not needed on the hot path. */

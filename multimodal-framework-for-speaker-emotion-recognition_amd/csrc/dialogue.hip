@@ -18,6 +18,7 @@
 namespace mser {
 
 int gemm(const mser_gemm_desc& d, hipStream_t s);   // gemm.hip
+int gemm_group(const mser_gemm_desc* d, int n, hipStream_t s);
 
 namespace {
 
@@ -515,15 +516,30 @@ mser_gemm_desc gd() {
   return g;
 }
 // C[dir][M, N] (+)= A[dir][M, K] W[dir][N, K]^T (+ R1[dir][M, N])       -- nn.Linear orientation, both directions in one launch
-int mm_nt(hipStream_t s, const float* A, long lda, long a_ds, const float* W, long ldw, long w_ds, float* C, long ldc, long c_ds, int M, int N,
-          int K, bool accum, const float* R1 = nullptr, long ldr = 0, long r_ds = 0) {
+mser_gemm_desc mm_nt_desc(const float* A, long lda, long a_ds, const float* W, long ldw, long w_ds, float* C, long ldc, long c_ds, int M, int N,
+                          int K, bool accum, const float* R1 = nullptr, long ldr = 0, long r_ds = 0) {
   mser_gemm_desc g = gd();
   g.A = A; g.B = W; g.C = C; g.M = M; g.N = N; g.K = K;
   g.sAm = lda; g.sAk = 1; g.sBk = 1; g.sBn = ldw; g.ldc = ldc;
   g.batch1 = 2; g.sA1 = a_ds; g.sB1 = w_ds; g.sC1 = c_ds;
   if (accum) g.flags |= MSER_GEMM_ACCUM;
   g.R1 = R1; g.ldr1 = ldr; g.sR1_1 = r_ds;
-  return gemm(g, s);
+  return g;
+}
+int mm_nt(hipStream_t s, const float* A, long lda, long a_ds, const float* W, long ldw, long w_ds, float* C, long ldc, long c_ds, int M, int N,
+          int K, bool accum, const float* R1 = nullptr, long ldr = 0, long r_ds = 0) {
+  return gemm(mm_nt_desc(A, lda, a_ds, W, ldw, w_ds, C, ldc, c_ds, M, N, K, accum, R1, ldr, r_ds), s);
+}
+// the accumulating form of mm_nn as a descriptor (for a grouped launch; C must be live)
+mser_gemm_desc mm_nn_acc_desc(const float* A, long lda, long a_ds, const float* W, long ldw, long w_ds, float* C, long ldc, long c_ds, int M,
+                              int N, int K) {
+  mser_gemm_desc g = gd();
+  g.A = A; g.B = W; g.C = C; g.M = M; g.N = N; g.K = K;
+  g.sAm = lda; g.sAk = 1; g.sBk = ldw; g.sBn = 1; g.ldc = ldc;
+  g.batch1 = 2; g.sA1 = a_ds; g.sB1 = w_ds; g.sC1 = c_ds;
+  g.flags |= MSER_GEMM_ACCUM;
+  g.splitk = 2;
+  return g;
 }
 // C[dir][M, N] (+)= A[dir][M, K] W[dir][K, N]        -- backward data gradient through an nn.Linear weight [K, N] (row-major, ld ldw)
 // The reduction runs over the 3H gate columns (K = 1500 at the reference's widths) while the output is only N <= 500 wide: without a
@@ -637,21 +653,29 @@ int mser_drnn_fwd(const mser_drnn_desc* dp, mser_stream_t stream) {
     const float* Et = w.Eh + (long)t * B * De;              float* En = w.Eh + (long)(t + 1) * B * De;
     const long g_ds = (long)(T + 1) * B * Dg, q_ds = (long)(T + 1) * B * 2 * Dp, e_ds = (long)(T + 1) * B * De;
     const float* q0s = w.q0sel + (long)t * B * Dp;
-    // -- g cell
-    MSER_TRY(mm_nt(s, q0s, Dp, TB * Dp, d.p[0].g_wih + Dm, Dm + Dp, DS(g_wih), w.gi_g, 3 * Dg, (long)B * 3 * Dg, B, 3 * Dg, Dp, false,
-                   w.GIg + (long)t * B * 3 * Dg, 3 * Dg, TB * 3 * Dg));
-    MSER_TRY(mm_nt(s, Ght, Dg, g_ds, d.p[0].g_whh, Dg, DS(g_whh), w.gh_g, 3 * Dg, (long)B * 3 * Dg, B, 3 * Dg, Dg, false));
-    hipLaunchKernelGGL(drnn_g_fwd_kernel, dim3(cdiv((long)B * Dg, 256), 1, 2), blk, 0, s, B, Dg, w.gi_g, w.gh_g, d.p[0].g_bhh, DS(g_bhh), Ght, Ghn,
-                       g_ds, w.sv_g + (long)t * B * 4 * Dg, TB * 4 * Dg, rng, d.drop_site[0], d.drop_site[1], p, (uint32_t)((long)t * B * Dg));
-    // -- attention over g_0 .. g_{t-1}
+    // -- the five products that read only the state left by step t-1 (q[b,s_b], g_{t-1}, q, q, e_{t-1}), both directions each: ONE
+    //    grouped launch (ten members) fills the chip where a product of its own keeps 47-94 workgroups busy for 18 us
+    {
+      mser_gemm_desc grp[5] = {
+        mm_nt_desc(q0s, Dp, TB * Dp, d.p[0].g_wih + Dm, Dm + Dp, DS(g_wih), w.gi_g, 3 * Dg, (long)B * 3 * Dg, B, 3 * Dg, Dp, false,
+                   w.GIg + (long)t * B * 3 * Dg, 3 * Dg, TB * 3 * Dg),
+        mm_nt_desc(Ght, Dg, g_ds, d.p[0].g_whh, Dg, DS(g_whh), w.gh_g, 3 * Dg, (long)B * 3 * Dg, B, 3 * Dg, Dg, false),
+        mm_nt_desc(Qt, Dp, q_ds, d.p[0].p_whh, Dp, DS(p_whh), w.gh_p, 3 * Dp, (long)2 * B * 3 * Dp, 2 * B, 3 * Dp, Dp, false),
+        mm_nt_desc(Qt, Dp, q_ds, d.p[0].l_whh, Dp, DS(l_whh), w.gh_l, 3 * Dp, (long)2 * B * 3 * Dp, 2 * B, 3 * Dp, Dp, false),
+        mm_nt_desc(Et, De, e_ds, d.p[0].e_whh, De, DS(e_whh), w.gh_e, 3 * De, (long)B * 3 * De, B, 3 * De, De, false)};
+      MSER_TRY(gemm_group(grp, 5, s));
+    }
+    // -- attention over g_0 .. g_{t-1}, then the p cell's input product (the chain of the step: attention -> p -> l -> e)
     if (t > 0) {
       hipLaunchKernelGGL(drnn_attn_fwd_kernel, dim3(B, 2), dim3(ATT_NT), (size_t)(Dg + T) * sizeof(float), s, B, Dg, T, t,
                          w.Xatt + (long)t * B * Dg, TB * Dg, w.Gh, g_ds, w.alpha + (long)t * B * T, TB * T, w.cvec + (long)t * B * Dg, TB * Dg);
     }
-    // -- p cell (both parties)
     MSER_TRY(mm_nt(s, w.cvec + (long)t * B * Dg, Dg, TB * Dg, d.p[0].p_wih + Dm, Dm + Dg, DS(p_wih), w.gi_p, 3 * Dp, (long)B * 3 * Dp, B, 3 * Dp, Dg,
                    false, w.GIp + (long)t * B * 3 * Dp, 3 * Dp, TB * 3 * Dp));
-    MSER_TRY(mm_nt(s, Qt, Dp, q_ds, d.p[0].p_whh, Dp, DS(p_whh), w.gh_p, 3 * Dp, (long)2 * B * 3 * Dp, 2 * B, 3 * Dp, Dp, false));
+    // -- g cell epilogue (g_t is first read by step t+1)
+    hipLaunchKernelGGL(drnn_g_fwd_kernel, dim3(cdiv((long)B * Dg, 256), 1, 2), blk, 0, s, B, Dg, w.gi_g, w.gh_g, d.p[0].g_bhh, DS(g_bhh), Ght, Ghn,
+                       g_ds, w.sv_g + (long)t * B * 4 * Dg, TB * 4 * Dg, rng, d.drop_site[0], d.drop_site[1], p, (uint32_t)((long)t * B * Dg));
+    // -- p cell (both parties)
     float* qs = w.dqs;            // (forward: scratch for the p cell's dropped output; the backward reuses the buffer)
     hipLaunchKernelGGL(drnn_p_fwd_kernel, dim3(cdiv((long)B * Dp, 256), 1, 2), blk, 0, s, B, Dp, w.gi_p, w.gh_p, d.p[0].p_bhh, DS(p_bhh), Qt, q_ds,
                        qs, w.sv_p + (long)t * B * 2 * 4 * Dp, TB * 2 * 4 * Dp, w.idx + (long)t * B, idx_ds, w.ss + (long)t * B * Dp, TB * Dp, rng,
@@ -659,17 +683,13 @@ int mser_drnn_fwd(const mser_drnn_desc* dp, mser_stream_t stream) {
     // -- l cell + blend
     MSER_TRY(mm_nt(s, w.ss + (long)t * B * Dp, Dp, TB * Dp, d.p[0].l_wih + Dm, Dm + Dp, DS(l_wih), w.gi_l, 3 * Dp, (long)B * 3 * Dp, B, 3 * Dp, Dp,
                    false, w.GIl + (long)t * B * 3 * Dp, 3 * Dp, TB * 3 * Dp));
-    MSER_TRY(mm_nt(s, Qt, Dp, q_ds, d.p[0].l_whh, Dp, DS(l_whh), w.gh_l, 3 * Dp, (long)2 * B * 3 * Dp, 2 * B, 3 * Dp, Dp, false));
     float* q0n = (t + 1 < T) ? w.q0sel + (long)(t + 1) * B * Dp : w.dss;         // (last step: a scratch target)
     hipLaunchKernelGGL(drnn_l_fwd_kernel, dim3(cdiv((long)B * Dp, 256), 1, 2), blk, 0, s, B, Dp, w.gi_l, w.gh_l, d.p[0].l_bhh, DS(l_bhh), Qt, Qn, q_ds,
                        qs, w.sv_l + (long)t * B * 2 * 4 * Dp, TB * 2 * 4 * Dp, w.qm + (long)t * B * 2, TB * 2, w.idx + (long)t * B,
                        w.idx + (long)(t + 1) * B, idx_ds, w.qsel + (long)t * B * Dp, TB * Dp, q0n, (t + 1 < T) ? TB * Dp : (long)B * Dp, rng,
                        d.drop_site[0] + 2, d.drop_site[1] + 2, p, (uint32_t)((long)t * B * 2 * Dp));
-    // -- e cell
+    // -- e cell (its input is not U, so b_ih is not part of a hoisted product: the epilogue adds it)
     MSER_TRY(mm_nt(s, w.qsel + (long)t * B * Dp, Dp, TB * Dp, d.p[0].e_wih, Dp, DS(e_wih), w.gi_e, 3 * De, (long)B * 3 * De, B, 3 * De, Dp, false));
-    MSER_TRY(mm_nt(s, Et, De, e_ds, d.p[0].e_whh, De, DS(e_whh), w.gh_e, 3 * De, (long)B * 3 * De, B, 3 * De, De, false));
-    // (the e cell's input is not U, so its b_ih is not part of a hoisted product: the epilogue adds it; bias_ih and bias_hh of one cell
-    // are the same distance apart in both directions, so one direction stride serves both)
     hipLaunchKernelGGL(drnn_e_fwd_kernel, dim3(cdiv((long)B * De, 256), 1, 2), blk, 0, s, B, De, w.gi_e, w.gh_e, d.p[0].e_bih, d.p[0].e_bhh, DS(e_bhh), Et, En, e_ds,
                        w.sv_e + (long)t * B * 4 * De, TB * 4 * De, d.out, (long)d.ldo, d.rev, t, rng, d.drop_site[0] + 3, d.drop_site[1] + 3, p,
                        (uint32_t)((long)t * B * De));
@@ -708,7 +728,6 @@ int mser_drnn_bwd(const mser_drnn_desc* dp, mser_stream_t stream) {
                        w.sv_e + (long)t * B * 4 * De, TB * 4 * De, w.Eh + (long)t * B * De, e_ds, w.dgi_e + (long)t * B * 3 * De,
                        w.dgh_e + (long)t * B * 3 * De, TB * 3 * De, rng, d.drop_site[0] + 3, d.drop_site[1] + 3, p, (uint32_t)((long)t * B * De));
     MSER_TRY(mm_nn(s, w.dgi_e + (long)t * B * 3 * De, 3 * De, TB * 3 * De, d.p[0].e_wih, Dp, DS(e_wih), w.dqsel, Dp, (long)B * Dp, B, Dp, 3 * De, false));
-    MSER_TRY(mm_nn(s, w.dgh_e + (long)t * B * 3 * De, 3 * De, TB * 3 * De, d.p[0].e_whh, De, DS(e_whh), w.dEc, De, (long)B * De, B, De, 3 * De, true));
     // -- l cell + blend
     hipLaunchKernelGGL(drnn_l_bwd_kernel, dim3(cdiv((long)B * Dp, 256), 1, 2), blk, 0, s, B, Dp, dQn, dQc, dq_ds, w.dqsel, dq0n, (long)B * Dp,
                        w.idx + (long)t * B, w.idx + (long)(t + 1) * B, idx_ds, w.qm + (long)t * B * 2, TB * 2, w.sv_l + (long)t * B * 2 * 4 * Dp,
@@ -716,14 +735,12 @@ int mser_drnn_bwd(const mser_drnn_desc* dp, mser_stream_t stream) {
                        w.dgh_l + (long)t * 2 * B * 3 * Dp, TB * 2 * 3 * Dp, w.dqs, rng, d.drop_site[0] + 2, d.drop_site[1] + 2, p,
                        (uint32_t)((long)t * B * 2 * Dp), t + 1 < T ? 1 : 0);
     MSER_TRY(mm_nn(s, w.dgi_l + (long)t * B * 3 * Dp, 3 * Dp, TB * 3 * Dp, d.p[0].l_wih + Dm, Dm + Dp, DS(l_wih), w.dss, Dp, (long)B * Dp, B, Dp, 3 * Dp, false));
-    MSER_TRY(mm_nn(s, w.dgh_l + (long)t * 2 * B * 3 * Dp, 3 * Dp, TB * 2 * 3 * Dp, d.p[0].l_whh, Dp, DS(l_whh), dQc, Dp, dq_ds, 2 * B, Dp, 3 * Dp, true));
     // -- p cell
     hipLaunchKernelGGL(drnn_p_bwd_kernel, dim3(cdiv((long)B * Dp, 256), 1, 2), blk, 0, s, B, Dp, w.dqs, w.dss, (long)B * Dp, w.idx + (long)t * B, idx_ds,
                        dQc, dq_ds, w.sv_p + (long)t * B * 2 * 4 * Dp, TB * 2 * 4 * Dp, w.Q + (long)t * B * 2 * Dp, q_ds,
                        w.dgi_p + (long)t * B * 3 * Dp, TB * 3 * Dp, w.dgh_p + (long)t * 2 * B * 3 * Dp, TB * 2 * 3 * Dp, rng, d.drop_site[0] + 1,
                        d.drop_site[1] + 1, p, (uint32_t)((long)t * B * 2 * Dp));
     MSER_TRY(mm_nn(s, w.dgi_p + (long)t * B * 3 * Dp, 3 * Dp, TB * 3 * Dp, d.p[0].p_wih + Dm, Dm + Dg, DS(p_wih), w.dc, Dg, (long)B * Dg, B, Dg, 3 * Dp, false));
-    MSER_TRY(mm_nn(s, w.dgh_p + (long)t * 2 * B * 3 * Dp, 3 * Dp, TB * 2 * 3 * Dp, d.p[0].p_whh, Dp, DS(p_whh), dQc, Dp, dq_ds, 2 * B, Dp, 3 * Dp, true));
     // -- attention over the history
     if (t > 0) {
       hipLaunchKernelGGL(drnn_attn_bwd_kernel, dim3(B, 2), dim3(ATT_NT), (size_t)(3 * Dg + 2 * T) * sizeof(float), s, B, Dg, T, t,
@@ -737,7 +754,15 @@ int mser_drnn_bwd(const mser_drnn_desc* dp, mser_stream_t stream) {
                        g_ds, w.sv_g + (long)t * B * 4 * Dg, TB * 4 * Dg, w.Gh + (long)t * B * Dg, w.dgi_g + (long)t * B * 3 * Dg,
                        w.dgh_g + (long)t * B * 3 * Dg, TB * 3 * Dg, rng, d.drop_site[0], d.drop_site[1], p, (uint32_t)((long)t * B * Dg));
     MSER_TRY(mm_nn(s, w.dgi_g + (long)t * B * 3 * Dg, 3 * Dg, TB * 3 * Dg, d.p[0].g_wih + Dm, Dm + Dp, DS(g_wih), dq0c, Dp, (long)B * Dp, B, Dp, 3 * Dg, false));
-    MSER_TRY(mm_nn(s, w.dgh_g + (long)t * B * 3 * Dg, 3 * Dg, TB * 3 * Dg, d.p[0].g_whh, Dg, DS(g_whh), w.dGh + (long)t * B * Dg, Dg, g_ds, B, Dg, 3 * Dg, true));
+    // -- the four hidden-path products of the step (into the state gradients that step t-1 reads): one grouped launch, split-K atomics
+    {
+      mser_gemm_desc grp[4] = {
+        mm_nn_acc_desc(w.dgh_e + (long)t * B * 3 * De, 3 * De, TB * 3 * De, d.p[0].e_whh, De, DS(e_whh), w.dEc, De, (long)B * De, B, De, 3 * De),
+        mm_nn_acc_desc(w.dgh_l + (long)t * 2 * B * 3 * Dp, 3 * Dp, TB * 2 * 3 * Dp, d.p[0].l_whh, Dp, DS(l_whh), dQc, Dp, dq_ds, 2 * B, Dp, 3 * Dp),
+        mm_nn_acc_desc(w.dgh_p + (long)t * 2 * B * 3 * Dp, 3 * Dp, TB * 2 * 3 * Dp, d.p[0].p_whh, Dp, DS(p_whh), dQc, Dp, dq_ds, 2 * B, Dp, 3 * Dp),
+        mm_nn_acc_desc(w.dgh_g + (long)t * B * 3 * Dg, 3 * Dg, TB * 3 * Dg, d.p[0].g_whh, Dg, DS(g_whh), w.dGh + (long)t * B * Dg, Dg, g_ds, B, Dg, 3 * Dg)};
+      MSER_TRY(gemm_group(grp, 4, s));
+    }
     MSER_TRY(check_launch("drnn_bwd step"));
     pp ^= 1;
   }

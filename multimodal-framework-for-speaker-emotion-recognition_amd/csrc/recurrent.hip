@@ -81,6 +81,7 @@ struct CellK {
   const uint32_t* rng; // dropout generator words {seed, step} (nullptr: every dropout site of the cell is the identity)
   unsigned* fault;     // sticky fault word (mser_cell_desc::fault) or nullptr
   int fwd_sentinel;    // forward chain hand-offs through self-validating payload instead of counter barriers (MSER_OPT_FWD_SENTINEL)
+  int bwd_sentinel;    // the same for the LSTHM BPTT chain (MSER_OPT_BWD_SENTINEL)
   int ksplit;          // BPTT matvec phase: every product's K = 4H reduction is split over `ksplit` workgroups (1 or 2); the
                        // partial results live in consecutive copies of dA / dHQp / dxc and the consumers add them
   DirP d[2];
@@ -437,7 +438,7 @@ constexpr float LOG2E = 1.4426950408889634f;
 // registers across the whole time loop) and all A fragments are fetched before the first MFMA.
 template <int NP, class ALoad, class BLoad>
 __device__ __forceinline__ void wg_mm32(int K, ALoad aload, BLoad bload, const float (*bpre)[8], float* red, float* tile,
-                                        bool red_aliases_a = false) {
+                                        bool red_aliases_a = false, unsigned* poll_abortw = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, half = lane >> 5;
   const int KC = ((K + NW * 16 - 1) / (NW * 16)) * 16;   // per-wave K chunk (multiple of 16)
@@ -450,6 +451,19 @@ __device__ __forceinline__ void wg_mm32(int K, ALoad aload, BLoad bload, const f
     for (int p = 0; p < NP; ++p) {
       if (kbeg + p * 16 < kend) aload(r, kbeg + p * 16 + half * 8, a[p]);
       else zero8(a[p]);
+    }
+    if (poll_abortw) {            // self-validating hand-off: the A rows come from other workgroups of this launch (see is_sent)
+      unsigned spins = 0;
+      while (true) {
+        bool bad = false;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) bad |= any_sent8(a[p]);
+        if (__builtin_amdgcn_ballot_w64(bad) == 0ull) break;
+        if (poll_giveup(spins, poll_abortw)) break;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+          if (kbeg + p * 16 < kend) aload(r, kbeg + p * 16 + half * 8, a[p]);
+      }
     }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -1303,7 +1317,7 @@ __device__ __forceinline__ RowMid lsthm_bwd_row_part1_saved(const CellK& P, cons
 
 // carry[2]: the dc carry of this thread's unit, both streams (in: from step t+1, out: for step t-1).  The persistent kernel keeps it in
 // registers (the same thread owns the same (row, unit) every step); it is also written to dc_carry for the per-step launches.
-template <bool PS, int JCT>
+template <bool PS, int JCT, bool SV = false>
 __device__ __forceinline__ void lsthm_bwd_row_part2(const CellK& P, const DirP& D, const WS& ws, int t, int b, const float* att, float* scr,
                                                     const RowPre& pre, const RowMid& mid, float* carry) {
   const int H = P.H, B = P.B, T = P.T;
@@ -1315,7 +1329,7 @@ __device__ __forceinline__ void lsthm_bwd_row_part2(const CellK& P, const DirP& 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long rowt = (long)t * B + b;
   const bool last = (t == T - 1);
-  const float* dA = D.dA + (long)b * H;          // [4][B][H]: U_l, V_l, U_a, V_a products of step t+1
+  const float* dA = D.dA + (long)(t + 1 < T ? t + 1 : t) * 8 * B * H + (long)b * H;          // [2][4][B][H]: U_l, V_l, U_a, V_a products of step t+1
   const long SA = (long)B * H;
   const float rsH = 1.0f / sqrtf((float)H);
   const int i = tid & (H - 1), q = tid / H;
@@ -1326,14 +1340,21 @@ __device__ __forceinline__ void lsthm_bwd_row_part2(const CellK& P, const DirP& 
   // the only operands that come from other workgroups of this launch: the four carry products of step t+1
   float dz_in = pre.dz_out, zi = pre.zi, dh2[2] = {pre.dh_out[0], pre.dh_out[1]}, dhq = pre.dhq;
   if (q == 0 && !last) {
-    dz_in += ldx<PS>(ws, dA + 1 * SA + i) + ldx<PS>(ws, dA + 3 * SA + i);
-    dh2[0] += ldx<PS>(ws, dA + 0 * SA + i);
-    dh2[1] += ldx<PS>(ws, dA + 2 * SA + i);
-    if (P.ksplit == 2) {       // second K-half of every carry product
-      dz_in += ldx<PS>(ws, dA + 5 * SA + i) + ldx<PS>(ws, dA + 7 * SA + i);
-      dh2[0] += ldx<PS>(ws, dA + 4 * SA + i);
-      dh2[1] += ldx<PS>(ws, dA + 6 * SA + i);
+    float c8[8];
+    const int nc = P.ksplit == 2 ? 8 : 4;          // (second K-half of every carry product)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c8[k] = k < nc ? ldx<PS>(ws, dA + k * SA + i) : 0.f;
+    if (SV) {                  // the carries come from the matvec roles of step t+1: poll until every word is final (see is_sent)
+      unsigned spins = 0;
+      while (__builtin_amdgcn_ballot_w64(any_sent8(c8)) != 0ull) {
+        if (poll_giveup(spins, P.sync + SYNC_ABORT)) break;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c8[k] = k < nc ? ldx<PS>(ws, dA + k * SA + i) : 0.f;
+      }
     }
+    dz_in += c8[1] + c8[3] + c8[5] + c8[7];
+    dh2[0] += c8[0] + c8[4];
+    dh2[1] += c8[2] + c8[6];
   }
   float du_cl = 0.f, dcl_att = 0.f;
   if (q == 0) {
@@ -1441,7 +1462,7 @@ struct LsthmBwdB {
 };
 
 // kh / ksplit: this workgroup reduces over gate columns [kh * 4H/ksplit, (kh+1) * 4H/ksplit) and writes partial copy kh.
-template <bool PS, int NP>
+template <bool PS, int NP, bool SV = false>
 __device__ __forceinline__ void lsthm_bwd_mat_body(const CellK& P, const DirP& D, const WS& ws, int t, int p, int n0, int mb,
                                                    const float (*bpre)[8], float* red, float* tile, int kh = 0, int ksplit = 1) {
   const int m = p < 4 ? p >> 1 : (p - 4) & 1;
@@ -1455,7 +1476,7 @@ __device__ __forceinline__ void lsthm_bwd_mat_body(const CellK& P, const DirP& D
     load8x<PS>(ws, dg + (long)b * 4 * H + k, a);
   };
   const int ldw = p >= 6 ? P.D : H;
-  wg_mm32<NP>(KH, aload, LsthmBwdB{Wp + (long)koff * ldw, n0, ldw, ldw}, bpre, red, tile);
+  wg_mm32<NP>(KH, aload, LsthmBwdB{Wp + (long)koff * ldw, n0, ldw, ldw}, bpre, red, tile, false, SV ? P.sync + SYNC_ABORT : nullptr);
 #pragma unroll
   for (int e = 0; e < 1024 / NT; ++e) {
     const int idx = threadIdx.x + e * NT;
@@ -1466,7 +1487,7 @@ __device__ __forceinline__ void lsthm_bwd_mat_body(const CellK& P, const DirP& D
         const int tau = D.rev ? D.rev[(long)t * B + b] : t;
         if (tau >= 0 && n0 + n < P.D) D.dxc[(((long)kh * 2 + m) * T * B + (long)tau * B + b) * P.D + n0 + n] = tile[idx];
       } else {
-        float* dst = p < 4 ? D.dA + (((long)kh * 4 + p) * B + b) * H : D.dHQp + ((((long)kh * 2 + m) * T + t) * B + b) * H;
+        float* dst = p < 4 ? D.dA + ((((long)t * 2 + kh) * 4 + p) * B + b) * H : D.dHQp + ((((long)kh * 2 + m) * T + t) * B + b) * H;
         stx<PS>(ws, dst + n0 + n, tile[idx]);
       }
     }
@@ -1492,8 +1513,83 @@ __global__ __launch_bounds__(NT) void lsthm_bwd_mat(CellK P, int t) {
 // persistent launch: grid (nwg, 1, ndir), nwg >= (H/32)*6*nmb.  Row phase: rows round-robin over all nwg workgroups;
 // matvec phase: the first (H/32)*6*nmb workgroups (4 carry products + 2 speaker-gradient products).  Two barriers per step;
 // the counter doubles as the "dHQ[t] is complete" signal for the concurrently running speaker BPTT (value 2*(T-t)*nwg).
+// MSER_OPT_BWD_SENTINEL form of lsthm_bwd_role below: the second seam of the step (carry products dA[t] of the matvec roles -> row
+// phase of step t-1) and the hand-off to the speaker BPTT roles (dHQ[t] / dHQp[t]) are self-validating -- written once per launch
+// into step-indexed arrays that MSER_PHASE_BWD_PREP filled with the sentinel, polled by their consumers -- while the first seam
+// (gate gradients -> matvec roles, 32 KB per consumer) keeps its counter barrier, which the weight-gradient roles also follow.
+template <int NP, int KSPLIT = 1>
+__device__ __forceinline__ void lsthm_bwd_role_sv(const CellK& P, const Role R, float* smem, const WS& ws) {
+  constexpr int NPM = NP / KSPLIT;
+  float* red = smem;
+  float* tile = smem + RED_FLOATS;
+  float* att = tile + 1024;
+  const int dir = R.z;
+  const DirP& D = P.d[dir];
+  const int H = P.H;
+  const unsigned nwg = R.gx;
+  const int w = R.x;
+  if (threadIdx.x == 0) s_poll_abort = 0;
+  drop_init(P, D);
+  const int nsl = H / 32, nslx = (P.D + 31) / 32;
+  const int per_kh = 6 * nsl + 2 * nslx;
+  const int per_mb = per_kh * KSPLIT;
+  const bool has_mat = w < per_mb * P.nmb;
+  const int mb = w / per_mb, kh = (w % per_mb) / per_kh, wr = w % per_kh;
+  const int p = wr < 6 * nsl ? wr / nsl : 6 + (wr - 6 * nsl) / nslx;
+  const int n0 = (wr < 6 * nsl ? wr % nsl : (wr - 6 * nsl) % nslx) * 32;
+  float bpre[NPM][8];
+  if (has_mat) {
+    const int m = p < 4 ? p >> 1 : (p - 4) & 1;
+    const float* Wp = p >= 6 ? D.W[m] : (p >= 4 ? D.S[m] : ((p & 1) ? D.V[m] : D.U[m]));
+    const int ldw = p >= 6 ? P.D : H;
+    preload_b<NPM>(4 * H / KSPLIT, LsthmBwdB{Wp + (long)kh * (4 * H / KSPLIT) * ldw, n0, ldw, ldw}, bpre);
+  }
+  att_prepare(D, H, att, red);
+  int* lds_ok = (int*)(att + att_floats(P.H));
+  unsigned nbar = 0;
+  unsigned* cnt = P.sync + SYNC_LSTHM_BWD + dir * SYNC_DIR;
+  STAMP_INIT();
+  constexpr int JCB = 2 * NP * NP;
+  const bool has_row = w < P.B;
+  const int rowb = has_row ? w : 0;
+  RowPre pre = lsthm_bwd_row_prefetch(P, D, P.T - 1, rowb);
+  RowPre pre_n = lsthm_bwd_row_prefetch(P, D, P.T > 1 ? P.T - 2 : 0, rowb);
+  RowMid mid = lsthm_bwd_row_part1_saved(P, D, P.T - 1, rowb, att, red, pre);
+  float carry[2] = {0.f, 0.f};
+  for (int t = P.T - 1; t >= 0; --t) {
+    if (has_row) lsthm_bwd_row_part2<true, JCB, true>(P, D, ws, t, w, att, red, pre, mid, carry);
+    for (int b = w + (int)nwg; b < P.B; b += (int)nwg) {
+      const RowPre pr = lsthm_bwd_row_prefetch(P, D, t, b);
+      const RowMid md = lsthm_bwd_row_part1<JCB>(P, D, t, b, att, red, pr);
+      float cr[2] = {pr.carry[0], pr.carry[1]};
+      lsthm_bwd_row_part2<true, JCB, true>(P, D, ws, t, b, att, red, pr, md, cr);
+    }
+    if (s_poll_abort) return;                    // (read behind part2's closing workgroup barrier: uniform)
+    STAMP_ACC(0);
+    // seam 1 (gate gradients -> matvec roles) keeps its counter barrier: every matvec workgroup reads a 32 KB slab of dgates[t];
+    // polling a payload of that size from 128 workgroups at once costs more fabric traffic than the barrier's bookkeeping saves
+    // (measured: 1379 us per launch with both seams self-validating against 1341 with both on the counter)
+    nbar += P.ext_spk ? 2u : 1u;
+    if (!dir_barrier(cnt, P.sync + SYNC_ABORT, nwg * (nbar - (P.ext_spk ? 1u : 0u)), lds_ok)) return;
+    STAMP_ACC(1);
+    if (has_mat && (t > 0 || p >= 4)) lsthm_bwd_mat_body<true, NPM, false>(P, D, ws, t, p, n0, mb, bpre, red, tile, kh, KSPLIT);
+    STAMP_ACC(2);
+    // seam 2 (carry products -> row phase of step t-1: 8 floats per unit) is self-validating: no arrive, no wait.  With an external
+    // speaker state the counter still advances (a linked consumer of the caller waits for "dHQp[t] published")
+    if (P.ext_spk) barrier_arrive(cnt);
+    if (t > 0) {
+      pre = pre_n;
+      if (t > 1) pre_n = lsthm_bwd_row_prefetch(P, D, t - 2, rowb);
+      mid = lsthm_bwd_row_part1_saved(P, D, t - 1, rowb, att, red, pre);
+    }
+    STAMP_ACC(3);
+  }
+  STAMP_DUMP(P, 32, R.x == 1 && R.z == 0);
+}
+
 template <int NP, int KSPLIT = 1>
 __device__ __forceinline__ void lsthm_bwd_role(const CellK& P, const Role R, float* smem, const WS& ws) {
+  if (P.bwd_sentinel) { lsthm_bwd_role_sv<NP, KSPLIT>(P, R, smem, ws); return; }
   constexpr int NPM = NP / KSPLIT;                 // k-passes per wave of the (K-split) matvec products
   float* red = smem;
   float* tile = smem + RED_FLOATS;
@@ -1673,6 +1769,32 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, cons
         }
       }
     }
+    if (WITHP && P.bwd_sentinel) {
+      // self-validating hand-off from the LSTHM BPTT (no counter in this mode): dHQ[t] and its per-product parts were filled with the
+      // sentinel (a NaN) by BWD_PREP, so a sum that is NaN still holds a word that has not been written: re-load until it is not
+#pragma unroll
+      for (int ii = 0; ii < MAXIT; ++ii) {
+        const int g = tid + (it0 + ii) * NT;
+        const int rr = g / G4, u = (g % G4) * 4;
+        const int slot = mb * 32 + rr;
+        const bool mine = it0 + ii < nit && slot < B && slot < Nc;
+        unsigned spins = 0;
+        while (__builtin_amdgcn_ballot_w64(mine && (v_hq[ii].x != v_hq[ii].x || v_hq[ii].y != v_hq[ii].y || v_hq[ii].z != v_hq[ii].z ||
+                                                    v_hq[ii].w != v_hq[ii].w)) != 0ull) {
+          if (poll_giveup(spins, P.sync + SYNC_ABORT)) break;
+          if (mine) {
+            const int r = off + slot;
+            const int np_ = P.ksplit == 2 ? 4 : 2;
+            float4 acc4 = ld4x<PS>(ws, D.dHQ + ((long)t * B + r) * H + u);
+            for (int k = 0; k < np_; ++k) {
+              const float4 qk = ld4x<PS>(ws, D.dHQp + (((long)k * T + t) * B + r) * H + u);
+              acc4.x += qk.x; acc4.y += qk.y; acc4.z += qk.z; acc4.w += qk.w;
+            }
+            v_hq[ii] = acc4;
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int ii = 0; ii < MAXIT; ++ii) {
       if (it0 + ii >= nit) break;
@@ -1765,7 +1887,9 @@ __device__ __forceinline__ void spk_bwd_role(const CellK& P, const Role R, float
   unsigned* cnt = P.sync + SYNC_SPK_BWD + dir * SYNC_DIR;
   const unsigned* lcnt = P.sync + SYNC_LSTHM_BWD + dir * SYNC_DIR;
   unsigned nbar = 0;
-  if (!dir_barrier(nullptr, P.sync + SYNC_ABORT, 0, lds_ok, lcnt, 2u * nwg_l)) return;          // dHQ[T-1] complete
+  const bool sv = P.bwd_sentinel != 0;          // the LSTHM BPTT publishes no counter: dHQ[t] / dHQp[t] validate themselves (spk_bwd_body)
+  if (threadIdx.x == 0) s_poll_abort = 0;
+  if (!sv && !dir_barrier(nullptr, P.sync + SYNC_ABORT, 0, lds_ok, lcnt, 2u * nwg_l)) return;          // dHQ[T-1] complete
   STAMP_INIT();
   for (int t = P.T - 1; t >= 0; --t) {
     spk_bwd_body<true, NP, true>(P, D, ws, t, p, n0, mb, (int)((p & 1) * R.gx + R.x), bpre, red, tile, dsg_s);
@@ -1774,7 +1898,8 @@ __device__ __forceinline__ void spk_bwd_role(const CellK& P, const Role R, float
       barrier_arrive(cnt);
       break;
     }
-    if (!dir_barrier(cnt, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok, lcnt, 2u * nwg_l * (unsigned)(P.T - t + 1))) return;
+    if (!dir_barrier(cnt, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok, sv ? nullptr : lcnt, 2u * nwg_l * (unsigned)(P.T - t + 1))) return;
+    if (s_poll_abort) return;
     STAMP_ACC(3);
   }
   STAMP_DUMP(P, 40, R.x == 0 && R.y == 0 && R.z == 0);
@@ -1983,7 +2108,12 @@ __device__ __forceinline__ void wgrad_role(const CellK& P, int id, const WS& ws,
     // dgates[t] is complete behind the row-phase barrier of step t (barrier 2(T-1-t)+1 of the LSTHM chain); dsg[t] behind
     // barrier T-t of the speaker chain
     const unsigned target = SPK ? nwg_src * (unsigned)(T - t_lo) : nwg_src * (2u * (unsigned)(T - 1 - t_lo) + 1u);
-    if (!lazy_wait(cnt, P.sync + SYNC_ABORT, target, lds_ok)) return;
+    // (MSER_OPT_BWD_SENTINEL: the LSTHM BPTT passes ONE counter barrier per step -- two with an external speaker state -- and
+    // dgates[t] is complete behind the first of step t)
+    const unsigned per = P.ext_spk ? 2u : 1u;
+    const unsigned target_sv = nwg_src * (per * (unsigned)(T - 1 - t_lo) + 1u);
+    constexpr bool sv = false;
+    if (!lazy_wait(cnt, P.sync + SYNC_ABORT, (!SPK && P.bwd_sentinel) ? target_sv : target, lds_ok)) return;
 #ifdef MSER_WGRAD_EXPERIMENT_SKIP       // diagnostic build only: follow the counters, do no work
     continue;
 #endif
@@ -2000,6 +2130,19 @@ __device__ __forceinline__ void wgrad_role(const CellK& P, int id, const WS& ws,
           const int roff = row * ldb4;
 #pragma unroll
           for (int q = 0; q < 4; ++q) b[q][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, roff + coff[q], 0, 0));
+        }
+        if (sv) {                // long sleeps between polls: this role is off the chain and must not crowd its requests
+          unsigned spins = 0;
+          while (__builtin_amdgcn_ballot_w64(is_sent(a[0]) || is_sent(a[1]) || is_sent(a[2]) || is_sent(a[3])) != 0ull) {
+            __builtin_amdgcn_s_sleep(48);
+            if (poll_giveup(spins, P.sync + SYNC_ABORT)) break;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int k = k0 + 2 * j + half;
+              const int row = t * B + (k < B ? k : B - 1);
+              a[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ws.r, aoff + row * 16 * H, 0, AUX_SC1));
+            }
+          }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -2206,7 +2349,8 @@ static void carve_dir(Carver& cv, DirP& d, int T, int B, int D, int H) {
   d.hz = cv.take<float>((T + 1) * (size_t)B * 3 * H);
   d.rstat = cv.take<float>(TB * H * 4);
   d.dgates = cv.take<float>(2 * TB * 4 * H);
-  d.dA = cv.take<float>(2 * 4 * SB);          // x2: K-split partial copies (CellK::ksplit)
+  d.dA = cv.take<float>((size_t)T * 2 * 4 * SB);   // [T][2 K-split copies][4 products][B][H]: indexed by the PRODUCING step (written once per
+                                                   // launch: the backward chain's self-validating hand-off needs that; 17 MB at c2)
   d.dHQ = cv.take<float>(TB * H);
   d.dHQp = cv.take<float>(2 * 2 * TB * H);
   // zeroed before every backward in ONE memset: [dc_carry | attacc | dxc] back to back (sizes rounded to 64 floats)
@@ -2339,6 +2483,7 @@ static int g_opt_ksplit = 1;          // MSER_OPT_BPTT_KSPLIT
 static int g_opt_stats_roles = 1;     // MSER_OPT_FWD_STATS_ROLES
 static int g_opt_xcd_place = 0;       // MSER_OPT_XCD_PLACEMENT (off: measured slower end to end)
 static int g_opt_fwd_sentinel = 1;    // MSER_OPT_FWD_SENTINEL
+static int g_opt_bwd_sentinel = 0;    // MSER_OPT_BWD_SENTINEL (off: measured 1345 us per BPTT launch against 1342 with the counter barriers)
 static int g_num_cus = 0;
 constexpr size_t PERSIST_MIN_LDS = 84 * 1024;     // > half of the 160 KiB LDS: at most ONE persistent workgroup per CU
 
@@ -2572,7 +2717,16 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       }
     }
   }
+  K.bwd_sentinel = (persist && g_opt_bwd_sentinel) ? 1 : 0;
   if (phases & MSER_PHASE_BWD_PREP) {
+    if (K.bwd_sentinel) {
+      // every word the BPTT chains hand from workgroup to workgroup starts as the sentinel (dgates | dA | dHQ | dHQp are carved back to
+      // back: one fill per direction)
+      for (int i = 0; i < d.ndir; ++i) {
+        DirP& k = K.d[i];
+        MSER_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)k.dgates, SENT_BITS, (size_t)((char*)(k.dHQp + 2 * 2 * TB * H) - (char*)k.dgates) / 4, s));
+      }
+    }
     for (int i = 0; i < d.ndir; ++i) {
       DirP& k = K.d[i];
       // dc_carry | attacc | dxc are carved back to back: one memset (dxc only where it is read without having been fully written:
@@ -2920,6 +3074,7 @@ int mser_set_option(int32_t key, int32_t value) {
     case MSER_OPT_XCD_PLACEMENT: g_opt_xcd_place = value ? 1 : 0; return 0;
     case MSER_OPT_FWD_STATS_ROLES: g_opt_stats_roles = value ? 1 : 0; return 0;
     case MSER_OPT_FWD_SENTINEL: g_opt_fwd_sentinel = value ? 1 : 0; return 0;
+    case MSER_OPT_BWD_SENTINEL: g_opt_bwd_sentinel = value ? 1 : 0; return 0;
     default: set_error("mser_set_option: unknown key %d", key); return -1;
   }
 }
