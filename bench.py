@@ -505,7 +505,43 @@ def main():
             "ms_per_step": round(ms_dr, 3), "utterances_per_s": round(Bd * Ld / (ms_dr * 1e-3), 1),
             "fp32_mfma_frac": round(gflop / (ms_dr * 1e-3) / 1e3 / 157.0, 4),
             "note": f"configs[3]; eager; ~{gflop:.0f} GFLOP of exact-fp32 GEMM work per training step against the 157 TFLOP/s fp32 matrix "
-                    "peak; first version: 13 launches per step and direction pair issued from a C++ host loop"}
+                    "peak; 9 (forward) + 10 (backward) launches per step and direction pair issued from a C++ host loop, the independent "
+                    "products of a step grouped into one launch"}
+        # BASELINE.json configs[4], one GPU's shard of it: hid = 1024 with the 8-head sequence attention, global batch 256 over 8 GPUs =
+        # 32 dialogues x L = 256 per GPU.  Above hid = 256 the weights (134 MB per phase) no longer fit the register files of
+        # co-resident workgroups: one launch per phase and step, weights streamed from HBM / the infinity cache.
+        tr5 = ModelTrainer(device, lr=1e-3, test_step=1, lr_decay=0.98, model="MARN1_sps", loss="NLL", n_classes=NCLS,
+                           dataset="IEMOCAP", d_r=D_R, hidden=1024, xattn_heads=8, quiet=True, dropout=False)
+        init_attention_weights(tr5.model)
+        tr5.train()
+        tr5.scheduler.step(0)
+        L5 = 256
+        rs = np.random.RandomState(5000)
+        x5 = torch.tensor(rs.standard_normal((L5, B, D_R + D_A)).astype(np.float32)).to(device)
+        q5 = torch.tensor(np.eye(2, dtype=np.float32)[rs.randint(0, 2, (L5, B))]).to(device)
+        u5 = torch.ones(B, L5, device=device)
+        l5 = torch.tensor(rs.randint(0, NCLS, (B, L5)).astype(np.int64)).to(device)
+        tr_main, tr = tr, tr5
+        try:
+            for _ in range(1):
+                tr.train_step(x5, q5, u5, l5)
+            torch.cuda.synchronize()
+            t5 = time.perf_counter()
+            for _ in range(3):
+                tr.train_step(x5, q5, u5, l5)
+            torch.cuda.synchronize()
+            ms_5 = (time.perf_counter() - t5) / 3 * 1e3
+        finally:
+            tr = tr_main
+        del tr5, x5, q5, u5, l5
+        torch.cuda.empty_cache()
+        wbytes = 2 * 2 * 4 * 1024 * 1024 * 4 * (3 + 2)       # per time step: 2 directions x 2 streams/cells x [4H, H] fp32 x (U, V, S + W_ih, W_hh)
+        variants["hid1024_8head_B32_L256_shard_of_configs4"] = {
+            "ms_per_step": round(ms_5, 3), "utterances_per_s": round(B * L5 / (ms_5 * 1e-3), 1),
+            "weight_stream_GBps": round(3 * wbytes * L5 / (ms_5 * 1e-3) / 1e9, 1),
+            "note": "configs[4] per-GPU shard (global batch 256 / 8 GPUs); eager, one launch per phase and time step; the recurrent weights "
+                    f"({wbytes / 1e6:.0f} MB) are re-read every step of the forward, the BPTT and (once more, hoisted) the weight gradients: "
+                    "weight_stream_GBps is that traffic over the step time, against 8000 GB/s"}
         log("variants done")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -1073,6 +1073,76 @@ __global__ __launch_bounds__(NT) void lsthm_fwd_z(CellK P, int t) {
   lsthm_z_body<false, 0>(P, P.d[blockIdx.y], ws, t, blockIdx.x, att, smem);
 }
 
+// ---- H > 512 (per-step launches only; BASELINE configs[4] runs H = 1024) ----------------------------------------------------------
+// The row phase of one dialogue row is shared by H/128 workgroups, each owning 128 query units i: the softmax of a unit runs over all
+// H keys and nothing is exchanged between the workgroups.  thread (il = tid % 128, q = tid / 128) covers keys [q H/4, (q+1) H/4) of
+// unit i0 + il.  LDS: att [2H+16] | kc float4[H] | partials 4 x [NT] | sh[16].  Leaves the same outputs as lsthm_z_body (z, out, rstat).
+constexpr int WIDE_IW = 128;
+static size_t z_wide_lds_bytes(int H) { return ((size_t)(2 * H + 16) + 4 * (size_t)H + 4 * NT + 16) * sizeof(float); }
+__global__ __launch_bounds__(NT) void lsthm_fwd_z_wide(CellK P, int t) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const DirP& D = P.d[blockIdx.y];
+  const int H = P.H, B = P.B, T = P.T, b = blockIdx.x, i0 = blockIdx.z * WIDE_IW;
+  float* att = smem;
+  float4* kc = reinterpret_cast<float4*>(att + 2 * H + 16);
+  float* part = reinterpret_cast<float*>(kc + H);
+  float* sh = part + 4 * NT;
+  att_prepare(D, H, att, sh);
+  drop_init(P, D);
+  constexpr int Q = NT / WIDE_IW;
+  const int tid = threadIdx.x, il = tid % WIDE_IW, q = tid / WIDE_IW, i = i0 + il, JC = H / Q;
+  const float* c_l = D.cstate + ((long)0 * (T + 1) + t + 1) * B * H + (long)b * H;
+  const float* c_a = D.cstate + ((long)1 * (T + 1) + t + 1) * B * H + (long)b * H;
+  float sp = 0.f;
+  for (int k = tid; k < H; k += NT) {
+    const float cv = c_a[k], w = att[k];
+    kc[k] = make_float4(w, cv, cv * w, 0.f);
+    sp = fmaf(att[H + k], cv, sp);
+  }
+  const float s = block_sum(sp, sh) / sqrtf((float)H);           // (its barriers publish kc)
+  const float u = c_l[i] * s;
+  const float mx = (u >= 0.f) ? u * att[2 * H] : u * att[2 * H + 1];
+  const float u2 = u * LOG2E, m2 = mx * LOG2E;
+  float Z = 0.f, N = 0.f, N2 = 0.f, N3 = 0.f;
+  const float4* kcc = kc + q * JC;
+  if (drop_attn_on(P, D)) {
+    const DropKey dk = s_drop[2];
+    const uint32_t e0 = drop_attn_row(P, t, b) + (uint32_t)(i * H + q * JC);
+    for (int jj = 0; jj < JC; ++jj) {
+      const float4 k4 = kcc[jj];
+      const float e = __builtin_amdgcn_exp2f(fmaf(u2, k4.x, -m2));
+      const float ef = e * drop_scale16(dk, e0 + (uint32_t)jj);
+      Z += e;
+      N = fmaf(ef, k4.y, N);
+      N2 = fmaf(ef, k4.z, N2);
+      N3 = fmaf(e, k4.x, N3);
+    }
+  } else {
+#pragma unroll 8
+    for (int jj = 0; jj < JC; ++jj) {
+      const float4 k4 = kcc[jj];
+      const float e = __builtin_amdgcn_exp2f(fmaf(u2, k4.x, -m2));
+      Z += e;
+      N = fmaf(e, k4.y, N);
+      N2 = fmaf(e, k4.z, N2);
+      N3 = fmaf(e, k4.x, N3);
+    }
+  }
+  part[tid] = Z; part[NT + tid] = N; part[2 * NT + tid] = N2; part[3 * NT + tid] = N3;
+  __syncthreads();
+  if (q == 0) {
+    for (int qq = 1; qq < Q; ++qq) {
+      Z += part[qq * WIDE_IW + il]; N += part[NT + qq * WIDE_IW + il];
+      N2 += part[2 * NT + qq * WIDE_IW + il]; N3 += part[3 * NT + qq * WIDE_IW + il];
+    }
+    const float z = N / Z;
+    D.hz[((long)(t + 1) * B + b) * 3 * H + 2 * H + i] = z;
+    const int tau = D.rev ? D.rev[(long)t * B + b] : t;
+    if (tau >= 0) D.out[((long)tau * B + b) * P.ldo + 2 * H + i] = z;
+    *reinterpret_cast<float4*>(D.rstat + (((long)t * B + b) * H + i) * 4) = make_float4(Z, N2, N3, s);
+  }
+}
+
 // persistent launch: grid (H/8, 2 streams, ndir*nmb); two barriers per step (gates -> z -> next gates).  Runs concurrently with
 // spk_fwd_persist: step t starts only once the speaker counter shows h_q[t] published (checked inside the previous barrier).
 // MSER_OPT_FWD_SENTINEL form of lsthm_fwd_role below: the same step without a single counter -- every operand that another
@@ -1510,6 +1580,110 @@ __global__ __launch_bounds__(NT) void lsthm_bwd_mat(CellK P, int t) {
   lsthm_bwd_mat_body<false, 0>(P, P.d[dir], ws, t, blockIdx.y, blockIdx.x * 32, mb, nullptr, smem, smem + RED_FLOATS);
 }
 
+// H > 512 (per-step launches only): the backward row phase of one dialogue row on H/128 workgroups, each owning 128 keys j (= the
+// units whose gate gradients it writes).  Every workgroup rebuilds the per-unit coefficients of ALL units from the statistics the
+// forward saved (rstat: no first exp2 pass) -- H element-wise evaluations against the H x 128 exponentials of its share of the
+// transposed pass.  LDS: att [2H+16] | coef [H][8] | partials 3 x [NT] | sh[16].  Same outputs as lsthm_bwd_row_body.
+static size_t bwd_row_wide_lds_bytes(int H) { return ((size_t)(2 * H + 16) + 8 * (size_t)H + 3 * NT + 16) * sizeof(float); }
+__global__ __launch_bounds__(NT) void lsthm_bwd_row_wide(CellK P, int t) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const DirP& D = P.d[blockIdx.y];
+  const int H = P.H, B = P.B, T = P.T, b = blockIdx.x, j0 = blockIdx.z * WIDE_IW;
+  float* att = smem;
+  float* coef = att + 2 * H + 16;
+  float* part = coef + 8 * H;
+  float* sh = part + 3 * NT;
+  att_prepare(D, H, att, sh);
+  drop_init(P, D);
+  constexpr int Q = NT / WIDE_IW;
+  const int tid = threadIdx.x, jl = tid % WIDE_IW, q = tid / WIDE_IW, j = j0 + jl, IC = H / Q;
+  const long rowt = (long)t * B + b, SA = (long)B * H;
+  const bool last = (t == T - 1);
+  const float* dA = D.dA + (long)(last ? t : t + 1) * 8 * SA + (long)b * H;       // [2][4][B][H]: U_l, V_l, U_a, V_a products of step t+1
+  const int tau = D.rev ? D.rev[rowt] : t;
+  const float* dorow = (tau >= 0) ? D.dout + ((long)tau * B + b) * P.ldo : nullptr;
+  const float* c_l = D.cstate + ((long)0 * (T + 1) + t + 1) * SA + (long)b * H;
+  const float* c_a = D.cstate + ((long)1 * (T + 1) + t + 1) * SA + (long)b * H;
+  // ---- per-unit coefficients of the whole row
+  float ducl = 0.f;
+  for (int k = tid; k < H; k += NT) {
+    const float4 st = *reinterpret_cast<const float4*>(D.rstat + ((rowt * H) + k) * 4);     // Z, N2, N3, s
+    const float cl = c_l[k];
+    const float zi = D.hz[((long)(t + 1) * B + b) * 3 * H + 2 * H + k];
+    float dz = dorow ? dorow[2 * H + k] : 0.f;
+    if (!last) dz += dA[1 * SA + k] + dA[3 * SA + k];
+    const float u = cl * st.w;
+    const float mx = (u >= 0.f) ? u * att[2 * H] : u * att[2 * H + 1];
+    const float du = dz * (st.y - zi * st.z) / st.x;
+    const float a = dz / st.x;
+    float* cf = coef + 8 * k;
+    cf[0] = u * LOG2E; cf[1] = mx * LOG2E; cf[2] = a; cf[3] = a * u; cf[4] = a * u * zi; cf[5] = du;
+    ducl = fmaf(du, cl, ducl);
+  }
+  const float ds = block_sum(ducl, sh);                            // (its barriers publish coef)
+  // ---- transposed pass: key j, units of chunk q
+  float S1 = 0.f, S2 = 0.f, S3 = 0.f;
+  {
+    const float wkj = att[j];
+    const float* cfc = coef + 8 * q * IC;
+    if (drop_attn_on(P, D)) {
+      const DropKey dk = s_drop[2];
+      const uint32_t e0 = drop_attn_row(P, t, b) + (uint32_t)(q * IC * H + j);
+      for (int ii = 0; ii < IC; ++ii) {
+        const float4 c4 = *reinterpret_cast<const float4*>(cfc + 8 * ii);
+        const float c5 = cfc[8 * ii + 4];
+        const float e = __builtin_amdgcn_exp2f(fmaf(c4.x, wkj, -c4.y));
+        const float ef = e * drop_scale16(dk, e0 + (uint32_t)(ii * H));
+        S1 = fmaf(c4.z, ef, S1);
+        S2 = fmaf(c4.w, ef, S2);
+        S3 = fmaf(c5, e, S3);
+      }
+    } else {
+#pragma unroll 8
+      for (int ii = 0; ii < IC; ++ii) {
+        const float4 c4 = *reinterpret_cast<const float4*>(cfc + 8 * ii);
+        const float c5 = cfc[8 * ii + 4];
+        const float e = __builtin_amdgcn_exp2f(fmaf(c4.x, wkj, -c4.y));
+        S1 = fmaf(c4.z, e, S1);
+        S2 = fmaf(c4.w, e, S2);
+        S3 = fmaf(c5, e, S3);
+      }
+    }
+  }
+  part[tid] = S1; part[NT + tid] = S2; part[2 * NT + tid] = S3;
+  __syncthreads();
+  if (q != 0) return;
+  for (int qq = 1; qq < Q; ++qq) { S1 += part[qq * WIDE_IW + jl]; S2 += part[NT + qq * WIDE_IW + jl]; S3 += part[2 * NT + qq * WIDE_IW + jl]; }
+  const float rsH = 1.0f / sqrtf((float)H);
+  const float cav = c_a[j], clv = c_l[j];
+  const float s = D.rstat[(rowt * H + j) * 4 + 3];
+  const float dca_att = S1 + ds * att[H + j] * rsH;
+  const float dcl_att = coef[8 * j + 5] * s;
+  float* acc = D.attacc + (long)b * 2 * H;
+  acc[j] += ds * cav * rsH;                    // dWq[j]
+  acc[H + j] += cav * S2 - S3;                 // dWk[j]
+  // ---- gate backward, both streams, unit j
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const float* g = D.gates + ((long)m * T * B + rowt) * 4 * H + j;
+    const float gf = g[0], gi = g[H], go = g[2 * H], gc = g[3 * H];
+    float dh = (dorow ? dorow[m * H + j] : 0.f) + (last ? 0.f : dA[(2 * m) * SA + j]);
+    if (drop_state_on(P, D)) dh *= drop_h(P, D, t, m, b, j);
+    const float cc = m ? cav : clv;
+    const float tc = tanhf(cc);
+    const float cprev = D.cstate[((long)m * (T + 1) + t) * SA + (long)b * H + j];
+    float* carry = D.dc_carry + (long)m * SA + (long)b * H + j;
+    const float dc = *carry + dh * go * (1.f - tc * tc) + (m ? dca_att : dcl_att);
+    float* dg = D.dgates + ((long)m * T * B + rowt) * 4 * H + j;
+    dg[0] = dc * cprev * gf * (1.f - gf);
+    dg[H] = dc * gc * gi * (1.f - gi);
+    dg[2 * H] = dh * tc * go * (1.f - go);
+    dg[3 * H] = dc * gi * (1.f - gc * gc);
+    *carry = dc * gf;
+  }
+  D.dHQ[rowt * H + j] = dorow ? dorow[3 * H + j] : 0.f;
+}
+
 // persistent launch: grid (nwg, 1, ndir), nwg >= (H/32)*6*nmb.  Row phase: rows round-robin over all nwg workgroups;
 // matvec phase: the first (H/32)*6*nmb workgroups (4 carry products + 2 speaker-gradient products).  Two barriers per step;
 // the counter doubles as the "dHQ[t] is complete" signal for the concurrently running speaker BPTT (value 2*(T-t)*nwg).
@@ -1678,7 +1852,10 @@ __device__ __forceinline__ SpkBwdLds spk_bwd_lds(float* smem, int H) {
   l.lds_ok = (int*)(l.dsg_s + 32 * (4 * H + 4));
   return l;
 }
-template <bool PS, int NP, bool WITHP = false>
+// MODE 0: the whole step.  H >= 512 (per-step launches only; the gate-gradient tile would not fit the LDS) runs it as two launches:
+// MODE 1 = the element-wise prologue alone (publishes dsg[t] and the carried cell gradient), MODE 2 = the products alone, with
+// the A operand read back from dsg[t].
+template <bool PS, int NP, bool WITHP = false, int MODE = 0>
 __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, const WS& ws, int t, int p, int n0, int mb, int wsel,
                                              const float (*bpre)[8], float* red, float* tile, float* dsg_s) {
   const int c = p >> 1;
@@ -1712,7 +1889,7 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, cons
     const int slot = mb * 32 + rr;
     dh0e[e] = 0.f;
     be[e] = -1;
-    if ((p & 1) == 0 && slot < Nc) {
+    if (MODE != 1 && (p & 1) == 0 && slot < Nc) {
       const int r = off + slot;
       be[e] = D.perm[(long)t * B + r];
       if (!last) dh0e[e] = (1.f - mn[r]) * ldx<PS>(ws, X_n + (long)r * H + n0 + n);
@@ -1726,7 +1903,7 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, cons
   const int nit = 32 * G4 / NT;                  // = H/64
   const int npub = 2 * (H / 32);                 // workgroups of this cell; group g is published by workgroup (g % G4) % npub
   auto f4 = [](float4 v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; };
-  for (int it0 = 0; it0 < nit; it0 += MAXIT) {
+  for (int it0 = 0; it0 < (MODE == 2 ? 0 : nit); it0 += MAXIT) {
     float4 v_dh[MAXIT], v_dc[MAXIT], v_x[MAXIT], v_hq[MAXIT], v_g[MAXIT][4], v_tc[MAXIT], v_co[MAXIT];
     float v_m[MAXIT];
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1831,18 +2008,28 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, cons
 #pragma unroll
         for (int k = 0; k < 4; ++k) st4x<PS>(ws, o + k * H, make_float4(d4[k][0], d4[k][1], d4[k][2], d4[k][3]));   // read by the wgrad roles
       }
-      float* l = dsg_s + rr * LDS_LD + u;
+      if (MODE == 0) {
+        float* l = dsg_s + rr * LDS_LD + u;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(l + k * H) = make_float4(d4[k][0], d4[k][1], d4[k][2], d4[k][3]);
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(l + k * H) = make_float4(d4[k][0], d4[k][1], d4[k][2], d4[k][3]);
+      }
     }
   }
-  if (Nc == 0) return;     // uniform per workgroup
+  if (Nc == 0 || MODE == 1) return;     // uniform per workgroup
   __syncthreads();
   STAMP_ACC(0);
 
   const float* Wp = (p & 1) ? D.Whh[c] : D.Wih[c];
-  auto aload = [&](int r, int k, float* a) { load8(dsg_s + r * LDS_LD + k, a); };
-  wg_mm32<NP>(4 * H, aload, LsthmBwdB{Wp, n0, H}, bpre, red, tile, red == dsg_s);
+  auto aload = [&](int r, int k, float* a) {
+    if (MODE == 2) {
+      const int slot = mb * 32 + r;
+      if (slot < B) load8(dsg_g + (long)slot * 4 * H + k, a);
+      else zero8(a);
+    } else {
+      load8(dsg_s + r * LDS_LD + k, a);
+    }
+  };
+  wg_mm32<NP>(4 * H, aload, LsthmBwdB{Wp, n0, H}, bpre, red, tile, MODE == 0 && red == dsg_s);
   STAMP_ACC(1);
 #pragma unroll
   for (int e = 0; e < 1024 / NT; ++e) {
@@ -1866,6 +2053,21 @@ __global__ __launch_bounds__(NT) void spk_bwd_step(CellK P, int t) {
   drop_init(P, P.d[dir]);
   spk_bwd_body<false, 0>(P, P.d[dir], ws, t, blockIdx.y, blockIdx.x * 32, mb, (int)((blockIdx.y & 1) * gridDim.x + blockIdx.x), nullptr, l.red, l.tile,
                          l.dsg_s);
+}
+
+// H >= 512: the step as two launches (see spk_bwd_body), same grid each
+__global__ __launch_bounds__(NT) void spk_bwd_pre_wide(CellK P, int t) {
+  const WS ws = make_ws(P.wsbase, P.wsbytes);
+  const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
+  drop_init(P, P.d[dir]);
+  spk_bwd_body<false, 0, false, 1>(P, P.d[dir], ws, t, blockIdx.y, blockIdx.x * 32, mb, (int)((blockIdx.y & 1) * gridDim.x + blockIdx.x), nullptr, nullptr,
+                                   nullptr, nullptr);
+}
+__global__ __launch_bounds__(NT) void spk_bwd_mat_wide(CellK P, int t) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WS ws = make_ws(P.wsbase, P.wsbytes);
+  const int dir = blockIdx.z / P.nmb, mb = blockIdx.z % P.nmb;
+  spk_bwd_body<false, 0, false, 2>(P, P.d[dir], ws, t, blockIdx.y, blockIdx.x * 32, mb, 0, nullptr, smem, smem + RED_FLOATS, nullptr);
 }
 
 // persistent launch: same grid, one barrier per step.  Runs concurrently with lsthm_bwd_persist: step t starts once that kernel's
@@ -2395,7 +2597,7 @@ static size_t carve_all(char* base, const mser_cell_desc& d, CellHost* out) {
 
 static int validate(const mser_cell_desc& d, bool bwd) {
   MSER_REQUIRE(d.T > 0 && d.B > 0 && d.D > 0, "marn_cell: bad sizes T=%d B=%d D=%d", d.T, d.B, d.D);
-  MSER_REQUIRE(d.H >= 32 && d.H <= 512 && (d.H & (d.H - 1)) == 0, "marn_cell: H=%d must be a power of two in [32,512]", d.H);
+  MSER_REQUIRE(d.H >= 32 && d.H <= 2048 && (d.H & (d.H - 1)) == 0, "marn_cell: H=%d must be a power of two in [32,2048]", d.H);
   MSER_REQUIRE(d.ndir == 1 || d.ndir == 2, "marn_cell: ndir=%d", d.ndir);
   MSER_REQUIRE(d.x_l && d.x_a && d.workspace, "marn_cell: null input/workspace");
   MSER_REQUIRE(((uintptr_t)d.workspace & 255) == 0, "marn_cell: workspace must be 256-byte aligned");
@@ -2407,12 +2609,9 @@ static int validate(const mser_cell_desc& d, bool bwd) {
     for (int i = 0; i < d.ndir; ++i)
       MSER_REQUIRE(d.p_state[i] >= 0.f && d.p_state[i] < 1.f && d.p_attn[i] >= 0.f && d.p_attn[i] < 1.f,
                    "marn_cell: dropout p out of [0,1) (direction %d: %f, %f)", i, d.p_state[i], d.p_attn[i]);
-  MSER_REQUIRE(d.workspace_bytes < 0x7fffffffULL, "marn_cell: workspace of %zu bytes exceeds the 2 GiB addressable through one buffer descriptor", d.workspace_bytes);
-  if (bwd) {
-    const size_t spk_tile = spk_bwd_lds_floats(d.H) * sizeof(float) + 64;
-    MSER_REQUIRE(spk_tile <= 160 * 1024, "marn_cell_bwd: H=%d not supported: the speaker BPTT's gate-gradient tile needs %zu bytes "
-                 "of LDS (> 160 KiB)", d.H, spk_tile);
-  }
+  // the persistent chains (H = 128, 256) address everything they hand over through ONE buffer descriptor over the workspace
+  if (d.H == 128 || d.H == 256)
+    MSER_REQUIRE(d.workspace_bytes < 0x7fffffffULL, "marn_cell: workspace of %zu bytes exceeds the 2 GiB addressable through one buffer descriptor", d.workspace_bytes);
   for (int i = 0; i < d.ndir; ++i) {
     const mser_cell_dir& r = d.dir[i];
     MSER_REQUIRE(r.qmask && r.out, "marn_cell: dir %d null qmask/out", i);
@@ -2643,6 +2842,7 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
     }
   } else {
     MSER_TRY(allow_lds((const void*)lsthm_fwd_gates, mm_lds));
+    if (H > 512) MSER_TRY(allow_lds((const void*)lsthm_fwd_z_wide, z_wide_lds_bytes(H)));
     for (int t = 0; t < T; ++t) {
       {
         ProfScope ps(MSER_PROF_LSTHM_FWD_GATES, s);
@@ -2650,7 +2850,8 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       }
       {
         ProfScope ps(MSER_PROF_LSTHM_FWD_Z, s);
-        hipLaunchKernelGGL(lsthm_fwd_z, dim3(B, d.ndir), dim3(NT), z_lds, s, K, t);
+        if (H > 512) hipLaunchKernelGGL(lsthm_fwd_z_wide, dim3(B, d.ndir, H / WIDE_IW), dim3(NT), z_wide_lds_bytes(H), s, K, t);
+        else hipLaunchKernelGGL(lsthm_fwd_z, dim3(B, d.ndir), dim3(NT), z_lds, s, K, t);
       }
     }
   }
@@ -2773,10 +2974,12 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
     }
   } else {
     MSER_TRY(allow_lds((const void*)lsthm_bwd_mat, mm_lds));
+    if (H > 512) MSER_TRY(allow_lds((const void*)lsthm_bwd_row_wide, bwd_row_wide_lds_bytes(H)));
     for (int t = T - 1; t >= 0; --t) {
       {
         ProfScope ps(MSER_PROF_LSTHM_BWD_ROW, s);
-        hipLaunchKernelGGL(lsthm_bwd_row, dim3(B, d.ndir), dim3(NT), row_lds, s, K, t);
+        if (H > 512) hipLaunchKernelGGL(lsthm_bwd_row_wide, dim3(B, d.ndir, H / WIDE_IW), dim3(NT), bwd_row_wide_lds_bytes(H), s, K, t);
+        else hipLaunchKernelGGL(lsthm_bwd_row, dim3(B, d.ndir), dim3(NT), row_lds, s, K, t);
       }
       if (t > 0) {
         ProfScope ps(MSER_PROF_LSTHM_BWD_MAT, s);
@@ -2883,11 +3086,18 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   }
   // ---- speaker chain, reverse time
   const size_t spk_lds = spk_bwd_lds_floats(H) * sizeof(float) + 64;
-  if (!persist) {      // persistent mode: the speaker BPTT chain already ran inside the fused launch of the LSTHM_BWD phase
+  if (!persist && spk_lds <= 160 * 1024) {      // persistent mode: the speaker BPTT chain already ran inside the fused launch of the LSTHM_BWD phase
     MSER_TRY(allow_lds((const void*)spk_bwd_step, spk_lds));
     for (int t = T - 1; t >= 0; --t) {
       ProfScope ps(MSER_PROF_SPK_BWD, s);
       hipLaunchKernelGGL(spk_bwd_step, dim3(H / 32, 4, d.ndir * K.nmb), dim3(NT), spk_lds, s, K, t);
+    }
+  } else if (!persist) {                        // H >= 512: the gate-gradient tile goes through global memory (two launches per step)
+    MSER_TRY(allow_lds((const void*)spk_bwd_mat_wide, mm_lds));
+    for (int t = T - 1; t >= 0; --t) {
+      ProfScope ps(MSER_PROF_SPK_BWD, s);
+      hipLaunchKernelGGL(spk_bwd_pre_wide, dim3(H / 32, 4, d.ndir * K.nmb), dim3(NT), 0, s, K, t);
+      hipLaunchKernelGGL(spk_bwd_mat_wide, dim3(H / 32, 4, d.ndir * K.nmb), dim3(NT), mm_lds, s, K, t);
     }
   }
   MSER_TRY(check_launch("spk_bwd"));

@@ -37,7 +37,8 @@ class ModelTrainer(nn.Module):
         self.device = torch.device(device)
         self.dataset = dataset
         if model == 'MARN1_sps':
-            self.model = MARN1_sps(n_classes, d_r=kwargs.get("d_r", 1024), hidden=kwargs.get("hidden", 128)).to(self.device)
+            self.model = MARN1_sps(n_classes, d_r=kwargs.get("d_r", 1024), hidden=kwargs.get("hidden", 128),
+                                   xattn_heads=kwargs.get("xattn_heads", 1)).to(self.device)
             if not kwargs.get("dropout", True):       # extension: dropout=False sets every Dropout p to 0 (parity configuration)
                 zero_dropout(self.model)
         elif model == 'MARN1_onlysp':          # the reference CLI's default (train.py:126); SURVEY.md 8(f) row f1

@@ -9,7 +9,7 @@ Differences that are deliberate and documented: in train mode the 13
 counter-based generator (the reference's CPU generator streams cannot be reproduced on a GPU; parity is defined at p = 0 / eval
 and, in train mode, mask for mask against the oracle);
 extra keyword-only constructor arguments (``d_r``, ``xattn_heads``, ``hidden``) default to the reference's hard-coded values;
-there is no CPU execution path.  ``hidden`` (128 or 256) sets every width the reference hard-codes as 128 (LSTHM cell, speaker
+there is no CPU execution path.  ``hidden`` (128, 256; 512-2048 on per-step launches) sets every width the reference hard-codes as 128 (LSTHM cell, speaker
 cell, rank-1 attention, sequence-level attention); at 256 parity is checked against the oracle only (the reference cannot be
 constructed at that width).
 """
@@ -266,8 +266,9 @@ class MARN1_sps(nn.Module):
 
     def __init__(self, n_classes, *, d_r=1024, xattn_heads=1, hidden=128):
         super(MARN1_sps, self).__init__()
-        if hidden not in (128, 256):
-            raise ValueError(f"hidden={hidden}: the recurrent chains are built for 128 (the reference's width) and 256")
+        if hidden not in (128, 256, 512, 1024, 2048):
+            raise ValueError(f"hidden={hidden}: the recurrent cell is built for 128 (the reference's width) and 256 (persistent chains) "
+                             f"and for 512, 1024, 2048 (one launch per phase and step)")
         self.d_l, self.d_a, self.d_r = 100, 100, d_r
         self.dh_l, self.dh_a = hidden, hidden
         self.dh_sp, self.dh_li = hidden, hidden

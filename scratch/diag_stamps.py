@@ -5,7 +5,8 @@ import numpy as np, torch
 from mser import ops
 from models.lsthm_sps import MARN_cell
 torch.manual_seed(0)
-m = MARN_cell(128, 128, 100, 100).cuda()
+HID = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+m = MARN_cell(HID, HID, 100, 100, dh_s=HID).cuda()
 T, N = 128, 32
 rs = np.random.RandomState(0)
 x_l = torch.tensor(rs.standard_normal((T, N, 100)).astype(np.float32)).cuda()
@@ -13,11 +14,11 @@ x_a = torch.tensor(rs.standard_normal((T, N, 100)).astype(np.float32)).cuda()
 qmask = torch.tensor(np.eye(2, dtype=np.float32)[rs.randint(0, 2, (T, N))]).cuda()
 P = dict(m.named_parameters())
 G = {k: torch.zeros_like(v) for k, v in P.items()}
-out = torch.zeros(T * N, 512, device="cuda"); dout = torch.randn(T * N, 512, device="cuda")
-ws = torch.zeros(ops.cell_workspace_bytes(T, N, 100, 128, 1), device="cuda", dtype=torch.uint8)
+out = torch.zeros(T * N, 4 * HID, device="cuda"); dout = torch.randn(T * N, 4 * HID, device="cuda")
+ws = torch.zeros(ops.cell_workspace_bytes(T, N, 100, HID, 1), device="cuda", dtype=torch.uint8)
 dirs = [dict(p=ops.cell_param_struct(lambda n: P[n].detach()), g=ops.cell_param_struct(lambda n: G[n]), qmask=qmask, rev=None, out=out, dout=dout)]
 dx_l, dx_a = torch.zeros(T * N, 100, device="cuda"), torch.zeros(T * N, 100, device="cuda")
-desc = ops.make_cell_desc(T, N, 100, 128, x_l.view(T * N, 100), x_a.view(T * N, 100), dirs, 512, ws, dx_l=dx_l, dx_a=dx_a)
+desc = ops.make_cell_desc(T, N, 100, HID, x_l.view(T * N, 100), x_a.view(T * N, 100), dirs, 4 * HID, ws, dx_l=dx_l, dx_a=dx_a)
 for _ in range(2):
     ops.marn_cell_fwd(desc)
 ops.marn_cell_status(desc)

@@ -454,6 +454,36 @@ def test_model_hidden_256_full_size_c2_vs_oracle(O):
         assert maxabs(p.grad, r) < 3e-4 * max(1e-3, float(r.norm())), n
 
 
+@pytest.mark.parametrize("H,heads,B,L", [(512, 1, 5, 6), (1024, 8, 3, 5), (1024, 1, 34, 3)])
+def test_model_wide_hidden_vs_oracle(O, H, heads, B, L):
+    """BASELINE.json configs[4] widths (hid = 1024 with the 8-head sequence attention; 512 on the way): above 256 the weights no
+    longer fit the register files of co-resident workgroups, the cell runs one launch per phase and step (weights streamed), the row
+    phases on H/128 workgroups per dialogue row and the speaker BPTT with its gate-gradient tile in global memory.  Forward and every
+    gradient against the CPU oracle; B = 34 covers a second 32-row block.  PARITY UNPINNED (the reference hard-codes 128)."""
+    from models.lsthm_sps import MARN1_sps
+    from loss import MaskedLoss
+    d_r = 64
+    P = O.seeded_params(seed=51, d_r=d_r, H=H)
+    net = MARN1_sps(6, d_r=d_r, hidden=H, xattn_heads=heads).cuda().eval()
+    load_params(net, P)
+    x, qmask, umask, label = O.seeded_batch(B, L, d_r=d_r, seed=52, ragged=True)
+    lp, _, _ = net(x.cuda(), qmask.cuda(), umask.cuda())
+    loss = MaskedLoss(torch.nn.NLLLoss)(lp, label.cuda().view(-1), umask.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    lp_ref, _, _ = O.marn1_sps_forward(Pr, x, qmask, umask, d_r=d_r, H=H, xattn_heads=heads)
+    loss_ref = O.masked_nll(lp_ref, label.view(-1), umask)
+    loss_ref.backward()
+    assert maxabs(lp, lp_ref) < LOGIT_TOL
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 2e-5
+    for n, p in net.named_parameters():
+        r = Pr[n].grad
+        if r is None:
+            continue
+        assert maxabs(p.grad, r) < 3e-4 * max(1e-3, float(r.norm())), n
+
+
 def test_model_multi_head_sequence_attention_vs_oracle(O):
     """``xattn_heads=8`` (BASELINE.json configs[4]'s 8-head cross-modal attention; a keyword extension: the reference's
     CrossAttention2/3 are single-head, model/lsthm_sps.py:88-101): the four sequence-level modules split their 128-wide projections
