@@ -82,6 +82,9 @@ struct CellK {
   unsigned* fault;     // sticky fault word (mser_cell_desc::fault) or nullptr
   int fwd_sentinel;    // forward chain hand-offs through self-validating payload instead of counter barriers (MSER_OPT_FWD_SENTINEL)
   int bwd_sentinel;    // the same for the LSTHM BPTT chain (MSER_OPT_BWD_SENTINEL)
+  int nodx;            // BPTT launch without the two dx = dgates W products (they run as GEMMs after the chain; frees their workgroups)
+  int fwd_rowsplit, bwd_rowsplit;   // persistent chains at H = 256: a dialogue row's rank-1 attention is shared by this many workgroups
+                       // (forward: 128 query units each; backward: 128 keys of the transposed pass each); 1 or 2
   int ksplit;          // BPTT matvec phase: every product's K = 4H reduction is split over `ksplit` workgroups (1 or 2); the
                        // partial results live in consecutive copies of dA / dHQp / dxc and the consumers add them
   DirP d[2];
@@ -774,11 +777,14 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // `after_loads` runs right behind the row's own operand loads: loads issued there are YOUNGER than the row's, so the row phase
 // does not wait for them (vmcnt retires in order) -- used to fetch the next step's early-product operands under the exp2 work.
 // STATS = false: the statistics are left to the stats roles of the fused launch (stats_fwd_role), off the chain.
-template <bool PS, int JCT, class Hook = NoHook, bool STATS = true, bool SV = false>       // JCT = keys per thread chunk when known at compile time (fully unrolled loops), 0 = runtime; SV: sentinel-validated loads
+// IWT > 0: this call covers only the IWT query units i0 .. i0 + IWT - 1 of the row (another workgroup covers the rest; every unit's
+// softmax still runs over all H keys, so nothing is exchanged): thread (tid % IWT, tid / IWT), H IWT / NT keys per thread.
+template <bool PS, int JCT, class Hook = NoHook, bool STATS = true, bool SV = false, int IWT = 0>       // JCT = keys per thread chunk when known at compile time (fully unrolled loops), 0 = runtime; SV: sentinel-validated loads
 __device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, const WS& ws, int t, int b, const float* att, float* scr,
-                                             Hook after_loads = Hook()) {
+                                             Hook after_loads = Hook(), int i0 = 0) {
   const int H = P.H, B = P.B, T = P.T;
-  const int Q = NT / H, JC = JCT ? JCT : H / Q;
+  const int IW = IWT ? IWT : H;
+  const int Q = NT / IW, JC = JCT ? JCT : H / Q;
   // per key j ONE 16-byte LDS word (Wk[j], c_a[j], c_a[j] Wk[j], -): the inner loop issues one broadcast ds_read_b128 per key
   float4* kc = reinterpret_cast<float4*>(scr);
   float* pZ = scr + 4 * H;
@@ -790,7 +796,7 @@ __device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, cons
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* c_l = D.cstate + ((long)0 * (T + 1) + t + 1) * B * H + (long)b * H;
   const float* c_a = D.cstate + ((long)1 * (T + 1) + t + 1) * B * H + (long)b * H;
-  const int i = tid & (H - 1), q = tid / H;
+  const int i = i0 + (tid & (IW - 1)), q = tid / IW;
   float sp = 0.f;
   float cv = 0.f;
   if (tid < H) cv = ldx<PS>(ws, c_a + tid);
@@ -864,8 +870,8 @@ __device__ __forceinline__ void lsthm_z_body(const CellK& P, const DirP& D, cons
   __syncthreads();
   if (q == 0) {
     for (int qq = 1; qq < Q; ++qq) {
-      Z += pZ[qq * H + i]; N += pN[qq * H + i];
-      if (STATS) { N2 += pN2[qq * H + i]; N3 += pN3[qq * H + i]; }
+      Z += pZ[qq * IW + tid]; N += pN[qq * IW + tid];
+      if (STATS) { N2 += pN2[qq * IW + tid]; N3 += pN3[qq * IW + tid]; }
     }
     const float z = N / Z;
     stx<PS>(ws, D.hz + ((long)(t + 1) * B + b) * 3 * H + 2 * H + i, z);
@@ -1185,7 +1191,11 @@ __device__ __forceinline__ void lsthm_fwd_role_sv(const CellK& P, const Role R, 
     STAMP_ACC(3);
     bool fetched = !more;
     auto fetch = [&]() { if (!fetched) { lsthm_early_aload<NP, 0>(P, D, ws, t + 1, m, mb, a); fetched = true; } };
-    for (int b = w; b < P.B; b += (int)nwg) lsthm_z_body<true, JCT, decltype(fetch), STATS, true>(P, D, ws, t, b, att, red, fetch);
+    if (NP == 6 && P.fwd_rowsplit == 2) {      // H = 256: 64 workgroups per direction, two per dialogue row (128 query units each)
+      if (w < 2 * P.B) lsthm_z_body<true, JCT / 2, decltype(fetch), STATS, true, 128>(P, D, ws, t, w >> 1, att, red, fetch, (w & 1) * 128);
+    } else {
+      for (int b = w; b < P.B; b += (int)nwg) lsthm_z_body<true, JCT, decltype(fetch), STATS, true>(P, D, ws, t, b, att, red, fetch);
+    }
     fetch();
     STAMP_ACC(4);
     if (!more) break;
@@ -1241,7 +1251,11 @@ __device__ __forceinline__ void lsthm_fwd_role(const CellK& P, const Role R, flo
     // h part of the next step's early product: requested behind the first row's own loads, in flight during the row phase
     bool fetched = !more;
     auto fetch = [&]() { if (!fetched) { lsthm_early_aload<NP, 0>(P, D, ws, t + 1, m, mb, a); fetched = true; } };
-    for (int b = w; b < P.B; b += (int)nwg) lsthm_z_body<true, JCT, decltype(fetch), STATS>(P, D, ws, t, b, att, red, fetch);
+    if (NP == 6 && P.fwd_rowsplit == 2) {
+      if (w < 2 * P.B) lsthm_z_body<true, JCT / 2, decltype(fetch), STATS, false, 128>(P, D, ws, t, w >> 1, att, red, fetch, (w & 1) * 128);
+    } else {
+      for (int b = w; b < P.B; b += (int)nwg) lsthm_z_body<true, JCT, decltype(fetch), STATS>(P, D, ws, t, b, att, red, fetch);
+    }
     fetch();                                                        // a workgroup that owns no row
     STAMP_ACC(4);
     if (!more) break;
@@ -1387,11 +1401,15 @@ __device__ __forceinline__ RowMid lsthm_bwd_row_part1_saved(const CellK& P, cons
 
 // carry[2]: the dc carry of this thread's unit, both streams (in: from step t+1, out: for step t-1).  The persistent kernel keeps it in
 // registers (the same thread owns the same (row, unit) every step); it is also written to dc_carry for the per-step launches.
-template <bool PS, int JCT, bool SV = false>
+// RS = 2 (H = 256, persistent chain): two workgroups share the row.  Both rebuild the coefficients of all H units (element-wise), each
+// runs the transposed pass for its 128 keys j0 .. j0 + 127 (thread (tid % 128, tid / 128): H / 4 units per thread instead of H / 2)
+// and finishes the gate backward of those units; JCT is then the per-thread unit count of that mapping.
+template <bool PS, int JCT, bool SV = false, int RS = 1>
 __device__ __forceinline__ void lsthm_bwd_row_part2(const CellK& P, const DirP& D, const WS& ws, int t, int b, const float* att, float* scr,
-                                                    const RowPre& pre, const RowMid& mid, float* carry) {
+                                                    const RowPre& pre, const RowMid& mid, float* carry, int slice = 0) {
   const int H = P.H, B = P.B, T = P.T;
-  const int Q = NT / H, JC = JCT ? JCT : H / Q;
+  const int JW = H / RS;                          // keys of the transposed pass handled by this workgroup
+  const int Q = NT / JW, JC = JCT ? JCT : H / Q;
   float* ca = scr;           float* cl = ca + H;   float* cw = cl + H;   float* coef = cw + H;
   float* p0 = coef + 8 * H;  float* p1 = p0 + NT;  float* p2 = p1 + NT;  float* sh = p2 + NT;
   const float* wk = att;
@@ -1440,14 +1458,16 @@ __device__ __forceinline__ void lsthm_bwd_row_part2(const CellK& P, const DirP& 
   __syncthreads();               // pass-1 partials consumed; coef published
   if (lane == 0) sh[wave] = du_cl;
   STAMP_ACC(6);
-  // ---- pass 2: per key index j (= i), sums over the units ii of chunk q
-  const int j = i;
+  // ---- pass 2: per key index j, sums over the units ii of chunk qc (RS = 1: j = i, qc = q)
+  const int j0 = slice * JW;
+  const int qc = RS == 1 ? q : tid / JW;
+  const int j = RS == 1 ? i : j0 + (tid & (JW - 1));
   float S1 = 0.f, S2 = 0.f, S3 = 0.f;
-  if (drop_attn_on(P, D)) {      // S1, S2 run over the dropped attention (mask element (i, j), i = q*JC + ii), S3 over the plain softmax
+  if (drop_attn_on(P, D)) {      // S1, S2 run over the dropped attention (mask element (i, j), i = qc*JC + ii), S3 over the plain softmax
     const DropKey dk = s_drop[2];
-    const uint32_t e0 = drop_attn_row(P, t, b) + (uint32_t)(q * JC * H + j);
+    const uint32_t e0 = drop_attn_row(P, t, b) + (uint32_t)(qc * JC * H + j);
     const float wkj = wk[j];
-    const float* cfc = coef + 8 * q * JC;
+    const float* cfc = coef + 8 * qc * JC;
     for (int ii = 0; ii < JC; ++ii) {
       const float4 c4 = *reinterpret_cast<const float4*>(cfc + 8 * ii);
       const float c5 = cfc[8 * ii + 4];
@@ -1459,7 +1479,7 @@ __device__ __forceinline__ void lsthm_bwd_row_part2(const CellK& P, const DirP& 
     }
   } else {
     const float wkj = wk[j];
-    const float* cfc = coef + 8 * q * JC;
+    const float* cfc = coef + 8 * qc * JC;
 #pragma unroll
     for (int ii = 0; ii < (JCT ? JCT : JC); ++ii) {
       const float4 c4 = *reinterpret_cast<const float4*>(cfc + 8 * ii);
@@ -1470,14 +1490,22 @@ __device__ __forceinline__ void lsthm_bwd_row_part2(const CellK& P, const DirP& 
       S3 = fmaf(c5, e, S3);
     }
   }
-  if (q > 0) { p0[tid] = S1; p1[tid] = S2; p2[tid] = S3; }
+  if (RS > 1 || q > 0) { p0[tid] = S1; p1[tid] = S2; p2[tid] = S3; }
   __syncthreads();
   STAMP_ACC(7);
-  if (q == 0) {
+  // the unit whose gate backward this thread finishes: RS = 1: j (= i, threads of chunk 0); RS = 2: unit tid of this workgroup's key
+  // range (the thread that holds the unit's saved state in `pre`), which collects all Q partials of key tid from LDS
+  if (RS == 1 ? q == 0 : (tid >= j0 && tid < j0 + JW)) {
     float ds = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) ds += sh[w];
-    for (int qq = 1; qq < Q; ++qq) { S1 += p0[qq * H + j]; S2 += p1[qq * H + j]; S3 += p2[qq * H + j]; }
+    if (RS == 1) {
+      for (int qq = 1; qq < Q; ++qq) { S1 += p0[qq * H + j]; S2 += p1[qq * H + j]; S3 += p2[qq * H + j]; }
+    } else {
+      S1 = S2 = S3 = 0.f;
+      for (int qq = 0; qq < Q; ++qq) { S1 += p0[qq * JW + tid - j0]; S2 += p1[qq * JW + tid - j0]; S3 += p2[qq * JW + tid - j0]; }
+    }
+    const int j = i;                         // (RS = 2: i == tid, the key this thread just collected)
     const float dca_att = S1 + ds * wq[j] * rsH;
     float* acc = D.attacc + (long)b * 2 * H;
     acc[j] += ds * ca[j] * rsH;                  // dWq[j]
@@ -1704,7 +1732,7 @@ __device__ __forceinline__ void lsthm_bwd_role_sv(const CellK& P, const Role R, 
   const int w = R.x;
   if (threadIdx.x == 0) s_poll_abort = 0;
   drop_init(P, D);
-  const int nsl = H / 32, nslx = (P.D + 31) / 32;
+  const int nsl = H / 32, nslx = P.nodx ? 0 : (P.D + 31) / 32;
   const int per_kh = 6 * nsl + 2 * nslx;
   const int per_mb = per_kh * KSPLIT;
   const bool has_mat = w < per_mb * P.nmb;
@@ -1724,15 +1752,19 @@ __device__ __forceinline__ void lsthm_bwd_role_sv(const CellK& P, const Role R, 
   unsigned* cnt = P.sync + SYNC_LSTHM_BWD + dir * SYNC_DIR;
   STAMP_INIT();
   constexpr int JCB = 2 * NP * NP;
-  const bool has_row = w < P.B;
-  const int rowb = has_row ? w : 0;
+  const bool rs2 = NP == 8 && P.bwd_rowsplit == 2;            // H = 256: two workgroups per dialogue row (needs 2 B <= nwg)
+  const bool has_row = rs2 ? w < 2 * P.B : w < P.B;
+  const int rowb = has_row ? (rs2 ? w >> 1 : w) : 0;
   RowPre pre = lsthm_bwd_row_prefetch(P, D, P.T - 1, rowb);
   RowPre pre_n = lsthm_bwd_row_prefetch(P, D, P.T > 1 ? P.T - 2 : 0, rowb);
   RowMid mid = lsthm_bwd_row_part1_saved(P, D, P.T - 1, rowb, att, red, pre);
   float carry[2] = {0.f, 0.f};
   for (int t = P.T - 1; t >= 0; --t) {
-    if (has_row) lsthm_bwd_row_part2<true, JCB, true>(P, D, ws, t, w, att, red, pre, mid, carry);
-    for (int b = w + (int)nwg; b < P.B; b += (int)nwg) {
+    if (has_row) {
+      if (rs2) lsthm_bwd_row_part2<true, JCB / 2, true, 2>(P, D, ws, t, rowb, att, red, pre, mid, carry, w & 1);
+      else lsthm_bwd_row_part2<true, JCB, true>(P, D, ws, t, w, att, red, pre, mid, carry);
+    }
+    for (int b = w + (int)nwg; b < (rs2 ? 0 : P.B); b += (int)nwg) {
       const RowPre pr = lsthm_bwd_row_prefetch(P, D, t, b);
       const RowMid md = lsthm_bwd_row_part1<JCB>(P, D, t, b, att, red, pr);
       float cr[2] = {pr.carry[0], pr.carry[1]};
@@ -1776,7 +1808,7 @@ __device__ __forceinline__ void lsthm_bwd_role(const CellK& P, const Role R, flo
   const int w = R.x;
   drop_init(P, D);
   // matvec roles: 6 products x H/32 slices (carries + speaker gradient), then 2 products x ceil(D/32) slices (dx = dgates W)
-  const int nsl = H / 32, nslx = (P.D + 31) / 32;
+  const int nsl = H / 32, nslx = P.nodx ? 0 : (P.D + 31) / 32;
   const int per_kh = 6 * nsl + 2 * nslx;
   const int per_mb = per_kh * KSPLIT;              // K-halves of one product sit per_kh workgroups apart
   const bool has_mat = w < per_mb * P.nmb;
@@ -1795,16 +1827,20 @@ __device__ __forceinline__ void lsthm_bwd_role(const CellK& P, const Role R, flo
   unsigned* cnt = P.sync + SYNC_LSTHM_BWD + dir * SYNC_DIR;
   STAMP_INIT();
   constexpr int JCB = 2 * NP * NP;                         // NP = H/32, keys per thread = H*H/NT
-  const bool has_row = w < P.B;
+  const bool rs2 = NP == 8 && P.bwd_rowsplit == 2;            // H = 256: two workgroups per dialogue row (needs 2 B <= nwg)
+  const bool has_row = rs2 ? w < 2 * P.B : w < P.B;
   // saved-state operands are fetched TWO steps ahead (a whole step for the loads to land); the dc carry stays in registers
-  const int rowb = has_row ? w : 0;
+  const int rowb = has_row ? (rs2 ? w >> 1 : w) : 0;
   RowPre pre = lsthm_bwd_row_prefetch(P, D, P.T - 1, rowb);
   RowPre pre_n = lsthm_bwd_row_prefetch(P, D, P.T > 1 ? P.T - 2 : 0, rowb);
   RowMid mid = lsthm_bwd_row_part1_saved(P, D, P.T - 1, rowb, att, red, pre);
   float carry[2] = {0.f, 0.f};
   for (int t = P.T - 1; t >= 0; --t) {
-    if (has_row) lsthm_bwd_row_part2<true, JCB>(P, D, ws, t, w, att, red, pre, mid, carry);
-    for (int b = w + (int)nwg; b < P.B; b += (int)nwg)
+    if (has_row) {
+      if (rs2) lsthm_bwd_row_part2<true, JCB / 2, false, 2>(P, D, ws, t, rowb, att, red, pre, mid, carry, w & 1);
+      else lsthm_bwd_row_part2<true, JCB>(P, D, ws, t, w, att, red, pre, mid, carry);
+    }
+    for (int b = w + (int)nwg; b < (rs2 ? 0 : P.B); b += (int)nwg)
       lsthm_bwd_row_body<true, JCB>(P, D, ws, t, b, att, red, lsthm_bwd_row_prefetch(P, D, t, b));
     STAMP_ACC(0);
     if (!dir_barrier(cnt, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok)) return;
@@ -1898,7 +1934,7 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, cons
 
   // element-wise prologue over 32 slots x H units, 4 consecutive units per thread-iteration (16-byte accesses: the phase is
   // bound by vector-memory instruction throughput, not by arithmetic).  All loads of an iteration batch are issued first.
-  constexpr int MAXIT = 4;
+  constexpr int MAXIT = NP >= 8 ? 2 : 4;        // (H = 256: 64 weight registers per lane; four batches in flight would spill)
   const int G4 = H / 4;                          // float4 groups per slot row
   const int nit = 32 * G4 / NT;                  // = H/64
   const int npub = 2 * (H / 32);                 // workgroups of this cell; group g is published by workgroup (g % G4) % npub
@@ -2581,7 +2617,7 @@ static size_t carve_all(char* base, const mser_cell_desc& d, CellHost* out) {
   Carver cv{base, 0};
   CellHost h;
   h.k.T = d.T; h.k.B = d.B; h.k.D = d.D; h.k.H = d.H; h.k.ndir = d.ndir; h.k.nmb = cdiv(d.B, 32); h.k.ldo = d.ldo;
-  h.k.wgrad_wgs = 0; h.k.ksplit = 1; h.k.place = 0; h.k.stats_wgs = 0;
+  h.k.wgrad_wgs = 0; h.k.ksplit = 1; h.k.place = 0; h.k.stats_wgs = 0; h.k.nodx = 0; h.k.fwd_rowsplit = h.k.bwd_rowsplit = 1;
   h.sync = cv.take<unsigned>(SYNC_WORDS);
   h.k.sync = h.sync;
   h.k.wsbase = base;
@@ -2682,6 +2718,7 @@ static int g_opt_ksplit = 1;          // MSER_OPT_BPTT_KSPLIT
 static int g_opt_stats_roles = 1;     // MSER_OPT_FWD_STATS_ROLES
 static int g_opt_xcd_place = 0;       // MSER_OPT_XCD_PLACEMENT (off: measured slower end to end)
 static int g_opt_fwd_sentinel = 1;    // MSER_OPT_FWD_SENTINEL
+static int g_opt_rowsplit = 1;        // MSER_OPT_H256_SPLIT: H = 256 persistent chains share a row phase between two workgroups, BPTT products K-split
 static int g_opt_bwd_sentinel = 0;    // MSER_OPT_BWD_SENTINEL (off: measured 1345 us per BPTT launch against 1342 with the counter barriers)
 static int g_num_cus = 0;
 constexpr size_t PERSIST_MIN_LDS = 84 * 1024;     // > half of the 160 KiB LDS: at most ONE persistent workgroup per CU
@@ -2722,6 +2759,7 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   const bool persist = persist_ok(H, ext ? fwd_wgs : 2 * fwd_wgs);        // speaker and LSTHM chains share one launch: all workgroups co-resident
   const size_t p_lds = persist_lds(mm_lds + (2 * (size_t)H + 16) * sizeof(float) + 64);
   K.fwd_sentinel = (persist && g_opt_fwd_sentinel) ? 1 : 0;
+  K.fwd_rowsplit = (persist && g_opt_rowsplit && H == 256 && 2 * B <= (H / 8) * 2 * K.nmb) ? 2 : 1;
   if (phases & MSER_PHASE_FWD_PREP) {
   MSER_CHECK_HIP(hipMemsetAsync(h.sync, 0, SYNC_WORDS * sizeof(unsigned), s));
   if (K.fwd_sentinel) {
@@ -2876,18 +2914,24 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   const size_t mm_lds = (RED_FLOATS + 1024) * sizeof(float);
   const size_t row_lds = row_lds_bytes(H);
   const int spk_wgs = ext ? 0 : (H / 32) * 4 * K.nmb;        // speaker BPTT: 4 products
-  const int mat_wgs1 = ((H / 32) * 6 + ((D + 31) / 32) * 2) * K.nmb;  // LSTHM BPTT matvec roles: 4 carries + 2 speaker-gradient + 2 dx products
+  // H = 256: the dx products leave the chain (GEMMs after it, as in the per-step mode) when that frees enough workgroups for the K-split
+  const bool nodx = g_opt_persistent && g_opt_rowsplit && g_opt_ksplit && H == 256 && !ext &&
+                    ((long)2 * (H / 32) * 6 * K.nmb + spk_wgs) * d.ndir <= num_cus();
+  K.nodx = nodx ? 1 : 0;
+  const int mat_wgs1 = ((H / 32) * 6 + (nodx ? 0 : ((D + 31) / 32) * 2)) * K.nmb;  // LSTHM BPTT matvec roles: 4 carries + 2 speaker-gradient + 2 dx products
   // K-split of the matvec phase (the longest phase of a BPTT step, MFMA-paced: 8 waves x 32 MFMAs on 4 SIMDs): two workgroups per
   // product halve it when the doubled grid still fits beside the speaker chain
   // XCD placement (claim_role) wants one 32-workgroup LSTHM group per XCD, which excludes the K-split (64 per direction); the
   // placement is worth more (-0.45 us per hand-off against -12 us per launch)
   const bool place_ok = g_opt_persistent && g_opt_xcd_place && H == 128 && mat_wgs1 <= 32 && num_cus() == 256 && !ext;
-  const int ksplit = (!place_ok && g_opt_persistent && g_opt_ksplit && H == 128 && ((long)2 * mat_wgs1 + spk_wgs) * d.ndir <= num_cus()) ? 2 : 1;
+  const int ksplit = (!place_ok && g_opt_persistent && g_opt_ksplit && (H == 128 || nodx) && ((long)2 * mat_wgs1 + spk_wgs) * d.ndir <= num_cus()) ? 2 : 1;
   K.ksplit = ksplit;
   const int mat_wgs = mat_wgs1 * ksplit;
   const int bwd_nwg = mat_wgs > 32 ? mat_wgs : 32;           // row phase spreads the B rows over all of them
   // both BPTT kernels run concurrently (pipelined): all their workgroups must be co-resident
   const bool persist = persist_ok(H, ((long)bwd_nwg + spk_wgs) * d.ndir);
+  if (!persist) K.nodx = 0;
+  K.bwd_rowsplit = (persist && g_opt_rowsplit && H == 256 && 2 * B <= bwd_nwg) ? 2 : 1;
   const size_t p_lds = persist_lds(mm_lds + (2 * (size_t)H + 16) * sizeof(float) + 64);
   const int SPLITK = 16;
   // Weight gradients inside the fused BPTT launch (wgrad_role): needs the persistent launch, the H = 128 tiling (16 / 8 column
@@ -2932,7 +2976,7 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       DirP& k = K.d[i];
       // dc_carry | attacc | dxc are carved back to back: one memset (dxc only where it is read without having been fully written:
       // rows at and beyond len_b receive no gradient from the reversed direction)
-      const size_t zbytes = (persist && k.rev) ? (size_t)((char*)(k.dxc + (size_t)ksplit * 2 * TB * D) - (char*)k.dc_carry)
+      const size_t zbytes = (persist && !K.nodx && k.rev) ? (size_t)((char*)(k.dxc + (size_t)ksplit * 2 * TB * D) - (char*)k.dc_carry)
                                                : (size_t)((char*)k.dxc - (char*)k.dc_carry);
       MSER_CHECK_HIP(hipMemsetAsync(k.dc_carry, 0, zbytes, s));
     }
@@ -2968,6 +3012,9 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
     } else if (H == 128) {
       MSER_TRY(allow_lds((const void*)cell_bwd_fused<4, 4>, f_lds));
       hipLaunchKernelGGL((cell_bwd_fused<4, 4>), dim3(grid), dim3(NT), f_lds, s, K, (unsigned)bwd_nwg);
+    } else if (ksplit == 2) {
+      MSER_TRY(allow_lds((const void*)cell_bwd_fused<8, 8, 2>, f_lds));
+      hipLaunchKernelGGL((cell_bwd_fused<8, 8, 2>), dim3(grid), dim3(NT), f_lds, s, K, (unsigned)bwd_nwg);
     } else {
       MSER_TRY(allow_lds((const void*)cell_bwd_fused<8, 8>, f_lds));
       hipLaunchKernelGGL((cell_bwd_fused<8, 8>), dim3(grid), dim3(NT), f_lds, s, K, (unsigned)bwd_nwg);
@@ -3010,7 +3057,7 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
           MSER_TRY(gemm(g, s));
         }
         // dx (direction order) = dg W_m
-        if (persist) {       // produced inside the BPTT kernel at natural time rows: summed below, both directions in one launch
+        if (persist && !K.nodx) {       // produced inside the BPTT kernel at natural time rows: summed below, both directions in one launch
         } else if (!k.rev) {
           g = gd(dg, 4 * H, 1, k.W[m], D, 1, dxs[m], D, (int)TB, D, 4 * H);
           g.flags = MSER_GEMM_ACCUM;
@@ -3045,13 +3092,13 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       MSER_TRY(colsum4(k.attacc + H, B, H, 2 * H, G.att_Wk, nullptr, nullptr, nullptr, s));
     }
   }
-  if ((phases & MSER_PHASE_LSTHM_BWD_DX) && (persist || d.dx_l_add[0] || d.dx_l_add[1] || d.dx_a_add[0] || d.dx_a_add[1])) {
+  if ((phases & MSER_PHASE_LSTHM_BWD_DX) && ((persist && !K.nodx) || d.dx_l_add[0] || d.dx_l_add[1] || d.dx_a_add[0] || d.dx_a_add[1])) {
     SumArgs sa;
     memset(&sa, 0, sizeof sa);
     sa.out[0] = d.dx_l; sa.out[1] = d.dx_a;
     sa.n = TB * D;
     int n[2] = {0, 0};
-    for (int i = 0; i < d.ndir && persist; ++i)
+    for (int i = 0; i < d.ndir && persist && !K.nodx; ++i)
       for (int kh = 0; kh < ksplit; ++kh)
         for (int m = 0; m < 2; ++m) sa.src[m][n[m]++] = K.d[i].dxc + ((long)kh * 2 + m) * TB * D;
     for (int j = 0; j < 2; ++j) {
@@ -3285,6 +3332,7 @@ int mser_set_option(int32_t key, int32_t value) {
     case MSER_OPT_FWD_STATS_ROLES: g_opt_stats_roles = value ? 1 : 0; return 0;
     case MSER_OPT_FWD_SENTINEL: g_opt_fwd_sentinel = value ? 1 : 0; return 0;
     case MSER_OPT_BWD_SENTINEL: g_opt_bwd_sentinel = value ? 1 : 0; return 0;
+    case MSER_OPT_H256_SPLIT: g_opt_rowsplit = value ? 1 : 0; return 0;
     default: set_error("mser_set_option: unknown key %d", key); return -1;
   }
 }
