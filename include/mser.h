@@ -310,7 +310,10 @@ enum { MSER_PHASE_SPEAKER_FWD = 1, MSER_PHASE_LSTHM_FWD = 2, MSER_PHASE_LSTHM_BW
        MSER_PHASE_LSTHM_BWD_DX = 16, MSER_PHASE_LSTHM_WGRAD = 32, MSER_PHASE_FWD_PREP = 64, MSER_PHASE_BWD_PREP = 128,
        /* modifier for SPEAKER_FWD and LSTHM_FWD (pass it to both): keep the forward chains as two persistent launches so that the
         * speaker chain, issued on another REAL stream, starts before the encoders finish.  Never inside stream capture. */
-       MSER_PHASE_SEPARATE_SPEAKER = 256 };
+       MSER_PHASE_SEPARATE_SPEAKER = 256,
+       /* modifier for FWD_PREP: also do the work of BWD_PREP (zeroed carries, accumulators and BPTT counters), so that ONE backward
+        * over this forward may leave BWD_PREP out -- it otherwise sits between the head's backward and the BPTT launch. */
+       MSER_PHASE_PREP_BOTH = 512 };
 /* Where a linked producer publishes direction `dir`'s speaker rows (hq_rows [T*B, H], inside the workspace) and the counter it
  * advances by per_step after each step (replicas x replica_stride words).  partner_wgs = the workgroups of the producer launch:
  * both kernels must be co-resident for the hand-off to progress.  Returns 1 if the persistent LSTHM launch will be used for these

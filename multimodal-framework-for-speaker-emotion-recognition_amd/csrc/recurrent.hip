@@ -2773,6 +2773,16 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       MSER_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)k.HQ, SENT_BITS, (size_t)TB * H, s));
     }
   }
+  if (phases & MSER_PHASE_PREP_BOTH) {
+    // what MSER_PHASE_BWD_PREP would do, now (off the critical path between the head's backward and the BPTT launch): the carries
+    // and accumulators over their whole allocated extent; the BPTT counters are part of the sync words zeroed above
+    for (int i = 0; i < d.ndir; ++i) {
+      DirP& k = K.d[i];
+      MSER_CHECK_HIP(hipMemsetAsync(k.dc_carry, 0, (size_t)((char*)(k.dxc + (size_t)2 * 2 * TB * D) - (char*)k.dc_carry), s));
+      if (g_opt_bwd_sentinel)
+        MSER_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)k.dgates, SENT_BITS, (size_t)((char*)(k.dHQp + 2 * 2 * TB * H) - (char*)k.dgates) / 4, s));
+    }
+  }
   if (ext && !d.ext_linked)      // "every h_q[t] is published": the LSTHM chain's waits on the speaker counter fall through
     MSER_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)(h.sync + SYNC_SPK_FWD), 0x3fffffff, 2 * SYNC_DIR, s));
   for (int i = 0; i < d.ndir; ++i) {

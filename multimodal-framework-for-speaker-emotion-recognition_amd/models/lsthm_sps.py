@@ -241,7 +241,7 @@ class _MARN1Fn(torch.autograd.Function):
     def forward(ctx, model, hook, x, qmask, umask):
         store = model._store
         lp, x_l, x_a, c = marn1_forward(store.p, x, qmask, umask, model.dims, use_streams=model.use_streams,
-                                        drop=model._drop_cfg(x.device))
+                                        drop=model._drop_cfg(x.device), prep_backward=bool(ctx.needs_input_grad[1]))
         ctx.model, ctx.c = model, c
         ctx.set_materialize_grads(False)
         return lp, x_l, x_a

@@ -84,6 +84,7 @@ class ModelCtx:
     qmask: Tensor = None
     drop: DropCfg = None
     cell_drop: tuple = None
+    zbuf: Tensor = None        # zeroed accumulators of the backward's attention branches, prepared by the forward (training)
 
 
 def _sub(P: Getter, prefix: str) -> Getter:
@@ -102,8 +103,9 @@ class _Streams:
 
 
 def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: ModelDims, use_streams: bool = True,
-                  drop: Optional[DropCfg] = None):
-    """x [L,B,d_r+d_a] f32, qmask [L,B,2] f32, umask [B,L] f32 -> (log_probs [B*L,C], x_l [L,B,D], x_a [L,B,D], ctx)."""
+                  drop: Optional[DropCfg] = None, prep_backward: bool = False):
+    """x [L,B,d_r+d_a] f32, qmask [L,B,2] f32, umask [B,L] f32 -> (log_probs [B*L,C], x_l [L,B,D], x_a [L,B,D], ctx).
+    prep_backward: a backward over this forward will follow (the forward then zeroes that backward's accumulators on a side stream)."""
     if drop is not None and not drop.any():
         drop = None
     Ln, B, Fin = x.shape
@@ -196,8 +198,13 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
         for st in side[:4]:
             st.wait_stream(cur)
         ev_prep = torch.cuda.Event()
+        # training: everything of the backward that only needs ZEROING (the cell's carries / accumulators / BPTT counters, the six
+        # accumulators of the attention branches) is done here, beside the encoders, instead of between the head's backward and the BPTT
+        c.zbuf = torch.empty(2 * N * H + 4 * N * D, device=x.device) if prep_backward else None
         with torch.cuda.stream(s_spk):
-            ops.marn_cell_run(desc, ops.PHASE_FWD_PREP)         # tables, initial states, counters: off the encoders' stream
+            if c.zbuf is not None:
+                c.zbuf.zero_()
+            ops.marn_cell_run(desc, ops.PHASE_FWD_PREP | (ops.PHASE_PREP_BOTH if c.zbuf is not None else 0))   # tables, initial states, counters: off the encoders' stream
             ev_prep.record(s_spk)
             ops.marn_cell_run(desc, ops.PHASE_SPEAKER_FWD | sep)   # qmask-only chain: overlaps the encoders AND the LSTHM chain
         text_branch()                                           # the longer branch (linear_in in front) is issued first
@@ -280,7 +287,9 @@ def _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams):
     dx_l = torch.empty(N, D, device=dev)                      # = d(y1r), then accumulates every x_l gradient
     dx_a = torch.empty(N, D, device=dev)
     dH = torch.empty(N, 10 * H, device=dev)
-    zbuf = torch.empty(2 * N * H + 4 * N * D, device=dev)     # ONE zero fill for the six accumulators of the attention branches
+    prepped = getattr(c, "zbuf", None) is not None            # the forward zeroed everything already (first backward over it only)
+    zbuf = c.zbuf if prepped else torch.empty(2 * N * H + 4 * N * D, device=dev)     # ONE zero fill for the six accumulators of the attention branches
+    c.zbuf = None
     dA1, dA2 = zbuf[:N * H].view(N, H), zbuf[N * H:2 * N * H].view(N, H)
     dxl_a, dxa_a, dxl_b, dxa_b = (zbuf[2 * N * H + i * N * D:2 * N * H + (i + 1) * N * D].view(N, D) for i in range(4))
     for r, pre, sl in ((c.cell_dirs[0], "marn_cell_f.", slice(0, 4 * H)), (c.cell_dirs[1], "marn_cell_b.", slice(4 * H, 8 * H))):
@@ -293,7 +302,9 @@ def _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams):
     ev_prep = None
     # (under stream capture the extra branch makes the graph executor order the attention branches behind the BPTT node: measured
     # +290 us per replay, so the zeroing stays inline there)
-    if side is not None and not torch.cuda.is_current_stream_capturing():
+    if prepped:
+        pass
+    elif side is not None and not torch.cuda.is_current_stream_capturing():
         s_prep = side[1]
         s_prep.wait_stream(cur)
         with torch.cuda.stream(s_prep):
@@ -369,7 +380,8 @@ def _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams):
             ev_h.record(cur)                                       # dH and the initial dx_l / dx_a are ready
         else:
             ev_h.record(cur)                                       # (capture: the attention branches fork BEFORE the prep nodes)
-            ops.marn_cell_run(desc, ops.PHASE_BWD_PREP)
+            if not prepped:
+                ops.marn_cell_run(desc, ops.PHASE_BWD_PREP)
         # critical chain first (host issue order matters: ~10 us per launch)
         if c.pipelined:
             s_spk.wait_stream(cur)
@@ -402,12 +414,15 @@ def _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams):
         with torch.cuda.stream(s_audio):
             audio_branch()
         text_branch(flush_stream=s_xb, audio_stream=s_audio)
+        # what is left in the batch (the first text layer's and linear_in's weight gradients) has all its operands on this stream: it goes
+        # out now, beside the other flush, instead of behind the joins
+        ops.wgrad_scope.flush()
         for st in (s_audio, s_spk, s_xa, s_xb):
             cur.wait_stream(st)
     else:
         xattn_a_bwd()
         xattn_b_bwd()
-        ops.marn_cell_run(desc, ops.PHASE_BWD_PREP | ops.PHASE_LSTHM_BWD)
+        ops.marn_cell_run(desc, (0 if prepped else ops.PHASE_BWD_PREP) | ops.PHASE_LSTHM_BWD)
         ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD_DX | ops.PHASE_LSTHM_WGRAD | ops.PHASE_SPEAKER_BWD)
         text_branch()
         audio_branch()
