@@ -2477,6 +2477,29 @@ __global__ void cell_prep_kernel(DirP D, int T, int B, int H) {
   }
 }
 
+// Every fill of MSER_PHASE_FWD_PREP as ONE launch (a hipGraph replay dispatches about one node per 5 us: ten memset nodes in front of
+// the forward delayed everything behind them).  Segments of 32-bit words with a value each (16-byte aligned starts, as Carver gives),
+// plus strided row blocks to zero (the reversed direction's output rows).
+struct FillArgs {
+  unsigned* p[8]; long n[8]; unsigned v[8]; int nseg;
+  float* q[2]; long rows[2], ld[2]; int width[2]; int nq;
+};
+__global__ __launch_bounds__(256) void cell_fill_kernel(FillArgs a) {
+  const long stride = (long)gridDim.x * blockDim.x, t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int sgi = 0; sgi < a.nseg; ++sgi) {
+    const unsigned v = a.v[sgi];
+    const long n4 = a.n[sgi] >> 2;
+    u32x4* p4 = reinterpret_cast<u32x4*>(a.p[sgi]);
+    const u32x4 v4 = {v, v, v, v};
+    for (long i = t0; i < n4; i += stride) p4[i] = v4;
+    for (long i = (n4 << 2) + t0; i < a.n[sgi]; i += stride) a.p[sgi][i] = v;
+  }
+  for (int qi = 0; qi < a.nq; ++qi) {
+    const long n = a.rows[qi] * a.width[qi];
+    for (long i = t0; i < n; i += stride) a.q[qi][(i / a.width[qi]) * a.ld[qi] + i % a.width[qi]] = 0.f;
+  }
+}
+
 __global__ void rowof_kernel(const int* perm, int* rowof, long TB, int B) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= TB) return;
@@ -2579,10 +2602,11 @@ static void carve_dir(Carver& cv, DirP& d, int T, int B, int D, int H) {
   d.hq_state = cv.take<float>(2 * (T + 1) * SB);
   d.cq_state = cv.take<float>(2 * (T + 1) * SB);
   d.sgates = cv.take<float>(2 * TB * 4 * H);
-  d.HQ = cv.take<float>(TB * H);
   d.tcq = cv.take<float>(2 * TB * H);
   d.pre = cv.take<float>(2 * TB * 4 * H);
   d.gates = cv.take<float>(2 * TB * 4 * H);
+  // HQ | cstate | hz back to back: the arrays the forward chains hand from workgroup to workgroup (ONE sentinel fill per direction)
+  d.HQ = cv.take<float>(TB * H);
   d.cstate = cv.take<float>(2 * (T + 1) * SB);
   d.hz = cv.take<float>((T + 1) * (size_t)B * 3 * H);
   d.rstat = cv.take<float>(TB * H * 4);
@@ -2761,27 +2785,28 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   K.fwd_sentinel = (persist && g_opt_fwd_sentinel) ? 1 : 0;
   K.fwd_rowsplit = (persist && g_opt_rowsplit && H == 256 && 2 * B <= (H / 8) * 2 * K.nmb) ? 2 : 1;
   if (phases & MSER_PHASE_FWD_PREP) {
-  MSER_CHECK_HIP(hipMemsetAsync(h.sync, 0, SYNC_WORDS * sizeof(unsigned), s));
-  if (K.fwd_sentinel) {
-    // every word the forward chains hand from workgroup to workgroup starts as the sentinel: h | h | z rows, the two cell states,
-    // the speaker rows.  (cell_prep_kernel, below, then zeroes the index-0 states; an external speaker state is copied over HQ by
-    // MSER_PHASE_LSTHM_FWD, a linked producer writes its rows while the chain polls them.)
+  {
+    // counters zeroed; every word the forward chains hand from workgroup to workgroup starts as the sentinel (HQ | cstate | hz, carved
+    // back to back; cell_prep_kernel, below, then zeroes the index-0 states; an external speaker state is copied over HQ by
+    // MSER_PHASE_LSTHM_FWD, a linked producer writes its rows while the chain polls them); MSER_PHASE_PREP_BOTH: what
+    // MSER_PHASE_BWD_PREP would do, now (off the critical path between the head's backward and the BPTT launch) -- the carries and
+    // accumulators over their whole allocated extent, the BPTT counters being part of the sync words; rows at and beyond len_b stay
+    // zero in the reversed direction's output (pad_sequence, :410)
+    FillArgs fa;
+    memset(&fa, 0, sizeof fa);
+    auto seg = [&](void* p, size_t words, unsigned v) { fa.p[fa.nseg] = (unsigned*)p; fa.n[fa.nseg] = (long)words; fa.v[fa.nseg] = v; ++fa.nseg; };
+    seg(h.sync, SYNC_WORDS, 0u);
     for (int i = 0; i < d.ndir; ++i) {
       DirP& k = K.d[i];
-      MSER_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)k.hz, SENT_BITS, (size_t)(T + 1) * B * 3 * H, s));
-      MSER_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)k.cstate, SENT_BITS, (size_t)2 * (T + 1) * SB, s));
-      MSER_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)k.HQ, SENT_BITS, (size_t)TB * H, s));
+      if (K.fwd_sentinel) seg(k.HQ, (size_t)((char*)(k.hz + (size_t)(T + 1) * B * 3 * H) - (char*)k.HQ) / 4, SENT_BITS);
+      if (phases & MSER_PHASE_PREP_BOTH) {
+        seg(k.dc_carry, (size_t)((char*)(k.dxc + (size_t)2 * 2 * TB * D) - (char*)k.dc_carry) / 4, 0u);
+        if (g_opt_bwd_sentinel) seg(k.dgates, (size_t)((char*)(k.dHQp + 2 * 2 * TB * H) - (char*)k.dgates) / 4, SENT_BITS);
+      }
+      if (k.rev) { fa.q[fa.nq] = k.out; fa.rows[fa.nq] = TB; fa.ld[fa.nq] = d.ldo; fa.width[fa.nq] = 4 * H; ++fa.nq; }
     }
-  }
-  if (phases & MSER_PHASE_PREP_BOTH) {
-    // what MSER_PHASE_BWD_PREP would do, now (off the critical path between the head's backward and the BPTT launch): the carries
-    // and accumulators over their whole allocated extent; the BPTT counters are part of the sync words zeroed above
-    for (int i = 0; i < d.ndir; ++i) {
-      DirP& k = K.d[i];
-      MSER_CHECK_HIP(hipMemsetAsync(k.dc_carry, 0, (size_t)((char*)(k.dxc + (size_t)2 * 2 * TB * D) - (char*)k.dc_carry), s));
-      if (g_opt_bwd_sentinel)
-        MSER_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)k.dgates, SENT_BITS, (size_t)((char*)(k.dHQp + 2 * 2 * TB * H) - (char*)k.dgates) / 4, s));
-    }
+    hipLaunchKernelGGL(cell_fill_kernel, dim3(2048), dim3(256), 0, s, fa);
+    MSER_TRY(check_launch("cell_fill"));
   }
   if (ext && !d.ext_linked)      // "every h_q[t] is published": the LSTHM chain's waits on the speaker counter fall through
     MSER_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)(h.sync + SYNC_SPK_FWD), 0x3fffffff, 2 * SYNC_DIR, s));
@@ -2790,8 +2815,6 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
     MSER_TRY(mser_build_slot_tables(d.dir[i].qmask, k.rev, T, B, k.party, k.perm, k.n0, k.qm, s));
     hipLaunchKernelGGL(cell_prep_kernel, dim3(64), dim3(256), 0, s, k, T, B, H);
     MSER_TRY(check_launch("cell_prep"));
-    if (k.rev)   // rows at and beyond len_b stay zero in the reversed output (pad_sequence, :410)
-      MSER_CHECK_HIP(hipMemset2DAsync(k.out, d.ldo * sizeof(float), 0, 4 * (size_t)H * sizeof(float), TB, s));
   }
   }
   const bool separate = persist && ((phases & MSER_PHASE_SEPARATE_SPEAKER) || ext);

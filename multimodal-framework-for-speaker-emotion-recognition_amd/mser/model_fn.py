@@ -201,13 +201,18 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
         # training: everything of the backward that only needs ZEROING (the cell's carries / accumulators / BPTT counters, the six
         # accumulators of the attention branches) is done here, beside the encoders, instead of between the head's backward and the BPTT
         c.zbuf = torch.empty(2 * N * H + 4 * N * D, device=x.device) if prep_backward else None
-        with torch.cuda.stream(s_spk):
-            if c.zbuf is not None:
-                c.zbuf.zero_()
-            ops.marn_cell_run(desc, ops.PHASE_FWD_PREP | (ops.PHASE_PREP_BOTH if c.zbuf is not None else 0))   # tables, initial states, counters: off the encoders' stream
-            ev_prep.record(s_spk)
-            ops.marn_cell_run(desc, ops.PHASE_SPEAKER_FWD | sep)   # qmask-only chain: overlaps the encoders AND the LSTHM chain
-        text_branch()                                           # the longer branch (linear_in in front) is issued first
+
+        def prep_branch():
+            with torch.cuda.stream(s_spk):
+                if c.zbuf is not None:
+                    c.zbuf.zero_()
+                ops.marn_cell_run(desc, ops.PHASE_FWD_PREP | (ops.PHASE_PREP_BOTH if c.zbuf is not None else 0))   # tables, initial states, counters: off the encoders' stream
+                ev_prep.record(s_spk)
+                ops.marn_cell_run(desc, ops.PHASE_SPEAKER_FWD | sep)   # qmask-only chain: overlaps the encoders AND the LSTHM chain
+        # (the preparation is issued FIRST although the encoders are the critical path: a hipGraph replay gave a branch forked behind
+        # them a queue only after the attention branches -- 3.29 against 3.21 ms per step; it is 6 nodes, ~35 us, since its fills share one launch)
+        prep_branch()
+        text_branch()                                           # the longer branch (linear_in in front) first
         with torch.cuda.stream(s_audio):
             audio_branch()
         cur.wait_stream(s_audio)                                # x_l and x_a are final
