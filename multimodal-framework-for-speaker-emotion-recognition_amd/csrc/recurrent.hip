@@ -569,11 +569,32 @@ struct SpkFwdB {
   }
 };
 
+// What a step's A rows need from the index tables (they do not depend on the chain): fetched one step ahead by the persistent kernel, so
+// that the gather of q_sel costs the step ONE memory round trip (the rows themselves) instead of three dependent ones (perm -> qm -> rows).
+struct SpkPre { int N0, N0p, b; float m; };
+__device__ __forceinline__ SpkPre spk_fwd_prefetch(const CellK& P, const DirP& D, int t, int c, int mb) {
+  SpkPre r;
+  const int B = P.B;
+  r.N0 = D.n0[t];
+  r.N0p = t > 0 ? D.n0[t - 1] : 0;
+  const int Nc = c ? B - r.N0 : r.N0, off = c ? r.N0 : 0;
+  const int slot = mb * 32 + (threadIdx.x & 31);
+  r.b = -1; r.m = 0.f;
+  if (slot < Nc && t > 0) {
+    r.b = D.perm[(long)t * B + off + slot];
+    r.m = D.qm[((long)(t - 1) * B + r.b) * 2 + c];
+  }
+  return r;
+}
+// carry (persistent kernel): this thread's cell state c_q[slot][u] and its four gate biases stay in registers across the steps
+struct SpkCarry { float cq, bias4[4]; };
+
 template <bool PS, int NP>
 __device__ __forceinline__ void spk_fwd_body(const CellK& P, const DirP& D, const WS& ws, int t, int c, int u0, int mb, bool writer,
-                                             const float (*bpre)[8], float* red, float* tile) {
+                                             const float (*bpre)[8], float* red, float* tile, const SpkPre* pre = nullptr,
+                                             SpkCarry* carry = nullptr) {
   const int H = P.H, B = P.B, T = P.T;
-  const int N0 = D.n0[t];
+  const int N0 = pre ? pre->N0 : D.n0[t];
   const int Nc = c ? B - N0 : N0, off = c ? N0 : 0;
   const long SB = (long)B * H;
   float* hq_new = D.hq_state + ((long)c * (T + 1) + t + 1) * SB;
@@ -604,20 +625,24 @@ __device__ __forceinline__ void spk_fwd_body(const CellK& P, const DirP& D, cons
 
   // epilogue operands that do not depend on the matvec: fetch them first
   float cq_prev = 0.f, bias4[4] = {0.f, 0.f, 0.f, 0.f};
-  if (tid < 256) {
+  if (carry) {
+    cq_prev = carry->cq;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[g] = carry->bias4[g];
+  } else if (tid < 256) {
     const int slot = mb * 32 + (tid >> 3), u = u0 + (tid & 7);
     if (slot < B) cq_prev = ldx<PS>(ws, cq_old + (long)slot * H + u);
 #pragma unroll
     for (int g = 0; g < 4; ++g) bias4[g] = D.bih[c][g * H + u] + D.bhh[c][g * H + u];
   }
-  const int N0p = t > 0 ? D.n0[t - 1] : 0;
+  const int N0p = pre ? pre->N0p : (t > 0 ? D.n0[t - 1] : 0);
   auto aload = [&](int r, int k, float* a) {
     const int slot = mb * 32 + r;
     if (slot >= B) { zero8(a); return; }
     if (k < H) {
       if (slot < Nc && t > 0) {
-        const int b = D.perm[(long)t * B + off + slot];
-        const float m = D.qm[((long)(t - 1) * B + b) * 2 + c];
+        const int b = pre ? pre->b : D.perm[(long)t * B + off + slot];             // (pre: r == this lane's slot)
+        const float m = pre ? pre->m : D.qm[((long)(t - 1) * B + b) * 2 + c];
         const float* h0 = (b < N0p) ? D.qsel + ((long)(0 * T + t - 1) * B + b) * H
                                     : D.qsel + ((long)(1 * T + t - 1) * B + (b - N0p)) * H;
         const float* hq = D.HQ + ((long)(t - 1) * B + b) * H;
@@ -650,6 +675,7 @@ __device__ __forceinline__ void spk_fwd_body(const CellK& P, const DirP& D, cons
       float hn = go * tcn;
       if (drop_state_on(P, D)) hn *= drop_hq(P, D, t, c, slot, u);          // :183 / :188: the dropped h_q IS the carried state
       D.tcq[((long)c * T + t) * SB + (long)slot * H + u] = tcn;
+      if (carry) carry->cq = cn;
       stx<PS>(ws, cq_new + (long)slot * H + u, cn);
       stx<PS>(ws, hq_new + (long)slot * H + u, hn);
       float* g = sg + (long)slot * 4 * H + u;
@@ -688,8 +714,18 @@ __device__ __forceinline__ void spk_fwd_role(const CellK& P, const Role R, float
   float bpre[NP][8];
   preload_b<NP>(2 * P.H, SpkFwdB{D, c, u0, P.H}, bpre);
   STAMP_INIT();
+  SpkCarry carry;
+  carry.cq = 0.f;                                  // c_q[.][0] = 0
+  {
+    const int u = u0 + (threadIdx.x & 7);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) carry.bias4[g] = threadIdx.x < 256 ? D.bih[c][g * P.H + u] + D.bhh[c][g * P.H + u] : 0.f;
+  }
+  SpkPre pre = spk_fwd_prefetch(P, D, 0, c, mb);
   for (int t = 0; t < P.T; ++t) {
-    spk_fwd_body<true, NP>(P, D, ws, t, c, u0, mb, R.x == 0, bpre, red, tile);
+    const SpkPre nxt = spk_fwd_prefetch(P, D, t + 1 < P.T ? t + 1 : t, c, mb);      // tables of the next step: in flight during this one
+    spk_fwd_body<true, NP>(P, D, ws, t, c, u0, mb, R.x == 0, bpre, red, tile, &pre, &carry);
+    pre = nxt;
     // the counter also tells the concurrently running LSTHM kernel that h_q[t] is published: arrive after the last step too
     if (!dir_barrier(P.sync + SYNC_SPK_FWD + dir * SYNC_DIR, P.sync + SYNC_ABORT, nwg * (unsigned)(t + 1), lds_ok, nullptr, 0, t + 1 < P.T)) return;
     STAMP_ACC(3);
@@ -2453,35 +2489,11 @@ __global__ void mnext_kernel(const float* qm, const int* party, float* mnext, in
   mnext[i] = (t + 1 < T) ? qm[i * 2 + party[i + B]] : 0.f;
 }
 
-// One launch instead of ~15 tiny ones per direction: inverse permutation, blend-weight table and the zero initial states
-// (index 0 of the (T+1)-long state arrays).  The host-side launch count matters: eager issue costs ~6-9 us per launch.
-__global__ void cell_prep_kernel(DirP D, int T, int B, int H) {
-  const long TB = (long)T * B, SB = (long)B * H;
-  const long n_tab = TB, n_zero = 6 * SB + (long)B * 3 * H;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_tab + n_zero; i += (long)gridDim.x * blockDim.x) {
-    if (i < n_tab) {
-      const long t = i / B;
-      D.rowof[t * B + D.perm[i]] = (int)(i - t * B);
-      D.mnext[i] = (t + 1 < T) ? D.qm[i * 2 + D.party[i + B]] : 0.f;
-    } else {
-      long j = i - n_tab;
-      if (j < 6 * SB) {
-        const int which = (int)(j / SB);          // 0,1: hq_state[c][0]; 2,3: cq_state[c][0]; 4,5: cstate[m][0]
-        const long e = j - (long)which * SB;
-        float* base = which < 2 ? D.hq_state : (which < 4 ? D.cq_state : D.cstate);
-        base[(long)(which & 1) * (T + 1) * SB + e] = 0.f;
-      } else {
-        D.hz[j - 6 * SB] = 0.f;
-      }
-    }
-  }
-}
-
 // Every fill of MSER_PHASE_FWD_PREP as ONE launch (a hipGraph replay dispatches about one node per 5 us: ten memset nodes in front of
 // the forward delayed everything behind them).  Segments of 32-bit words with a value each (16-byte aligned starts, as Carver gives),
 // plus strided row blocks to zero (the reversed direction's output rows).
 struct FillArgs {
-  unsigned* p[8]; long n[8]; unsigned v[8]; int nseg;
+  unsigned* p[32]; long n[32]; unsigned v[32]; int nseg;
   float* q[2]; long rows[2], ld[2]; int width[2]; int nq;
 };
 __global__ __launch_bounds__(256) void cell_fill_kernel(FillArgs a) {
@@ -2498,6 +2510,52 @@ __global__ __launch_bounds__(256) void cell_fill_kernel(FillArgs a) {
     const long n = a.rows[qi] * a.width[qi];
     for (long i = t0; i < n; i += stride) a.q[qi][(i / a.width[qi]) * a.ld[qi] + i % a.width[qi]] = 0.f;
   }
+}
+
+// The index tables of both directions in ONE launch (grid (T, ndir), one thread per dialogue): party, the stable partition perm and
+// its inverse rowof, n0, the qmask rows in direction time order and mnext[t][b] = qmask_t[b][party_{t+1}[b]] -- what
+// mser_build_slot_tables + cell_prep_kernel's table half did in two launches per direction.
+struct TabArgs { const float* qmask[2]; const int* rev[2]; int *party[2], *perm[2], *rowof[2], *n0[2]; float *qm[2], *mnext[2]; int T, B; };
+__global__ __launch_bounds__(1024) void cell_tables_kernel(TabArgs a) {
+  __shared__ int cnt0[17];
+  const int t = blockIdx.x, dir = blockIdx.y, b = threadIdx.x, T = a.T, B = a.B;
+  const int lane = b & 63, wave = b >> 6;
+  const float* qmask = a.qmask[dir];
+  const int* rev = a.rev[dir];
+  int p = 1;          // inactive lanes count as party 1 so they never enter the party-0 ballot
+  if (b < B) {
+    float m0 = 0.f, m1 = 0.f, n0v = 0.f, n1v = 0.f;
+    const int src_t = rev ? rev[(long)t * B + b] : t;
+    if (src_t >= 0) { m0 = qmask[((long)src_t * B + b) * 2]; m1 = qmask[((long)src_t * B + b) * 2 + 1]; }
+    p = (m1 > m0) ? 1 : 0;
+    float mn = 0.f;
+    if (t + 1 < T) {
+      const int src_n = rev ? rev[(long)(t + 1) * B + b] : t + 1;
+      if (src_n >= 0) { n0v = qmask[((long)src_n * B + b) * 2]; n1v = qmask[((long)src_n * B + b) * 2 + 1]; }
+      mn = (n1v > n0v) ? m1 : m0;          // this step's mask value at the NEXT step's party
+    }
+    a.party[dir][(long)t * B + b] = p;
+    a.qm[dir][((long)t * B + b) * 2] = m0;
+    a.qm[dir][((long)t * B + b) * 2 + 1] = m1;
+    a.mnext[dir][(long)t * B + b] = mn;
+  }
+  const unsigned long long bal = __ballot(p == 0);
+  const int before0 = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) cnt0[wave] = __popcll(bal);
+  __syncthreads();
+  int base0 = 0, total0 = 0;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int w = 0; w < nw; ++w) {
+    if (w < wave) base0 += cnt0[w];
+    total0 += cnt0[w];
+  }
+  if (b < B) {
+    const int idx0 = base0 + before0;
+    const int row = (p == 0) ? idx0 : total0 + (b - idx0);
+    a.perm[dir][(long)t * B + row] = b;
+    a.rowof[dir][(long)t * B + b] = row;
+  }
+  if (b == 0) a.n0[dir][t] = total0;
 }
 
 __global__ void rowof_kernel(const int* perm, int* rowof, long TB, int B) {
@@ -2798,7 +2856,16 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
     seg(h.sync, SYNC_WORDS, 0u);
     for (int i = 0; i < d.ndir; ++i) {
       DirP& k = K.d[i];
-      if (K.fwd_sentinel) seg(k.HQ, (size_t)((char*)(k.hz + (size_t)(T + 1) * B * 3 * H) - (char*)k.HQ) / 4, SENT_BITS);
+      // index 0 of the (T+1)-long state arrays = the zero initial states; everything else of HQ | cstate | hz the sentinel
+      const size_t SBw = (size_t)SB, TSB = (size_t)(T + 1) * SB;
+      for (int c2 = 0; c2 < 2; ++c2) { seg(k.hq_state + c2 * TSB, SBw, 0u); seg(k.cq_state + c2 * TSB, SBw, 0u); seg(k.cstate + c2 * TSB, SBw, 0u); }
+      seg(k.hz, (size_t)B * 3 * H, 0u);
+      if (K.fwd_sentinel) {
+        seg(k.HQ, (size_t)((char*)k.cstate - (char*)k.HQ) / 4, SENT_BITS);
+        seg(k.cstate + SBw, TSB - SBw, SENT_BITS);
+        seg(k.cstate + TSB + SBw, (size_t)((char*)k.hz - (char*)(k.cstate + TSB + SBw)) / 4, SENT_BITS);
+        seg(k.hz + (size_t)B * 3 * H, (size_t)T * B * 3 * H, SENT_BITS);
+      }
       if (phases & MSER_PHASE_PREP_BOTH) {
         seg(k.dc_carry, (size_t)((char*)(k.dxc + (size_t)2 * 2 * TB * D) - (char*)k.dc_carry) / 4, 0u);
         if (g_opt_bwd_sentinel) seg(k.dgates, (size_t)((char*)(k.dHQp + 2 * 2 * TB * H) - (char*)k.dgates) / 4, SENT_BITS);
@@ -2810,11 +2877,18 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   }
   if (ext && !d.ext_linked)      // "every h_q[t] is published": the LSTHM chain's waits on the speaker counter fall through
     MSER_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)(h.sync + SYNC_SPK_FWD), 0x3fffffff, 2 * SYNC_DIR, s));
-  for (int i = 0; i < d.ndir; ++i) {
-    DirP& k = K.d[i];
-    MSER_TRY(mser_build_slot_tables(d.dir[i].qmask, k.rev, T, B, k.party, k.perm, k.n0, k.qm, s));
-    hipLaunchKernelGGL(cell_prep_kernel, dim3(64), dim3(256), 0, s, k, T, B, H);
-    MSER_TRY(check_launch("cell_prep"));
+  {
+    MSER_REQUIRE(B <= 1024, "marn_cell: B=%d > 1024 dialogues per call", B);
+    TabArgs ta;
+    memset(&ta, 0, sizeof ta);
+    ta.T = T; ta.B = B;
+    for (int i = 0; i < d.ndir; ++i) {
+      DirP& k = K.d[i];
+      ta.qmask[i] = d.dir[i].qmask; ta.rev[i] = k.rev; ta.party[i] = k.party; ta.perm[i] = k.perm; ta.rowof[i] = k.rowof;
+      ta.n0[i] = k.n0; ta.qm[i] = k.qm; ta.mnext[i] = k.mnext;
+    }
+    hipLaunchKernelGGL(cell_tables_kernel, dim3(T, d.ndir), dim3(cdiv(B, 64) * 64), 0, s, ta);
+    MSER_TRY(check_launch("cell_tables"));
   }
   }
   const bool separate = persist && ((phases & MSER_PHASE_SEPARATE_SPEAKER) || ext);

@@ -142,14 +142,20 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
     c.enc = [None] * 4
     Pl, Pa = _sub(P, "encoder_l."), _sub(P, "encoder_a.")
 
-    def text_branch():
-        ops.linear(c.x2d[:, :d.d_r], P("linear_in.weight"), c.xl0, bias=P("linear_in.bias"))
-        e1, c.enc[0] = F_.encoder_layer_fwd(c.xl0, None, Pl, lay, d.n_head, d.d_k, d.d_v, drops=enc_drops(0), need_attn=False)
-        _, c.enc[1] = F_.encoder_layer_fwd(c.xl0, e1, Pl, lay, d.n_head, d.d_k, d.d_v, out=c.x_l, drops=enc_drops(1), need_attn=False)
+    e1 = [None, None]
 
-    def audio_branch():
-        e1, c.enc[2] = F_.encoder_layer_fwd(xa0, None, Pa, lay, d.n_head, d.d_k, d.d_v, drops=enc_drops(2), need_attn=False)
-        _, c.enc[3] = F_.encoder_layer_fwd(xa0, e1, Pa, lay, d.n_head, d.d_k, d.d_v, out=c.x_a, drops=enc_drops(3), need_attn=False)
+    def text_branch(stage=None):         # stage 0 / 1: first / second encoder pass alone (None: both)
+        if stage in (None, 0):
+            ops.linear(c.x2d[:, :d.d_r], P("linear_in.weight"), c.xl0, bias=P("linear_in.bias"))
+            e1[0], c.enc[0] = F_.encoder_layer_fwd(c.xl0, None, Pl, lay, d.n_head, d.d_k, d.d_v, drops=enc_drops(0), need_attn=False)
+        if stage in (None, 1):
+            _, c.enc[1] = F_.encoder_layer_fwd(c.xl0, e1[0], Pl, lay, d.n_head, d.d_k, d.d_v, out=c.x_l, drops=enc_drops(1), need_attn=False)
+
+    def audio_branch(stage=None):
+        if stage in (None, 0):
+            e1[1], c.enc[2] = F_.encoder_layer_fwd(xa0, None, Pa, lay, d.n_head, d.d_k, d.d_v, drops=enc_drops(2), need_attn=False)
+        if stage in (None, 1):
+            _, c.enc[3] = F_.encoder_layer_fwd(xa0, e1[1], Pa, lay, d.n_head, d.d_k, d.d_v, out=c.x_a, drops=enc_drops(3), need_attn=False)
 
     c.lens = torch.empty(B, device=x.device, dtype=torch.int32)
     c.rev = torch.empty(Ln, B, device=x.device, dtype=torch.int32)
@@ -212,9 +218,12 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
         # (the preparation is issued FIRST although the encoders are the critical path: a hipGraph replay gave a branch forked behind
         # them a queue only after the attention branches -- 3.29 against 3.21 ms per step; it is 6 nodes, ~35 us, since its fills share one launch)
         prep_branch()
-        text_branch()                                           # the longer branch (linear_in in front) first
-        with torch.cuda.stream(s_audio):
-            audio_branch()
+        # the two branches are issued layer by layer in alternation: the replay dispatches nodes in issue order (~6 us each), a branch
+        # issued whole behind the other started 70 us late
+        for stage in (0, 1):
+            text_branch(stage)                                  # the longer branch (linear_in in front) first
+            with torch.cuda.stream(s_audio):
+                audio_branch(stage)
         cur.wait_stream(s_audio)                                # x_l and x_a are final
         ev_x = torch.cuda.Event()
         ev_x.record(cur)
