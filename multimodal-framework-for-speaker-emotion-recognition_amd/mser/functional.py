@@ -479,9 +479,9 @@ def xattn_fwd(x1: Tensor, a1: Optional[Tensor], x2: Tensor, a2: Optional[Tensor]
     c.dk, c.dv = Dk // heads, Dv // heads
     c.Q = _empty(x1.shape[0], Dk, like=x1)
     c.KV = _empty(x2.shape[0], Dk + Dv, like=x1)
-    ops.matmul(x1, Wq, c.Q, alpha_dev=a1)
-    ops.matmul(x2, Wk, c.KV[:, :Dk], alpha_dev=a2)
-    ops.matmul(x2, Wv, c.KV[:, Dk:], alpha_dev=a2)
+    # the three projections are independent: one grouped launch (they sit in front of the recurrent chains' launch; three nodes of
+    # ~12 us each kept the branch running into the chains' first steps, where its traffic slows their hand-offs)
+    ops.matmul_group([(x1, Wq, c.Q, a1), (x2, Wk, c.KV[:, :Dk], a2), (x2, Wv, c.KV[:, Dk:], a2)])
     if FUSED_XATTN and c.dk == c.dv:
         d = _xattn_desc(c, out, Dk)
         if ops.xattn_seq_supported(d):

@@ -234,6 +234,8 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
         # The critical chain is ISSUED first (the host needs ~10 us per launch): pipelined, the LSTHM kernel follows the speaker
         # kernel step by step through a device-side counter; both are persistent (64 + 64 workgroups) and the attention GEMMs,
         # issued afterwards on two side streams, fill the other CUs.
+        # (issuing the attention branches first and the chains behind them measured the same step time: what the chains lose to the
+        # branches' traffic in their first ~80 us equals what waiting for the branches would cost)
         ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD | sep)
         s_xa.wait_event(ev_x)
         s_xb.wait_event(ev_x)

@@ -180,6 +180,27 @@ def matmul(x: Tensor, Wkn: Tensor, out: Tensor, accum: bool = False, alpha_dev: 
              ldr1=_ld(R1) if R1 is not None else 0)
 
 
+def matmul_group(items) -> None:
+    """Several independent products out_i[rows,N] = alpha_i * x_i[rows,K] @ W_i[K,N] (torch.matmul layout) as ONE grouped launch
+    (mser_gemm_grouped): items = [(x, Wkn, out, alpha_dev or None), ...]."""
+    descs = []
+    for x, Wkn, out, alpha_dev in items:
+        if not (x.is_cuda and Wkn.is_cuda and out.is_cuda):
+            raise RuntimeError("mser ops need GPU tensors (the product path has no CPU fallback)")
+        d = L.GemmDesc()
+        rows, K = x.shape
+        d.A, d.B, d.C = x.data_ptr(), Wkn.data_ptr(), out.data_ptr()
+        d.M, d.N, d.K = rows, Wkn.shape[1], K
+        d.sAm, d.sAk, d.sBk, d.sBn, d.ldc = _ld(x), 1, Wkn.stride(0), 1, _ld(out)
+        d.batch1 = d.batch2 = 1
+        d.alpha = 1.0
+        d.alpha_dev = alpha_dev.data_ptr() if alpha_dev is not None else None
+        d.splitk = 1
+        descs.append(d)
+    arr = (L.GemmDesc * len(descs))(*descs)
+    L.check(_lib().mser_gemm_grouped(arr, len(descs), _stream()), "mser_gemm_grouped")
+
+
 def matmul_nt(dy: Tensor, Wkn: Tensor, out: Tensor, accum: bool = False, alpha_dev: Optional[Tensor] = None) -> None:
     """out[rows,K] (+)= alpha * dy[rows,N] @ Wkn[K,N]^T"""
     rows, N = dy.shape
