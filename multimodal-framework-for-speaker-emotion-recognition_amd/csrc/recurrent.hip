@@ -569,6 +569,19 @@ struct SpkFwdB {
   }
 };
 
+// Gate non-linearities of the persistent chains on the hardware transcendentals (v_exp_f32, v_rcp_f32: ~1 ulp each): the libm
+// expf / tanhf the per-step launches use cost ~60-80 instructions per value, five values per (row, unit) on the critical path of
+// every step.  Absolute error ~1e-7 per value; through 128 steps the log-probs move by < 2e-6 (the parity tests run this path).
+// (-DMSER_FAST_NL=0 keeps libm in the chains; measured on one box, alternating: 3.206 / 3.210 ms per step with libm, 3.182 / 3.180 with
+// these forms -- while the speaker chain paced the forward at 6.5 us per step the same switch measured nothing.)
+#ifndef MSER_FAST_NL
+#define MSER_FAST_NL 1
+#endif
+constexpr bool FASTNL = MSER_FAST_NL != 0;
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-LOG2E * x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 2.0f * sigmoid_fast(2.0f * x) - 1.0f; }
+
+
 // What a step's A rows need from the index tables (they do not depend on the chain): fetched one step ahead by the persistent kernel, so
 // that the gather of q_sel costs the step ONE memory round trip (the rows themselves) instead of three dependent ones (perm -> qm -> rows).
 struct SpkPre { int N0, N0p, b; float m; };
@@ -666,12 +679,13 @@ __device__ __forceinline__ void spk_fwd_body(const CellK& P, const DirP& D, cons
     const int rr = tid >> 3, uu = tid & 7;
     const int slot = mb * 32 + rr, u = u0 + uu;
     if (slot < B) {
-      const float gi = sigmoidf_(tile[rr * 32 + 0 + uu] + bias4[0]);
-      const float gf = sigmoidf_(tile[rr * 32 + 8 + uu] + bias4[1]);
-      const float gg = tanhf(tile[rr * 32 + 16 + uu] + bias4[2]);
-      const float go = sigmoidf_(tile[rr * 32 + 24 + uu] + bias4[3]);
+      const bool fnl = PS && FASTNL;                          // (persistent chain: hardware exp / rcp forms, see sigmoid_fast)
+      const float gi = fnl ? sigmoid_fast(tile[rr * 32 + 0 + uu] + bias4[0]) : sigmoidf_(tile[rr * 32 + 0 + uu] + bias4[0]);
+      const float gf = fnl ? sigmoid_fast(tile[rr * 32 + 8 + uu] + bias4[1]) : sigmoidf_(tile[rr * 32 + 8 + uu] + bias4[1]);
+      const float gg = fnl ? tanh_fast(tile[rr * 32 + 16 + uu] + bias4[2]) : tanhf(tile[rr * 32 + 16 + uu] + bias4[2]);
+      const float go = fnl ? sigmoid_fast(tile[rr * 32 + 24 + uu] + bias4[3]) : sigmoidf_(tile[rr * 32 + 24 + uu] + bias4[3]);
       const float cn = gf * cq_prev + gi * gg;
-      const float tcn = tanhf(cn);
+      const float tcn = fnl ? tanh_fast(cn) : tanhf(cn);
       float hn = go * tcn;
       if (drop_state_on(P, D)) hn *= drop_hq(P, D, t, c, slot, u);          // :183 / :188: the dropped h_q IS the carried state
       D.tcq[((long)c * T + t) * SB + (long)slot * H + u] = tcn;
@@ -1008,18 +1022,8 @@ __device__ __forceinline__ GatePre lsthm_gate_prefetch(const CellK& P, const Dir
   return g;
 }
 
-// Gate non-linearities of the persistent chains on the hardware transcendentals (v_exp_f32, v_rcp_f32: ~1 ulp each): the libm
-// expf / tanhf the per-step launches use cost ~60-80 instructions per value, five values per (row, unit) on the critical path of
-// every step.  Absolute error ~1e-7 per value; through 128 steps the log-probs move by < 2e-6 (the parity tests run this path).
-__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-LOG2E * x)); }
-__device__ __forceinline__ float tanh_fast(float x) { return 2.0f * sigmoid_fast(2.0f * x) - 1.0f; }
-
 // Gates phase of step t: acc (early product, in registers) += z_{t-1} V^T, cross-wave reduction, LSTM epilogue.
 // c_state: this thread's cell state c_{t-1}[b][u] (the same thread owns the same (b, u) every step: it never leaves the register).
-#ifndef MSER_FAST_NL
-#define MSER_FAST_NL 0        // measured: no change of the step time (the chain is bound by the hand-off latency, not by the epilogue); the libm forms stay
-#endif
-constexpr bool FASTNL = MSER_FAST_NL != 0;
 template <int NP, bool SV = false>
 __device__ __forceinline__ void lsthm_gates_late(const CellK& P, const DirP& D, const WS& ws, int t, int m, int u0, int mb,
                                                  const float (*bpre)[8], f32x16 acc, const GatePre& gp, float& c_state, float* red,

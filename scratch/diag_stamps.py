@@ -21,7 +21,10 @@ out2 = torch.zeros(T * N, 4 * HID, device="cuda")
 dirs = [dict(p=ops.cell_param_struct(lambda n: P[n].detach()), g=ops.cell_param_struct(lambda n: G[n]), qmask=qmask, rev=None, out=out, dout=dout)]
 if NDIR == 2:
     G2 = {k: torch.zeros_like(v) for k, v in P.items()}
-    dirs.append(dict(p=ops.cell_param_struct(lambda n: P[n].detach()), g=ops.cell_param_struct(lambda n: G2[n]), qmask=qmask, rev=None, out=out2, dout=dout))
+    rev = None
+    if len(sys.argv) > 4 and sys.argv[4] == "rev":            # the second direction reversed in time (full lengths), as the model runs it
+        rev = torch.arange(T - 1, -1, -1, dtype=torch.int32, device="cuda").view(T, 1).expand(T, N).contiguous()
+    dirs.append(dict(p=ops.cell_param_struct(lambda n: P[n].detach()), g=ops.cell_param_struct(lambda n: G2[n]), qmask=qmask, rev=rev, out=out2, dout=dout))
 dx_l, dx_a = torch.zeros(T * N, 100, device="cuda"), torch.zeros(T * N, 100, device="cuda")
 desc = ops.make_cell_desc(T, N, 100, HID, x_l.view(T * N, 100), x_a.view(T * N, 100), dirs, 4 * HID, ws, dx_l=dx_l, dx_a=dx_a)
 for _ in range(2):
