@@ -1792,7 +1792,7 @@ __device__ __forceinline__ void lsthm_bwd_role_sv(const CellK& P, const Role R, 
   unsigned* cnt = P.sync + SYNC_LSTHM_BWD + dir * SYNC_DIR;
   STAMP_INIT();
   constexpr int JCB = 2 * NP * NP;
-  const bool rs2 = NP == 8 && P.bwd_rowsplit == 2;            // H = 256: two workgroups per dialogue row (needs 2 B <= nwg)
+  const bool rs2 = P.bwd_rowsplit == 2;                       // two workgroups per dialogue row (needs 2 B <= nwg)
   const bool has_row = rs2 ? w < 2 * P.B : w < P.B;
   const int rowb = has_row ? (rs2 ? w >> 1 : w) : 0;
   RowPre pre = lsthm_bwd_row_prefetch(P, D, P.T - 1, rowb);
@@ -1867,7 +1867,7 @@ __device__ __forceinline__ void lsthm_bwd_role(const CellK& P, const Role R, flo
   unsigned* cnt = P.sync + SYNC_LSTHM_BWD + dir * SYNC_DIR;
   STAMP_INIT();
   constexpr int JCB = 2 * NP * NP;                         // NP = H/32, keys per thread = H*H/NT
-  const bool rs2 = NP == 8 && P.bwd_rowsplit == 2;            // H = 256: two workgroups per dialogue row (needs 2 B <= nwg)
+  const bool rs2 = P.bwd_rowsplit == 2;                       // two workgroups per dialogue row (needs 2 B <= nwg)
   const bool has_row = rs2 ? w < 2 * P.B : w < P.B;
   // saved-state operands are fetched TWO steps ahead (a whole step for the loads to land); the dc carry stays in registers
   const int rowb = has_row ? (rs2 ? w >> 1 : w) : 0;
@@ -3042,7 +3042,7 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   // both BPTT kernels run concurrently (pipelined): all their workgroups must be co-resident
   const bool persist = persist_ok(H, ((long)bwd_nwg + spk_wgs) * d.ndir);
   if (!persist) K.nodx = 0;
-  K.bwd_rowsplit = (persist && g_opt_rowsplit && H == 256 && 2 * B <= bwd_nwg) ? 2 : 1;
+  K.bwd_rowsplit = (persist && g_opt_rowsplit && 2 * B <= bwd_nwg) ? 2 : 1;      // (H = 128: 64 workgroups per direction with the K-split)
   const size_t p_lds = persist_lds(mm_lds + (2 * (size_t)H + 16) * sizeof(float) + 64);
   const int SPLITK = 16;
   // Weight gradients inside the fused BPTT launch (wgrad_role): needs the persistent launch, the H = 128 tiling (16 / 8 column
