@@ -1974,7 +1974,7 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, cons
 
   // element-wise prologue over 32 slots x H units, 4 consecutive units per thread-iteration (16-byte accesses: the phase is
   // bound by vector-memory instruction throughput, not by arithmetic).  All loads of an iteration batch are issued first.
-  constexpr int MAXIT = NP >= 8 ? 2 : 4;        // (H = 256: 64 weight registers per lane; four batches in flight would spill)
+  constexpr int MAXIT = NP > 0 ? 2 : 4;         // groups in flight per batch (persistent kernels: H = 128 has two per thread in all; H = 256 four, and with its 64 weight registers per lane four in flight would spill)
   const int G4 = H / 4;                          // float4 groups per slot row
   const int nit = 32 * G4 / NT;                  // = H/64
   const int npub = 2 * (H / 32);                 // workgroups of this cell; group g is published by workgroup (g % G4) % npub
