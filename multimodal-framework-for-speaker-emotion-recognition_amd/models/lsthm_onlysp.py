@@ -94,6 +94,8 @@ class _OnlyspFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlp, dxl, dxa):
         model, c = ctx.model, ctx.c
+        if c is None:           # the saved activations are released by the first backward (as autograd does without retain_graph)
+            raise RuntimeError("backward through this forward a second time: its saved activations have been freed; run the forward again")
         store = model._store
         if store.grads_were_reset():
             store.zero_grad()

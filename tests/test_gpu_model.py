@@ -484,6 +484,35 @@ def test_model_wide_hidden_vs_oracle(O, H, heads, B, L):
         assert maxabs(p.grad, r) < 3e-4 * max(1e-3, float(r.norm())), n
 
 
+def test_second_backward_over_one_forward_is_refused(O):
+    """One backward per forward: the model's autograd node releases its saved activations in the backward (and the forward has
+    prepared the zeroed state of exactly one backward, MSER_PHASE_PREP_BOTH).  A second backward over the same forward must fail
+    loudly, like autograd's own "backward through the graph a second time", instead of reading freed or stale buffers."""
+    from models.lsthm_sps import MARN1_sps
+    from loss import MaskedLoss
+    d_r, B, L = 64, 6, 11
+    P = O.seeded_params(seed=61, d_r=d_r)
+    net = MARN1_sps(6, d_r=d_r).cuda().eval()
+    load_params(net, P)
+    x, qmask, umask, label = O.seeded_batch(B, L, d_r=d_r, seed=62, ragged=True)
+    lp, _, _ = net(x.cuda(), qmask.cuda(), umask.cuda())
+    loss = MaskedLoss(torch.nn.NLLLoss)(lp, label.cuda().view(-1), umask.cuda())
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time"):
+        loss.backward()
+    # and a fresh forward / backward afterwards is unaffected
+    net.zero_grad(set_to_none=True)
+    lp, _, _ = net(x.cuda(), qmask.cuda(), umask.cuda())
+    MaskedLoss(torch.nn.NLLLoss)(lp, label.cuda().view(-1), umask.cuda()).backward()
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    lp_ref, _, _ = O.marn1_sps_forward(Pr, x, qmask, umask, d_r=d_r)
+    O.masked_nll(lp_ref, label.view(-1), umask).backward()
+    for n, p in net.named_parameters():
+        r = Pr[n].grad
+        if r is not None:
+            assert maxabs(p.grad, r) < 3e-4 * max(1e-3, float(r.norm())), n
+
+
 def test_model_multi_head_sequence_attention_vs_oracle(O):
     """``xattn_heads=8`` (BASELINE.json configs[4]'s 8-head cross-modal attention; a keyword extension: the reference's
     CrossAttention2/3 are single-head, model/lsthm_sps.py:88-101): the four sequence-level modules split their 128-wide projections
