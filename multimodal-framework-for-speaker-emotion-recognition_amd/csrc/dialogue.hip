@@ -303,14 +303,20 @@ __global__ __launch_bounds__(ATT_NT) void drnn_attn_fwd_kernel(int B, int Dg, in
 }
 // backward: dalpha_s = <dc, g_s>; ds = alpha (dalpha - sum alpha dalpha); dx = sum ds_s g_s; dGh[s+1] += alpha_s dc + ds_s x
 __global__ __launch_bounds__(ATT_NT) void drnn_attn_bwd_kernel(int B, int Dg, int T, int t, const float* Xatt_t, long x_ds, const float* Gh,
-                                                               float* dGh, long gh_ds, const float* alpha_t, long al_ds, const float* dc,
+                                                               float* dGh, long gh_ds, const float* alpha_t, long al_ds, float* dc,
                                                                long c_ds, float* dX_t) {
   extern __shared__ float sm[];
   float* x = sm; float* dcv = sm + Dg; float* ds = sm + 2 * Dg; float* al = ds + T;
   __shared__ float red[ATT_NT / 64];
   const int b = blockIdx.x, dir = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int u = tid; u < Dg; u += ATT_NT) { x[u] = Xatt_t[(long)dir * x_ds + (long)b * Dg + u]; dcv[u] = dc[(long)dir * c_ds + (long)b * Dg + u]; }
+  // (dc, like dqsel / dss / dq0sel, is a split-K accumulation target of the step's data-gradient GEMMs: its one reader clears it for the
+  // next step, which saves a memset node per product and step)
+  for (int u = tid; u < Dg; u += ATT_NT) {
+    x[u] = Xatt_t[(long)dir * x_ds + (long)b * Dg + u];
+    dcv[u] = dc[(long)dir * c_ds + (long)b * Dg + u];
+    dc[(long)dir * c_ds + (long)b * Dg + u] = 0.f;
+  }
   for (int s = tid; s < t; s += ATT_NT) al[s] = alpha_t[(long)dir * al_ds + (long)b * T + s];
   __syncthreads();
   const float* G = Gh + (long)dir * gh_ds + (long)b * Dg;
@@ -382,7 +388,7 @@ __global__ void drnn_e_bwd_kernel(int B, int H, const float* dout, long ldo, con
 
 // l cell + blend: dQn (gradient at Q[t+1]) = dQnext + [p == idx_t] dqsel + [p == idx_{t+1}] dq0sel_next.
 // d ql = dQn (1 - m), d qs_blend = dQn m (-> dqs); GRU backward of the l cell; dQcur = d ql z (direct path; the GEMM adds dgh W_hh).
-__global__ void drnn_l_bwd_kernel(int B, int H, const float* dQn, float* dQc, long q_ds, const float* dqsel, const float* dq0n, long sel_ds,
+__global__ void drnn_l_bwd_kernel(int B, int H, const float* dQn, float* dQc, long q_ds, float* dqsel, float* dq0n, long sel_ds,
                                   const int* idx, const int* idx_next, long idx_ds, const float* qm, long qm_ds, const float* save,
                                   long sv_ds, const float* Qt, long qh_ds, float* dgi, long dgi_ds, float* dgh, long dgh_ds, float* dqs,
                                   const uint32_t* rng, uint32_t site0, uint32_t site1, float p, uint32_t idx0, int has_next) {
@@ -413,10 +419,12 @@ __global__ void drnn_l_bwd_kernel(int B, int H, const float* dQn, float* dQc, lo
   }
   float* o = dgi + (long)dir * dgi_ds + (long)b * 3 * H + u;     // both parties share the input row [U_t | ss]
   o[0] = sr; o[H] = sz; o[2 * H] = sna;
+  dqsel[(long)dir * sel_ds + (long)b * H + u] = 0.f;             // read-and-clear (this thread is the only reader of the element)
+  dq0n[(long)dir * sel_ds + (long)b * H + u] = 0.f;
 }
 
 // p cell: d qs = dqs (blend) + [p == idx_t] dss; GRU backward; dQcur += d qs z
-__global__ void drnn_p_bwd_kernel(int B, int H, const float* dqs, const float* dss, long sel_ds, const int* idx, long idx_ds, float* dQc,
+__global__ void drnn_p_bwd_kernel(int B, int H, const float* dqs, float* dss, long sel_ds, const int* idx, long idx_ds, float* dQc,
                                   long q_ds, const float* save, long sv_ds, const float* Qt, long qh_ds, float* dgi, long dgi_ds, float* dgh,
                                   long dgh_ds, const uint32_t* rng, uint32_t site0, uint32_t site1, float p, uint32_t idx0) {
   const int dir = blockIdx.z;
@@ -441,6 +449,7 @@ __global__ void drnn_p_bwd_kernel(int B, int H, const float* dqs, const float* d
   }
   float* o = dgi + (long)dir * dgi_ds + (long)b * 3 * H + u;
   o[0] = sr; o[H] = sz; o[2 * H] = sna;
+  dss[(long)dir * sel_ds + (long)b * H + u] = 0.f;               // read-and-clear
 }
 
 // g cell: dh' = dGh[t+1]; direct path dGh[t] += dh' z
@@ -715,32 +724,36 @@ int mser_drnn_bwd(const mser_drnn_desc* dp, mser_stream_t stream) {
   MSER_CHECK_HIP(hipMemsetAsync(w.dQ, 0, (size_t)2 * 2 * B * 2 * Dp * sizeof(float), s));
   MSER_CHECK_HIP(hipMemsetAsync(w.dEc, 0, (size_t)2 * B * De * sizeof(float), s));
   MSER_CHECK_HIP(hipMemsetAsync(w.dq0sel, 0, (size_t)2 * 2 * B * Dp * sizeof(float), s));
+  // accumulation targets of the per-step data-gradient products: zero once, their readers clear them again (see drnn_attn_bwd_kernel)
+  MSER_CHECK_HIP(hipMemsetAsync(w.dqsel, 0, (size_t)2 * B * Dp * sizeof(float), s));
+  MSER_CHECK_HIP(hipMemsetAsync(w.dss, 0, (size_t)2 * B * Dp * sizeof(float), s));
+  MSER_CHECK_HIP(hipMemsetAsync(w.dc, 0, (size_t)2 * B * Dg * sizeof(float), s));
   const dim3 blk(256);
   const long dq_ds = (long)B * 2 * Dp;                     // dir stride inside one ping-pong half of dQ
   int pp = 0;
   for (int t = T - 1; t >= 0; --t) {
     float* dQn = w.dQ + (long)pp * 2 * dq_ds;               // gradient at Q[t+1] left by step t+1
     float* dQc = w.dQ + (long)(1 - pp) * 2 * dq_ds;         // gradient at Q[t] built by this step
-    const float* dq0n = w.dq0sel + (long)((t + 1) & 1) * 2 * B * Dp;
+    float* dq0n = w.dq0sel + (long)((t + 1) & 1) * 2 * B * Dp;
     float* dq0c = w.dq0sel + (long)(t & 1) * 2 * B * Dp;
     // -- e cell
     hipLaunchKernelGGL(drnn_e_bwd_kernel, dim3(cdiv((long)B * De, 256), 1, 2), blk, 0, s, B, De, d.dout, (long)d.ldo, d.rev, t, w.dEc, (long)B * De,
                        w.sv_e + (long)t * B * 4 * De, TB * 4 * De, w.Eh + (long)t * B * De, e_ds, w.dgi_e + (long)t * B * 3 * De,
                        w.dgh_e + (long)t * B * 3 * De, TB * 3 * De, rng, d.drop_site[0] + 3, d.drop_site[1] + 3, p, (uint32_t)((long)t * B * De));
-    MSER_TRY(mm_nn(s, w.dgi_e + (long)t * B * 3 * De, 3 * De, TB * 3 * De, d.p[0].e_wih, Dp, DS(e_wih), w.dqsel, Dp, (long)B * Dp, B, Dp, 3 * De, false));
+    MSER_TRY(mm_nn(s, w.dgi_e + (long)t * B * 3 * De, 3 * De, TB * 3 * De, d.p[0].e_wih, Dp, DS(e_wih), w.dqsel, Dp, (long)B * Dp, B, Dp, 3 * De, true));
     // -- l cell + blend
     hipLaunchKernelGGL(drnn_l_bwd_kernel, dim3(cdiv((long)B * Dp, 256), 1, 2), blk, 0, s, B, Dp, dQn, dQc, dq_ds, w.dqsel, dq0n, (long)B * Dp,
                        w.idx + (long)t * B, w.idx + (long)(t + 1) * B, idx_ds, w.qm + (long)t * B * 2, TB * 2, w.sv_l + (long)t * B * 2 * 4 * Dp,
                        TB * 2 * 4 * Dp, w.Q + (long)t * B * 2 * Dp, q_ds, w.dgi_l + (long)t * B * 3 * Dp, TB * 3 * Dp,
                        w.dgh_l + (long)t * 2 * B * 3 * Dp, TB * 2 * 3 * Dp, w.dqs, rng, d.drop_site[0] + 2, d.drop_site[1] + 2, p,
                        (uint32_t)((long)t * B * 2 * Dp), t + 1 < T ? 1 : 0);
-    MSER_TRY(mm_nn(s, w.dgi_l + (long)t * B * 3 * Dp, 3 * Dp, TB * 3 * Dp, d.p[0].l_wih + Dm, Dm + Dp, DS(l_wih), w.dss, Dp, (long)B * Dp, B, Dp, 3 * Dp, false));
+    MSER_TRY(mm_nn(s, w.dgi_l + (long)t * B * 3 * Dp, 3 * Dp, TB * 3 * Dp, d.p[0].l_wih + Dm, Dm + Dp, DS(l_wih), w.dss, Dp, (long)B * Dp, B, Dp, 3 * Dp, true));
     // -- p cell
     hipLaunchKernelGGL(drnn_p_bwd_kernel, dim3(cdiv((long)B * Dp, 256), 1, 2), blk, 0, s, B, Dp, w.dqs, w.dss, (long)B * Dp, w.idx + (long)t * B, idx_ds,
                        dQc, dq_ds, w.sv_p + (long)t * B * 2 * 4 * Dp, TB * 2 * 4 * Dp, w.Q + (long)t * B * 2 * Dp, q_ds,
                        w.dgi_p + (long)t * B * 3 * Dp, TB * 3 * Dp, w.dgh_p + (long)t * 2 * B * 3 * Dp, TB * 2 * 3 * Dp, rng, d.drop_site[0] + 1,
                        d.drop_site[1] + 1, p, (uint32_t)((long)t * B * 2 * Dp));
-    MSER_TRY(mm_nn(s, w.dgi_p + (long)t * B * 3 * Dp, 3 * Dp, TB * 3 * Dp, d.p[0].p_wih + Dm, Dm + Dg, DS(p_wih), w.dc, Dg, (long)B * Dg, B, Dg, 3 * Dp, false));
+    MSER_TRY(mm_nn(s, w.dgi_p + (long)t * B * 3 * Dp, 3 * Dp, TB * 3 * Dp, d.p[0].p_wih + Dm, Dm + Dg, DS(p_wih), w.dc, Dg, (long)B * Dg, B, Dg, 3 * Dp, true));
     // -- attention over the history
     if (t > 0) {
       hipLaunchKernelGGL(drnn_attn_bwd_kernel, dim3(B, 2), dim3(ATT_NT), (size_t)(3 * Dg + 2 * T) * sizeof(float), s, B, Dg, T, t,
@@ -753,7 +766,7 @@ int mser_drnn_bwd(const mser_drnn_desc* dp, mser_stream_t stream) {
     hipLaunchKernelGGL(drnn_g_bwd_kernel, dim3(cdiv((long)B * Dg, 256), 1, 2), blk, 0, s, B, Dg, w.dGh + (long)(t + 1) * B * Dg, w.dGh + (long)t * B * Dg,
                        g_ds, w.sv_g + (long)t * B * 4 * Dg, TB * 4 * Dg, w.Gh + (long)t * B * Dg, w.dgi_g + (long)t * B * 3 * Dg,
                        w.dgh_g + (long)t * B * 3 * Dg, TB * 3 * Dg, rng, d.drop_site[0], d.drop_site[1], p, (uint32_t)((long)t * B * Dg));
-    MSER_TRY(mm_nn(s, w.dgi_g + (long)t * B * 3 * Dg, 3 * Dg, TB * 3 * Dg, d.p[0].g_wih + Dm, Dm + Dp, DS(g_wih), dq0c, Dp, (long)B * Dp, B, Dp, 3 * Dg, false));
+    MSER_TRY(mm_nn(s, w.dgi_g + (long)t * B * 3 * Dg, 3 * Dg, TB * 3 * Dg, d.p[0].g_wih + Dm, Dm + Dp, DS(g_wih), dq0c, Dp, (long)B * Dp, B, Dp, 3 * Dg, true));
     // -- the four hidden-path products of the step (into the state gradients that step t-1 reads): one grouped launch, split-K atomics
     {
       mser_gemm_desc grp[4] = {
