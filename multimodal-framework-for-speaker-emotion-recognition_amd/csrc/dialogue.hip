@@ -36,6 +36,9 @@ __device__ __forceinline__ Gate gru_gate(const float* gi, const float* gh, const
   ghn_out = ghn;
   return g;
 }
+// The hidden products gh (and the e cell's input product) are split-K accumulation targets of the next step's GEMMs: the one thread that
+// reads an element clears it (no memset node per product and step).
+__device__ __forceinline__ void clear3(float* g3, int H, int u) { g3[u] = 0.f; g3[H + u] = 0.f; g3[2 * H + u] = 0.f; }
 // dh: gradient at h' (after undoing the dropout factor).  Returns the gate pre-activation gradients and the direct path to hprev.
 struct GateGrad { float dar, daz, dan, danr, dhp; };
 __device__ __forceinline__ GateGrad gru_gate_bwd(float dh, float r, float z, float n, float ghn, float hprev) {
@@ -145,7 +148,7 @@ struct StepF {
 };
 
 // ---- g cell epilogue: (dir, b, u) ---------------------------------------------------------------------------------------------------
-__global__ void drnn_g_fwd_kernel(int B, int H, const float* gi, const float* gh, const float* bhh, long bhh_ds, const float* hprev,
+__global__ void drnn_g_fwd_kernel(int B, int H, const float* gi, long gi_ds, float* gh, const float* bhh, long bhh_ds, const float* hprev,
                                   float* hnew, long st_ds, float* save, long sv_ds, const uint32_t* rng, uint32_t site0, uint32_t site1,
                                   float p, uint32_t idx0) {
   const int dir = blockIdx.z;
@@ -155,7 +158,8 @@ __global__ void drnn_g_fwd_kernel(int B, int H, const float* gi, const float* gh
   const long row = (long)dir * B + b;
   float ghn;
   const float hp = hprev[(long)dir * st_ds + (long)b * H + u];
-  const Gate g = gru_gate(gi + row * 3 * H, gh + row * 3 * H, bhh + dir * bhh_ds, H, u, hp, ghn);
+  const Gate g = gru_gate(gi + (long)dir * gi_ds + (long)b * 3 * H, gh + row * 3 * H, bhh + dir * bhh_ds, H, u, hp, ghn);
+  clear3(gh + row * 3 * H, H, u);
   float h = g.h;
   if (rng) h *= drop_scale(drop_key(rng, dir ? site1 : site0, p), idx0 + (uint32_t)e);
   hnew[(long)dir * st_ds + (long)b * H + u] = h;
@@ -164,7 +168,7 @@ __global__ void drnn_g_fwd_kernel(int B, int H, const float* gi, const float* gh
 }
 
 // ---- p cell epilogue: (dir, b, u), both parties; also ss[d][b] = qs[b, idx] ------------------------------------------------------------
-__global__ void drnn_p_fwd_kernel(int B, int H, const float* gi, const float* gh, const float* bhh, long bhh_ds, const float* Qt, long q_ds,
+__global__ void drnn_p_fwd_kernel(int B, int H, const float* gi, long gi_ds, float* gh, const float* bhh, long bhh_ds, const float* Qt, long q_ds,
                                   float* qs, float* save, long sv_ds, const int* idx, long idx_ds, float* ss, long ss_ds,
                                   const uint32_t* rng, uint32_t site0, uint32_t site1, float p, uint32_t idx0) {
   const int dir = blockIdx.z;
@@ -179,7 +183,8 @@ __global__ void drnn_p_fwd_kernel(int B, int H, const float* gi, const float* gh
     const long row = ((long)dir * B + b) * 2 + pt;
     float ghn;
     const float hp = Qt[(long)dir * q_ds + ((long)b * 2 + pt) * H + u];
-    const Gate g = gru_gate(gi + ((long)dir * B + b) * 3 * H, gh + row * 3 * H, bhh + dir * bhh_ds, H, u, hp, ghn);
+    const Gate g = gru_gate(gi + (long)dir * gi_ds + (long)b * 3 * H, gh + row * 3 * H, bhh + dir * bhh_ds, H, u, hp, ghn);
+    clear3(gh + row * 3 * H, H, u);
     float h = g.h;
     if (rng) h *= drop_scale(dk, idx0 + (uint32_t)(((long)b * 2 + pt) * H + u));
     qs[row * H + u] = h;
@@ -190,7 +195,7 @@ __global__ void drnn_p_fwd_kernel(int B, int H, const float* gi, const float* gh
 }
 
 // ---- l cell epilogue + blend: Q[t+1] = ql (1 - m) + qs m ; qsel = Q[t+1][b, idx_t] ; q0next = Q[t+1][b, idx_{t+1}] -----------------------
-__global__ void drnn_l_fwd_kernel(int B, int H, const float* gi, const float* gh, const float* bhh, long bhh_ds, const float* Qt, float* Qn,
+__global__ void drnn_l_fwd_kernel(int B, int H, const float* gi, long gi_ds, float* gh, const float* bhh, long bhh_ds, const float* Qt, float* Qn,
                                   long q_ds, const float* qs, float* save, long sv_ds, const float* qm, long qm_ds, const int* idx,
                                   const int* idx_next, long idx_ds, float* qsel, long sel_ds, float* q0next, long q0n_ds, const uint32_t* rng,
                                   uint32_t site0, uint32_t site1, float p, uint32_t idx0) {
@@ -206,7 +211,8 @@ __global__ void drnn_l_fwd_kernel(int B, int H, const float* gi, const float* gh
     const long row = ((long)dir * B + b) * 2 + pt;
     float ghn;
     const float hp = Qt[(long)dir * q_ds + ((long)b * 2 + pt) * H + u];
-    const Gate g = gru_gate(gi + ((long)dir * B + b) * 3 * H, gh + row * 3 * H, bhh + dir * bhh_ds, H, u, hp, ghn);
+    const Gate g = gru_gate(gi + (long)dir * gi_ds + (long)b * 3 * H, gh + row * 3 * H, bhh + dir * bhh_ds, H, u, hp, ghn);
+    clear3(gh + row * 3 * H, H, u);
     float h = g.h;
     if (rng) h *= drop_scale(dk, idx0 + (uint32_t)(((long)b * 2 + pt) * H + u));
     float* sv = save + (long)dir * sv_ds + ((long)b * 2 + pt) * 4 * H + u;
@@ -220,7 +226,7 @@ __global__ void drnn_l_fwd_kernel(int B, int H, const float* gi, const float* gh
 }
 
 // ---- e cell epilogue: also writes the emotion row at its natural time position ---------------------------------------------------------
-__global__ void drnn_e_fwd_kernel(int B, int H, const float* gi, const float* gh, const float* bih, const float* bhh, long bhh_ds, const float* hprev,
+__global__ void drnn_e_fwd_kernel(int B, int H, float* gi, float* gh, const float* bih, const float* bhh, long bhh_ds, const float* hprev,
                                   float* hnew, long st_ds, float* save, long sv_ds, float* out, long ldo, const int* rev, int t,
                                   const uint32_t* rng, uint32_t site0, uint32_t site1, float p, uint32_t idx0) {
   const int dir = blockIdx.z;
@@ -231,6 +237,8 @@ __global__ void drnn_e_fwd_kernel(int B, int H, const float* gi, const float* gh
   float ghn;
   const float hp = hprev[(long)dir * st_ds + (long)b * H + u];
   const Gate g = gru_gate(gi + row * 3 * H, gh + row * 3 * H, bhh + dir * bhh_ds, H, u, hp, ghn, bih + dir * bhh_ds);
+  clear3(gi + row * 3 * H, H, u);
+  clear3(gh + row * 3 * H, H, u);
   float h = g.h;
   if (rng) h *= drop_scale(drop_key(rng, dir ? site1 : site0, p), idx0 + (uint32_t)e);
   hnew[(long)dir * st_ds + (long)b * H + u] = h;
@@ -527,11 +535,12 @@ mser_gemm_desc gd() {
 // C[dir][M, N] (+)= A[dir][M, K] W[dir][N, K]^T (+ R1[dir][M, N])       -- nn.Linear orientation, both directions in one launch
 mser_gemm_desc mm_nt_desc(const float* A, long lda, long a_ds, const float* W, long ldw, long w_ds, float* C, long ldc, long c_ds, int M, int N,
                           int K, bool accum, const float* R1 = nullptr, long ldr = 0, long r_ds = 0) {
+  // accum: C is initialised (hoisted product or cleared by its reader); the product is added with split-K float atomics (mser::gemm picks the split)
   mser_gemm_desc g = gd();
   g.A = A; g.B = W; g.C = C; g.M = M; g.N = N; g.K = K;
   g.sAm = lda; g.sAk = 1; g.sBk = 1; g.sBn = ldw; g.ldc = ldc;
   g.batch1 = 2; g.sA1 = a_ds; g.sB1 = w_ds; g.sC1 = c_ds;
-  if (accum) g.flags |= MSER_GEMM_ACCUM;
+  if (accum) { g.flags |= MSER_GEMM_ACCUM; g.splitk = 2; }
   g.R1 = R1; g.ldr1 = ldr; g.sR1_1 = r_ds;
   return g;
 }
@@ -654,6 +663,8 @@ int mser_drnn_fwd(const mser_drnn_desc* dp, mser_stream_t stream) {
       MSER_TRY(gemm(g, s));
     }
   }
+  // the per-step hidden products (and gi_e) are accumulation targets cleared by their readers: zero them once (carved back to back)
+  MSER_CHECK_HIP(hipMemsetAsync(w.gi_g, 0, (size_t)((char*)(w.gh_e + (size_t)2 * B * 3 * De) - (char*)w.gi_g), s));
   const dim3 blk(256);
   const long idx_ds = TB + B;
   for (int t = 0; t < T; ++t) {
@@ -666,12 +677,11 @@ int mser_drnn_fwd(const mser_drnn_desc* dp, mser_stream_t stream) {
     //    grouped launch (ten members) fills the chip where a product of its own keeps 47-94 workgroups busy for 18 us
     {
       mser_gemm_desc grp[5] = {
-        mm_nt_desc(q0s, Dp, TB * Dp, d.p[0].g_wih + Dm, Dm + Dp, DS(g_wih), w.gi_g, 3 * Dg, (long)B * 3 * Dg, B, 3 * Dg, Dp, false,
-                   w.GIg + (long)t * B * 3 * Dg, 3 * Dg, TB * 3 * Dg),
-        mm_nt_desc(Ght, Dg, g_ds, d.p[0].g_whh, Dg, DS(g_whh), w.gh_g, 3 * Dg, (long)B * 3 * Dg, B, 3 * Dg, Dg, false),
-        mm_nt_desc(Qt, Dp, q_ds, d.p[0].p_whh, Dp, DS(p_whh), w.gh_p, 3 * Dp, (long)2 * B * 3 * Dp, 2 * B, 3 * Dp, Dp, false),
-        mm_nt_desc(Qt, Dp, q_ds, d.p[0].l_whh, Dp, DS(l_whh), w.gh_l, 3 * Dp, (long)2 * B * 3 * Dp, 2 * B, 3 * Dp, Dp, false),
-        mm_nt_desc(Et, De, e_ds, d.p[0].e_whh, De, DS(e_whh), w.gh_e, 3 * De, (long)B * 3 * De, B, 3 * De, De, false)};
+        mm_nt_desc(q0s, Dp, TB * Dp, d.p[0].g_wih + Dm, Dm + Dp, DS(g_wih), w.GIg + (long)t * B * 3 * Dg, 3 * Dg, TB * 3 * Dg, B, 3 * Dg, Dp, true),
+        mm_nt_desc(Ght, Dg, g_ds, d.p[0].g_whh, Dg, DS(g_whh), w.gh_g, 3 * Dg, (long)B * 3 * Dg, B, 3 * Dg, Dg, true),
+        mm_nt_desc(Qt, Dp, q_ds, d.p[0].p_whh, Dp, DS(p_whh), w.gh_p, 3 * Dp, (long)2 * B * 3 * Dp, 2 * B, 3 * Dp, Dp, true),
+        mm_nt_desc(Qt, Dp, q_ds, d.p[0].l_whh, Dp, DS(l_whh), w.gh_l, 3 * Dp, (long)2 * B * 3 * Dp, 2 * B, 3 * Dp, Dp, true),
+        mm_nt_desc(Et, De, e_ds, d.p[0].e_whh, De, DS(e_whh), w.gh_e, 3 * De, (long)B * 3 * De, B, 3 * De, De, true)};
       MSER_TRY(gemm_group(grp, 5, s));
     }
     // -- attention over g_0 .. g_{t-1}, then the p cell's input product (the chain of the step: attention -> p -> l -> e)
@@ -679,26 +689,26 @@ int mser_drnn_fwd(const mser_drnn_desc* dp, mser_stream_t stream) {
       hipLaunchKernelGGL(drnn_attn_fwd_kernel, dim3(B, 2), dim3(ATT_NT), (size_t)(Dg + T) * sizeof(float), s, B, Dg, T, t,
                          w.Xatt + (long)t * B * Dg, TB * Dg, w.Gh, g_ds, w.alpha + (long)t * B * T, TB * T, w.cvec + (long)t * B * Dg, TB * Dg);
     }
-    MSER_TRY(mm_nt(s, w.cvec + (long)t * B * Dg, Dg, TB * Dg, d.p[0].p_wih + Dm, Dm + Dg, DS(p_wih), w.gi_p, 3 * Dp, (long)B * 3 * Dp, B, 3 * Dp, Dg,
-                   false, w.GIp + (long)t * B * 3 * Dp, 3 * Dp, TB * 3 * Dp));
+    MSER_TRY(mm_nt(s, w.cvec + (long)t * B * Dg, Dg, TB * Dg, d.p[0].p_wih + Dm, Dm + Dg, DS(p_wih), w.GIp + (long)t * B * 3 * Dp, 3 * Dp, TB * 3 * Dp, B,
+                   3 * Dp, Dg, true));                  // (in place on the hoisted U part of this step's input product)
     // -- g cell epilogue (g_t is first read by step t+1)
-    hipLaunchKernelGGL(drnn_g_fwd_kernel, dim3(cdiv((long)B * Dg, 256), 1, 2), blk, 0, s, B, Dg, w.gi_g, w.gh_g, d.p[0].g_bhh, DS(g_bhh), Ght, Ghn,
+    hipLaunchKernelGGL(drnn_g_fwd_kernel, dim3(cdiv((long)B * Dg, 256), 1, 2), blk, 0, s, B, Dg, w.GIg + (long)t * B * 3 * Dg, TB * 3 * Dg, w.gh_g, d.p[0].g_bhh, DS(g_bhh), Ght, Ghn,
                        g_ds, w.sv_g + (long)t * B * 4 * Dg, TB * 4 * Dg, rng, d.drop_site[0], d.drop_site[1], p, (uint32_t)((long)t * B * Dg));
     // -- p cell (both parties)
     float* qs = w.dqs;            // (forward: scratch for the p cell's dropped output; the backward reuses the buffer)
-    hipLaunchKernelGGL(drnn_p_fwd_kernel, dim3(cdiv((long)B * Dp, 256), 1, 2), blk, 0, s, B, Dp, w.gi_p, w.gh_p, d.p[0].p_bhh, DS(p_bhh), Qt, q_ds,
+    hipLaunchKernelGGL(drnn_p_fwd_kernel, dim3(cdiv((long)B * Dp, 256), 1, 2), blk, 0, s, B, Dp, w.GIp + (long)t * B * 3 * Dp, TB * 3 * Dp, w.gh_p, d.p[0].p_bhh, DS(p_bhh), Qt, q_ds,
                        qs, w.sv_p + (long)t * B * 2 * 4 * Dp, TB * 2 * 4 * Dp, w.idx + (long)t * B, idx_ds, w.ss + (long)t * B * Dp, TB * Dp, rng,
                        d.drop_site[0] + 1, d.drop_site[1] + 1, p, (uint32_t)((long)t * B * 2 * Dp));
     // -- l cell + blend
-    MSER_TRY(mm_nt(s, w.ss + (long)t * B * Dp, Dp, TB * Dp, d.p[0].l_wih + Dm, Dm + Dp, DS(l_wih), w.gi_l, 3 * Dp, (long)B * 3 * Dp, B, 3 * Dp, Dp,
-                   false, w.GIl + (long)t * B * 3 * Dp, 3 * Dp, TB * 3 * Dp));
+    MSER_TRY(mm_nt(s, w.ss + (long)t * B * Dp, Dp, TB * Dp, d.p[0].l_wih + Dm, Dm + Dp, DS(l_wih), w.GIl + (long)t * B * 3 * Dp, 3 * Dp, TB * 3 * Dp, B,
+                   3 * Dp, Dp, true));
     float* q0n = (t + 1 < T) ? w.q0sel + (long)(t + 1) * B * Dp : w.dss;         // (last step: a scratch target)
-    hipLaunchKernelGGL(drnn_l_fwd_kernel, dim3(cdiv((long)B * Dp, 256), 1, 2), blk, 0, s, B, Dp, w.gi_l, w.gh_l, d.p[0].l_bhh, DS(l_bhh), Qt, Qn, q_ds,
+    hipLaunchKernelGGL(drnn_l_fwd_kernel, dim3(cdiv((long)B * Dp, 256), 1, 2), blk, 0, s, B, Dp, w.GIl + (long)t * B * 3 * Dp, TB * 3 * Dp, w.gh_l, d.p[0].l_bhh, DS(l_bhh), Qt, Qn, q_ds,
                        qs, w.sv_l + (long)t * B * 2 * 4 * Dp, TB * 2 * 4 * Dp, w.qm + (long)t * B * 2, TB * 2, w.idx + (long)t * B,
                        w.idx + (long)(t + 1) * B, idx_ds, w.qsel + (long)t * B * Dp, TB * Dp, q0n, (t + 1 < T) ? TB * Dp : (long)B * Dp, rng,
                        d.drop_site[0] + 2, d.drop_site[1] + 2, p, (uint32_t)((long)t * B * 2 * Dp));
     // -- e cell (its input is not U, so b_ih is not part of a hoisted product: the epilogue adds it)
-    MSER_TRY(mm_nt(s, w.qsel + (long)t * B * Dp, Dp, TB * Dp, d.p[0].e_wih, Dp, DS(e_wih), w.gi_e, 3 * De, (long)B * 3 * De, B, 3 * De, Dp, false));
+    MSER_TRY(mm_nt(s, w.qsel + (long)t * B * Dp, Dp, TB * Dp, d.p[0].e_wih, Dp, DS(e_wih), w.gi_e, 3 * De, (long)B * 3 * De, B, 3 * De, Dp, true));
     hipLaunchKernelGGL(drnn_e_fwd_kernel, dim3(cdiv((long)B * De, 256), 1, 2), blk, 0, s, B, De, w.gi_e, w.gh_e, d.p[0].e_bih, d.p[0].e_bhh, DS(e_bhh), Et, En, e_ds,
                        w.sv_e + (long)t * B * 4 * De, TB * 4 * De, d.out, (long)d.ldo, d.rev, t, rng, d.drop_site[0] + 3, d.drop_site[1] + 3, p,
                        (uint32_t)((long)t * B * De));
