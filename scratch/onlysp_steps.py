@@ -15,3 +15,9 @@ for i in range(12):
     loss, _ = tr.train_step(x, qmask, umask, label)
 torch.cuda.synchronize()
 print("loss", float(loss))
+import time
+t0 = time.perf_counter()
+for i in range(20):
+    tr.train_step(x, qmask, umask, label)
+torch.cuda.synchronize()
+print(f"MARN1_onlysp: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms/step (eager)")
