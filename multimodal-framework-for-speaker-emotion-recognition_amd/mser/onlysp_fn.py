@@ -181,16 +181,23 @@ def onlysp_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mod
     def xa_drop(i):
         return drop.site(F_.SITE_XATTN + i, drop.p_xattn[i]) if drop is not None else None
 
-    s_x.wait_stream(cur)
-    with torch.cuda.stream(s_x):
-        c.xa[0] = F_.xattn_fwd(c.x_l, w, c.x_a, v, P("crossatt_l2a.Wq"), P("crossatt_l2a.Wk"), P("crossatt_l2a.Wv"), lay, lay, c.A1, 1,
-                               drop=xa_drop(0))
-        c.xa[2] = F_.xattn_fwd(c.x_a, v, c.A1, v1, P("crossatt_l2a_1.Wq"), P("crossatt_l2a_1.Wk"), P("crossatt_l2a_1.Wv"), lay, lay,
-                               c.Hcat[:, 8 * H:9 * H], 1, drop=xa_drop(2))
-        c.xa[1] = F_.xattn_fwd(c.x_a, v, c.x_l, w, P("crossatt_a2l.Wq"), P("crossatt_a2l.Wk"), P("crossatt_a2l.Wv"), lay, lay, c.A2, 1,
-                               drop=xa_drop(1))
-        c.xa[3] = F_.xattn_fwd(c.x_l, w, c.A2, v2, P("crossatt_a2l_1.Wq"), P("crossatt_a2l_1.Wk"), P("crossatt_a2l_1.Wv"), lay, lay,
-                               c.Hcat[:, 9 * H:10 * H], 1, drop=xa_drop(3))
+    # (eager mode: the HOST needs ~8 us per launch, so the recurrent chains -- the critical path -- are issued first and the 8 launches
+    # of the attention modules behind them; the side stream only waits for the encoders' outputs, through this event)
+    ev_x = torch.cuda.Event()
+    ev_x.record(cur)
+
+    def xattn_branch():
+        s_x.wait_event(ev_x)
+        with torch.cuda.stream(s_x):
+            c.xa[0] = F_.xattn_fwd(c.x_l, w, c.x_a, v, P("crossatt_l2a.Wq"), P("crossatt_l2a.Wk"), P("crossatt_l2a.Wv"), lay, lay, c.A1, 1,
+                                   drop=xa_drop(0))
+            c.xa[2] = F_.xattn_fwd(c.x_a, v, c.A1, v1, P("crossatt_l2a_1.Wq"), P("crossatt_l2a_1.Wk"), P("crossatt_l2a_1.Wv"), lay, lay,
+                                   c.Hcat[:, 8 * H:9 * H], 1, drop=xa_drop(2))
+            c.xa[1] = F_.xattn_fwd(c.x_a, v, c.x_l, w, P("crossatt_a2l.Wq"), P("crossatt_a2l.Wk"), P("crossatt_a2l.Wv"), lay, lay, c.A2, 1,
+                                   drop=xa_drop(1))
+            c.xa[3] = F_.xattn_fwd(c.x_l, w, c.A2, v2, P("crossatt_a2l_1.Wq"), P("crossatt_a2l_1.Wk"), P("crossatt_a2l_1.Wv"), lay, lay,
+                                   c.Hcat[:, 9 * H:10 * H], 1, drop=xa_drop(3))
+
 
     # ---- the two cells: GRU speaker chains, then the LSTHM chains of both directions in one launch
     lens = torch.empty(B, device=dev, dtype=torch.int32)
@@ -236,10 +243,12 @@ def onlysp_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mod
         with torch.cuda.stream(s_g):
             ops.gru_speaker_fwd([g.desc for g in c.gru])             # producer: both directions' chains, one launch, its own stream
         ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD)                 # consumer: follows the producer step by step
+        xattn_branch()
         cur.wait_stream(s_g)
     else:
         ops.gru_speaker_fwd([g.desc for g in c.gru])                 # both directions' chains in one launch
         ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD)
+        xattn_branch()
     cur.wait_stream(s_x)
     if drop is not None and drop.p_rec > 0:
         for i in range(2):
@@ -287,21 +296,27 @@ def onlysp_backward(c: OnlyspCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: O
         # ---- sequence-level attention modules: on a side stream beside the recurrent chains, into accumulators of their own
         cur = torch.cuda.current_stream()
         s_audio, s_x = _Streams.get(dev)[:2]
-        dx_l = torch.zeros(N, D, device=dev) if dx_l_out is None else dx_l_out.reshape(N, D).clone()
-        dx_a = torch.zeros(N, D, device=dev) if dx_a_out is None else dx_a_out.reshape(N, D).clone()
-        dxl_x, dxa_x = torch.zeros(N, D, device=dev), torch.zeros(N, D, device=dev)
-        dA1, dA2 = torch.zeros(N, H, device=dev), torch.zeros(N, H, device=dev)
+        zbuf = torch.zeros(4 * N * D + 2 * N * H, device=dev)          # ONE fill for the six zero-initialised accumulators
+        zd = [zbuf[i * N * D:(i + 1) * N * D].view(N, D) for i in range(4)]
+        dx_l = zd[0] if dx_l_out is None else dx_l_out.reshape(N, D).clone()
+        dx_a = zd[1] if dx_a_out is None else dx_a_out.reshape(N, D).clone()
+        dxl_x, dxa_x = zd[2], zd[3]
+        dA1, dA2 = zbuf[4 * N * D:4 * N * D + N * H].view(N, H), zbuf[4 * N * D + N * H:].view(N, H)
 
         def xb(i, name, dout, dx1, dx2, ga1, ga2):
             F_.xattn_bwd(c.xa[i], dout, P(name + ".Wq"), P(name + ".Wk"), P(name + ".Wv"), G(name + ".Wq"), G(name + ".Wk"),
                          G(name + ".Wv"), dx1, dx2, ga1, ga2)
 
-        s_x.wait_stream(cur)
-        with torch.cuda.stream(s_x):
-            xb(2, "crossatt_l2a_1", dH[:, 8 * H:9 * H], dxa_x, dA1, G("v"), G("v1"))
-            xb(0, "crossatt_l2a", dA1, dxl_x, dxa_x, G("w"), G("v"))
-            xb(3, "crossatt_a2l_1", dH[:, 9 * H:10 * H], dxl_x, dA2, G("w"), G("v2"))
-            xb(1, "crossatt_a2l", dA2, dxa_x, dxl_x, G("v"), G("w"))
+        ev_h = torch.cuda.Event()
+        ev_h.record(cur)                               # dH and the zeroed accumulators are ready
+
+        def xattn_branch():                            # issued BEHIND the BPTT launches (host issue order, as in the forward)
+            s_x.wait_event(ev_h)
+            with torch.cuda.stream(s_x):
+                xb(2, "crossatt_l2a_1", dH[:, 8 * H:9 * H], dxa_x, dA1, G("v"), G("v1"))
+                xb(0, "crossatt_l2a", dA1, dxl_x, dxa_x, G("w"), G("v"))
+                xb(3, "crossatt_a2l_1", dH[:, 9 * H:10 * H], dxl_x, dA2, G("w"), G("v2"))
+                xb(1, "crossatt_a2l", dA2, dxa_x, dxl_x, G("v"), G("w"))
         # ---- LSTHM chains of both directions (ext speaker state), then the GRU chains
         dhq = [torch.empty(N, H, device=dev) for _ in range(2)]
         for r, pre, sl in ((c.cell_dirs[0], "marn_cell_f.", slice(0, 4 * H)), (c.cell_dirs[1], "marn_cell_b.", slice(4 * H, 8 * H))):
@@ -325,10 +340,12 @@ def onlysp_backward(c: OnlyspCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: O
             ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD)            # producer (main stream)
             with torch.cuda.stream(s_g):
                 ops.gru_speaker_bwd([g.desc for g in c.gru])        # consumer: both directions' BPTT, one launch, its own stream
+            xattn_branch()
             ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD_DX | ops.PHASE_LSTHM_WGRAD)
             cur.wait_stream(s_g)
         else:
             ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD)
+            xattn_branch()
             ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD_DX | ops.PHASE_LSTHM_WGRAD | ops.PHASE_SPEAKER_BWD)
             for i in range(2):
                 ops.gru_speaker_set_grads(c.gru[i].desc, dhq[i], dgs[i][0], dgs[i][1])
