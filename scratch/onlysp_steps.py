@@ -21,3 +21,26 @@ for i in range(20):
     tr.train_step(x, qmask, umask, label)
 torch.cuda.synchronize()
 print(f"MARN1_onlysp: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms/step (eager)")
+# hipGraph replay of the same step (under capture the GRU and LSTHM chains run one after the other: the counter links are eager-only)
+if "--graph" in sys.argv:
+    tr.optim.sync_hyperparams()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        tr.forward_backward(x, qmask, umask, label)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        tr.forward_backward(x, qmask, umask, label)
+        tr.optimizer_step(umask, sync_hp=False)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        graph.replay()
+    torch.cuda.synchronize()
+    print(f"MARN1_onlysp: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms/step (hipGraph replay)")
+    from mser import fault
+    fault.check(dev, "onlysp graph replay")
