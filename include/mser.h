@@ -313,7 +313,10 @@ enum { MSER_PHASE_SPEAKER_FWD = 1, MSER_PHASE_LSTHM_FWD = 2, MSER_PHASE_LSTHM_BW
        MSER_PHASE_SEPARATE_SPEAKER = 256,
        /* modifier for FWD_PREP: also do the work of BWD_PREP (zeroed carries, accumulators and BPTT counters), so that ONE backward
         * over this forward may leave BWD_PREP out -- it otherwise sits between the head's backward and the BPTT launch. */
-       MSER_PHASE_PREP_BOTH = 512 };
+       MSER_PHASE_PREP_BOTH = 512,
+       /* the hoisted input products x W^T of the LSTHM streams alone (they need only x_l / x_a, not FWD_PREP: a caller can run the
+        * preparation on another stream beside them); LSTHM_FWD | PRE_DONE then goes straight to the chains. */
+       MSER_PHASE_LSTHM_PRE = 1024, MSER_PHASE_PRE_DONE = 2048 };
 /* Where a linked producer publishes direction `dir`'s speaker rows (hq_rows [T*B, H], inside the workspace) and the counter it
  * advances by per_step after each step (replicas x replica_stride words).  partner_wgs = the workgroups of the producer launch:
  * both kernels must be co-resident for the hand-off to progress.  Returns 1 if the persistent LSTHM launch will be used for these

@@ -208,13 +208,17 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
         # accumulators of the attention branches) is done here, beside the encoders, instead of between the head's backward and the BPTT
         c.zbuf = torch.empty(2 * N * H + 4 * N * D, device=x.device) if prep_backward else None
 
+        LATE_PREP = True           # see below, at the chains' launch (False: the preparation beside the encoders, as in round 1)
+
         def prep_branch():
             with torch.cuda.stream(s_spk):
                 if c.zbuf is not None:
                     c.zbuf.zero_()
-                ops.marn_cell_run(desc, ops.PHASE_FWD_PREP | (ops.PHASE_PREP_BOTH if c.zbuf is not None else 0))   # tables, initial states, counters: off the encoders' stream
+                if not LATE_PREP:
+                    ops.marn_cell_run(desc, ops.PHASE_FWD_PREP | (ops.PHASE_PREP_BOTH if c.zbuf is not None else 0))   # tables, initial states, counters: off the encoders' stream
                 ev_prep.record(s_spk)
-                ops.marn_cell_run(desc, ops.PHASE_SPEAKER_FWD | sep)   # qmask-only chain: overlaps the encoders AND the LSTHM chain
+                if not LATE_PREP:
+                    ops.marn_cell_run(desc, ops.PHASE_SPEAKER_FWD | sep)   # qmask-only chain: overlaps the encoders AND the LSTHM chain
         # (the preparation is issued FIRST although the encoders are the critical path: a hipGraph replay gave a branch forked behind
         # them a queue only after the attention branches -- 3.29 against 3.21 ms per step; it is 6 nodes, ~35 us, since its fills share one launch)
         prep_branch()
@@ -236,7 +240,21 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
         # issued afterwards on two side streams, fill the other CUs.
         # (issuing the attention branches first and the chains behind them measured the same step time: what the chains lose to the
         # branches' traffic in their first ~80 us equals what waiting for the branches would cost)
-        ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD | sep)
+        if LATE_PREP:
+            # the cell's preparation (47 MB of fills: sentinel words of the hand-off arrays, zeroed carries) runs RIGHT IN FRONT of the chains
+            # although it costs ~20 us of the critical path there: done early, beside the encoders, those arrays have left the
+            # infinity cache by the time the chains hand data through them, and every hand-off pays for it (cell-only measurement,
+            # scratch/diag_stamps.py trash: 775 us per forward launch right behind the preparation, 917 us with 1 GB of traffic between;
+            # in the step: 836 against 870 us per forward launch, the step time itself unchanged within the noise)
+            # -- on the side stream, beside the hoisted input products of the LSTHM streams (50 us on this stream)
+            s_spk.wait_event(ev_x)
+            with torch.cuda.stream(s_spk):
+                ops.marn_cell_run(desc, ops.PHASE_FWD_PREP | (ops.PHASE_PREP_BOTH if c.zbuf is not None else 0) | ops.PHASE_SPEAKER_FWD | sep)
+            ops.marn_cell_run(desc, ops.PHASE_LSTHM_PRE)
+            cur.wait_stream(s_spk)
+            ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD | ops.PHASE_PRE_DONE | sep)
+        else:
+            ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD | sep)
         s_xa.wait_event(ev_x)
         s_xb.wait_event(ev_x)
         with torch.cuda.stream(s_xa):

@@ -47,11 +47,31 @@ if len(sys.argv) > 3 and sys.argv[3] == "time":
     from mser import _lib as L_
     lib = L_.load()
     for nm, kid, fn in (("cell_fwd_fused", 2, ops.marn_cell_fwd), ("cell_bwd_fused", 4, ops.marn_cell_bwd)):
-        L_.check(lib.mser_prof_enable(kid, 64), "prof_enable")
-        for _ in range(5):
+        nrep = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+        L_.check(lib.mser_prof_enable(kid, 2 * nrep + 64), "prof_enable")
+        for _ in range(nrep):
             fn(desc)
         torch.cuda.synchronize()
         tot, cnt = ctypes.c_float(0), ctypes.c_int32(0)
         L_.check(lib.mser_prof_collect(ctypes.byref(tot), ctypes.byref(cnt)), "prof_collect")
         lib.mser_prof_enable(0, 0)
         print(f"{nm}: {tot.value * 1e3 / max(cnt.value, 1):.1f} us per launch ({cnt.value} launches), T={T} ndir={NDIR}")
+
+# does the state of the caches matter?  usage: ... <H> <ndir> trash [rev]: preparation, then 1 GB of unrelated traffic, then the chain launch
+if len(sys.argv) > 3 and sys.argv[3] == "trash":
+    import ctypes
+    from mser import _lib as L_
+    lib = L_.load()
+    big = torch.empty(256 * 1024 * 1024, device="cuda")
+    for label, trash in (("prep -> chain", False), ("prep -> 1 GB fill -> chain", True)) * 2:
+        L_.check(lib.mser_prof_enable(2, 256), "prof_enable")
+        for _ in range(20):
+            ops.marn_cell_run(desc, ops.PHASE_FWD_PREP | ops.PHASE_SPEAKER_FWD)
+            if trash:
+                big.fill_(1.0)
+            ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD)
+        torch.cuda.synchronize()
+        tot, cnt = ctypes.c_float(0), ctypes.c_int32(0)
+        L_.check(lib.mser_prof_collect(ctypes.byref(tot), ctypes.byref(cnt)), "prof_collect")
+        lib.mser_prof_enable(0, 0)
+        print(f"cell_fwd_fused, {label}: {tot.value * 1e3 / max(cnt.value, 1):.1f} us per launch ({cnt.value} launches)")
