@@ -26,7 +26,7 @@ def _g(golden_dir, name):
     return np.load(os.path.join(golden_dir, name), allow_pickle=False)
 
 
-def _check_grads(g, named, rel=3e-4):
+def _check_grads(g, named, rel=1e-4):        # (measured worst over the fixed cases and scratch/fuzz_parity.py: 1e-5 of the tensor norm)
     bad = []
     for name, p in named:
         gn = float(g["gnorm/" + name])
