@@ -467,8 +467,9 @@ def main():
         variants["dropout_on"] = {"ms_per_step": round(ms_d, 4), "utterances_per_s": round(B * L / (ms_d * 1e-3), 1),
                                   "note": "all 13 sites live; counter-based masks, re-evaluated in the backward instead of stored; eager launches"}
         # MARN1_onlysp, the reference CLI's default model (GRU speaker state per dialogue), same batch
-        for tag, dp in (("marn1_onlysp", False), ("marn1_onlysp_dropout_on", True)):
-            tro = ModelTrainer(device, lr=1e-3, test_step=1, lr_decay=0.98, model="MARN1_onlysp", loss="NLL", n_classes=NCLS,
+        for tag, mname, dp in (("marn1_onlysp", "MARN1_onlysp", False), ("marn1_onlysp_dropout_on", "MARN1_onlysp", True),
+                               ("marn1_nsps", "MARN1_nsps", False), ("marn1_no_en", "MARN1_no_en", False)):
+            tro = ModelTrainer(device, lr=1e-3, test_step=1, lr_decay=0.98, model=mname, loss="NLL", n_classes=NCLS,
                                dataset="IEMOCAP", d_r=D_R, quiet=True, dropout=dp)
             init_attention_weights(tro.model)
             tro.train()
@@ -480,7 +481,9 @@ def main():
                 tr = tr_main
             del tro
             variants[tag] = {"ms_per_step": round(ms_o2, 4), "utterances_per_s": round(B * L / (ms_o2 * 1e-3), 1),
-                             "note": "GRU speaker chains counter-linked to the LSTHM chains (concurrent launches on two streams); eager launches"}
+                             "note": "SURVEY 8(f) f1; GRU speaker chains" + (" counter-linked to the LSTHM chains (concurrent launches on two streams)"
+                                                                              if mname == "MARN1_onlysp" else " (listener blend), then the LSTHM chains")
+                                     + "; eager launches"}
         # BASELINE.json configs[3]: DialogueRNN-style global / party / listener / emotion GRUs with attention over the growing history
         # (model/DialogueRNN.py BiModel as model_trainer.py:35-47 builds it), B = 64 dialogues x L = 200 utterances, D_m = 712
         trd = ModelTrainer(device, lr=1e-3, test_step=1, lr_decay=0.98, model="DialogueRNN", loss="NLL", n_classes=NCLS,
