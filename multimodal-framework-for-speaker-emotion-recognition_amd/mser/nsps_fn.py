@@ -129,6 +129,19 @@ def nsps_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Model
         e1a, c.enc[2] = F_.encoder_layer_fwd(xa0, None, Pa, lay, d.n_head, d.d_k, d.d_v, drops=enc_drops(2), need_attn=False)
         _, c.enc[3] = F_.encoder_layer_fwd(xa0, e1a, Pa, lay, d.n_head, d.d_k, d.d_v, out=c.x_a, drops=enc_drops(3), need_attn=False)
     ops.linear(c.x2d[:, :d.d_r], P("linear_in.weight"), c.xl0, bias=P("linear_in.bias"))
+    # The speaker chains of this variant read the PRE-encoder features (linear_in's output and the raw audio) and qmask only: they run
+    # on a stream of their own beside the encoders (two 16-dialogue blocks per direction: 4 CUs), complete before the LSTHM chains start.
+    lens = torch.empty(B, device=dev, dtype=torch.int32)
+    c.rev = torch.empty(Ln, B, device=dev, dtype=torch.int32)
+    ops.build_reverse_index(umask, lens, c.rev)
+    s_g = _Streams.get(dev)[2]
+    s_g.wait_stream(cur)
+    c.gru = []
+    with torch.cuda.stream(s_g):
+        for i, (pre, rev) in enumerate((("marn_cell_f.", None), ("marn_cell_b.", c.rev))):
+            site = drop.site(F_.SITE_CELL + 4 * i, drop.p_cell[i]) if drop is not None else None
+            c.gru.append(gru_speaker_dir_fwd(_sub(P, pre), c.xl0, xa0, qmask, rev, None, Ln, B, H, site, launch=False, lblend=True))
+        ops.gru_speaker_fwd([g.desc for g in c.gru])
     if no_en:
         c.x_l = c.xl0                                                   # lsthm_no_en.py:306,:309: no text encoder
     else:
@@ -151,9 +164,6 @@ def nsps_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Model
         _xattn_ln_fwd(c, 1, P, "crossatt_a2l", c.x_a, c.x_l, lay, c.Lb[:, 2 * H:], xa_drop(1))      # attn2 -> l (:352)
 
     # ---- the two cells: GRU speaker chains on the pre-encoder features, then the LSTHM chains of both directions in one launch
-    lens = torch.empty(B, device=dev, dtype=torch.int32)
-    c.rev = torch.empty(Ln, B, device=dev, dtype=torch.int32)
-    ops.build_reverse_index(umask, lens, c.rev)
     c.cell_ws = torch.empty(ops.cell_workspace_bytes(Ln, B, D, H, 2), device=dev, dtype=torch.uint8)
     c.Hc = [torch.empty(N, 4 * H, device=dev), torch.empty(N, 4 * H, device=dev)]
     c.cell_dirs = [
@@ -162,14 +172,10 @@ def nsps_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Model
     ]
     if drop is not None and (any(p_ > 0 for p_ in drop.p_cell) or any(p_ > 0 for p_ in drop.p_cell_attn)):
         c.cell_drop = (drop.rng, [F_.SITE_CELL, F_.SITE_CELL + 4], drop.p_cell, drop.p_cell_attn)
-    c.gru = []
-    for i, (pre, rev) in enumerate((("marn_cell_f.", None), ("marn_cell_b.", c.rev))):
-        site = drop.site(F_.SITE_CELL + 4 * i, drop.p_cell[i]) if drop is not None else None
-        c.gru.append(gru_speaker_dir_fwd(_sub(P, pre), c.xl0, xa0, qmask, rev, None, Ln, B, H, site, launch=False, lblend=True))
     desc = ops.make_cell_desc(Ln, B, D, H, c.x_l, c.x_a, c.cell_dirs, 4 * H, c.cell_ws, drop=c.cell_drop,
                               ext_hq=[g.hs for g in c.gru])
     ops.marn_cell_run(desc, ops.PHASE_FWD_PREP)
-    ops.gru_speaker_fwd([g.desc for g in c.gru])
+    cur.wait_stream(s_g)                                             # the speaker rows h_s are complete
     ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD)
     # h_l / h_a of both directions -> their column blocks of l and a; dropout_rec on each of the four (:317-318,:330-331)
     for i in range(2):
@@ -267,12 +273,16 @@ def nsps_backward(c: NspsCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: Optio
         dgs = [(torch.empty(N, 3 * H, device=dev), torch.empty(N, 3 * H, device=dev)) for _ in range(2)]
         ops.marn_cell_run(desc, ops.PHASE_BWD_PREP | ops.PHASE_LSTHM_BWD)
         ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD_DX | ops.PHASE_LSTHM_WGRAD | ops.PHASE_SPEAKER_BWD)
-        for i in range(2):
-            ops.gru_speaker_set_grads(c.gru[i].desc, dhq[i], dgs[i][0], dgs[i][1])
-        ops.gru_speaker_bwd([g.desc for g in c.gru])
+        # the GRU BPTT feeds only linear_in (through dxl0) and its own parameters: on its own stream beside the encoders' backward
         dxl0 = torch.zeros(N, D, device=dev)              # gradient at linear_in's output through the GRU inputs (x = cat[x_l0 | audio])
-        for i, pre in enumerate(("marn_cell_f.", "marn_cell_b.")):
-            gru_speaker_dir_bwd(c.gru[i], _sub(P, pre), _sub(G, pre), dgs[i][0], dgs[i][1], dxl0, None, Ln, B, H)
+        s_g = _Streams.get(dev)[2]
+        s_g.wait_stream(cur)
+        with torch.cuda.stream(s_g):
+            for i in range(2):
+                ops.gru_speaker_set_grads(c.gru[i].desc, dhq[i], dgs[i][0], dgs[i][1])
+            ops.gru_speaker_bwd([g.desc for g in c.gru])
+            for i, pre in enumerate(("marn_cell_f.", "marn_cell_b.")):
+                gru_speaker_dir_bwd(c.gru[i], _sub(P, pre), _sub(G, pre), dgs[i][0], dgs[i][1], dxl0, None, Ln, B, H)
         # ---- encoders and linear_in
         cur.wait_stream(s_x)
         ops.add_rows(dx_l, dx_l, dxl_x)
@@ -283,10 +293,12 @@ def nsps_backward(c: NspsCtx, P: Getter, G: Getter, dlp: Tensor, dx_l_out: Optio
             d2a = F_.encoder_layer_bwd(c.enc[3], dx_a, Pa, Ga)         # grad of (audio + first pass): flows to both
             F_.encoder_layer_bwd(c.enc[2], d2a, Pa, Ga)                # the raw audio features need no gradient
         if c.no_en:
+            cur.wait_stream(s_g)                                       # dxl0 and the GRU gradient products' operands are complete
             ops.add_rows(dxl0, dxl0, dx_l)
         else:
             d2 = F_.encoder_layer_bwd(c.enc[1], dx_l, Pl, Gl)
             d1 = F_.encoder_layer_bwd(c.enc[0], d2, Pl, Gl)
+            cur.wait_stream(s_g)
             ops.add_rows(dxl0, dxl0, d1)
             ops.add_rows(dxl0, dxl0, d2)
         ops.grad_weight(dxl0, c.x2d[:, :d.d_r], G("linear_in.weight"))
