@@ -263,12 +263,25 @@ __global__ __launch_bounds__(ATT_NT) void drnn_attn_fwd_kernel(int B, int Dg, in
   __syncthreads();
   const float* G = Gh + (long)dir * gh_ds + (long)b * Dg;               // g_s at G + (s + 1) * B * Dg
   const long gs = (long)B * Dg;
-  for (int s = wave; s < t; s += ATT_NT / 64) {
-    const float* g = G + (long)(s + 1) * gs;
-    float a = 0.f;
-    for (int u = lane; u < Dg; u += 64) a = fmaf(x[u], g[u], a);
-    a = wave_sum(a);
-    if (lane == 0) sc[s] = a;
+  // four history rows per wave and trip: their loads are independent and in flight together (one row per trip made the score pass a
+  // chain of t/16 dependent round trips)
+  for (int s = wave * 4; s < t; s += (ATT_NT / 64) * 4) {
+    const float* g0 = G + (long)(s + 1) * gs;
+    const float* g1 = G + (long)(min(s + 1, t - 1) + 1) * gs;
+    const float* g2 = G + (long)(min(s + 2, t - 1) + 1) * gs;
+    const float* g3 = G + (long)(min(s + 3, t - 1) + 1) * gs;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int u = lane; u < Dg; u += 64) {
+      const float xv = x[u];
+      a0 = fmaf(xv, g0[u], a0); a1 = fmaf(xv, g1[u], a1); a2 = fmaf(xv, g2[u], a2); a3 = fmaf(xv, g3[u], a3);
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+    if (lane == 0) {
+      sc[s] = a0;
+      if (s + 1 < t) sc[s + 1] = a1;
+      if (s + 2 < t) sc[s + 2] = a2;
+      if (s + 3 < t) sc[s + 3] = a3;
+    }
   }
   __syncthreads();
   float mx = -INFINITY;
@@ -330,12 +343,23 @@ __global__ __launch_bounds__(ATT_NT) void drnn_attn_bwd_kernel(int B, int Dg, in
   const float* G = Gh + (long)dir * gh_ds + (long)b * Dg;
   float* dG = dGh + (long)dir * gh_ds + (long)b * Dg;
   const long gs = (long)B * Dg;
-  for (int s = wave; s < t; s += ATT_NT / 64) {
-    const float* g = G + (long)(s + 1) * gs;
-    float a = 0.f;
-    for (int u = lane; u < Dg; u += 64) a = fmaf(dcv[u], g[u], a);
-    a = wave_sum(a);
-    if (lane == 0) ds[s] = a;                 // dalpha_s
+  for (int s = wave * 4; s < t; s += (ATT_NT / 64) * 4) {          // (four rows per trip, as in the forward)
+    const float* g0 = G + (long)(s + 1) * gs;
+    const float* g1 = G + (long)(min(s + 1, t - 1) + 1) * gs;
+    const float* g2 = G + (long)(min(s + 2, t - 1) + 1) * gs;
+    const float* g3 = G + (long)(min(s + 3, t - 1) + 1) * gs;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int u = lane; u < Dg; u += 64) {
+      const float dv = dcv[u];
+      a0 = fmaf(dv, g0[u], a0); a1 = fmaf(dv, g1[u], a1); a2 = fmaf(dv, g2[u], a2); a3 = fmaf(dv, g3[u], a3);
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+    if (lane == 0) {                          // dalpha_s
+      ds[s] = a0;
+      if (s + 1 < t) ds[s + 1] = a1;
+      if (s + 2 < t) ds[s + 2] = a2;
+      if (s + 3 < t) ds[s + 3] = a3;
+    }
   }
   __syncthreads();
   float dot = 0.f;
