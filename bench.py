@@ -411,8 +411,9 @@ def main():
 
         def time_steps(batch, n=10, tag=None, graph_ok=True):
             """ms per step of the current trainer `tr` on `batch`: eager launches and, where the step captures (MARN1_sps at any
-            width; the GRU-speaker variants and DialogueRNN run their linked / host-loop schedules eagerly), a hipGraph replay of it,
-            whichever is faster -- the same choice the headline makes."""
+            width, MARN1_nsps / no_en; MARN1_onlysp and DialogueRNN run their linked / host-loop schedules eagerly), a hipGraph replay of it,
+            whichever is faster -- the same choice the headline makes.  (MARN1_onlysp's counter-linked launches are eager-only; the nsps
+            variants' speaker chains run beside the encoders on plain stream dependencies and capture.)"""
             for _ in range(3):
                 tr.train_step(*batch)
             torch.cuda.synchronize()
@@ -422,7 +423,7 @@ def main():
             torch.cuda.synchronize()
             ms_e = (time.perf_counter() - t) / n * 1e3
             ms_g = None
-            if graph_ok and not args.no_graph and type(tr.model).__name__ == "MARN1_sps":
+            if graph_ok and not args.no_graph and type(tr.model).__name__ in ("MARN1_sps", "MARN1_nsps", "MARN1_no_en"):
                 try:
                     tr.optim.sync_hyperparams()
                     side_s = torch.cuda.Stream(device=device)
@@ -510,7 +511,7 @@ def main():
             tro.scheduler.step(0)
             tr_main, tr = tr, tro
             try:
-                ms_o2 = time_steps((x, qmask, umask, label))
+                ms_o2 = time_steps((x, qmask, umask, label), tag=tag)
             finally:
                 tr = tr_main
             del tro
