@@ -316,7 +316,9 @@ enum { MSER_PHASE_SPEAKER_FWD = 1, MSER_PHASE_LSTHM_FWD = 2, MSER_PHASE_LSTHM_BW
        MSER_PHASE_PREP_BOTH = 512,
        /* the hoisted input products x W^T of the LSTHM streams alone (they need only x_l / x_a, not FWD_PREP: a caller can run the
         * preparation on another stream beside them); LSTHM_FWD | PRE_DONE then goes straight to the chains. */
-       MSER_PHASE_LSTHM_PRE = 1024, MSER_PHASE_PRE_DONE = 2048 };
+       MSER_PHASE_LSTHM_PRE = 1024, MSER_PHASE_PRE_DONE = 2048,
+       /* the same, one input stream at a time: the products over x_l / over x_a alone (each can follow its own encoder branch) */
+       MSER_PHASE_LSTHM_PRE_L = 4096, MSER_PHASE_LSTHM_PRE_A = 8192 };
 /* Where a linked producer publishes direction `dir`'s speaker rows (hq_rows [T*B, H], inside the workspace) and the counter it
  * advances by per_step after each step (replicas x replica_stride words).  partner_wgs = the workgroups of the producer launch:
  * both kernels must be co-resident for the hand-off to progress.  Returns 1 if the persistent LSTHM launch will be used for these

@@ -2931,18 +2931,23 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   // x W^T products of both streams and directions are independent: ONE grouped launch (they sit on the critical path right in front
   // of the chain).  MSER_PHASE_LSTHM_PRE runs them alone (they need only x_l / x_a: the caller can overlap MSER_PHASE_FWD_PREP on
   // another stream), MSER_PHASE_LSTHM_FWD | MSER_PHASE_PRE_DONE then skips them.
-  if ((phases & MSER_PHASE_LSTHM_PRE) || ((phases & MSER_PHASE_LSTHM_FWD) && !(phases & MSER_PHASE_PRE_DONE))) {
+  if ((phases & (MSER_PHASE_LSTHM_PRE | MSER_PHASE_LSTHM_PRE_L | MSER_PHASE_LSTHM_PRE_A)) ||
+      ((phases & MSER_PHASE_LSTHM_FWD) && !(phases & MSER_PHASE_PRE_DONE))) {
+    // which streams: PRE_L / PRE_A = the products over x_l / x_a alone (each needs only its own encoder branch), otherwise both
+    const bool only = (phases & (MSER_PHASE_LSTHM_PRE_L | MSER_PHASE_LSTHM_PRE_A)) && !(phases & (MSER_PHASE_LSTHM_PRE | MSER_PHASE_LSTHM_FWD));
+    const bool want[2] = {!only || (phases & MSER_PHASE_LSTHM_PRE_L) != 0, !only || (phases & MSER_PHASE_LSTHM_PRE_A) != 0};
     std::vector<mser_gemm_desc> pg;
     for (int i = 0; i < d.ndir; ++i) {
       DirP& k = K.d[i];
       const float* xs[2] = {d.x_l, d.x_a};
       long lds[2] = {d.ldxl, d.ldxa};
       if (k.rev) {
-        MSER_TRY(mser_reverse_by_length(d.x_l, d.ldxl, k.rev, h.xrev[0], D, T, B, D, s));
-        MSER_TRY(mser_reverse_by_length(d.x_a, d.ldxa, k.rev, h.xrev[1], D, T, B, D, s));
+        if (want[0]) MSER_TRY(mser_reverse_by_length(d.x_l, d.ldxl, k.rev, h.xrev[0], D, T, B, D, s));
+        if (want[1]) MSER_TRY(mser_reverse_by_length(d.x_a, d.ldxa, k.rev, h.xrev[1], D, T, B, D, s));
         xs[0] = h.xrev[0]; xs[1] = h.xrev[1]; lds[0] = lds[1] = D;
       }
       for (int m = 0; m < 2; ++m) {
+        if (!want[m]) continue;
         float* pre = k.pre + (long)m * TB * 4 * H;
         mser_gemm_desc g = gd(xs[m], lds[m], 1, k.W[m], 1, D, pre, 4 * H, (int)TB, 4 * H, D);
         g.bias = k.Wb[m];
@@ -3556,7 +3561,7 @@ int mser_marn_cell_pipelined(int32_t B, int32_t H, int32_t ndir) {
 
 int mser_marn_cell_run(const mser_cell_desc* d, int32_t phases, mser_stream_t stream) {
   if (!d) { set_error("mser_marn_cell_run: null descriptor"); return -1; }
-  if (phases & (MSER_PHASE_FWD_PREP | MSER_PHASE_SPEAKER_FWD | MSER_PHASE_LSTHM_FWD | MSER_PHASE_LSTHM_PRE))
+  if (phases & (MSER_PHASE_FWD_PREP | MSER_PHASE_SPEAKER_FWD | MSER_PHASE_LSTHM_FWD | MSER_PHASE_LSTHM_PRE | MSER_PHASE_LSTHM_PRE_L | MSER_PHASE_LSTHM_PRE_A))
     MSER_TRY(marn_cell_fwd(*d, (hipStream_t)stream, phases));
   if (phases & (MSER_PHASE_BWD_PREP | MSER_PHASE_LSTHM_BWD | MSER_PHASE_LSTHM_BWD_DX | MSER_PHASE_LSTHM_WGRAD | MSER_PHASE_SPEAKER_BWD))
     MSER_TRY(marn_cell_bwd(*d, (hipStream_t)stream, phases));

@@ -228,6 +228,11 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
             text_branch(stage)                                  # the longer branch (linear_in in front) first
             with torch.cuda.stream(s_audio):
                 audio_branch(stage)
+        if LATE_PREP:
+            # the audio stream's hoisted input products follow the audio branch at once (it finishes ~50 us before the text branch, which
+            # has linear_in in front): the critical path in front of the chains then holds the text stream's half of them only
+            with torch.cuda.stream(s_audio):
+                ops.marn_cell_run(desc, ops.PHASE_LSTHM_PRE_A)
         cur.wait_stream(s_audio)                                # x_l and x_a are final
         ev_x = torch.cuda.Event()
         ev_x.record(cur)
@@ -250,7 +255,7 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
             s_spk.wait_event(ev_x)
             with torch.cuda.stream(s_spk):
                 ops.marn_cell_run(desc, ops.PHASE_FWD_PREP | (ops.PHASE_PREP_BOTH if c.zbuf is not None else 0) | ops.PHASE_SPEAKER_FWD | sep)
-            ops.marn_cell_run(desc, ops.PHASE_LSTHM_PRE)
+            ops.marn_cell_run(desc, ops.PHASE_LSTHM_PRE_L)
             cur.wait_stream(s_spk)
             ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD | ops.PHASE_PRE_DONE | sep)
         else:

@@ -779,6 +779,7 @@ def set_option(key: int, value: int) -> None:
 
 PHASE_SPEAKER_FWD, PHASE_LSTHM_FWD, PHASE_LSTHM_BWD, PHASE_SPEAKER_BWD, PHASE_LSTHM_BWD_DX, PHASE_LSTHM_WGRAD = 1, 2, 4, 8, 16, 32
 PHASE_FWD_PREP, PHASE_BWD_PREP, PHASE_SEPARATE_SPEAKER, PHASE_PREP_BOTH, PHASE_LSTHM_PRE, PHASE_PRE_DONE = 64, 128, 256, 512, 1024, 2048
+PHASE_LSTHM_PRE_L, PHASE_LSTHM_PRE_A = 4096, 8192
 
 
 def marn_cell_pipelined(B: int, H: int, ndir: int) -> bool:
