@@ -1972,6 +1972,7 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, cons
     }
   }
 
+  STAMP_ACC(4);
   // element-wise prologue over 32 slots x H units, 4 consecutive units per thread-iteration (16-byte accesses: the phase is
   // bound by vector-memory instruction throughput, not by arithmetic).  All loads of an iteration batch are issued first.
   constexpr int MAXIT = NP > 0 ? 2 : 4;         // groups in flight per batch (persistent kernels: H = 128 has two per thread in all; H = 256 four, and with its 64 weight registers per lane four in flight would spill)
@@ -2022,6 +2023,7 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, cons
         }
       }
     }
+    STAMP_ACC(5);
     if (WITHP && P.bwd_sentinel) {
       // self-validating hand-off from the LSTHM BPTT (no counter in this mode): dHQ[t] and its per-product parts were filled with the
       // sentinel (a NaN) by BWD_PREP, so a sum that is NaN still holds a word that has not been written: re-load until it is not
@@ -2091,6 +2093,7 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, cons
       }
     }
   }
+  STAMP_ACC(6);
   if (Nc == 0 || MODE == 1) return;     // uniform per workgroup
   __syncthreads();
   STAMP_ACC(0);
