@@ -204,6 +204,50 @@ def test_persistent_status_clean(O):
     assert torch.isfinite(out).all()
 
 
+def test_cell_phases_vs_one_call(O):
+    """The schedulable phases of the cell against the single calls mser_marn_cell_fwd / _bwd on the same inputs: preparation that also
+    covers the backward (MSER_PHASE_PREP_BOTH, so that MSER_PHASE_BWD_PREP is left out), the hoisted input products one stream at a time
+    (MSER_PHASE_LSTHM_PRE_A / PRE_L) and the chains with MSER_PHASE_PRE_DONE -- what the model's forward issues on three streams.  The
+    forward outputs must agree bit for bit, the backward's input gradients and in-launch weight gradients to rounding of the
+    order-dependent sums."""
+    from models.lsthm_sps import MARN_cell
+    from mser import ops
+    m = MARN_cell(128, 128, 100, 100).cuda().eval()
+    T, N = 37, 32
+    rs = np.random.RandomState(3)
+    x_l = torch.tensor(rs.standard_normal((T * N, 100)).astype(np.float32)).cuda()
+    x_a = torch.tensor(rs.standard_normal((T * N, 100)).astype(np.float32)).cuda()
+    qmask = torch.tensor(np.eye(2, dtype=np.float32)[rs.randint(0, 2, (T, N))]).cuda()
+    dout = torch.tensor(rs.standard_normal((T * N, 512)).astype(np.float32)).cuda()
+    P = dict(m.named_parameters())
+    res = []
+    for phased in (False, True):
+        G = {k: torch.zeros_like(v) for k, v in P.items()}
+        out = torch.zeros(T * N, 512, device="cuda")
+        ws = torch.zeros(ops.cell_workspace_bytes(T, N, 100, 128, 1), device="cuda", dtype=torch.uint8)
+        dx_l, dx_a = torch.zeros(T * N, 100, device="cuda"), torch.zeros(T * N, 100, device="cuda")
+        dirs = [dict(p=ops.cell_param_struct(lambda n: P[n].detach()), g=ops.cell_param_struct(lambda n: G[n]), qmask=qmask, rev=None,
+                     out=out, dout=dout)]
+        desc = ops.make_cell_desc(T, N, 100, 128, x_l, x_a, dirs, 512, ws, dx_l=dx_l, dx_a=dx_a)
+        if phased:
+            ops.marn_cell_run(desc, ops.PHASE_LSTHM_PRE_A)
+            ops.marn_cell_run(desc, ops.PHASE_LSTHM_PRE_L)
+            ops.marn_cell_run(desc, ops.PHASE_FWD_PREP | ops.PHASE_PREP_BOTH | ops.PHASE_SPEAKER_FWD)
+            ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD | ops.PHASE_PRE_DONE)
+            ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD)                       # no BWD_PREP: the forward's preparation covered it
+            ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD_DX | ops.PHASE_LSTHM_WGRAD | ops.PHASE_SPEAKER_BWD)
+        else:
+            ops.marn_cell_fwd(desc)
+            ops.marn_cell_bwd(desc)
+        ops.marn_cell_status(desc)
+        res.append((out.clone(), dx_l.clone(), dx_a.clone(), {k: v.clone() for k, v in G.items()}))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in ((res[0][1], res[1][1]), (res[0][2], res[1][2])):
+        assert maxabs(a, b) <= 1e-6 * max(1.0, float(a.abs().max()))
+    for k in res[0][3]:
+        assert maxabs(res[0][3][k], res[1][3][k]) <= 1e-6 * max(1e-3, float(res[0][3][k].abs().max())), k
+
+
 def test_trainer_three_steps_vs_reference_golden(O, golden_dir):
     """ModelTrainer.train_network (MaskedLoss + fused flat Adam with L2 decay + closed-form StepLR) against the reference's own
     trainer run with every Dropout p = 0 (tests/golden/make_golden.py::trainer_case): 2 epochs x 3 ragged batches."""
