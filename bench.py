@@ -243,12 +243,20 @@ def main():
             # process makes any GPU call, relay rank 0's JSON line and leave with the children's exit code.
             raise SystemExit(self_launch(args.gpus))
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # MSER_BENCH_REHEARSE=gloo: the N-rank flow of this script on ONE GPU (every rank on device 0, gloo through pinned host staging) -- a
+    # rehearsal of the launch / barrier / reduce / report logic where no multi-GPU box is at hand; its number means nothing.
+    rehearse = os.environ.get("MSER_BENCH_REHEARSE") == "gloo"
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    red_dev = torch.device("cpu") if rehearse else device          # where the script's own small reductions live
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from mser import _lib
     from model_trainer import ModelTrainer
@@ -313,7 +321,7 @@ def main():
             return (time.perf_counter() - t) / n
         t_graph = probe(step)
         t_eager = probe(lambda: tr.train_step(x, qmask, umask, label))
-        flag = torch.tensor([1.0 if t_eager < t_graph else 0.0], device=device)
+        flag = torch.tensor([1.0 if t_eager < t_graph else 0.0], device=red_dev)
         if world > 1:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)        # every rank must take the same path
         if float(flag) > 0:
@@ -331,7 +339,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    ms = torch.tensor([elapsed * 1e3 / args.steps], device=device, dtype=torch.float64)
+    ms = torch.tensor([elapsed * 1e3 / args.steps], device=red_dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(ms, op=dist.ReduceOp.MAX)
     ms_per_step = float(ms)

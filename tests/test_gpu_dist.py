@@ -237,3 +237,23 @@ def test_data_parallel_two_ranks_rccl(O, tmp_path):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (the driver's multi-GPU tier); the one-GPU gloo test above covers the device path")
     _run_two_ranks(O, tmp_path, "nccl")
+
+
+def test_bench_two_rank_flow_rehearsed_on_one_gpu():
+    """`python bench.py --gpus 2` end to end on the one-GPU box: the script starts its two ranks itself (child torch.distributed.run), each
+    rank runs its shard (graph-captured forward + backward, eager pack -> all-reduce -> Adam), the timings are MAX-reduced, rank 0 prints
+    the one JSON line.  MSER_BENCH_REHEARSE=gloo puts both ranks on device 0 and the collective on gloo through pinned host staging; the
+    number is meaningless, the launch / barrier / reduce / report logic is the one the N-GPU run uses."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MSER_BENCH_REHEARSE="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
+                        "--no-variants", "--no-roofline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 2
+    assert line["value"] > 0 and line["config"]["parallelism"] == "dp2" and line["scaling"] == "weak"
