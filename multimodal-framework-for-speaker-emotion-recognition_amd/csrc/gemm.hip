@@ -281,10 +281,11 @@ static int plan(const mser_gemm_desc& d, long group_tiles, Plan& P) {
   if (d.splitk > 1 && d.K > 0) {
     const long all = group_tiles > 0 ? group_tiles * (c1 ? 2 : 1) : tiles;
     long want = (2 * FILL + all - 1) / all;
-    if (group_tiles > 0) {
-      // inside a group no member may become the straggler: at most 16 k-tiles per workgroup (a tiny member that the group-wide
+    if (group_tiles > 0 && tiles < 64) {
+      // inside a group no SMALL member may become the straggler: at most 16 k-tiles per workgroup (a tiny member that the group-wide
       // count left unsplit ran its whole K = B*L reduction in ONE workgroup: 90 us at the end of the step), and many short
-      // workgroups also even out the last round of the grid
+      // workgroups also even out the last round of the grid.  A member of 64 tiles or more spreads over the chip by itself: splitting
+      // it only multiplies its output atomics (hid = 256 / 1024 and DialogueRNN weight gradients: 8 float atomics per output element)
       const long ktiles = cdiv(d.K, BKT);
       const long cap = (ktiles + 15) / 16;
       if (want < cap) want = cap;
