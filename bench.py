@@ -261,6 +261,10 @@ def main():
     from mser import _lib
     from model_trainer import ModelTrainer
     lib = _lib.load()
+    if rehearse and world > 1:
+        # ranks share ONE GPU: their persistent launches (160-208 workgroups each) cannot be co-resident and could hold CUs the other
+        # waits for; the rehearsal is about this script's launch / reduce / report logic, so it runs one launch per step instead
+        lib.mser_set_option(1, 0)          # MSER_OPT_PERSISTENT = 0
 
     torch.manual_seed(0)
     # headline = parity configuration (every Dropout p = 0, SURVEY.md 7 "Dropout"); the train-mode step with the reference's
