@@ -667,7 +667,9 @@ __device__ __forceinline__ void spk_fwd_body(const CellK& P, const DirP& D, cons
       } else {
         zero8(a);
       }
-      if (writer) store8x<PS>(ws, qs + (long)slot * H + k, a);
+      // q_sel is saved for the BPTT / weight gradients: every workgroup of the cell gathers the same rows, each stores the one 8-unit
+      // fragment column that matches its own unit slice (one workgroup storing all of them paced the whole chain at H = 256)
+      if ((k >> 3) == (u0 >> 3)) store8x<PS>(ws, qs + (long)slot * H + k, a);
     } else {
       load8x<PS>(ws, hq_old + (long)slot * H + (k - H), a);
     }
