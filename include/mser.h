@@ -355,13 +355,20 @@ int mser_marn_cell_run(const mser_cell_desc* d, int32_t phases, mser_stream_t st
  * MSER_OPT_FWD_SENTINEL = 1 (default): the persistent forward chains hand their state from workgroup to workgroup through
  * self-validating payload (the state arrays start as a sentinel bit pattern, consumers re-load until their words are final)
  * instead of counter barriers: one store->load trip per seam, no store drain, no atomics.  0: the counter barriers.
- * MSER_OPT_BWD_SENTINEL = 0 (default; 1 = measured without gain): the second seam of the LSTHM BPTT step and the hand-off to the speaker BPTT (carry
- * products, speaker-state gradients in step-indexed arrays) self-validating as well; the first seam keeps its counter barrier.
+ * MSER_OPT_BWD_SENTINEL = 2 (default): both seams of the LSTHM BPTT step (gate gradients -> matvec roles, carry products -> next row
+ * phase) and the hand-off to the speaker BPTT (speaker-state gradients in step-indexed arrays) self-validating as well; the chain's
+ * counter then only advances (the weight-gradient roles and a linked consumer follow it).  1: the first seam keeps its counter
+ * barrier.  0: counter barriers on both seams.
  * MSER_OPT_H256_SPLIT = 1 (default): persistent chains at H = 256 share every dialogue row's rank-1 attention between two workgroups
  * (forward: 128 query units each, backward: 128 keys of the transposed pass each) and K-split the BPTT products; the two dx products
- * then run as GEMMs after the chain (their workgroups are what the K-split needs).  0: one workgroup per row, no K-split. */
+ * then run as GEMMs after the chain (their workgroups are what the K-split needs).  0: one workgroup per row, no K-split.
+ * MSER_OPT_SPK_BWD_KSPLIT = 1 (default): the speaker BPTT roles of the persistent launch split each step's product over its REDUCTION
+ * index (a workgroup owns 16 hidden units of a cell: gate gradients and the dc carry local, partial products summed in a fixed order
+ * by the next step's owner of each column) instead of over its output columns (every workgroup rebuilding the whole gate-gradient
+ * tile).  0: the output-split form. */
 enum { MSER_OPT_PERSISTENT = 1, MSER_OPT_WGRAD_INKERNEL = 2, MSER_OPT_BPTT_KSPLIT = 3, MSER_OPT_XCD_PLACEMENT = 4,
-       MSER_OPT_FWD_STATS_ROLES = 5, MSER_OPT_FWD_SENTINEL = 6, MSER_OPT_BWD_SENTINEL = 7, MSER_OPT_H256_SPLIT = 8 };
+       MSER_OPT_FWD_STATS_ROLES = 5, MSER_OPT_FWD_SENTINEL = 6, MSER_OPT_BWD_SENTINEL = 7, MSER_OPT_H256_SPLIT = 8,
+       MSER_OPT_SPK_BWD_KSPLIT = 9 };
 int mser_set_option(int32_t key, int32_t value);
 /* Synchronises `stream` and reports whether a persistent kernel of the last fwd/bwd call on this workspace gave up at a
  * barrier (bounded spins; returns -2 and a message in that case).  Diagnostic; not needed on the hot path. */

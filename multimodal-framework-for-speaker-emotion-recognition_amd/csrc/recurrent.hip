@@ -56,6 +56,9 @@ struct DirP {
   float *dgates, *dc_carry, *dA, *attacc, *dHQ, *dHQp;   // dHQp[2][T][B][H]: dgates_m @ S_m per step (pipelined mode)
   float *dsg, *Xb, *dhprev, *dcprev;   // Xb[2][B][H]: grad wrt q_{t-1}[b, party_t[b]], ping-pong by step parity
   float* mnext;                        // [T][B]: qmask_t[r][party_{t+1}[r]] (0 at the last step)
+  // speaker BPTT as a reduce-scatter (spk_bwd_role_ks): per-K-slice partial products, ping-pong by step parity
+  float* Xp;                           // [2][H/16 slices][H/16 column groups][B][16]: partials of X_t (dialogue-row indexed)
+  float* dhp;                          // [2][2 cells][H/16][H/16][B][16]: partials of dgates W_hh (slot indexed)
   // in-kernel weight-gradient roles (cell_bwd_fused): LSTHM input rows in direction time order and the gradient tensors
   const float* xw[2]; long ldxw[2];
   float *gW[2], *gU[2], *gV[2], *gS[2], *gWih[2], *gWhh[2];
@@ -85,6 +88,7 @@ struct CellK {
   int nodx;            // BPTT launch without the two dx = dgates W products (they run as GEMMs after the chain; frees their workgroups)
   int fwd_rowsplit, bwd_rowsplit;   // persistent chains at H = 256: a dialogue row's rank-1 attention is shared by this many workgroups
                        // (forward: 128 query units each; backward: 128 keys of the transposed pass each); 1 or 2
+  int spk_ks;          // speaker BPTT roles in the K-split (reduce-scatter) form (MSER_OPT_SPK_BWD_KSPLIT)
   int ksplit;          // BPTT matvec phase: every product's K = 4H reduction is split over `ksplit` workgroups (1 or 2); the
                        // partial results live in consecutive copies of dA / dHQp / dxc and the consumers add them
   DirP d[2];
@@ -467,12 +471,14 @@ __device__ __forceinline__ void wg_mm32(int K, ALoad aload, BLoad bload, const f
         for (int p = 0; p < NP; ++p)
           if (kbeg + p * 16 < kend) aload(r, kbeg + p * 16 + half * 8, a[p]);
       }
+      STAMP_ACC(4);
     }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][j], bpre[p][j], acc, 0, 0, 0);
     }
+    if (poll_abortw) STAMP_ACC(5);
   } else {
     for (int kb = kbeg; kb < kend; kb += 16) {
       float a[8], b[8];
@@ -1322,18 +1328,25 @@ __device__ __forceinline__ void lsthm_fwd_role(const CellK& P, const Role R, flo
 // can be fetched while the inter-workgroup barrier of the previous phase is still in flight (threads tid < H hold unit tid).
 struct RowPre {
   float cav, clv, dz_out, zi, dh_out[2], gsv[2][4], cprev[2], carry[2], dhq;
+  float4 st;           // the row's softmax statistics saved by the forward (rstat: Z, N2, N3, s)
 };
-__device__ __forceinline__ RowPre lsthm_bwd_row_prefetch(const CellK& P, const DirP& D, int t, int b) {
+// known / tau_known: the natural time position of (t, b) when the caller has fetched it already (persistent roles, a step ahead: a
+// table lookup here would be a DEPENDENT load, and waiting for it means waiting for every older vector-memory operation of the wave:
+// loads and stores share one in-order counter on gfx9).
+__device__ __forceinline__ int lsthm_tau(const DirP& D, int t, int b, int B) { return D.rev ? D.rev[(long)t * B + b] : t; }
+__device__ __forceinline__ RowPre lsthm_bwd_row_prefetch(const CellK& P, const DirP& D, int t, int b, bool known = false, int tau_known = 0) {
   RowPre r;
   const int H = P.H, B = P.B, T = P.T;
   const int i = threadIdx.x;
   r.cav = r.clv = r.dz_out = r.zi = r.dhq = 0.f;
+  r.st = make_float4(1.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int m = 0; m < 2; ++m) { r.dh_out[m] = r.cprev[m] = r.carry[m] = 0.f; r.gsv[m][0] = r.gsv[m][1] = r.gsv[m][2] = r.gsv[m][3] = 0.f; }
   if (i < H) {
     const long rowt = (long)t * B + b;
+    r.st = *reinterpret_cast<const float4*>(D.rstat + (rowt * H + i) * 4);
     const long SA = (long)B * H;
-    const int tau = D.rev ? D.rev[rowt] : t;
+    const int tau = known ? tau_known : lsthm_tau(D, t, b, B);
     const float* dorow = (tau >= 0) ? D.dout + ((long)tau * B + b) * P.ldo : nullptr;
     r.clv = D.cstate[((long)0 * (T + 1) + t + 1) * B * H + (long)b * H + i];
     r.cav = D.cstate[((long)1 * (T + 1) + t + 1) * B * H + (long)b * H + i];
@@ -1428,9 +1441,11 @@ __device__ __forceinline__ RowMid lsthm_bwd_row_part1_saved(const CellK& P, cons
                                                             const RowPre& pre) {
   const int H = P.H;
   float* ca = scr;  float* cl = ca + H;  float* cw = cl + H;
-  const int tid = threadIdx.x, i = tid & (H - 1);
-  const float4 st = *reinterpret_cast<const float4*>(D.rstat + (((long)t * P.B + b) * H + i) * 4);
-  const float cli = D.cstate[((long)0 * (P.T + 1) + t + 1) * P.B * H + (long)b * H + i];
+  // (the statistics and c_l come with `pre`, fetched two steps ahead: with self-validating hand-offs nothing hides a load here;
+  //  only threads tid < H -- chunk q = 0 -- use the result)
+  const int tid = threadIdx.x;
+  const float4 st = pre.st;
+  const float cli = pre.clv;
   if (tid < H) {
     const float cv = pre.cav;
     ca[tid] = cv; cl[tid] = pre.clv; cw[tid] = cv * att[tid];
@@ -1446,9 +1461,11 @@ __device__ __forceinline__ RowMid lsthm_bwd_row_part1_saved(const CellK& P, cons
 // RS = 2 (H = 256, persistent chain): two workgroups share the row.  Both rebuild the coefficients of all H units (element-wise), each
 // runs the transposed pass for its 128 keys j0 .. j0 + 127 (thread (tid % 128, tid / 128): H / 4 units per thread instead of H / 2)
 // and finishes the gate backward of those units; JCT is then the per-thread unit count of that mapping.
+// attreg (persistent roles): the row's dWq / dWk contributions of this thread's unit accumulate in two registers over the whole sequence
+// (the same thread owns the same (row, unit) every step) instead of a global read-modify-write per step, whose load sat on the chain.
 template <bool PS, int JCT, bool SV = false, int RS = 1>
 __device__ __forceinline__ void lsthm_bwd_row_part2(const CellK& P, const DirP& D, const WS& ws, int t, int b, const float* att, float* scr,
-                                                    const RowPre& pre, const RowMid& mid, float* carry, int slice = 0) {
+                                                    const RowPre& pre, const RowMid& mid, float* carry, int slice = 0, float* attreg = nullptr) {
   const int H = P.H, B = P.B, T = P.T;
   const int JW = H / RS;                          // keys of the transposed pass handled by this workgroup
   const int Q = NT / JW, JC = JCT ? JCT : H / Q;
@@ -1549,9 +1566,14 @@ __device__ __forceinline__ void lsthm_bwd_row_part2(const CellK& P, const DirP& 
     }
     const int j = i;                         // (RS = 2: i == tid, the key this thread just collected)
     const float dca_att = S1 + ds * wq[j] * rsH;
-    float* acc = D.attacc + (long)b * 2 * H;
-    acc[j] += ds * ca[j] * rsH;                  // dWq[j]
-    acc[H + j] += ca[j] * S2 - S3;               // dWk[j]
+    if (attreg) {
+      attreg[0] += ds * ca[j] * rsH;             // dWq[j]
+      attreg[1] += ca[j] * S2 - S3;              // dWk[j]
+    } else {
+      float* acc = D.attacc + (long)b * 2 * H;
+      acc[j] += ds * ca[j] * rsH;
+      acc[H + j] += ca[j] * S2 - S3;
+    }
     // ---- gate backward, both streams (unit i == j)
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -1567,7 +1589,7 @@ __device__ __forceinline__ void lsthm_bwd_row_part2(const CellK& P, const DirP& 
       stx<PS>(ws, dg + 2 * H, dh * tc * go * (1.f - go));
       stx<PS>(ws, dg + 3 * H, dc * gi * (1.f - gc * gc));
       carry[m] = dc * gf;
-      D.dc_carry[(long)m * SA + (long)b * H + i] = dc * gf;
+      if (!attreg) D.dc_carry[(long)m * SA + (long)b * H + i] = dc * gf;       // (persistent roles: the carry lives in `carry`)
     }
     stx<PS>(ws, D.dHQ + rowt * H + i, dhq);
   }
@@ -1580,6 +1602,17 @@ __device__ __forceinline__ void lsthm_bwd_row_body(const CellK& P, const DirP& D
   const RowMid mid = lsthm_bwd_row_part1<JCT>(P, D, t, b, att, scr, pre);
   float carry[2] = {pre.carry[0], pre.carry[1]};
   lsthm_bwd_row_part2<PS, JCT>(P, D, ws, t, b, att, scr, pre, mid, carry);
+}
+
+// end of a persistent BPTT role: the attention-vector gradients this thread accumulated for (row, unit tid) join attacc (one owner per
+// element: with two workgroups per row each owns the keys of its slice)
+__device__ __forceinline__ void lsthm_bwd_flush_att(const CellK& P, const DirP& D, bool has_row, bool rs2, int rowb, int w, const float* attreg) {
+  const int H = P.H, tid = threadIdx.x;
+  if (!has_row || tid >= H) return;
+  if (rs2 && (tid / (H / 2)) != (w & 1)) return;
+  float* acc = D.attacc + (long)rowb * 2 * H;
+  acc[tid] += attreg[0];
+  acc[H + tid] += attreg[1];
 }
 
 // Matvec phase, role (product p, output slice n0..n0+31, row block mb):
@@ -1616,6 +1649,12 @@ __device__ __forceinline__ void lsthm_bwd_mat_body(const CellK& P, const DirP& D
     load8x<PS>(ws, dg + (long)b * 4 * H + k, a);
   };
   const int ldw = p >= 6 ? P.D : H;
+  int taue[1024 / NT];           // dx rows: natural time positions, requested before the product (not a dependent load behind it)
+#pragma unroll
+  for (int e = 0; e < 1024 / NT; ++e) {
+    const int b = mb * 32 + ((threadIdx.x + e * NT) >> 5);
+    taue[e] = (p >= 6 && b < B) ? lsthm_tau(D, t, b, B) : -1;
+  }
   wg_mm32<NP>(KH, aload, LsthmBwdB{Wp + (long)koff * ldw, n0, ldw, ldw}, bpre, red, tile, false, SV ? P.sync + SYNC_ABORT : nullptr);
 #pragma unroll
   for (int e = 0; e < 1024 / NT; ++e) {
@@ -1624,7 +1663,7 @@ __device__ __forceinline__ void lsthm_bwd_mat_body(const CellK& P, const DirP& D
     const int b = mb * 32 + rr;
     if (b < B) {
       if (p >= 6) {              // dx of this direction at the natural time position (consumed after the launch: plain store)
-        const int tau = D.rev ? D.rev[(long)t * B + b] : t;
+        const int tau = taue[e];
         if (tau >= 0 && n0 + n < P.D) D.dxc[(((long)kh * 2 + m) * T * B + (long)tau * B + b) * P.D + n0 + n] = tile[idx];
       } else {
         float* dst = p < 4 ? D.dA + ((((long)t * 2 + kh) * 4 + p) * B + b) * H : D.dHQp + ((((long)kh * 2 + m) * T + t) * B + b) * H;
@@ -1799,12 +1838,14 @@ __device__ __forceinline__ void lsthm_bwd_role_sv(const CellK& P, const Role R, 
   const int rowb = has_row ? (rs2 ? w >> 1 : w) : 0;
   RowPre pre = lsthm_bwd_row_prefetch(P, D, P.T - 1, rowb);
   RowPre pre_n = lsthm_bwd_row_prefetch(P, D, P.T > 1 ? P.T - 2 : 0, rowb);
+  int tau_pp = lsthm_tau(D, P.T > 3 ? P.T - 3 : 0, rowb, P.B);      // natural time position of step t - 2, fetched a step before its use
   RowMid mid = lsthm_bwd_row_part1_saved(P, D, P.T - 1, rowb, att, red, pre);
   float carry[2] = {0.f, 0.f};
+  float attreg[2] = {0.f, 0.f};
   for (int t = P.T - 1; t >= 0; --t) {
     if (has_row) {
-      if (rs2) lsthm_bwd_row_part2<true, JCB / 2, true, 2>(P, D, ws, t, rowb, att, red, pre, mid, carry, w & 1);
-      else lsthm_bwd_row_part2<true, JCB, true>(P, D, ws, t, w, att, red, pre, mid, carry);
+      if (rs2) lsthm_bwd_row_part2<true, JCB / 2, true, 2>(P, D, ws, t, rowb, att, red, pre, mid, carry, w & 1, attreg);
+      else lsthm_bwd_row_part2<true, JCB, true>(P, D, ws, t, w, att, red, pre, mid, carry, 0, attreg);
     }
     for (int b = w + (int)nwg; b < (rs2 ? 0 : P.B); b += (int)nwg) {
       const RowPre pr = lsthm_bwd_row_prefetch(P, D, t, b);
@@ -1814,24 +1855,51 @@ __device__ __forceinline__ void lsthm_bwd_role_sv(const CellK& P, const Role R, 
     }
     if (s_poll_abort) return;                    // (read behind part2's closing workgroup barrier: uniform)
     STAMP_ACC(0);
+    // Where the saved state of step t-2 is requested matters: the wave's vector-memory operations retire in order, so whatever waits
+    // next also waits for these loads (HBM latency).  Right behind the arrive nothing is outstanding (its drain), and the next wait is
+    // the matvec phase's for the OTHER workgroups' gate gradients, which is longer than the loads take: hidden.  Requested behind the
+    // matvec phase instead they stood in front of the carry poll of the next row phase (measured: 1.2 us per step).
+    auto rotate = [&]() {
+      if (t == 0) return;
+      asm volatile("" : "+v"(tau_pp));           // the table word fetched a step ago is consumed here, where waiting for it is free
+      pre = pre_n;
+      if (t > 1) pre_n = lsthm_bwd_row_prefetch(P, D, t - 2, rowb, true, tau_pp);
+      tau_pp = lsthm_tau(D, t > 3 ? t - 3 : 0, rowb, P.B);
+    };
     // seam 1 (gate gradients -> matvec roles) keeps its counter barrier: every matvec workgroup reads a 32 KB slab of dgates[t];
     // polling a payload of that size from 128 workgroups at once costs more fabric traffic than the barrier's bookkeeping saves
     // (measured: 1379 us per launch with both seams self-validating against 1341 with both on the counter)
     nbar += P.ext_spk ? 2u : 1u;
-    if (!dir_barrier(cnt, P.sync + SYNC_ABORT, nwg * (nbar - (P.ext_spk ? 1u : 0u)), lds_ok)) return;
-    STAMP_ACC(1);
-    if (has_mat && (t > 0 || p >= 4)) lsthm_bwd_mat_body<true, NPM, false>(P, D, ws, t, p, n0, mb, bpre, red, tile, kh, KSPLIT);
+    if (P.bwd_sentinel == 2) {
+      // both seams self-validating: the counter only advances (the weight-gradient roles and a linked consumer follow it); the
+      // drain of this workgroup's own stores overlaps the wait for everybody else's inside the matvec phase's validated A loads
+      barrier_arrive(cnt);
+      STAMP_ACC(1);
+      rotate();
+      if (has_mat && (t > 0 || p >= 4)) lsthm_bwd_mat_body<true, NPM, true>(P, D, ws, t, p, n0, mb, bpre, red, tile, kh, KSPLIT);
+      if (s_poll_abort) return;                  // (read behind the product's workgroup barriers: uniform)
+    } else {
+      if (!dir_barrier(cnt, P.sync + SYNC_ABORT, nwg * (nbar - (P.ext_spk ? 1u : 0u)), lds_ok)) return;
+      STAMP_ACC(1);
+      rotate();
+      if (has_mat && (t > 0 || p >= 4)) lsthm_bwd_mat_body<true, NPM, false>(P, D, ws, t, p, n0, mb, bpre, red, tile, kh, KSPLIT);
+    }
     STAMP_ACC(2);
-    // seam 2 (carry products -> row phase of step t-1: 8 floats per unit) is self-validating: no arrive, no wait.  With an external
-    // speaker state the counter still advances (a linked consumer of the caller waits for "dHQp[t] published")
-    if (P.ext_spk) barrier_arrive(cnt);
-    if (t > 0) {
-      pre = pre_n;
-      if (t > 1) pre_n = lsthm_bwd_row_prefetch(P, D, t - 2, rowb);
+    // seam 2 (carry products -> row phase of step t-1: 8 floats per unit) is self-validating: no arrive, no wait.
+    // With an external speaker state a linked consumer of the caller follows the COUNTER ("2 nwg (T - t) arrivals = dHQ[t] and its
+    // parts are published").  That reading is only sound if no workgroup adds an arrival of step t-1 before every workgroup has added
+    // both of step t -- and nothing else orders the workgroups that form dgates_m S_m (nobody in the chain consumes their tiles):
+    // so this seam stays a full counter barrier there (the next step's preparation runs in its shadow).
+    if (P.ext_spk) {
+      barrier_arrive(cnt);
+      if (t > 0) mid = lsthm_bwd_row_part1_saved(P, D, t - 1, rowb, att, red, pre);
+      if (!barrier_wait(cnt, P.sync + SYNC_ABORT, nwg * nbar, lds_ok)) return;
+    } else if (t > 0) {
       mid = lsthm_bwd_row_part1_saved(P, D, t - 1, rowb, att, red, pre);
     }
     STAMP_ACC(3);
   }
+  lsthm_bwd_flush_att(P, D, has_row, rs2, rowb, w, attreg);
   STAMP_DUMP(P, 32, R.x == 1 && R.z == 0);
 }
 
@@ -1875,12 +1943,14 @@ __device__ __forceinline__ void lsthm_bwd_role(const CellK& P, const Role R, flo
   const int rowb = has_row ? (rs2 ? w >> 1 : w) : 0;
   RowPre pre = lsthm_bwd_row_prefetch(P, D, P.T - 1, rowb);
   RowPre pre_n = lsthm_bwd_row_prefetch(P, D, P.T > 1 ? P.T - 2 : 0, rowb);
+  int tau_pp = lsthm_tau(D, P.T > 3 ? P.T - 3 : 0, rowb, P.B);      // natural time position of step t - 2, fetched a step before its use
   RowMid mid = lsthm_bwd_row_part1_saved(P, D, P.T - 1, rowb, att, red, pre);
   float carry[2] = {0.f, 0.f};
+  float attreg[2] = {0.f, 0.f};
   for (int t = P.T - 1; t >= 0; --t) {
     if (has_row) {
-      if (rs2) lsthm_bwd_row_part2<true, JCB / 2, false, 2>(P, D, ws, t, rowb, att, red, pre, mid, carry, w & 1);
-      else lsthm_bwd_row_part2<true, JCB>(P, D, ws, t, w, att, red, pre, mid, carry);
+      if (rs2) lsthm_bwd_row_part2<true, JCB / 2, false, 2>(P, D, ws, t, rowb, att, red, pre, mid, carry, w & 1, attreg);
+      else lsthm_bwd_row_part2<true, JCB>(P, D, ws, t, w, att, red, pre, mid, carry, 0, attreg);
     }
     for (int b = w + (int)nwg; b < (rs2 ? 0 : P.B); b += (int)nwg)
       lsthm_bwd_row_body<true, JCB>(P, D, ws, t, b, att, red, lsthm_bwd_row_prefetch(P, D, t, b));
@@ -1895,12 +1965,14 @@ __device__ __forceinline__ void lsthm_bwd_role(const CellK& P, const Role R, flo
     ++nbar;
     if (t > 0) {
       pre = pre_n;
-      if (t > 1) pre_n = lsthm_bwd_row_prefetch(P, D, t - 2, rowb);
+      if (t > 1) pre_n = lsthm_bwd_row_prefetch(P, D, t - 2, rowb, true, tau_pp);
+      tau_pp = lsthm_tau(D, t > 3 ? t - 3 : 0, rowb, P.B);
       mid = lsthm_bwd_row_part1_saved(P, D, t - 1, rowb, att, red, pre);
       if (!barrier_wait(cnt, P.sync + SYNC_ABORT, nwg * nbar, lds_ok)) return;
     }
     STAMP_ACC(3);
   }
+  lsthm_bwd_flush_att(P, D, has_row, rs2, rowb, w, attreg);
   STAMP_DUMP(P, 32, R.x == 1 && R.z == 0);
 }
 
@@ -2189,6 +2261,268 @@ __device__ __forceinline__ void spk_bwd_role(const CellK& P, const Role R, float
   STAMP_DUMP(P, 48, R.x == 2 && R.y == 1 && R.z == 0);
 }
 
+// ---- speaker BPTT as a reduce-scatter (MSER_OPT_SPK_BWD_KSPLIT, persistent launch only) -------------------------------------------
+// spk_bwd_role above splits the step's product over its OUTPUT columns: every one of a cell's 2 H/32 workgroups needs the cell's
+// whole 32 x 4H gate-gradient tile as its A operand and therefore rebuilds it from 245 KB (H = 128) of write-through loads per step --
+// an all-gather, ~1 GB per launch of redundant traffic and the pacing phase of the launch (5.4 of 9.8 us per step).
+// Here a workgroup owns SPK_UW = 16 hidden units of one cell for all 32 slots of its block, i.e. a K-slice of 64 gate columns:
+//   * everything element-wise about those units is local: the dc carry never leaves its register (thread = (slot, unit) in every
+//     step), gates / tanh c / c_prev are this thread's own six saved values (fetched a step ahead);
+//   * the product is [32 x 64] . [64 x 2H] = the K-slice's CONTRIBUTION to every column of dgates W_ih and dgates W_hh: one 32 x 32
+//     output tile per wave (two at H = 256, sharing the A fragments), K = 64 entirely inside the wave -- no cross-wave reduction;
+//   * the H/16 partial tiles of a column meet at the NEXT step's owner of that column, which adds them in a fixed order
+//     (deterministic): 16 KB + 16 KB of partials and 6-10 KB of the LSTHM chain's dHQ parts per workgroup and step instead of 245 KB.
+//     Layout of a partial array: [producer slice w][column group n/16][row][16], so a consumer reads 2 KB contiguous per producer.
+// Still ONE seam per step (the counter barrier of the speaker group, which the weight-gradient roles follow as before).  The terms
+// that bypass the product -- dh_0 = (1 - mnext) X_{t+1} into X_t (:204-207, h_0 branch) and the identity of a skipped cell (:180 /
+// :185) -- are added by the owner of the column to its own partial (it is the one workgroup that holds them).
+constexpr int SPK_UW = 16;
+struct SpkKsPre { int N0, b; float mn, g4[4], tc, co; };
+// thread (slot = tid / 16, unit = u0 + tid % 16) of step t: index tables and the unit's saved forward state
+// (N0 = n0[t] is passed in: the role fetches it one step earlier still, so that no address here waits for a load)
+__device__ __forceinline__ SpkKsPre spk_ks_prefetch(const CellK& P, const DirP& D, int t, int N0, int c, int mb, int u0) {
+  SpkKsPre r;
+  const int H = P.H, B = P.B, T = P.T;
+  const long SB = (long)B * H;
+  const int slot = mb * 32 + (threadIdx.x >> 4), u = u0 + (threadIdx.x & 15);
+  r.N0 = N0;
+  const int Nc = c ? B - r.N0 : r.N0, off = c ? r.N0 : 0;
+  r.b = -1; r.mn = 0.f; r.tc = 0.f; r.co = 0.f;
+  r.g4[0] = r.g4[1] = r.g4[2] = r.g4[3] = 0.f;
+  if (slot < Nc) {
+    r.b = D.perm[(long)t * B + off + slot];
+    r.mn = D.mnext[(long)t * B + off + slot];          // (0 at the last step)
+  }
+  if (slot < B && Nc != 0) {
+    const float* g0 = D.sgates + ((long)c * T + t) * B * 4 * H + (long)slot * 4 * H + u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.g4[k] = g0[k * H];
+    r.tc = D.tcq[((long)c * T + t) * SB + (long)slot * H + u];
+    r.co = D.cq_state[((long)c * (T + 1) + t) * SB + (long)slot * H + u];
+  }
+  return r;
+}
+
+// LDS (floats): pa[4][32][16] | px[4][32][16] | dsg_s[32][68] | xs[32][16] | hs[32][16] | rowb[32] (int) | lds_ok
+__host__ __device__ __forceinline__ size_t spk_ks_lds_floats() { return 2 * 2048 + 32 * 68 + 2 * 512 + 32 + 16; }
+
+template <int NPS>       // NPS = H / 32
+__device__ __forceinline__ void spk_bwd_role_ks(const CellK& P, const Role R, float* smem, const WS& ws, unsigned nwg_l) {
+  constexpr int H = 32 * NPS, NSL = H / SPK_UW, NG = H / 16, PW = NSL / 4, NTW = 2 * NPS / NW, LDA = 68;
+  static_assert(NTW == 1 || NTW == 2, "speaker BPTT K-split: H = 128 or 256");
+  float* pa = smem;
+  float* px = pa + 2048;
+  float* dsg_s = px + 2048;
+  float* xs = dsg_s + 32 * LDA;
+  float* hs = xs + 512;
+  int* rowb = (int*)(hs + 512);
+  int* lds_ok = rowb + 32;
+  const int B = P.B, T = P.T;
+  const long SB = (long)B * H;
+  const int dir = R.z / P.nmb, mb = R.z % P.nmb;
+  const DirP& D = P.d[dir];
+  const int lin = R.y * R.gx + R.x;                    // 0 .. H/8 - 1: (cell, K-slice)
+  const int c = lin / NSL, w = lin % NSL, u0 = w * SPK_UW;
+  const unsigned nwg = R.gx * R.gy * P.nmb;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  drop_init(P, D);
+  // ---- this wave's output tiles: NTW == 1: waves 0..NPS-1 -> W_ih column tiles, NPS..2NPS-1 -> W_hh; NTW == 2: tile 0 = W_ih, 1 = W_hh
+  int tkind[NTW], tnt[NTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    tkind[i] = NTW == 1 ? wave / NPS : i;
+    tnt[i] = NTW == 1 ? wave % NPS : wave;
+  }
+  // B fragments: k = gate p (0..3) x unit (half * 8 + j) of the slice; element W[(p H + u0 + half 8 + j)][32 nt + r]
+  float bpre[NTW][4][8];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    const float* Wp = tkind[i] ? D.Whh[c] : D.Wih[c];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bpre[i][p][j] = Wp[(long)(p * H + u0 + half * 8 + j) * H + 32 * tnt[i] + r];
+  }
+  unsigned* cnt = P.sync + SYNC_SPK_BWD + dir * SYNC_DIR;
+  const unsigned* lcnt = P.sync + SYNC_LSTHM_BWD + dir * SYNC_DIR;
+  unsigned nbar = 0;
+  const bool sv = P.bwd_sentinel != 0;          // the LSTHM BPTT publishes no counter: dHQ[t] / dHQp[t] validate themselves (see is_sent)
+  if (threadIdx.x == 0) s_poll_abort = 0;
+  if (!sv && !dir_barrier(nullptr, P.sync + SYNC_ABORT, 0, lds_ok, lcnt, 2u * nwg_l)) return;          // dHQ[T-1] complete
+  STAMP_INIT();
+  // phase-1 coordinates: thread (g = tid / 128, slot = (tid / 4) % 32, unit quad): g takes the producers w' = g, g + 4, ...
+  const int g1 = tid >> 7, sl1 = (tid >> 2) & 31, q4 = (tid & 3) * 4;
+  const int slot1 = mb * 32 + sl1;
+  // phase-2 coordinates: thread (slot = tid / 16, unit)
+  const int sl2 = tid >> 4, uu = tid & 15;
+  const int slot2 = mb * 32 + sl2;
+  const int nparts = 1 + 2 * P.ksplit;                 // dHQ (output quarter) + the per-product parts dgates_m S_m
+  float dc_reg = 0.f;                                  // dc carry of (slot2, u0 + uu): in a register for the whole sequence
+  SpkKsPre pre = spk_ks_prefetch(P, D, T - 1, D.n0[T - 1], c, mb, u0);
+  int n0_next = D.n0[T > 1 ? T - 2 : 0];               // n0[t - 1], fetched two steps ahead of its use as an address
+  for (int t = T - 1; t >= 0; --t) {
+    const bool last = (t == T - 1);
+    const int cur = t & 1, nxt = cur ^ 1;
+    const int N0 = pre.N0;
+    const int Nc = c ? B - N0 : N0, off = c ? N0 : 0;
+    const float* dhp_n = D.dhp + ((long)nxt * 2 + c) * NSL * SB;
+    const float* Xp_n = D.Xp + (long)nxt * NSL * SB;
+    float* dhp_c = D.dhp + ((long)cur * 2 + c) * NSL * SB;
+    float* Xp_c = D.Xp + (long)cur * NSL * SB;
+    // ---- phase 1: this workgroup's 16 columns of the previous step's partial products and of dHQ[t], 16-byte loads, all issued first
+    float4 va[PW], vx[PW], vh[2];
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < PW; ++k) va[k] = vx[k] = z4;
+    vh[0] = vh[1] = z4;
+    if (slot1 < B) {
+      if (!last) {
+#pragma unroll
+        for (int k = 0; k < PW; ++k) va[k] = ld4x<true>(ws, dhp_n + (((long)(g1 + 4 * k) * NG + w) * B + slot1) * 16 + q4);
+      }
+      if (slot1 < Nc) {
+        const int r1 = off + slot1;
+        if (!last) {
+#pragma unroll
+          for (int k = 0; k < PW; ++k) vx[k] = ld4x<true>(ws, Xp_n + (((long)(g1 + 4 * k) * NG + w) * B + r1) * 16 + q4);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int a = g1 + 4 * k;
+          if (a < nparts) {
+            const float* src = a == 0 ? D.dHQ + ((long)t * B + r1) * H : D.dHQp + (((long)(a - 1) * T + t) * B + r1) * H;
+            vh[k] = ld4x<true>(ws, src + u0 + q4);
+          }
+        }
+      }
+    }
+    // the next step's tables and saved state: younger than the loads above, consumed a step later
+    const SpkKsPre nxtp = spk_ks_prefetch(P, D, t > 0 ? t - 1 : 0, n0_next, c, mb, u0);
+    n0_next = D.n0[t > 1 ? t - 2 : 0];
+    if (sv) {                // self-validating hand-off from the LSTHM BPTT: BWD_PREP filled dHQ / dHQp with the sentinel; re-load until final
+      const bool mine = slot1 < B && slot1 < Nc;
+      auto bad4 = [](float4 v) { return is_sent(v.x) || is_sent(v.y) || is_sent(v.z) || is_sent(v.w); };
+      unsigned spins = 0;
+      while (__builtin_amdgcn_ballot_w64(mine && (bad4(vh[0]) || bad4(vh[1]))) != 0ull) {
+        if (poll_giveup(spins, P.sync + SYNC_ABORT)) break;
+        if (mine) {
+          const int r1 = off + slot1;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int a = g1 + 4 * k;
+            if (a < nparts) {
+              const float* src = a == 0 ? D.dHQ + ((long)t * B + r1) * H : D.dHQp + (((long)(a - 1) * T + t) * B + r1) * H;
+              vh[k] = ld4x<true>(ws, src + u0 + q4);
+            }
+          }
+        }
+      }
+    }
+    STAMP_ACC(4);
+    {
+      float4 sa = vh[0], sx = z4;
+      sa.x += vh[1].x; sa.y += vh[1].y; sa.z += vh[1].z; sa.w += vh[1].w;
+#pragma unroll
+      for (int k = 0; k < PW; ++k) {
+        sa.x += va[k].x; sa.y += va[k].y; sa.z += va[k].z; sa.w += va[k].w;
+        sx.x += vx[k].x; sx.y += vx[k].y; sx.z += vx[k].z; sx.w += vx[k].w;
+      }
+      *reinterpret_cast<float4*>(pa + (g1 * 32 + sl1) * 16 + q4) = sa;
+      *reinterpret_cast<float4*>(px + (g1 * 32 + sl1) * 16 + q4) = sx;
+    }
+    __syncthreads();
+    STAMP_ACC(5);
+    // ---- phase 2: element-wise LSTMCell backward of (slot2, u0 + uu); fixed summation order over the four thread groups
+    {
+      const int o = sl2 * 16 + uu;
+      const float a = ((pa[o] + pa[512 + o]) + pa[1024 + o]) + pa[1536 + o];
+      const float x = ((px[o] + px[512 + o]) + px[1024 + o]) + px[1536 + o];
+      float dh = a + pre.mn * x;                          // dh_q = dhprev + dHQ + mnext X_{t+1}   (x = 0 beyond Nc and at the last step)
+      float d4[4] = {0.f, 0.f, 0.f, 0.f};
+      float hfold = 0.f;
+      if (Nc == 0) {                                      // skipped cell: identity on (h, c); no dropout was drawn (:180 / :185)
+        hfold = dh;
+      } else {
+        if (slot2 < B && drop_state_on(P, D)) dh *= drop_hq(P, D, t, c, slot2, u0 + uu);
+        const float gi = pre.g4[0], gf = pre.g4[1], gg = pre.g4[2], go = pre.g4[3], tc = pre.tc;
+        const float dcn = dc_reg + dh * go * (1.f - tc * tc);
+        d4[0] = dcn * gg * gi * (1.f - gi);
+        d4[1] = dcn * pre.co * gf * (1.f - gf);
+        d4[2] = dcn * gi * (1.f - gg * gg);
+        d4[3] = dh * tc * go * (1.f - go);
+        dc_reg = dcn * gf;
+      }
+      if (slot2 >= B) { d4[0] = d4[1] = d4[2] = d4[3] = 0.f; hfold = 0.f; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dsg_s[sl2 * LDA + k * 16 + uu] = d4[k];
+      xs[o] = (1.f - pre.mn) * x;                         // dh_0 branch of the blend: straight into X_t (rows beyond Nc: x = 0)
+      hs[o] = hfold;
+      if (uu == 0) rowb[sl2] = pre.b;
+      if (slot2 < B) {                                    // dsg[t]: read by the weight-gradient roles behind this step's barrier
+        float* og = D.dsg + ((long)c * T + t) * B * 4 * H + (long)slot2 * 4 * H + u0 + uu;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) stx<true>(ws, og + k * H, d4[k]);
+      }
+    }
+    STAMP_ACC(6);
+    __syncthreads();
+    STAMP_ACC(0);
+    // ---- phase 3: the K-slice's contribution to all columns of dgates W_ih | dgates W_hh
+    {
+      float a[4][8];
+      if (Nc != 0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) load8(dsg_s + r * LDA + p * 16 + half * 8, a[p]);
+      }
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) {
+        f32x16 acc = {0};
+        if (Nc != 0) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][j], bpre[i][p][j], acc, 0, 0, 0);
+        }
+        const int n = 32 * tnt[i] + r;                    // output column of this lane
+        const bool mine = (n >> 4) == w;                  // a column of this workgroup's own units: takes the bypass terms
+        float* dst = (tkind[i] ? dhp_c : Xp_c) + ((long)w * NG + (n >> 4)) * B * 16 + (n & 15);
+        if (tkind[i] == 0) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+            const int b = rowb[row];
+            float v = acc[e];
+            if (mine) v += xs[row * 16 + (n & 15)];
+            if (b >= 0) stx<true>(ws, dst + (long)b * 16, v);          // X_t[perm_t[off + slot]] (gather of q_sel, :242-257)
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+            const int slot = mb * 32 + row;
+            float v = acc[e];
+            if (mine) v += hs[row * 16 + (n & 15)];
+            if (slot < B) stx<true>(ws, dst + (long)slot * 16, v);
+          }
+        }
+      }
+    }
+    STAMP_ACC(1);
+    pre = nxtp;
+    STAMP_ACC(2);
+    if (t == 0) {              // no consumer inside the chain, but the weight-gradient roles wait for dsg[0]: arrive only
+      barrier_arrive(cnt);
+      break;
+    }
+    if (!dir_barrier(cnt, P.sync + SYNC_ABORT, nwg * ++nbar, lds_ok, sv ? nullptr : lcnt, 2u * nwg_l * (unsigned)(T - t + 1))) return;
+    if (s_poll_abort) return;
+    STAMP_ACC(3);
+  }
+  STAMP_DUMP(P, 40, lin == 0 && R.z == 0);
+  STAMP_DUMP(P, 48, lin == NSL + 2 && R.z == 0);
+}
+
 // ================================================================================================ fused persistent launches
 // Both chains of a pass live in ONE launch: blockIdx.x < n_l are the LSTHM-chain workgroups (the critical chain first), the rest
 // the speaker-chain workgroups.  They run concurrently as independent groups linked only by the producer's step counter
@@ -2395,7 +2729,12 @@ __device__ __forceinline__ void wgrad_role(const CellK& P, int id, const WS& ws,
     // dgates[t] is complete behind the first of step t)
     const unsigned per = P.ext_spk ? 2u : 1u;
     const unsigned target_sv = nwg_src * (per * (unsigned)(T - 1 - t_lo) + 1u);
-    constexpr bool sv = false;
+    // MSER_OPT_BWD_SENTINEL = 2: nothing waits at the chain's first seam any more, so the counter is only a HINT here -- a workgroup
+    // that owns no dialogue row adds its arrival of a step at once, and one whose product needs only half of the gate columns may
+    // even have added the NEXT arrival before a row workgroup has drained its last stores: "count >= target" no longer implies
+    // "dgates[t] complete" (found with an external speaker state, two arrivals per step: every weight gradient NaN).  The gate
+    // gradients validate themselves instead, as for the chain's own consumers.
+    const bool sv = !SPK && P.bwd_sentinel == 2;
     if (!lazy_wait(cnt, P.sync + SYNC_ABORT, (!SPK && P.bwd_sentinel) ? target_sv : target, lds_ok)) return;
 #ifdef MSER_WGRAD_EXPERIMENT_SKIP       // diagnostic build only: follow the counters, do no work
     continue;
@@ -2479,7 +2818,8 @@ __global__ __launch_bounds__(NT) void cell_bwd_fused(CellK P, unsigned bwd_nwg) 
   } else if (id < n_l + n_s) {
     id -= n_l;
     const Role R{id % gx, (id / gx) % gy, id / (gx * gy), gx, gy};
-    spk_bwd_role<NPS>(P, R, smem, ws, bwd_nwg);
+    if (P.spk_ks) spk_bwd_role_ks<NPS>(P, R, smem, ws, bwd_nwg);
+    else spk_bwd_role<NPS>(P, R, smem, ws, bwd_nwg);
   } else {
     id -= n_l + n_s;
     // LSTHM weight gradients first ((4H/32)/2 workgroups per (dir, stream)), then the speaker cells ((4H/32)/4 per (dir, cell))
@@ -2695,6 +3035,10 @@ static void carve_dir(Carver& cv, DirP& d, int T, int B, int D, int H) {
   d.dhprev = cv.take<float>(2 * 2 * SB);
   d.dcprev = cv.take<float>(2 * 2 * SB);
   d.mnext = cv.take<float>(TB);
+  // partial products of the K-split speaker BPTT (persistent widths only)
+  const size_t nsl = (H == 128 || H == 256) ? (size_t)H / 16 : 0;
+  d.Xp = cv.take<float>(2 * nsl * SB);
+  d.dhp = cv.take<float>(2 * 2 * nsl * SB);
 }
 
 struct CellHost {
@@ -2708,7 +3052,7 @@ static size_t carve_all(char* base, const mser_cell_desc& d, CellHost* out) {
   Carver cv{base, 0};
   CellHost h;
   h.k.T = d.T; h.k.B = d.B; h.k.D = d.D; h.k.H = d.H; h.k.ndir = d.ndir; h.k.nmb = cdiv(d.B, 32); h.k.ldo = d.ldo;
-  h.k.wgrad_wgs = 0; h.k.ksplit = 1; h.k.place = 0; h.k.stats_wgs = 0; h.k.nodx = 0; h.k.fwd_rowsplit = h.k.bwd_rowsplit = 1;
+  h.k.wgrad_wgs = 0; h.k.spk_ks = 0; h.k.ksplit = 1; h.k.place = 0; h.k.stats_wgs = 0; h.k.nodx = 0; h.k.fwd_rowsplit = h.k.bwd_rowsplit = 1;
   h.sync = cv.take<unsigned>(SYNC_WORDS);
   h.k.sync = h.sync;
   h.k.wsbase = base;
@@ -2810,7 +3154,9 @@ static int g_opt_stats_roles = 1;     // MSER_OPT_FWD_STATS_ROLES
 static int g_opt_xcd_place = 0;       // MSER_OPT_XCD_PLACEMENT (off: measured slower end to end)
 static int g_opt_fwd_sentinel = 1;    // MSER_OPT_FWD_SENTINEL
 static int g_opt_rowsplit = 1;        // MSER_OPT_H256_SPLIT: H = 256 persistent chains share a row phase between two workgroups, BPTT products K-split
-static int g_opt_bwd_sentinel = 0;    // MSER_OPT_BWD_SENTINEL (off: measured 1345 us per BPTT launch against 1342 with the counter barriers)
+static int g_opt_spk_ks = 1;          // MSER_OPT_SPK_BWD_KSPLIT
+static int g_opt_bwd_sentinel = 2;    // MSER_OPT_BWD_SENTINEL (2: both seams of the LSTHM BPTT self-validating; round 2 measured no gain -- the speaker roles
+                                      // paced the launch then; with them out of the way: 1321 -> 1225 (seam 2) -> 1166 us (both) per launch)
 static int g_num_cus = 0;
 constexpr size_t PERSIST_MIN_LDS = 84 * 1024;     // > half of the 160 KiB LDS: at most ONE persistent workgroup per CU
 
@@ -3089,7 +3435,8 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       }
     }
   }
-  K.bwd_sentinel = (persist && g_opt_bwd_sentinel) ? 1 : 0;
+  K.bwd_sentinel = persist ? g_opt_bwd_sentinel : 0;
+  K.spk_ks = (persist && !ext && g_opt_spk_ks) ? 1 : 0;
   if (phases & MSER_PHASE_BWD_PREP) {
     if (K.bwd_sentinel) {
       // every word the BPTT chains hand from workgroup to workgroup starts as the sentinel (dgates | dA | dHQ | dHQp are carved back to
@@ -3113,7 +3460,7 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   // ---- LSTHM chain, reverse time
   if (persist) {
     // ONE launch for both BPTT chains: bwd_nwg*ndir LSTHM workgroups + spk_wgs*ndir speaker workgroups
-    const size_t f_lds = persist_lds(std::max(p_lds, spk_bwd_lds_floats(H) * sizeof(float) + 64));
+    const size_t f_lds = persist_lds(std::max(p_lds, (K.spk_ks ? spk_ks_lds_floats() : spk_bwd_lds_floats(H)) * sizeof(float) + 64));
     const unsigned roles = (unsigned)(((long)bwd_nwg + spk_wgs) * d.ndir + K.wgrad_wgs);
     K.place = (place_ok && bwd_nwg == 32 && spk_wgs == 16 && num_cus() == 256) ? 1 : 0;
     if (K.place) {
@@ -3458,8 +3805,9 @@ int mser_set_option(int32_t key, int32_t value) {
     case MSER_OPT_XCD_PLACEMENT: g_opt_xcd_place = value ? 1 : 0; return 0;
     case MSER_OPT_FWD_STATS_ROLES: g_opt_stats_roles = value ? 1 : 0; return 0;
     case MSER_OPT_FWD_SENTINEL: g_opt_fwd_sentinel = value ? 1 : 0; return 0;
-    case MSER_OPT_BWD_SENTINEL: g_opt_bwd_sentinel = value ? 1 : 0; return 0;
+    case MSER_OPT_BWD_SENTINEL: g_opt_bwd_sentinel = value == 2 ? 2 : (value ? 1 : 0); return 0;
     case MSER_OPT_H256_SPLIT: g_opt_rowsplit = value ? 1 : 0; return 0;
+    case MSER_OPT_SPK_BWD_KSPLIT: g_opt_spk_ks = value ? 1 : 0; return 0;
     default: set_error("mser_set_option: unknown key %d", key); return -1;
   }
 }

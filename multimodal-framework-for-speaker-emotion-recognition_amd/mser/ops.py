@@ -771,6 +771,7 @@ MSER_OPT_FWD_STATS_ROLES = 5
 MSER_OPT_FWD_SENTINEL = 6
 MSER_OPT_BWD_SENTINEL = 7
 MSER_OPT_H256_SPLIT = 8
+MSER_OPT_SPK_BWD_KSPLIT = 9
 
 
 def set_option(key: int, value: int) -> None:

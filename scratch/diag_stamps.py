@@ -36,7 +36,7 @@ ops.marn_cell_status(desc)
 # phase stamps (build with `make EXTRA=-DMSER_STAMPS`): average s_memrealtime ticks (10 ns) per step and phase
 w = ws.view(torch.int32).cpu().numpy()
 SYNC_STAMPS = 8 * 8 * 32 + 10 * 32 + 32      # SYNC_ABORT + SYNC_LINE (recurrent.hip)
-for name, base in (("lsthm_fwd [z loads(+poll), mm, epilogue, hq early mm (+barrier1), row (+c poll), h early mm (+barrier2)]", 24), ("lsthm_bwd [row2, barrier1, mat, shadow+barrier2, sh1, p1a, p2a, p2b]", 32),
+for name, base in (("lsthm_fwd [z loads(+poll), mm, epilogue, hq early mm (+barrier1), row (+c poll), h early mm (+barrier2)]", 24), ("lsthm_bwd [row tail, arrive|barrier1, mat rest, post-mat, (sv2: A poll, mfma), carries+coef, pass2]", 32),
                    ("spk_bwd wg0 [sync, product, epilogue, barrier, table loads, load issue, wait+compute+stores]", 40), ("spk_bwd wg(2,1)", 48)):
     v = w[SYNC_STAMPS - 16 + base: SYNC_STAMPS - 16 + base + 8]
     print(name, [round(int(x) * 0.01, 2) for x in v], "us/step; sum", round(float(v.sum()) * 0.01, 2))

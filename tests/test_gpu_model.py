@@ -345,8 +345,8 @@ def test_model_long_sequence_vs_oracle(O):
 
 
 def test_backward_options_agree(O):
-    """In-launch weight gradients / K-split matvec (the defaults) against the grouped split-K GEMMs after the chains and the
-    unsplit matvec: same gradients up to summation order."""
+    """In-launch weight gradients / K-split matvec / reduce-scatter speaker BPTT (the defaults) against the grouped split-K GEMMs
+    after the chains, the unsplit matvec and the output-split speaker BPTT: same gradients up to summation order."""
     from models.lsthm_sps import MARN1_sps
     from loss import MaskedLoss
     from mser import ops
@@ -355,7 +355,10 @@ def test_backward_options_agree(O):
     x, qmask, umask, label = (t.cuda() for t in O.seeded_batch(B, L, d_r=d_r, seed=14, ragged=True))
     grads = []
     try:
-        for wg, ks, xp in ((1, 1, 0), (0, 0, 0), (1, 1, 1)):      # defaults | plain | experimental XCD placement of the roles
+        # defaults | plain | experimental XCD placement of the roles | output-split speaker BPTT | counter barriers on one / both seams of the BPTT
+        for wg, ks, xp, sk, sv in ((1, 1, 0, 1, 2), (0, 0, 0, 0, 2), (1, 1, 1, 1, 2), (1, 1, 0, 0, 2), (1, 1, 0, 1, 1), (1, 1, 0, 1, 0), (1, 1, 0, 0, 0)):
+            ops.set_option(ops.MSER_OPT_BWD_SENTINEL, sv)
+            ops.set_option(ops.MSER_OPT_SPK_BWD_KSPLIT, sk)
             ops.set_option(ops.MSER_OPT_WGRAD_INKERNEL, wg)
             ops.set_option(ops.MSER_OPT_BPTT_KSPLIT, ks)
             ops.set_option(ops.MSER_OPT_XCD_PLACEMENT, xp)
@@ -368,6 +371,8 @@ def test_backward_options_agree(O):
         ops.set_option(ops.MSER_OPT_WGRAD_INKERNEL, 1)
         ops.set_option(ops.MSER_OPT_BPTT_KSPLIT, 1)
         ops.set_option(ops.MSER_OPT_XCD_PLACEMENT, 0)
+        ops.set_option(ops.MSER_OPT_SPK_BWD_KSPLIT, 1)
+        ops.set_option(ops.MSER_OPT_BWD_SENTINEL, 2)
     for other in grads[1:]:
         assert grads[0].keys() == other.keys()
         for n in grads[0]:
