@@ -1030,6 +1030,28 @@ __device__ __forceinline__ GatePre lsthm_gate_prefetch(const CellK& P, const Dir
   return g;
 }
 
+// The pre-activation row alone (the three bias vectors do not depend on the step: the role adds their sum, fetched once), through
+// buffer loads with a per-thread offset register and scalar per-step offsets (no vector address arithmetic per load).
+template <int HC>
+__device__ __forceinline__ GatePre lsthm_gate_prefetch_buf(const CellK& P, const DirP& D, const WS& ws, int t, int m, int u0, int mb) {
+  GatePre g;
+  g.pre4[0] = g.pre4[1] = g.pre4[2] = g.pre4[3] = 0.f;
+  g.tau = -1;
+  const int tid = threadIdx.x;
+  const int B = P.B, T = P.T;
+  if (tid < 256) {
+    const int b = mb * 32 + (tid >> 3), u = u0 + (tid & 7);
+    if (b < B) {
+      const int vo = (b * 4 * HC + u) * 4;
+      const int so = (int)((const char*)D.pre - ws.base) + ((m * T + t) * B) * 4 * HC * 4;
+#pragma unroll
+      for (int gt = 0; gt < 4; ++gt) g.pre4[gt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ws.r, vo + gt * HC * 4, so, 0));
+      g.tau = D.rev ? D.rev[(long)t * B + b] : t;
+    }
+  }
+  return g;
+}
+
 // Gates phase of step t: acc (early product, in registers) += z_{t-1} V^T, cross-wave reduction, LSTM epilogue.
 // c_state: this thread's cell state c_{t-1}[b][u] (the same thread owns the same (b, u) every step: it never leaves the register).
 template <int NP, bool SV = false>
@@ -1226,9 +1248,22 @@ __device__ __forceinline__ void lsthm_fwd_role_sv(const CellK& P, const Role R, 
   lsthm_early_aload_valid<NP, 1>(P, D, ws, 0, m, mb, a);
   f32x16 acc = lsthm_early_mm<NP, 1>(a, bpre, lsthm_early_mm<NP, 0>(a, bpre, f32x16{0}));
   GatePre gp = lsthm_gate_prefetch(P, D, 0, m, u0, mb);
+  // the step-independent part of the pre-activation: U.bias + V.bias + S.bias of this thread's (gate, unit)
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  if (threadIdx.x < 256) {
+    const int u = u0 + (threadIdx.x & 7);
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt) bsum[gt] = D.Ub[m][gt * P.H + u] + D.Vb[m][gt * P.H + u] + D.Sb[m][gt * P.H + u];
+  }
   float c_state = 0.f;
   for (int t = 0; t < P.T; ++t) {
     const bool more = t + 1 < P.T;
+    // next step's pre-activation row: requested HERE, in front of the longest wait of the step (the poll for z_{t-1} below), because the
+    // wave's loads retire in order -- requested in front of the h_t poll at the bottom of the step it was what that poll waited for
+    GatePre gp_n = gp;
+    if (more) {
+      gp_n = lsthm_gate_prefetch_buf<128 * NP / 3>(P, D, ws, t + 1, m, u0, mb);
+    }
     if (more) lsthm_early_aload<NP, 1>(P, D, ws, t + 1, m, mb, a);  // h_q[t+1] (the speaker chain normally runs far ahead): requested now,
     lsthm_gates_late<NP, true>(P, D, ws, t, m, u0, mb, bpre, acc, gp, c_state, red, tile);           // validated after the gates phase
     if (s_poll_abort) return;                                       // (read behind the phase's workgroup barriers: uniform)
@@ -1247,7 +1282,9 @@ __device__ __forceinline__ void lsthm_fwd_role_sv(const CellK& P, const Role R, 
     fetch();
     STAMP_ACC(4);
     if (!more) break;
-    gp = lsthm_gate_prefetch(P, D, t + 1, m, u0, mb);
+    gp = gp_n;
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt) gp.pre4[gt] += bsum[gt];
     lsthm_early_aload_valid<NP, 0>(P, D, ws, t + 1, m, mb, a);      // h_t of every workgroup of the direction
     acc = lsthm_early_mm<NP, 0>(a, bpre, acc);
     STAMP_ACC(5);
@@ -1359,6 +1396,52 @@ __device__ __forceinline__ RowPre lsthm_bwd_row_prefetch(const CellK& P, const D
       if (dorow) r.dh_out[m] = dorow[m * H + i];
       r.cprev[m] = D.cstate[((long)m * (T + 1) + t) * B * H + (long)b * H + i];
       r.carry[m] = D.dc_carry[(long)m * SA + (long)b * H + i];
+    }
+  }
+  return r;
+}
+
+// The same operands for the persistent roles, through buffer loads whose per-thread part of the address is ONE register (the unit index;
+// gate / stream strides are immediate offsets) and whose per-step part is scalar arithmetic: the 64-bit vector address arithmetic of
+// the plain form was ~300 instructions on the two waves that hold the row's units, issued in front of the loads the chain was waiting
+// to issue (0.7 us per step).  tau: the natural time position of (t, b), uniform, already in hand (< 0: a padded step, no dout row).
+// dc_carry is not fetched (the persistent roles keep it in registers).
+template <int HC>
+__device__ __forceinline__ RowPre lsthm_bwd_row_prefetch_buf(const CellK& P, const DirP& D, const WS& ws, __amdgpu_buffer_rsrc_t rdout, int t,
+                                                             int b, int tau) {
+  RowPre r;
+  r.cav = r.clv = r.dz_out = r.zi = r.dhq = 0.f;
+  r.st = make_float4(1.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int m = 0; m < 2; ++m) { r.dh_out[m] = r.cprev[m] = r.carry[m] = 0.f; r.gsv[m][0] = r.gsv[m][1] = r.gsv[m][2] = r.gsv[m][3] = 0.f; }
+  const int i = threadIdx.x;
+  if (i < HC) {
+    const int T = P.T, B = P.B;
+    const int vo = i * 4;
+    const int rowt = t * B + b;
+    auto soff = [&](const float* base, int floats) { return (int)((const char*)base - ws.base) + floats * 4; };
+    auto ld = [&](int voff, int so) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ws.r, voff, so, 0)); };
+    {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ws.r, i * 16, soff(D.rstat, rowt * HC * 4), 0);
+      r.st = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+    r.clv = ld(vo, soff(D.cstate, ((0 * (T + 1) + t + 1) * B + b) * HC));
+    r.cav = ld(vo, soff(D.cstate, ((1 * (T + 1) + t + 1) * B + b) * HC));
+    r.zi = ld(vo, soff(D.hz, ((t + 1) * B + b) * 3 * HC + 2 * HC));
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int sg = soff(D.gates, (m * T * B + rowt) * 4 * HC);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r.gsv[m][k] = ld(vo + k * HC * 4, sg);
+      r.cprev[m] = ld(vo, soff(D.cstate, ((m * (T + 1) + t) * B + b) * HC));
+    }
+    if (tau >= 0) {                // uniform
+      const int sd = (tau * B + b) * (int)P.ldo * 4;
+      auto ldo_ = [&](int voff) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdout, voff, sd, 0)); };
+      r.dh_out[0] = ldo_(vo);
+      r.dh_out[1] = ldo_(vo + HC * 4);
+      r.dz_out = ldo_(vo + 2 * HC * 4);
+      r.dhq = ldo_(vo + 3 * HC * 4);
     }
   }
   return r;
@@ -1839,6 +1922,7 @@ __device__ __forceinline__ void lsthm_bwd_role_sv(const CellK& P, const Role R, 
   RowPre pre = lsthm_bwd_row_prefetch(P, D, P.T - 1, rowb);
   RowPre pre_n = lsthm_bwd_row_prefetch(P, D, P.T > 1 ? P.T - 2 : 0, rowb);
   int tau_pp = lsthm_tau(D, P.T > 3 ? P.T - 3 : 0, rowb, P.B);      // natural time position of step t - 2, fetched a step before its use
+  const __amdgpu_buffer_rsrc_t rdout = __builtin_amdgcn_make_buffer_rsrc((void*)D.dout, 0, 0x7ffffffc, 0x00020000);
   RowMid mid = lsthm_bwd_row_part1_saved(P, D, P.T - 1, rowb, att, red, pre);
   float carry[2] = {0.f, 0.f};
   float attreg[2] = {0.f, 0.f};
@@ -1863,7 +1947,7 @@ __device__ __forceinline__ void lsthm_bwd_role_sv(const CellK& P, const Role R, 
       if (t == 0) return;
       asm volatile("" : "+v"(tau_pp));           // the table word fetched a step ago is consumed here, where waiting for it is free
       pre = pre_n;
-      if (t > 1) pre_n = lsthm_bwd_row_prefetch(P, D, t - 2, rowb, true, tau_pp);
+      if (t > 1) pre_n = lsthm_bwd_row_prefetch_buf<32 * NP>(P, D, ws, rdout, t - 2, rowb, __builtin_amdgcn_readfirstlane(tau_pp));
       tau_pp = lsthm_tau(D, t > 3 ? t - 3 : 0, rowb, P.B);
     };
     // seam 1 (gate gradients -> matvec roles) keeps its counter barrier: every matvec workgroup reads a 32 KB slab of dgates[t];
@@ -1944,6 +2028,7 @@ __device__ __forceinline__ void lsthm_bwd_role(const CellK& P, const Role R, flo
   RowPre pre = lsthm_bwd_row_prefetch(P, D, P.T - 1, rowb);
   RowPre pre_n = lsthm_bwd_row_prefetch(P, D, P.T > 1 ? P.T - 2 : 0, rowb);
   int tau_pp = lsthm_tau(D, P.T > 3 ? P.T - 3 : 0, rowb, P.B);      // natural time position of step t - 2, fetched a step before its use
+  const __amdgpu_buffer_rsrc_t rdout = __builtin_amdgcn_make_buffer_rsrc((void*)D.dout, 0, 0x7ffffffc, 0x00020000);
   RowMid mid = lsthm_bwd_row_part1_saved(P, D, P.T - 1, rowb, att, red, pre);
   float carry[2] = {0.f, 0.f};
   float attreg[2] = {0.f, 0.f};
@@ -1965,7 +2050,7 @@ __device__ __forceinline__ void lsthm_bwd_role(const CellK& P, const Role R, flo
     ++nbar;
     if (t > 0) {
       pre = pre_n;
-      if (t > 1) pre_n = lsthm_bwd_row_prefetch(P, D, t - 2, rowb, true, tau_pp);
+      if (t > 1) pre_n = lsthm_bwd_row_prefetch_buf<32 * NP>(P, D, ws, rdout, t - 2, rowb, __builtin_amdgcn_readfirstlane(tau_pp));
       tau_pp = lsthm_tau(D, t > 3 ? t - 3 : 0, rowb, P.B);
       mid = lsthm_bwd_row_part1_saved(P, D, t - 1, rowb, att, red, pre);
       if (!barrier_wait(cnt, P.sync + SYNC_ABORT, nwg * nbar, lds_ok)) return;
