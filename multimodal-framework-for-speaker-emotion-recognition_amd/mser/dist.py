@@ -89,3 +89,26 @@ def broadcast_replica(store, optim=None, src: int = 0, group=None) -> None:
             t.copy_(h)
         else:
             dist.broadcast(t, src, group=group)
+
+
+def _small_all_reduce(t: torch.Tensor, op, group=None) -> torch.Tensor:
+    """All-reduce of a few words.  RCCL ("nccl") reduces device tensors; gloo (the tests' backend, also two ranks on one GPU) reduces
+    a host copy."""
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        return h.to(t.device)
+    dist.all_reduce(t, op=op, group=group)
+    return t
+
+
+def agree_on_fault(local_bits: int, device="cpu", group=None) -> int:
+    """The OR of every rank's fault bits (mser.fault), identical on all ranks: ONE tiny MAX all-reduce over the three bit flags.
+    Every rank must take the same control flow after a fault (raise, or fall back to per-step launches and replay) -- a rank that
+    carried on alone would block at the next collective.  World 1 / no process group: the local bits."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return int(local_bits)
+    dev = device if dist.get_backend(group) != "gloo" else "cpu"
+    flags = torch.tensor([float(bool(local_bits & (1 << k))) for k in range(3)], device=dev)
+    flags = _small_all_reduce(flags, dist.ReduceOp.MAX, group)
+    return sum((1 << k) for k in range(3) if float(flags[k]) > 0)

@@ -43,12 +43,26 @@ def peek(device) -> int:
     return int(word(device).item())
 
 
-def check(device, where: str = "") -> None:
-    """Synchronising read; raises RuntimeError (and clears the word) if any kernel reported a fault since the last check."""
+def describe(bits: int) -> str:
+    return "; ".join(txt for bit, txt in _NAMES.items() if bits & bit) or f"unknown bits {bits:#x}"
+
+
+def clear(device) -> None:
+    word(device).zero_()
+
+
+def check(device, where: str = "", agreed_bits=None) -> None:
+    """Synchronising read; raises RuntimeError (and clears the word) if any kernel reported a fault since the last check.
+    agreed_bits (data-parallel callers): the OR over ALL ranks' words (mser.dist.agree_on_fault) -- every rank raises when any rank
+    faulted, naming its own bits and the others'."""
     w = word(device)
     v = int(w.item())
-    if v:
+    bits = v if agreed_bits is None else (v | int(agreed_bits))
+    if bits:
         w.zero_()
-        reasons = "; ".join(txt for bit, txt in _NAMES.items() if v & bit) or f"unknown bits {v:#x}"
-        raise RuntimeError(f"libmser device fault{' in ' + where if where else ''} (code {v:#x}): {reasons}. "
+        other = bits & ~v
+        txt = describe(v) if v else ""
+        if other:
+            txt = (txt + "; " if txt else "") + f"another rank reported: {describe(other)}"
+        raise RuntimeError(f"libmser device fault{' in ' + where if where else ''} (code {bits:#x}): {txt}. "
                            "The optimiser skipped every update issued while the fault was set.")

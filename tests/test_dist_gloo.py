@@ -76,3 +76,28 @@ def test_shard_batch_contiguous_and_validates():
     assert torch.equal(torch.cat([p[2] for p in parts], 0), umask)
     with pytest.raises(ValueError):
         shard_batch(x, qmask, umask, label, 0, 4)
+
+
+def _fault_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mser.dist import agree_on_fault
+    res = [agree_on_fault(0),                                # nobody faulted
+           agree_on_fault(1 if rank == 1 else 0),            # only rank 1 timed out: EVERY rank must see it
+           agree_on_fault(4 if rank == 0 else 2),            # different bits on different ranks: the OR
+           agree_on_fault(0)]
+    torch.save(res, out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fault_bits_are_agreed_by_all_ranks(tmp_path):
+    """only the rank that faulted used to raise at epoch end; the others carried on into the next collective.  The
+    decision is collective now (mser.dist.agree_on_fault: one MAX all-reduce over the bit flags): every rank gets the same bits."""
+    out = str(tmp_path / "bits")
+    mp.spawn(_fault_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0", weights_only=True), torch.load(out + ".1", weights_only=True)
+    assert r0 == r1 == [0, 1, 6, 0]
+    from mser.dist import agree_on_fault
+    assert agree_on_fault(5) == 5                            # no process group: the local bits

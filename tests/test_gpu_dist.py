@@ -98,9 +98,23 @@ def test_fault_word_skips_adam_and_trainer_raises(O):
     assert float(ar.faults) == 1.0
     r = x[:, :, :64]
     batch = [r, r, r, r, torch.zeros(5, 3, 4), x[:, :, 64:], qmask, umask, label, ["v"] * 3]
-    with pytest.raises(RuntimeError, match="device fault"):
+    # round 3: a chain time-out is retried ONCE with one launch per time step -- the trainer switches the launch mode,
+    # replays the steps whose updates the device skipped, and the epoch completes; a second time-out (or any other fault) raises
+    from mser import ops
+    try:
         tr.train_network(1, [batch])
-    assert fault.peek(dev) == 0                          # check() cleared it: the next epoch trains again
+        assert fault.peek(dev) == 0 and tr._fell_back
+        assert not torch.equal(tr.model.flat_store.data, before)     # the replayed step did update
+        w.fill_(1)
+        with pytest.raises(RuntimeError, match="device fault"):
+            tr.train_network(1, [batch])
+        assert fault.peek(dev) == 0                          # check() cleared it: the next epoch trains again
+        w.fill_(4)                                           # a bad label is never retried
+        with pytest.raises(RuntimeError, match="label"):
+            tr.train_network(1, [batch])
+    finally:
+        ops.set_option(ops.MSER_OPT_PERSISTENT, 1)
+    before = tr.model.flat_store.data.clone()
     tr.train_network(1, [batch])
     assert not torch.equal(tr.model.flat_store.data, before)
     # all-reduced flag alone (another rank faulted): this rank skips too
@@ -189,8 +203,30 @@ def _dp_worker(rank, world, port, backend, out_path, d_r, Bg, Ln):
     flat = tr.model.flat_store.data.detach().cpu()
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
+    # ---- a fault on ONE rank must raise on EVERY rank (train_network and eval_network decide collectively); rank 1 plants
+    # a bad-label bit in its fault word, rank 0's word stays clean
+    from mser import fault
+    sd = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
+    r = xs[:, :, :d_r].contiguous()
+    batch = [r.cpu(), r.cpu(), r.cpu(), r.cpu(), torch.zeros(Ln, xs.shape[1], 4), xs[:, :, d_r:].cpu(), qs.cpu(), us.cpu(), ls.cpu(),
+             ["v"] * xs.shape[1]]
+    raised = []
+    for fn in (lambda: tr.train_network(1, [batch]), lambda: tr.eval_network([batch])):
+        if rank == 1:
+            fault.word(dev).fill_(4)
+        try:
+            fn()
+            raised.append("")
+        except RuntimeError as e:
+            raised.append(str(e))
+    clean = True
+    try:
+        tr.train_network(1, [batch])                      # and the next epoch runs on both ranks (no rank was left behind)
+    except RuntimeError:
+        clean = False
+    torch.save(dict(raised=raised, clean=clean), out_path + f".fault{rank}")
     if rank == 0:
-        torch.save(dict(flat=flat, same=bool(all(torch.equal(g, flat) for g in gathered))), out_path)
+        torch.save(dict(flat=flat, same=bool(all(torch.equal(g, flat) for g in gathered)), sd=sd), out_path)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -227,6 +263,21 @@ def _run_two_ranks(O, tmp_path, backend):
     mp.spawn(_dp_worker, args=(world, _free_port(), backend, out, d_r, Bg, Ln), nprocs=world, join=True)
     res = torch.load(out, weights_only=True)
     assert res["same"], "replicas diverged"
+    # every rank raised for rank 1's fault, in training and in evaluation, and both went on afterwards
+    for rk in range(world):
+        fr = torch.load(out + f".fault{rk}", weights_only=True)
+        assert len(fr["raised"]) == 2 and all("device fault" in m and "label" in m for m in fr["raised"]), (rk, fr["raised"])
+        assert ("another rank" in fr["raised"][0]) == (rk == 0)
+        assert fr["clean"], rk
+    # SURVEY 8(e) as the REFERENCE computes it (tests/golden/make_golden.py::dp_case: the reference on each shard separately, gradients
+    # combined with the mask counts, one torch.optim.Adam step; twice): the replicas' parameters against that fixture
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dp_two_shards.npz"), allow_pickle=False)
+    assert (int(g["d_r"]), int(g["B"]), int(g["L"]), int(g["world"]), int(g["seed_params"]), int(g["seed_batch"])) == (d_r, Bg, Ln, world, 31, 32)
+    worst = 0.0
+    for k in res["sd"]:
+        got = res["sd"][k].reshape(-1).numpy()[g["idx/" + k]]
+        worst = max(worst, float(np.abs(got - g["p/" + k]).max()))
+    assert worst < 5e-6, worst
     from mser import ops
     shared = torch.cuda.device_count() < world              # the workers then ran one launch per step (see _dp_worker): so does the reference
     if shared:

@@ -273,8 +273,10 @@ def test_trainer_three_steps_vs_reference_golden(O, golden_dir):
         if k.startswith("p/"):
             got = sd[k[2:]].detach().cpu().numpy().reshape(-1)[:16]
             worst = max(worst, float(np.abs(got - g[k]).max()))
-    # six Adam steps of lr 1e-3: parameters moved by up to ~6e-3; agreement to 3e-4 pins the optimiser arithmetic
-    assert worst < 3e-4, worst
+    # six Adam steps of lr 1e-3: parameters moved by up to ~6e-3; 5e-5 (3e-4 was 5 % of the move and pinned little) is what an
+    # element with a gradient of the order of Adam's eps can differ by; every parameter in full is compared with the oracle's trainer run
+    # in tests/test_gpu_round3.py::test_trainer_all_parameters_vs_oracle_trainer
+    assert worst < 5e-5, worst
 
 
 def test_checkpoint_roundtrip(O, tmp_path):

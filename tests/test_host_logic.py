@@ -198,3 +198,46 @@ def test_nsps_constructor_takes_the_dataset_argument():
     assert list(inspect.signature(MARN_cell.forward).parameters)[1:] == ["x", "x_l", "x_a", "qmask"]
     ca = CrossAttention2(100, 100, 100)
     assert tuple(ca.Wq.shape) == (100, 100) and ca.layer_norm.eps == 1e-6 and torch.all(ca.Wv == 1.0)
+
+
+def _checkpoint_pattern(j, numel):          # tests/golden/make_golden.py::checkpoint_pattern
+    i = np.arange(numel, dtype=np.int64)
+    return (((i * 7 + j * 13) % 61) - 30).astype(np.float32) / 64.0
+
+
+def test_reference_written_checkpoint_loads(golden_dir, tmp_path):
+    """Checkpoint interchange, reference -> build (reference model_trainer.py:170-187): a file written by the REFERENCE's own
+    ``ModelTrainer.save_parameters`` (tests/golden/make_golden.py::checkpoint_case, gzip-ed) is read by the build's ``load_parameters``
+    (``weights_only=True``): same 120 keys in the same order under the ``model.`` prefix, every tensor arrives, nothing is skipped.  A
+    ``module.``-prefixed copy (what a ``DataParallel`` run of the reference would have written, :179) loads as well, and a tensor of the
+    wrong shape is skipped with the reference's message."""
+    import gzip
+    import shutil
+    from model_trainer import ModelTrainer
+    path = str(tmp_path / "model_0001.model")
+    with gzip.open(os.path.join(golden_dir, "ref_checkpoint_model_0001.model.gz"), "rb") as f_in, open(path, "wb") as f_out:
+        shutil.copyfileobj(f_in, f_out)
+    meta = np.load(os.path.join(golden_dir, "ref_checkpoint_keys.npz"), allow_pickle=False)
+    loaded = torch.load(path, map_location="cpu", weights_only=True)
+    assert list(loaded.keys()) == [str(k) for k in meta["keys"]]
+    tr = ModelTrainer("cpu", 1e-3, 1, 0.98, "MARN1_sps", "NLL", 6, "IEMOCAP", quiet=True)
+    assert list(tr.state_dict().keys()) == list(loaded.keys())           # key names AND order interchange
+    with torch.no_grad():
+        for v in tr.state_dict().values():
+            v.fill_(123.0)
+    tr.load_parameters(path)
+    for j, (k, v) in enumerate(tr.state_dict().items()):
+        assert np.array_equal(v.detach().numpy().reshape(-1), _checkpoint_pattern(j, v.numel())), k
+    # DataParallel-style prefix (:179) and a shape mismatch (:183-185: printed and skipped)
+    pre = {"module." + k: v for k, v in loaded.items()}
+    pre["module.model.w"] = torch.zeros(3)
+    p2 = str(tmp_path / "model_dp.model")
+    torch.save(pre, p2)
+    tr2 = ModelTrainer("cpu", 1e-3, 1, 0.98, "MARN1_sps", "NLL", 6, "IEMOCAP", quiet=True)
+    w_before = tr2.state_dict()["model.w"].clone()
+    tr2.load_parameters(p2)
+    sd2 = tr2.state_dict()
+    assert torch.equal(sd2["model.w"], w_before)
+    for j, (k, v) in enumerate(sd2.items()):
+        if k != "model.w":
+            assert np.array_equal(v.detach().numpy().reshape(-1), _checkpoint_pattern(j, v.numel())), k

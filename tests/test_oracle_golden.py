@@ -196,6 +196,76 @@ def test_bimodel_vs_reference(golden_dir, tag):
     _check_grads(g, list(P.items()))
 
 
+@pytest.mark.parametrize("tag", ["long", "small_long"])
+def test_bimodel_long_vs_reference(golden_dir, tag):
+    """Round 3: the same restatement beyond 64 history rows -- the trainer's widths at B = 4 x L = 200 (BASELINE configs[3]'s length) and
+    small widths at B = 33 x L = 150 (tests/golden/make_golden.py::bimodel_long_cases); three attention rows each (t = 70, 129, last)."""
+    g = _g(golden_dir, f"bimodel_{tag}.npz")
+    dims = {k: int(g[k]) for k in ("D_m", "D_g", "D_p", "D_e", "D_h")}
+    B, L, seed = int(g["B"]), int(g["L"]), int(g["seed"])
+    P = {k: v.clone().requires_grad_(True) for k, v in O.bimodel_seeded_params(seed=seed, **dims).items()}
+    U, qmask, umask, label = O.bimodel_seeded_batch(B, L, D_m=dims["D_m"], seed=seed + 1, ragged=True)
+    lp, alpha, a_f, a_b = O.bimodel_forward(P, U, qmask, umask)
+    loss = O.masked_nll(lp.transpose(0, 1).reshape(-1, lp.shape[2]), label.view(-1), umask)
+    loss.backward()
+    assert np.abs(lp.detach().numpy() - g["logits"]).max() < 5e-5
+    assert abs(float(loss) - float(g["loss"])) < 2e-6
+    ts = [int(t) for t in g["alpha_ts"]]
+    assert np.abs(torch.stack([alpha[t] for t in ts], 0).detach().numpy() - g["alpha"]).max() < 2e-6
+    for nm, al in (("alpha_f", a_f), ("alpha_b", a_b)):
+        for t in ts:
+            assert np.abs(al[t].detach().numpy() - g[f"{nm}/{t + 1}"]).max() < 2e-6, (nm, t)
+    _check_grads(g, list(P.items()))
+
+
+def test_library_self_attention_backward_vs_reference(golden_dir):
+    """oracle.self_attention_lib forward AND backward (inputs and every parameter) against the reference's own autograd with
+    mask and multiplicative weights (tests/golden/make_golden.py::sa_backward_case)."""
+    g = _g(golden_dir, "sa_backward.npz")
+    P = {k[len("sa_p/"):]: _t(g[k]).requires_grad_(True) for k in g.files if k.startswith("sa_p/")}
+    q, k, v = (_t(g[n]).requires_grad_(True) for n in ("sa_q", "sa_k", "sa_v"))
+    out = O.self_attention_lib(P, "", q, k, v, 4, 16, 16, attention_mask=torch.tensor(g["sa_mask"]), attention_weights=_t(g["sa_w"]))
+    (out * _t(g["sa_wsum"])).sum().backward()
+    assert np.abs(out.detach().numpy() - g["sa_out"]).max() < 2e-6
+    for n, t in (("sa_dq", q), ("sa_dk", k), ("sa_dv", v)):
+        assert np.abs(t.grad.numpy() - g[n]).max() < 1e-5 * max(1.0, np.abs(g[n]).max()), n
+    for n, t in P.items():
+        assert np.abs(t.grad.numpy() - g["sa_g/" + n]).max() < 1e-5 * max(1.0, np.abs(g["sa_g/" + n]).max()), n
+
+
+def test_data_parallel_step_vs_reference(golden_dir):
+    """the oracle run on two contiguous shards separately, gradients combined with the mask counts, one Adam step (twice)
+    against the REFERENCE doing the same (tests/golden/make_golden.py::dp_case).  Pins what the two-rank tests must reproduce."""
+    g = _g(golden_dir, "dp_two_shards.npz")
+    d_r, Bg, Ln, world = int(g["d_r"]), int(g["B"]), int(g["L"]), int(g["world"])
+    P = {k: v.clone() for k, v in O.seeded_params(seed=int(g["seed_params"]), d_r=d_r).items()}
+    x, qmask, umask, label = O.seeded_batch(Bg, Ln, d_r=d_r, seed=int(g["seed_batch"]), ragged=True)
+    per = Bg // world
+    M = {k: torch.zeros_like(v) for k, v in P.items()}
+    V = {k: torch.zeros_like(v) for k, v in P.items()}
+    losses = []
+    for step in (1, 2):
+        acc, cnt = {}, 0.0
+        for r in range(world):
+            sl = slice(r * per, (r + 1) * per)
+            Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+            lp, _, _ = O.marn1_sps_forward(Pr, x[:, sl].contiguous(), qmask[:, sl].contiguous(), umask[sl].contiguous(), d_r=d_r)
+            loss = O.masked_nll(lp, label[sl].reshape(-1), umask[sl])
+            loss.backward()
+            n = float(umask[sl].sum())
+            losses.append(float(loss.detach()))
+            for k_, v_ in Pr.items():
+                if v_.grad is not None:
+                    acc[k_] = acc.get(k_, 0) + n * v_.grad
+            cnt += n
+        for k_ in acc:
+            O.adam_step(P[k_], acc[k_] / cnt, M[k_], V[k_], step, 1e-3, wd=2e-5)
+    assert np.abs(np.array(losses) - g["shard_losses"]).max() < 2e-6
+    for k_ in P:
+        got = P[k_].reshape(-1).numpy()[g["idx/" + k_]]
+        assert np.abs(got - g["p/" + k_]).max() < 2e-7, k_
+
+
 def test_trainer_lr_schedule(golden_dir):
     g = _g(golden_dir, "trainer.npz")
     assert O.step_lr(1e-3, 0.98, 1, 1) == pytest.approx(float(g["lr1"]), rel=1e-12)
