@@ -163,7 +163,10 @@ int mser_encoder_layer_wgrad_descs(const mser_encoder_desc* d, mser_gemm_desc* o
  * Sequence-level cross-modal attention core (model/lsthm_sps.py:88-101 CrossAttention2, :116-129 CrossAttention3, after the three
  * projection products): O = dropout(softmax(scale Q K^T)) V per (dialogue, head), fused: one workgroup per (32-query tile, head,
  * dialogue), scores and probabilities never leave LDS; the forward saves only the row statistics (max of the scaled logits,
- * 1 / sum).  The backward recomputes P from them; dk_ / dv are ACCUMULATED with float atomics (zero them first), dq is written.
+ * 1 / sum).  The backward recomputes P from them; dq is written.  dk_ / dv receive contributions from every query tile of a dialogue:
+ * part_stride == 0: ACCUMULATED with float atomics (zero them first; order-dependent rounding); part_stride != 0 (floats, a multiple
+ * of 4): tile t STORES its contribution at dk_ / dv + t * part_stride (the caller provides ceil(Lq / 32) slabs, no zeroing) and a second
+ * launch adds slabs 1.. onto slab 0 in a fixed order: bit-reproducible gradients.
  * q / k / v / o / dO / dq / dk_ / dv are row views [rows, ld] with head h in columns h*dk .. h*dk+dk-1 (dk == dv);
  * row(b, l) = b*sb + l*sl on the query side (sbq, slq) and on the key side (sbk, slk).  Supported: Lk <= 128, dk % 8 == 0,
  * dk <= 128 (mser_xattn_seq_supported); otherwise compose it from mser_gemm + mser_softmax_rows.
@@ -179,6 +182,7 @@ typedef struct mser_xattn_desc {
   const uint32_t* rng; uint32_t site; float p;
   const float* dO; int64_t lddo;         /* backward */
   float* dq; int64_t lddq; float* dk_; int64_t lddk; float* dv; int64_t lddv;
+  int64_t part_stride;                   /* backward: see above (0 = atomic accumulation) */
 } mser_xattn_desc;
 int mser_xattn_seq_supported(const mser_xattn_desc* d);
 int mser_xattn_seq_fwd(const mser_xattn_desc* d, mser_stream_t stream);
@@ -368,7 +372,10 @@ int mser_marn_cell_run(const mser_cell_desc* d, int32_t phases, mser_stream_t st
  * tile).  0: the output-split form. */
 enum { MSER_OPT_PERSISTENT = 1, MSER_OPT_WGRAD_INKERNEL = 2, MSER_OPT_BPTT_KSPLIT = 3, MSER_OPT_XCD_PLACEMENT = 4,
        MSER_OPT_FWD_STATS_ROLES = 5, MSER_OPT_FWD_SENTINEL = 6, MSER_OPT_BWD_SENTINEL = 7, MSER_OPT_H256_SPLIT = 8,
-       MSER_OPT_SPK_BWD_KSPLIT = 9 };
+       MSER_OPT_SPK_BWD_KSPLIT = 9,
+       /* value = n: with both seams of the LSTHM BPTT self-validating, n x 64 clocks pass between a workgroup's arrive and its first look
+        * at the other workgroups' gate gradients (measured: they are usually visible at the first look already; default 0) */
+       MSER_OPT_BWD_POLL_DELAY = 10 };
 int mser_set_option(int32_t key, int32_t value);
 /* Synchronises `stream` and reports whether a persistent kernel of the last fwd/bwd call on this workspace gave up at a
  * barrier (bounded spins; returns -2 and a message in that case).  Diagnostic; not needed on the hot path. */

@@ -88,6 +88,7 @@ struct CellK {
   int nodx;            // BPTT launch without the two dx = dgates W products (they run as GEMMs after the chain; frees their workgroups)
   int fwd_rowsplit, bwd_rowsplit;   // persistent chains at H = 256: a dialogue row's rank-1 attention is shared by this many workgroups
                        // (forward: 128 query units each; backward: 128 keys of the transposed pass each); 1 or 2
+  int poll_delay;      // LSTHM BPTT, both seams self-validating: clocks / 64 between the arrive and the first look at the gate gradients
   int spk_ks;          // speaker BPTT roles in the K-split (reduce-scatter) form (MSER_OPT_SPK_BWD_KSPLIT)
   int ksplit;          // BPTT matvec phase: every product's K = 4H reduction is split over `ksplit` workgroups (1 or 2); the
                        // partial results live in consecutive copies of dA / dHQp / dxc and the consumers add them
@@ -348,6 +349,9 @@ __device__ __forceinline__ bool dir_barrier(unsigned* cnt, unsigned* abortw, uns
 // Every poll is bounded: a wave that gives up raises the abort word (and the caller's sticky fault word), sets s_poll_abort and goes
 // on with garbage; all waves of the workgroup leave together at the next point where they are synchronised anyway.
 constexpr unsigned SENT_BITS = 0x7fc0dead;
+__device__ __forceinline__ void sleep_n(int n) {      // n x 64 clocks (s_sleep takes an immediate)
+  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+}
 __device__ __forceinline__ bool is_sent(float v) { return __float_as_uint(v) == SENT_BITS; }
 __device__ __forceinline__ bool any_sent8(const float* a) {
   bool b = false;
@@ -462,14 +466,17 @@ __device__ __forceinline__ void wg_mm32(int K, ALoad aload, BLoad bload, const f
     if (poll_abortw) {            // self-validating hand-off: the A rows come from other workgroups of this launch (see is_sent)
       unsigned spins = 0;
       while (true) {
-        bool bad = false;
+        // only the fragments that still hold a sentinel word are requested again (a re-load of the whole slab per failed look was
+        // most of the launch's memory-side read traffic)
+        unsigned long long badm[NP];
+        bool any = false;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) bad |= any_sent8(a[p]);
-        if (__builtin_amdgcn_ballot_w64(bad) == 0ull) break;
+        for (int p = 0; p < NP; ++p) { badm[p] = __builtin_amdgcn_ballot_w64(any_sent8(a[p])); any |= badm[p] != 0ull; }
+        if (!any) break;
         if (poll_giveup(spins, poll_abortw)) break;
 #pragma unroll
         for (int p = 0; p < NP; ++p)
-          if (kbeg + p * 16 < kend) aload(r, kbeg + p * 16 + half * 8, a[p]);
+          if (badm[p] != 0ull && kbeg + p * 16 < kend) aload(r, kbeg + p * 16 + half * 8, a[p]);
       }
       STAMP_ACC(4);
     }
@@ -1960,6 +1967,9 @@ __device__ __forceinline__ void lsthm_bwd_role_sv(const CellK& P, const Role R, 
       barrier_arrive(cnt);
       STAMP_ACC(1);
       rotate();
+      // the other workgroups' gate gradients cannot be there yet (they finish their row phases when this one does, and a store takes
+      // as long again to become visible): the first look is delayed by about one round trip instead of being issued in vain
+      if (P.poll_delay > 0) sleep_n(P.poll_delay);
       if (has_mat && (t > 0 || p >= 4)) lsthm_bwd_mat_body<true, NPM, true>(P, D, ws, t, p, n0, mb, bpre, red, tile, kh, KSPLIT);
       if (s_poll_abort) return;                  // (read behind the product's workgroup barriers: uniform)
     } else {
@@ -3137,7 +3147,7 @@ static size_t carve_all(char* base, const mser_cell_desc& d, CellHost* out) {
   Carver cv{base, 0};
   CellHost h;
   h.k.T = d.T; h.k.B = d.B; h.k.D = d.D; h.k.H = d.H; h.k.ndir = d.ndir; h.k.nmb = cdiv(d.B, 32); h.k.ldo = d.ldo;
-  h.k.wgrad_wgs = 0; h.k.spk_ks = 0; h.k.ksplit = 1; h.k.place = 0; h.k.stats_wgs = 0; h.k.nodx = 0; h.k.fwd_rowsplit = h.k.bwd_rowsplit = 1;
+  h.k.wgrad_wgs = 0; h.k.spk_ks = 0; h.k.poll_delay = 0; h.k.ksplit = 1; h.k.place = 0; h.k.stats_wgs = 0; h.k.nodx = 0; h.k.fwd_rowsplit = h.k.bwd_rowsplit = 1;
   h.sync = cv.take<unsigned>(SYNC_WORDS);
   h.k.sync = h.sync;
   h.k.wsbase = base;
@@ -3240,6 +3250,7 @@ static int g_opt_xcd_place = 0;       // MSER_OPT_XCD_PLACEMENT (off: measured s
 static int g_opt_fwd_sentinel = 1;    // MSER_OPT_FWD_SENTINEL
 static int g_opt_rowsplit = 1;        // MSER_OPT_H256_SPLIT: H = 256 persistent chains share a row phase between two workgroups, BPTT products K-split
 static int g_opt_spk_ks = 1;          // MSER_OPT_SPK_BWD_KSPLIT
+static int g_opt_poll_delay = 0;      // MSER_OPT_BWD_POLL_DELAY
 static int g_opt_bwd_sentinel = 2;    // MSER_OPT_BWD_SENTINEL (2: both seams of the LSTHM BPTT self-validating; round 2 measured no gain -- the speaker roles
                                       // paced the launch then; with them out of the way: 1321 -> 1225 (seam 2) -> 1166 us (both) per launch)
 static int g_num_cus = 0;
@@ -3522,6 +3533,7 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   }
   K.bwd_sentinel = persist ? g_opt_bwd_sentinel : 0;
   K.spk_ks = (persist && !ext && g_opt_spk_ks) ? 1 : 0;
+  K.poll_delay = g_opt_poll_delay;
   if (phases & MSER_PHASE_BWD_PREP) {
     if (K.bwd_sentinel) {
       // every word the BPTT chains hand from workgroup to workgroup starts as the sentinel (dgates | dA | dHQ | dHQp are carved back to
@@ -3893,6 +3905,7 @@ int mser_set_option(int32_t key, int32_t value) {
     case MSER_OPT_BWD_SENTINEL: g_opt_bwd_sentinel = value == 2 ? 2 : (value ? 1 : 0); return 0;
     case MSER_OPT_H256_SPLIT: g_opt_rowsplit = value ? 1 : 0; return 0;
     case MSER_OPT_SPK_BWD_KSPLIT: g_opt_spk_ks = value ? 1 : 0; return 0;
+    case MSER_OPT_BWD_POLL_DELAY: g_opt_poll_delay = value < 0 ? 0 : (value > 256 ? 256 : value); return 0;
     default: set_error("mser_set_option: unknown key %d", key); return -1;
   }
 }

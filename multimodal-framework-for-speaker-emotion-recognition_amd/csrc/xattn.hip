@@ -5,8 +5,13 @@
 //   forward : one workgroup per (32-query tile, head, dialogue): the Q tile and K of the head in LDS -> S = scale Q K^T on the fp32
 //             MFMA -> row softmax by wavefront butterflies (two columns per lane) -> dropout -> V over K's LDS buffer -> O = P V.
 //             Nothing of size [B, L, L] goes to HBM: only the row statistics (max, 1 / sum) are saved.
-//   backward: the same tiling; P is recomputed from Q, K and the statistics; dV += Pd^T dO and dK += dS^T Q are accumulated with float
-//             atomics (the query tiles of a dialogue meet there; the caller zeroes dk / dv), dQ = dS K is owned by the tile.
+//   backward: the same tiling; P is recomputed from Q, K and the statistics; dQ = dS K is owned by the tile.  The query tiles of a
+//             dialogue meet in dV = sum Pd^T dO and dK = sum dS^T Q: with mser_xattn_desc::part_stride != 0 every tile STORES its
+//             contribution into its own slab and a second launch adds the (<= 4) slabs in a fixed order -- deterministic, and plain
+//             coalesced stores instead of 32 k float atomics per workgroup; part_stride == 0 keeps the atomic accumulation (the
+//             caller zeroes dk / dv).  (An owner-computes form -- key-tile workgroups walking the query tiles, recomputing the
+//             transposed blocks -- was built and measured: same 30 us alone, but twice the workgroups: 175 instead of 118 us beside
+//             the BPTT launch, which leaves ~48 CUs free.  Not kept.)
 //
 // A (dialogue, head) has L <= 128 keys of width dk <= 128: K (and then V) take 66 KB of LDS, the query tile 17 KB, the score tile
 // 17 KB -- 101 KB forward, 135 KB backward -- where the encoder's per-head kernel (csrc/encoder.hip), which keeps q, k, v and the
@@ -15,6 +20,7 @@
 // MFMA operand conventions as in csrc/encoder.hip.
 #include "common.h"
 #include "../../include/mser.h"
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -67,6 +73,7 @@ struct XArgs {
   float* stats;                        // [nb, nh, Lq, 2]
   const float* dO; long lddo;
   float* dq; float* dk_; float* dv; long lddq, lddk, lddv;
+  long part_stride;                    // floats between the per-query-tile slabs of dk_ / dv (0: accumulate atomically)
   int nb, nh, Lq, Lk, dk;
   float scale;
   const uint32_t* rng; uint32_t site; float p;
@@ -225,7 +232,11 @@ __global__ __launch_bounds__(XT) void xattn_bwd_kernel(XArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int key = ti * 32 + acc_row(i, half);
-        if (key < Lk) atomicAdd(a.dv + ((long)b * a.sbk + (long)key * a.slk) * a.lddv + h * dk + col, acc[i]);
+        if (key < Lk) {
+          float* dst = a.dv + ((long)b * a.sbk + (long)key * a.slk) * a.lddv + h * dk + col;
+          if (a.part_stride) dst[(long)qt * a.part_stride] = acc[i];
+          else atomicAdd(dst, acc[i]);
+        }
       }
     }
   }
@@ -279,11 +290,31 @@ __global__ __launch_bounds__(XT) void xattn_bwd_kernel(XArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int key = ti * 32 + acc_row(i, half);
-          if (key < Lk) atomicAdd(a.dk_ + ((long)b * a.sbk + (long)key * a.slk) * a.lddk + h * dk + col, acc[i]);
+          if (key < Lk) {
+            float* dst = a.dk_ + ((long)b * a.sbk + (long)key * a.slk) * a.lddk + h * dk + col;
+            if (a.part_stride) dst[(long)qt * a.part_stride] = acc[i];
+            else atomicAdd(dst, acc[i]);
+          }
         }
       }
     }
   }
+}
+
+// slab 0 += slab 1 + slab 2 + ... (fixed order) for the dK and dV views: rows x width each
+__global__ void xattn_reduce_kernel(float* dk_, long lddk, float* dv, long lddv, long rows, int width, long part_stride, int nslab) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int w4 = width >> 2;
+  if (i >= rows * w4) return;
+  const long r = i / w4;
+  const int c = (int)(i - r * w4) << 2;
+  float* base = (blockIdx.y ? dv + r * lddv : dk_ + r * lddk) + c;
+  float4 s4 = *reinterpret_cast<const float4*>(base);
+  for (int k = 1; k < nslab; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(base + (long)k * part_stride);
+    s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+  }
+  *reinterpret_cast<float4*>(base) = s4;
 }
 
 size_t xattn_lds_bytes(int Lk, int dk, bool bwd) {
@@ -308,6 +339,7 @@ XArgs xargs(const mser_xattn_desc& d) {
   a.sbq = d.sbq; a.slq = d.slq; a.sbk = d.sbk; a.slk = d.slk;
   a.o = d.o; a.ldo = d.ldo; a.stats = d.stats;
   a.dO = d.dO; a.lddo = d.lddo; a.dq = d.dq; a.dk_ = d.dk_; a.dv = d.dv; a.lddq = d.lddq; a.lddk = d.lddk; a.lddv = d.lddv;
+  a.part_stride = d.part_stride;
   a.nb = d.nb; a.nh = d.nh; a.Lq = d.Lq; a.Lk = d.Lk; a.dk = d.dk; a.scale = d.scale;
   a.rng = (d.rng && d.p > 0.f) ? d.rng : nullptr; a.site = d.site; a.p = d.p;
   return a;
@@ -328,6 +360,9 @@ int validate(const mser_xattn_desc& d, bool bwd) {
   if (bwd) {
     MSER_REQUIRE(d.dO && d.dq && d.dk_ && d.dv, "mser_xattn_seq_bwd: null gradient buffer");
     MSER_REQUIRE(al16(d.dO) && d.lddo % 4 == 0, "mser_xattn_seq_bwd: dO must be 16-byte aligned, lddo a multiple of 4");
+    if (d.part_stride != 0)
+      MSER_REQUIRE(d.part_stride > 0 && d.part_stride % 4 == 0 && al16(d.dk_) && al16(d.dv) && d.lddk % 4 == 0 && d.lddv % 4 == 0 && (d.nh * d.dk) % 4 == 0,
+                   "mser_xattn_seq_bwd: slabs need 16-byte aligned dk_ / dv, leading dimensions and part_stride that are multiples of 4");
   }
   return 0;
 }
@@ -358,7 +393,18 @@ int mser_xattn_seq_bwd(const mser_xattn_desc* d, mser_stream_t stream) {
   MSER_TRY(allow((const void*)xattn_bwd_kernel, lds));
   ProfScope ps(MSER_PROF_XATTN_BWD, (hipStream_t)stream);
   hipLaunchKernelGGL(xattn_bwd_kernel, dim3((d->Lq + QT - 1) / QT, d->nh, d->nb), dim3(XT), lds, (hipStream_t)stream, xargs(*d));
-  return check_launch("mser_xattn_seq_bwd");
+  MSER_TRY(check_launch("mser_xattn_seq_bwd"));
+  const int nslab = (d->Lq + QT - 1) / QT;
+  if (d->part_stride != 0 && nslab > 1) {
+    // the rows the launch wrote: every key row of every dialogue, i.e. the whole [rows, nh*dk] views (rows = the views' row count)
+    long rows = 0;
+    for (int bb = 0; bb < 2; ++bb) rows = std::max(rows, (long)(d->nb - 1) * d->sbk + (long)(d->Lk - 1) * d->slk + 1);
+    const int width = d->nh * d->dk;
+    hipLaunchKernelGGL(xattn_reduce_kernel, dim3((unsigned)((rows * (width / 4) + 255) / 256), 2), dim3(256), 0, (hipStream_t)stream, d->dk_,
+                       (long)d->lddk, d->dv, (long)d->lddv, rows, width, (long)d->part_stride, nslab);
+    return check_launch("mser_xattn_seq_bwd (slab sum)");
+  }
+  return 0;
 }
 
 }  // extern "C"

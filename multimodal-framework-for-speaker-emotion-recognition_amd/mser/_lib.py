@@ -115,7 +115,7 @@ class XAttnDesc(C.Structure):
                 ("o", C.c_void_p), ("ldo", C.c_int64), ("stats", C.c_void_p), ("scale", C.c_float),
                 ("rng", C.c_void_p), ("site", C.c_uint32), ("p", C.c_float),
                 ("dO", C.c_void_p), ("lddo", C.c_int64), ("dq", C.c_void_p), ("lddq", C.c_int64), ("dk_", C.c_void_p), ("lddk", C.c_int64),
-                ("dv", C.c_void_p), ("lddv", C.c_int64)]
+                ("dv", C.c_void_p), ("lddv", C.c_int64), ("part_stride", C.c_int64)]
 
 
 class HeadTailDesc(C.Structure):

@@ -502,13 +502,20 @@ def xattn_bwd(c: XAttnCtx, dout: Tensor, Wq: Tensor, Wk: Tensor, Wv: Tensor, gWq
     Dk = Wq.shape[1]
     dQ = torch.empty_like(c.Q)
     if c.fused is not None:
-        dKV = torch.zeros_like(c.KV)                        # dK / dV are accumulated over the query tiles (float atomics)
+        # dK / dV meet contributions from every 32-query tile: each tile stores into its own slab, the launch's second kernel adds them
+        # in a fixed order (deterministic; round 2 used float atomics into a zeroed buffer)
+        nslab = (c.l1.nl + 31) // 32
+        slabs = torch.empty((nslab,) + tuple(c.KV.shape), device=c.KV.device, dtype=c.KV.dtype)
+        dKV = slabs[0]
         dO = dout if (dout.stride(1) == 1 and dout.stride(0) % 4 == 0 and dout.data_ptr() % 16 == 0) else dout.contiguous()
         d = c.fused
         d.dO, d.lddo = dO.data_ptr(), dO.stride(0)
         d.dq, d.lddq = dQ.data_ptr(), dQ.stride(0)
         d.dk_, d.lddk = dKV.data_ptr(), dKV.stride(0)
         d.dv, d.lddv = dKV[:, Dk:].data_ptr(), dKV.stride(0)
+        d.part_stride = slabs.stride(0) if nslab > 1 else 0
+        if nslab == 1:
+            dKV.zero_()
         ops.xattn_seq_bwd(d)
         c._keep_bwd = dO
     else:

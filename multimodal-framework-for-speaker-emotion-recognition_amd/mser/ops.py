@@ -772,6 +772,7 @@ MSER_OPT_FWD_SENTINEL = 6
 MSER_OPT_BWD_SENTINEL = 7
 MSER_OPT_H256_SPLIT = 8
 MSER_OPT_SPK_BWD_KSPLIT = 9
+MSER_OPT_BWD_POLL_DELAY = 10
 
 
 def set_option(key: int, value: int) -> None:

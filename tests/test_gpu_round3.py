@@ -346,3 +346,29 @@ def test_batch_prefetcher_ingest_is_bit_exact(O):
         res.append((avg, acc, tr.model.flat_store.data.clone()))
     assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
     assert maxabs(res[0][2], res[1][2]) < 1e-6                     # (the weight-gradient GEMMs' split-K atomics: equal to rounding)
+
+
+# ------------------------------------------------------------------------------------------------ deterministic sequence-attention backward
+def test_cross_attention_module_gradients_are_bit_reproducible(O):
+    """CrossAttention2 / CrossAttention3 (reference model/lsthm_sps.py:88-101, :116-129) -- the fused backward
+    accumulated dK / dV over the query tiles with float atomics; every element now has one owning workgroup, so two runs of the same
+    backward give bit-identical input and weight gradients."""
+    from models.lsthm_sps import CrossAttention2, CrossAttention3
+    rs = np.random.RandomState(17)
+    for cls, d2 in ((CrossAttention2, 100), (CrossAttention3, 128)):
+        m = cls(100, 128, 128).cuda().eval()
+        with torch.no_grad():
+            for p in m.parameters():
+                p.copy_(torch.tensor((0.3 * rs.standard_normal(tuple(p.shape))).astype(np.float32)))
+        a0 = torch.tensor(rs.standard_normal((128, 32, 100)).astype(np.float32)).cuda()
+        b0 = torch.tensor(rs.standard_normal((128, 32, d2)).astype(np.float32)).cuda()
+        w = torch.tensor(rs.standard_normal((128, 32, 128)).astype(np.float32)).cuda()
+        runs = []
+        for _ in range(2):
+            a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+            m.zero_grad()
+            (m(a, b) * w).sum().backward()
+            runs.append([a.grad.clone(), b.grad.clone()] + [p.grad.clone() for p in m.parameters()])
+        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])       # input gradients: bit for bit
+        for x, y in zip(runs[0][2:], runs[1][2:]):                    # Wq / Wk / Wv: behind a split-K GEMM whose partials meet in float
+            assert maxabs(x, y) <= 1e-6 * max(1.0, float(x.abs().max()))      # atomics (csrc/gemm.hip): equal to rounding
