@@ -375,7 +375,12 @@ enum { MSER_OPT_PERSISTENT = 1, MSER_OPT_WGRAD_INKERNEL = 2, MSER_OPT_BPTT_KSPLI
        MSER_OPT_SPK_BWD_KSPLIT = 9,
        /* value = n: with both seams of the LSTHM BPTT self-validating, n x 64 clocks pass between a workgroup's arrive and its first look
         * at the other workgroups' gate gradients (measured: they are usually visible at the first look already; default 0) */
-       MSER_OPT_BWD_POLL_DELAY = 10 };
+       MSER_OPT_BWD_POLL_DELAY = 10,
+       /* 1: cells wider than 512 (BASELINE configs[4]: hid = 1024) run every time step of a chain inside ONE launch per chain and pass (one
+        * workgroup per CU, the per-step phases separated by counter barriers, hand-offs stored write-through and loaded through the
+        * caches) instead of 3 + 4 launches per time step; 0 (default; the persistent launches hold every CU and serialise the GEMMs the
+        * per-step launches overlap: measured slower end to end): one launch per phase and step */
+       MSER_OPT_WIDE_PERSISTENT = 11 };
 int mser_set_option(int32_t key, int32_t value);
 /* Synchronises `stream` and reports whether a persistent kernel of the last fwd/bwd call on this workspace gave up at a
  * barrier (bounded spins; returns -2 and a message in that case).  Diagnostic; not needed on the hot path. */

@@ -27,6 +27,7 @@
 //    cross-check of the persistent path (tests/test_gpu_model.py::test_persistent_vs_per_step_launches).
 #include "common.h"
 #include "../../include/mser.h"
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -155,14 +156,17 @@ __device__ __forceinline__ WS make_ws(void* base, unsigned bytes) {
 }
 constexpr int AUX_SC1 = 16;
 
-template <bool PS>
+// PS = 0: plain accesses; 1: write-through stores and L1 / L2-bypassing loads (the chains' hand-off form); 2: write-through stores but
+// CACHED loads -- for hand-offs through arrays that are indexed by the time step (a consumer never holds a stale line of an address
+// nobody has read before) and whose operands are read by many workgroups (the wide cells' persistent launches, see cell_wide_*)
+template <int PS>
 __device__ __forceinline__ float ldx(const WS& w, const float* p) {
-  if constexpr (PS) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(w.r, (int)((const char*)p - w.base), 0, AUX_SC1));
+  if constexpr (PS == 1) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(w.r, (int)((const char*)p - w.base), 0, AUX_SC1));
   else return *p;
 }
-template <bool PS>
+template <int PS>
 __device__ __forceinline__ void stx(const WS& w, float* p, float v) {
-  if constexpr (PS) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), w.r, (int)((const char*)p - w.base), 0, AUX_SC1);
+  if constexpr (PS != 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), w.r, (int)((const char*)p - w.base), 0, AUX_SC1);
   else *p = v;
 }
 __device__ __forceinline__ void load8(const float* p, float* a) {
@@ -171,9 +175,9 @@ __device__ __forceinline__ void load8(const float* p, float* a) {
   a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w;
   a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
 }
-template <bool PS>
+template <int PS>
 __device__ __forceinline__ void load8x(const WS& w, const float* p, float* a) {
-  if constexpr (PS) {
+  if constexpr (PS == 1) {
     const int off = (int)((const char*)p - w.base);
     const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(w.r, off, 0, AUX_SC1);
     const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(w.r, off + 16, 0, AUX_SC1);
@@ -183,9 +187,9 @@ __device__ __forceinline__ void load8x(const WS& w, const float* p, float* a) {
     load8(p, a);
   }
 }
-template <bool PS>
+template <int PS>
 __device__ __forceinline__ void store8x(const WS& w, float* p, const float* a) {
-  if constexpr (PS) {
+  if constexpr (PS != 0) {
     const int off = (int)((const char*)p - w.base);
     u32x4 v0, v1;
     v0.x = __float_as_uint(a[0]); v0.y = __float_as_uint(a[1]); v0.z = __float_as_uint(a[2]); v0.w = __float_as_uint(a[3]);
@@ -197,18 +201,18 @@ __device__ __forceinline__ void store8x(const WS& w, float* p, const float* a) {
     *reinterpret_cast<float4*>(p + 4) = make_float4(a[4], a[5], a[6], a[7]);
   }
 }
-template <bool PS>
+template <int PS>
 __device__ __forceinline__ float4 ld4x(const WS& w, const float* p) {
-  if constexpr (PS) {
+  if constexpr (PS == 1) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w.r, (int)((const char*)p - w.base), 0, AUX_SC1);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
   } else {
     return *reinterpret_cast<const float4*>(p);
   }
 }
-template <bool PS>
+template <int PS>
 __device__ __forceinline__ void st4x(const WS& w, float* p, float4 v) {
-  if constexpr (PS) {
+  if constexpr (PS != 0) {
     u32x4 u;
     u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
     __builtin_amdgcn_raw_buffer_store_b128(u, w.r, (int)((const char*)p - w.base), 0, AUX_SC1);
@@ -447,7 +451,10 @@ constexpr float LOG2E = 1.4426950408889634f;
 // aload(r, k, a[8]) returns A[row r][k..k+7]; bload(n, k, b[8]) returns B[k..k+7][col n].
 // NP > 0: the B fragments of this wave's NP k-passes were loaded once into bpre[][] (persistent kernels keep the weights in
 // registers across the whole time loop) and all A fragments are fetched before the first MFMA.
-template <int NP, class ALoad, class BLoad>
+// UN (NP == 0 only): k-passes whose operand loads are issued together before their MFMAs run.  The streaming form used to wait for
+// every pass's loads in turn and relied on 6-8 waves per SIMD to hide that; the wide persistent launches run one workgroup per CU
+// (2 waves per SIMD), so they keep UN = 4 passes in flight per wave instead.
+template <int NP, int UN = 1, class ALoad, class BLoad>
 __device__ __forceinline__ void wg_mm32(int K, ALoad aload, BLoad bload, const float (*bpre)[8], float* red, float* tile,
                                         bool red_aliases_a = false, unsigned* poll_abortw = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -487,12 +494,21 @@ __device__ __forceinline__ void wg_mm32(int K, ALoad aload, BLoad bload, const f
     }
     if (poll_abortw) STAMP_ACC(5);
   } else {
-    for (int kb = kbeg; kb < kend; kb += 16) {
-      float a[8], b[8];
-      aload(r, kb + half * 8, a);
-      bload(r, kb + half * 8, b);
+    for (int kb = kbeg; kb < kend; kb += 16 * UN) {
+      float a[UN][8], b[UN][8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+      for (int u = 0; u < UN; ++u) {
+        if (UN == 1 || kb + 16 * u < kend) {
+          aload(r, kb + 16 * u + half * 8, a[u]);
+          bload(r, kb + 16 * u + half * 8, b[u]);
+        } else {
+          zero8(a[u]); zero8(b[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][j], b[u][j], acc, 0, 0, 0);
     }
   }
   if (red_aliases_a) __syncthreads();        // `red` shares storage with the LDS-staged A operand: every wave has read its part
@@ -615,12 +631,16 @@ __device__ __forceinline__ SpkPre spk_fwd_prefetch(const CellK& P, const DirP& D
 // carry (persistent kernel): this thread's cell state c_q[slot][u] and its four gate biases stay in registers across the steps
 struct SpkCarry { float cq, bias4[4]; };
 
-template <bool PS, int NP>
+template <int PS, int NP>
 __device__ __forceinline__ void spk_fwd_body(const CellK& P, const DirP& D, const WS& ws, int t, int c, int u0, int mb, bool writer,
                                              const float (*bpre)[8], float* red, float* tile, const SpkPre* pre = nullptr,
                                              SpkCarry* carry = nullptr) {
   const int H = P.H, B = P.B, T = P.T;
-  const int N0 = pre ? pre->N0 : D.n0[t];
+  // (per-step launches: the lane's row of the index tables once per call -- inside aload they were two dependent loads in front of
+  //  EVERY k-chunk's gather; at hid = 1024 the launch took 75 us for 134 MB of weights)
+  SpkPre pre_local;
+  if (!pre) { pre_local = spk_fwd_prefetch(P, D, t, c, mb); pre = &pre_local; }
+  const int N0 = pre->N0;
   const int Nc = c ? B - N0 : N0, off = c ? N0 : 0;
   const long SB = (long)B * H;
   float* hq_new = D.hq_state + ((long)c * (T + 1) + t + 1) * SB;
@@ -688,13 +708,13 @@ __device__ __forceinline__ void spk_fwd_body(const CellK& P, const DirP& D, cons
     }
   };
   STAMP_ACC(0);
-  wg_mm32<NP>(2 * H, aload, SpkFwdB{D, c, u0, H}, bpre, red, tile);
+  wg_mm32<NP, (PS == 2 ? 4 : 1)>(2 * H, aload, SpkFwdB{D, c, u0, H}, bpre, red, tile);
   STAMP_ACC(1);
   if (tid < 256) {
     const int rr = tid >> 3, uu = tid & 7;
     const int slot = mb * 32 + rr, u = u0 + uu;
     if (slot < B) {
-      const bool fnl = PS && FASTNL;                          // (persistent chain: hardware exp / rcp forms, see sigmoid_fast)
+      const bool fnl = PS == 1 && FASTNL;                          // (persistent chain: hardware exp / rcp forms, see sigmoid_fast)
       const float gi = fnl ? sigmoid_fast(tile[rr * 32 + 0 + uu] + bias4[0]) : sigmoidf_(tile[rr * 32 + 0 + uu] + bias4[0]);
       const float gf = fnl ? sigmoid_fast(tile[rr * 32 + 8 + uu] + bias4[1]) : sigmoidf_(tile[rr * 32 + 8 + uu] + bias4[1]);
       const float gg = fnl ? tanh_fast(tile[rr * 32 + 16 + uu] + bias4[2]) : tanhf(tile[rr * 32 + 16 + uu] + bias4[2]);
@@ -777,7 +797,7 @@ struct LsthmFwdB {
 
 // WITHS: the speaker term S h_q[t] is part of the step (K = 3H) instead of the hoisted pre-activation GEMM, so that the chain
 // can run CONCURRENTLY with the speaker chain that produces h_q (pipelined persistent kernels).
-template <bool PS, int NP, bool WITHS = false>
+template <int PS, int NP, bool WITHS = false>
 __device__ __forceinline__ void lsthm_gates_body(const CellK& P, const DirP& D, const WS& ws, int t, int m, int u0, int mb,
                                                  const float (*bpre)[8], float* red, float* tile) {
   const int H = P.H, B = P.B, T = P.T;
@@ -812,7 +832,7 @@ __device__ __forceinline__ void lsthm_gates_body(const CellK& P, const DirP& D, 
     else load8x<PS>(ws, D.HQ + ((long)t * B + b) * H + (k - 2 * H), a);
   };
   STAMP_ACC(0);
-  wg_mm32<NP>(WITHS ? 3 * H : 2 * H, aload, LsthmFwdB{D, m, u0, H}, bpre, red, tile);
+  wg_mm32<NP, (PS == 2 ? 4 : 1)>(WITHS ? 3 * H : 2 * H, aload, LsthmFwdB{D, m, u0, H}, bpre, red, tile);
   STAMP_ACC(1);
   if (tid < 256) {
     const int rr = tid >> 3, uu = tid & 7;
@@ -1162,10 +1182,11 @@ __global__ __launch_bounds__(NT) void lsthm_fwd_z(CellK P, int t) {
 // unit i0 + il.  LDS: att [2H+16] | kc float4[H] | partials 4 x [NT] | sh[16].  Leaves the same outputs as lsthm_z_body (z, out, rstat).
 constexpr int WIDE_IW = 128;
 static size_t z_wide_lds_bytes(int H) { return ((size_t)(2 * H + 16) + 4 * (size_t)H + 4 * NT + 16) * sizeof(float); }
-__global__ __launch_bounds__(NT) void lsthm_fwd_z_wide(CellK P, int t) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const DirP& D = P.d[blockIdx.y];
-  const int H = P.H, B = P.B, T = P.T, b = blockIdx.x, i0 = blockIdx.z * WIDE_IW;
+// PS = true: inside the persistent wide launch (cell_wide_fwd_persist): c_l / c_a come from other workgroups of the same launch and z goes
+// to them (write-through / L1-bypassing accesses through `ws`)
+template <int PS>
+__device__ __forceinline__ void lsthm_fwd_z_wide_body(const CellK& P, const DirP& D, const WS& ws, int t, int b, int zblk, float* smem) {
+  const int H = P.H, B = P.B, T = P.T, i0 = zblk * WIDE_IW;
   float* att = smem;
   float4* kc = reinterpret_cast<float4*>(att + 2 * H + 16);
   float* part = reinterpret_cast<float*>(kc + H);
@@ -1178,12 +1199,12 @@ __global__ __launch_bounds__(NT) void lsthm_fwd_z_wide(CellK P, int t) {
   const float* c_a = D.cstate + ((long)1 * (T + 1) + t + 1) * B * H + (long)b * H;
   float sp = 0.f;
   for (int k = tid; k < H; k += NT) {
-    const float cv = c_a[k], w = att[k];
+    const float cv = ldx<PS>(ws, c_a + k), w = att[k];
     kc[k] = make_float4(w, cv, cv * w, 0.f);
     sp = fmaf(att[H + k], cv, sp);
   }
   const float s = block_sum(sp, sh) / sqrtf((float)H);           // (its barriers publish kc)
-  const float u = c_l[i] * s;
+  const float u = ldx<PS>(ws, c_l + i) * s;
   const float mx = (u >= 0.f) ? u * att[2 * H] : u * att[2 * H + 1];
   const float u2 = u * LOG2E, m2 = mx * LOG2E;
   float Z = 0.f, N = 0.f, N2 = 0.f, N3 = 0.f;
@@ -1219,11 +1240,16 @@ __global__ __launch_bounds__(NT) void lsthm_fwd_z_wide(CellK P, int t) {
       N2 += part[2 * NT + qq * WIDE_IW + il]; N3 += part[3 * NT + qq * WIDE_IW + il];
     }
     const float z = N / Z;
-    D.hz[((long)(t + 1) * B + b) * 3 * H + 2 * H + i] = z;
+    stx<PS>(ws, D.hz + ((long)(t + 1) * B + b) * 3 * H + 2 * H + i, z);
     const int tau = D.rev ? D.rev[(long)t * B + b] : t;
     if (tau >= 0) D.out[((long)tau * B + b) * P.ldo + 2 * H + i] = z;
     *reinterpret_cast<float4*>(D.rstat + (((long)t * B + b) * H + i) * 4) = make_float4(Z, N2, N3, s);
   }
+}
+__global__ __launch_bounds__(NT) void lsthm_fwd_z_wide(CellK P, int t) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WS ws = make_ws(P.wsbase, P.wsbytes);
+  lsthm_fwd_z_wide_body<false>(P, P.d[blockIdx.y], ws, t, blockIdx.x, blockIdx.z, smem);
 }
 
 // persistent launch: grid (H/8, 2 streams, ndir*nmb); two barriers per step (gates -> z -> next gates).  Runs concurrently with
@@ -1725,7 +1751,7 @@ struct LsthmBwdB {
 };
 
 // kh / ksplit: this workgroup reduces over gate columns [kh * 4H/ksplit, (kh+1) * 4H/ksplit) and writes partial copy kh.
-template <bool PS, int NP, bool SV = false>
+template <int PS, int NP, bool SV = false>
 __device__ __forceinline__ void lsthm_bwd_mat_body(const CellK& P, const DirP& D, const WS& ws, int t, int p, int n0, int mb,
                                                    const float (*bpre)[8], float* red, float* tile, int kh = 0, int ksplit = 1) {
   const int m = p < 4 ? p >> 1 : (p - 4) & 1;
@@ -1745,7 +1771,7 @@ __device__ __forceinline__ void lsthm_bwd_mat_body(const CellK& P, const DirP& D
     const int b = mb * 32 + ((threadIdx.x + e * NT) >> 5);
     taue[e] = (p >= 6 && b < B) ? lsthm_tau(D, t, b, B) : -1;
   }
-  wg_mm32<NP>(KH, aload, LsthmBwdB{Wp + (long)koff * ldw, n0, ldw, ldw}, bpre, red, tile, false, SV ? P.sync + SYNC_ABORT : nullptr);
+  wg_mm32<NP, (PS == 2 ? 4 : 1)>(KH, aload, LsthmBwdB{Wp + (long)koff * ldw, n0, ldw, ldw}, bpre, red, tile, false, SV ? P.sync + SYNC_ABORT : nullptr);
 #pragma unroll
   for (int e = 0; e < 1024 / NT; ++e) {
     const int idx = threadIdx.x + e * NT;
@@ -1784,10 +1810,9 @@ __global__ __launch_bounds__(NT) void lsthm_bwd_mat(CellK P, int t) {
 // forward saved (rstat: no first exp2 pass) -- H element-wise evaluations against the H x 128 exponentials of its share of the
 // transposed pass.  LDS: att [2H+16] | coef [H][8] | partials 3 x [NT] | sh[16].  Same outputs as lsthm_bwd_row_body.
 static size_t bwd_row_wide_lds_bytes(int H) { return ((size_t)(2 * H + 16) + 8 * (size_t)H + 3 * NT + 16) * sizeof(float); }
-__global__ __launch_bounds__(NT) void lsthm_bwd_row_wide(CellK P, int t) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const DirP& D = P.d[blockIdx.y];
-  const int H = P.H, B = P.B, T = P.T, b = blockIdx.x, j0 = blockIdx.z * WIDE_IW;
+template <int PS>
+__device__ __forceinline__ void lsthm_bwd_row_wide_body(const CellK& P, const DirP& D, const WS& ws, int t, int b, int zblk, float* smem) {
+  const int H = P.H, B = P.B, T = P.T, j0 = zblk * WIDE_IW;
   float* att = smem;
   float* coef = att + 2 * H + 16;
   float* part = coef + 8 * H;
@@ -1810,7 +1835,7 @@ __global__ __launch_bounds__(NT) void lsthm_bwd_row_wide(CellK P, int t) {
     const float cl = c_l[k];
     const float zi = D.hz[((long)(t + 1) * B + b) * 3 * H + 2 * H + k];
     float dz = dorow ? dorow[2 * H + k] : 0.f;
-    if (!last) dz += dA[1 * SA + k] + dA[3 * SA + k];
+    if (!last) dz += ldx<PS>(ws, dA + 1 * SA + k) + ldx<PS>(ws, dA + 3 * SA + k);
     const float u = cl * st.w;
     const float mx = (u >= 0.f) ? u * att[2 * H] : u * att[2 * H + 1];
     const float du = dz * (st.y - zi * st.z) / st.x;
@@ -1851,7 +1876,7 @@ __global__ __launch_bounds__(NT) void lsthm_bwd_row_wide(CellK P, int t) {
   }
   part[tid] = S1; part[NT + tid] = S2; part[2 * NT + tid] = S3;
   __syncthreads();
-  if (q != 0) return;
+  if (q == 0) {
   for (int qq = 1; qq < Q; ++qq) { S1 += part[qq * WIDE_IW + jl]; S2 += part[NT + qq * WIDE_IW + jl]; S3 += part[2 * NT + qq * WIDE_IW + jl]; }
   const float rsH = 1.0f / sqrtf((float)H);
   const float cav = c_a[j], clv = c_l[j];
@@ -1866,7 +1891,7 @@ __global__ __launch_bounds__(NT) void lsthm_bwd_row_wide(CellK P, int t) {
   for (int m = 0; m < 2; ++m) {
     const float* g = D.gates + ((long)m * T * B + rowt) * 4 * H + j;
     const float gf = g[0], gi = g[H], go = g[2 * H], gc = g[3 * H];
-    float dh = (dorow ? dorow[m * H + j] : 0.f) + (last ? 0.f : dA[(2 * m) * SA + j]);
+    float dh = (dorow ? dorow[m * H + j] : 0.f) + (last ? 0.f : ldx<PS>(ws, dA + (2 * m) * SA + j));
     if (drop_state_on(P, D)) dh *= drop_h(P, D, t, m, b, j);
     const float cc = m ? cav : clv;
     const float tc = tanhf(cc);
@@ -1874,13 +1899,19 @@ __global__ __launch_bounds__(NT) void lsthm_bwd_row_wide(CellK P, int t) {
     float* carry = D.dc_carry + (long)m * SA + (long)b * H + j;
     const float dc = *carry + dh * go * (1.f - tc * tc) + (m ? dca_att : dcl_att);
     float* dg = D.dgates + ((long)m * T * B + rowt) * 4 * H + j;
-    dg[0] = dc * cprev * gf * (1.f - gf);
-    dg[H] = dc * gc * gi * (1.f - gi);
-    dg[2 * H] = dh * tc * go * (1.f - go);
-    dg[3 * H] = dc * gi * (1.f - gc * gc);
+    stx<PS>(ws, dg, dc * cprev * gf * (1.f - gf));
+    stx<PS>(ws, dg + H, dc * gc * gi * (1.f - gi));
+    stx<PS>(ws, dg + 2 * H, dh * tc * go * (1.f - go));
+    stx<PS>(ws, dg + 3 * H, dc * gi * (1.f - gc * gc));
     *carry = dc * gf;
   }
   D.dHQ[rowt * H + j] = dorow ? dorow[3 * H + j] : 0.f;
+  }
+}
+__global__ __launch_bounds__(NT) void lsthm_bwd_row_wide(CellK P, int t) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WS ws = make_ws(P.wsbase, P.wsbytes);
+  lsthm_bwd_row_wide_body<false>(P, P.d[blockIdx.y], ws, t, blockIdx.x, blockIdx.z, smem);
 }
 
 // persistent launch: grid (nwg, 1, ndir), nwg >= (H/32)*6*nmb.  Row phase: rows round-robin over all nwg workgroups;
@@ -2100,7 +2131,7 @@ __device__ __forceinline__ SpkBwdLds spk_bwd_lds(float* smem, int H) {
 // MODE 0: the whole step.  H >= 512 (per-step launches only; the gate-gradient tile would not fit the LDS) runs it as two launches:
 // MODE 1 = the element-wise prologue alone (publishes dsg[t] and the carried cell gradient), MODE 2 = the products alone, with
 // the A operand read back from dsg[t].
-template <bool PS, int NP, bool WITHP = false, int MODE = 0>
+template <int PS, int NP, bool WITHP = false, int MODE = 0>
 __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, const WS& ws, int t, int p, int n0, int mb, int wsel,
                                              const float (*bpre)[8], float* red, float* tile, float* dsg_s) {
   const int c = p >> 1;
@@ -2137,7 +2168,7 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, cons
     if (MODE != 1 && (p & 1) == 0 && slot < Nc) {
       const int r = off + slot;
       be[e] = D.perm[(long)t * B + r];
-      if (!last) dh0e[e] = (1.f - mn[r]) * ldx<PS>(ws, X_n + (long)r * H + n0 + n);
+      if (!last) dh0e[e] = (1.f - mn[r]) * ldx<(PS ? 1 : 0)>(ws, X_n + (long)r * H + n0 + n);
     }
   }
 
@@ -2146,8 +2177,14 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, cons
   // bound by vector-memory instruction throughput, not by arithmetic).  All loads of an iteration batch are issued first.
   constexpr int MAXIT = NP > 0 ? 2 : 4;         // groups in flight per batch (persistent kernels: H = 128 has two per thread in all; H = 256 four, and with its 64 weight registers per lane four in flight would spill)
   const int G4 = H / 4;                          // float4 groups per slot row
-  const int nit = 32 * G4 / NT;                  // = H/64
   const int npub = 2 * (H / 32);                 // workgroups of this cell; group g is published by workgroup (g % G4) % npub
+  // MODE 1 (the prologue as its own launch / phase: nothing stays in LDS) visits ONLY the groups this workgroup publishes -- 32 slots x
+  // G4 / npub = 4 column groups -- instead of rebuilding all 32 x G4 of them (at hid = 1024 every one of the cell's 64 workgroups loaded the
+  // whole 32 x 4096 tile's operands to store 1/64 of it: 45 of the launch's 50 us)
+  const int cgn = G4 / npub;
+  const int ngrp = MODE == 1 ? 32 * cgn : 32 * G4;
+  const int nit = (ngrp + NT - 1) / NT;          // MODE 0 / 2: = H/64
+  auto grp = [&](int e) { return MODE == 1 ? (e / cgn) * G4 + wsel + npub * (e % cgn) : e; };
   auto f4 = [](float4 v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; };
   for (int it0 = 0; it0 < (MODE == 2 ? 0 : nit); it0 += MAXIT) {
     float4 v_dh[MAXIT], v_dc[MAXIT], v_x[MAXIT], v_hq[MAXIT], v_g[MAXIT][4], v_tc[MAXIT], v_co[MAXIT];
@@ -2155,20 +2192,21 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, cons
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int ii = 0; ii < MAXIT; ++ii) {
-      const int g = tid + (it0 + ii) * NT;
+      const int ge = tid + (it0 + ii) * NT;
+      const int g = grp(ge < ngrp ? ge : 0);
       const int rr = g / G4, u = (g % G4) * 4;
       const int slot = mb * 32 + rr;
       v_dh[ii] = v_dc[ii] = v_x[ii] = v_hq[ii] = v_tc[ii] = v_co[ii] = z4;
       v_g[ii][0] = v_g[ii][1] = v_g[ii][2] = v_g[ii][3] = z4;
       v_m[ii] = 0.f;
-      if (it0 + ii < nit && slot < B) {
+      if (ge < ngrp && slot < B) {
         if (!last) {
-          v_dh[ii] = ld4x<PS>(ws, dhprev_n + (long)slot * H + u);
-          v_dc[ii] = ld4x<PS>(ws, dcprev_n + (long)slot * H + u);
+          v_dh[ii] = ld4x<(PS ? 1 : 0)>(ws, dhprev_n + (long)slot * H + u);      // (ping-pong buffers: addresses are reused every second
+          v_dc[ii] = ld4x<(PS ? 1 : 0)>(ws, dcprev_n + (long)slot * H + u);      //  step, so their loads bypass the caches in mode 2 as well)
         }
         if (slot < Nc) {
           const int r = off + slot;
-          if (!last) { v_x[ii] = ld4x<PS>(ws, X_n + (long)r * H + u); v_m[ii] = mn[r]; }
+          if (!last) { v_x[ii] = ld4x<(PS ? 1 : 0)>(ws, X_n + (long)r * H + u); v_m[ii] = mn[r]; }
           if (WITHP) {       // pipelined: dHQ[t] = dout_hq (row phase) + dgates_l S_l + dgates_a S_a (matvec phase), all just published
             const float4 q0 = ld4x<PS>(ws, D.dHQ + ((long)t * B + r) * H + u);
             const float4 q1 = ld4x<PS>(ws, D.dHQp + (((long)0 * T + t) * B + r) * H + u);
@@ -2198,10 +2236,11 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, cons
       // sentinel (a NaN) by BWD_PREP, so a sum that is NaN still holds a word that has not been written: re-load until it is not
 #pragma unroll
       for (int ii = 0; ii < MAXIT; ++ii) {
-        const int g = tid + (it0 + ii) * NT;
+        const int ge = tid + (it0 + ii) * NT;
+      const int g = grp(ge < ngrp ? ge : 0);
         const int rr = g / G4, u = (g % G4) * 4;
         const int slot = mb * 32 + rr;
-        const bool mine = it0 + ii < nit && slot < B && slot < Nc;
+        const bool mine = ge < ngrp && slot < B && slot < Nc;
         unsigned spins = 0;
         while (__builtin_amdgcn_ballot_w64(mine && (v_hq[ii].x != v_hq[ii].x || v_hq[ii].y != v_hq[ii].y || v_hq[ii].z != v_hq[ii].z ||
                                                     v_hq[ii].w != v_hq[ii].w)) != 0ull) {
@@ -2222,7 +2261,9 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, cons
 #pragma unroll
     for (int ii = 0; ii < MAXIT; ++ii) {
       if (it0 + ii >= nit) break;
-      const int g = tid + (it0 + ii) * NT;
+      const int ge = tid + (it0 + ii) * NT;
+      if (ge >= ngrp) continue;
+      const int g = grp(ge);
       const int rr = g / G4, u = (g % G4) * 4;
       const int slot = mb * 32 + rr;
       const bool wr = ((g % G4) % npub) == wsel;          // this workgroup publishes this group's results
@@ -2271,13 +2312,13 @@ __device__ __forceinline__ void spk_bwd_body(const CellK& P, const DirP& D, cons
   auto aload = [&](int r, int k, float* a) {
     if (MODE == 2) {
       const int slot = mb * 32 + r;
-      if (slot < B) load8(dsg_g + (long)slot * 4 * H + k, a);
+      if (slot < B) load8x<PS>(ws, dsg_g + (long)slot * 4 * H + k, a);
       else zero8(a);
     } else {
       load8(dsg_s + r * LDS_LD + k, a);
     }
   };
-  wg_mm32<NP>(4 * H, aload, LsthmBwdB{Wp, n0, H}, bpre, red, tile, MODE == 0 && red == dsg_s);
+  wg_mm32<NP, (PS == 2 ? 4 : 1)>(4 * H, aload, LsthmBwdB{Wp, n0, H}, bpre, red, tile, MODE == 0 && red == dsg_s);
   STAMP_ACC(1);
 #pragma unroll
   for (int e = 0; e < 1024 / NT; ++e) {
@@ -2924,6 +2965,152 @@ __global__ __launch_bounds__(NT) void cell_bwd_fused(CellK P, unsigned bwd_nwg) 
   }
 }
 
+// ================================================================================================ wide cells (H > 512): persistent form
+// BASELINE configs[4] runs hid = 1024: the recurrent weights (134 MB per phase) cannot be register-resident, so every step streams them
+// from the infinity cache / HBM -- round 2 did that with SEVEN launches per time step (speaker step, gates, row phase; BPTT row phase,
+// matvec, speaker prologue, speaker products), 1792 launches per training step whose dispatch gaps (~10 us each) were a fifth of the
+// step.  These three kernels run the same per-step bodies inside ONE launch per pass: the grid is one workgroup per CU, a phase's
+// (virtual) blocks are dealt round-robin to the workgroups, and a phase boundary is a counter barrier among all of them (2 us instead
+// of a launch).
+// Coherence (accessor mode 2): what a phase hands to the next is STORED write-through and LOADED through the caches.  A step's A rows
+// (393 KB at hid = 1024) are read by 512 virtual blocks and must hit the L2: with the narrow chains' L1 / L2-bypassing loads every one
+// of those reads went to the memory side (122 ms per step against 95 for the per-step launches), and agent-scope release / acquire
+// fences around a plain-access phase cost ~60 us each (they walk the whole L2: 216 ms per step).  Cached loads are safe here because
+// every hand-off array is indexed by the time step -- no cache can hold a stale line of an address that nobody has read since the
+// launch began -- except the speaker BPTT's three ping-pong buffers, whose loads bypass the caches.  The workspace exceeds the 2 GiB one
+// buffer descriptor addresses at this width (5 GB): each direction gets a descriptor over just its hand-off arrays (forward
+// qsel .. hz: 1.3 GB at B = 32, L = 256; backward dgates .. dcprev).
+struct WideWS { WS f[2], b[2]; };
+__device__ __forceinline__ WideWS make_wide_ws(const CellK& P) {
+  WideWS w;
+  for (int i = 0; i < P.ndir; ++i) {
+    const DirP& D = P.d[i];
+    w.f[i] = make_ws(D.qsel, (unsigned)((const char*)(D.hz + (long)(P.T + 1) * P.B * 3 * P.H) - (const char*)D.qsel));
+    w.b[i] = make_ws(D.dgates, (unsigned)((const char*)(D.dcprev + 2L * 2 * P.B * P.H) - (const char*)D.dgates));
+  }
+  if (P.ndir == 1) { w.f[1] = w.f[0]; w.b[1] = w.b[0]; }
+  return w;
+}
+static size_t wide_lds_bytes(int H) {
+  size_t m = (RED_FLOATS + 1024) * sizeof(float);
+  m = std::max(m, z_wide_lds_bytes(H));
+  m = std::max(m, bwd_row_wide_lds_bytes(H));
+  return m + 64;                  // + the barrier's ok word
+}
+
+// The speaker chain and the LSTHM chain stay TWO launches (as in the per-step form): fused into one time loop their weights -- 134 MB
+// of speaker-cell matrices and 134 MB of U / V per step -- no longer fit the 256 MB infinity cache together and every step streamed
+// from HBM (49.5 ms for the fused forward launch against 19.3 + 18.4 ms for the two loops; scratch/wide_prof.py).
+__global__ __launch_bounds__(NT) void cell_wide_spkfwd_persist(CellK P, unsigned lds_floats) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WideWS W = make_wide_ws(P);
+  const int G = gridDim.x, w = blockIdx.x;
+  set_logical_wg((unsigned)w, P.fault);
+  int* lds_ok = (int*)(smem + lds_floats);
+  unsigned* cnt = P.sync + SYNC_SPK_FWD;
+  unsigned nbar = 0;
+  const int gx = P.H / 8;
+  const int Vs = gx * 2 * P.ndir * P.nmb;
+  for (int t = 0; t < P.T; ++t) {
+    for (int vb = w; vb < Vs; vb += G) {
+      const int x = vb % gx, y = (vb / gx) & 1, z = vb / (gx * 2);
+      const int dir = z / P.nmb, mb = z % P.nmb;
+      drop_init(P, P.d[dir]);
+      spk_fwd_body<2, 0>(P, P.d[dir], W.f[dir], t, y, x * 8, mb, x == 0, nullptr, smem, smem + RED_FLOATS);
+      __syncthreads();
+    }
+    if (!dir_barrier(cnt, P.sync + SYNC_ABORT, (unsigned)G * ++nbar, lds_ok, nullptr, 0, t + 1 < P.T)) return;
+  }
+}
+
+// LSTHM forward: gates(t) -> row phase(t) (two barriers per step); S h_q[t] arrives in the hoisted pre-activations, as in the per-step form
+__global__ __launch_bounds__(NT) void cell_wide_fwd_persist(CellK P, unsigned lds_floats) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WideWS W = make_wide_ws(P);
+  const int G = gridDim.x, w = blockIdx.x;
+  set_logical_wg((unsigned)w, P.fault);
+  int* lds_ok = (int*)(smem + lds_floats);
+  unsigned* cnt = P.sync + SYNC_LSTHM_FWD;
+  unsigned nbar = 0;
+  const int gx = P.H / 8, nz = P.H / WIDE_IW;
+  const int Vs = gx * 2 * P.ndir * P.nmb, Vz = P.B * P.ndir * nz;
+  for (int t = 0; t < P.T; ++t) {
+    for (int vb = w; vb < Vs; vb += G) {
+      const int x = vb % gx, y = (vb / gx) & 1, z = vb / (gx * 2);
+      const int dir = z / P.nmb, mb = z % P.nmb;
+      drop_init(P, P.d[dir]);
+      lsthm_gates_body<2, 0>(P, P.d[dir], W.f[dir], t, y, x * 8, mb, nullptr, smem, smem + RED_FLOATS);
+      __syncthreads();
+    }
+    if (!dir_barrier(cnt, P.sync + SYNC_ABORT, (unsigned)G * ++nbar, lds_ok)) return;
+    for (int vb = w; vb < Vz; vb += G) {
+      const int b = vb % P.B, rest = vb / P.B;
+      const int dir = rest % P.ndir, zb = rest / P.ndir;
+      lsthm_fwd_z_wide_body<2>(P, P.d[dir], W.f[dir], t, b, zb, smem);
+      __syncthreads();
+    }
+    if (!dir_barrier(cnt, P.sync + SYNC_ABORT, (unsigned)G * ++nbar, lds_ok, nullptr, 0, t + 1 < P.T)) return;
+  }
+}
+
+// BPTT of the LSTHM streams: row phase(t) -> the four carry products of step t (two barriers per step); dHQ += dgates S and the
+// speaker BPTT follow after the launch, as in the per-step form
+__global__ __launch_bounds__(NT) void cell_wide_bwd_persist(CellK P, unsigned lds_floats) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WideWS W = make_wide_ws(P);
+  const int G = gridDim.x, w = blockIdx.x;
+  set_logical_wg((unsigned)w, P.fault);
+  int* lds_ok = (int*)(smem + lds_floats);
+  unsigned* cnt = P.sync + SYNC_LSTHM_BWD;
+  unsigned nbar = 0;
+  const int nz = P.H / WIDE_IW, gm = P.H / 32;
+  const int Vr = P.B * P.ndir * nz, Vm = gm * 4 * P.ndir * P.nmb;
+  for (int t = P.T - 1; t >= 0; --t) {
+    for (int vb = w; vb < Vr; vb += G) {
+      const int b = vb % P.B, rest = vb / P.B;
+      const int dir = rest % P.ndir, zb = rest / P.ndir;
+      lsthm_bwd_row_wide_body<2>(P, P.d[dir], W.b[dir], t, b, zb, smem);
+      __syncthreads();
+    }
+    if (t == 0) break;                       // no carries needed behind the first step
+    if (!dir_barrier(cnt, P.sync + SYNC_ABORT, (unsigned)G * ++nbar, lds_ok)) return;
+    for (int vb = w; vb < Vm; vb += G) {
+      const int x = vb % gm, y = (vb / gm) & 3, z = vb / (gm * 4);
+      const int dir = z / P.nmb, mb = z % P.nmb;
+      lsthm_bwd_mat_body<2, 0>(P, P.d[dir], W.b[dir], t, y, x * 32, mb, nullptr, smem, smem + RED_FLOATS);
+      __syncthreads();
+    }
+    if (!dir_barrier(cnt, P.sync + SYNC_ABORT, (unsigned)G * ++nbar, lds_ok)) return;
+  }
+}
+
+// speaker BPTT: prologue(t) (publishes the gate-gradient tile and the carried cell gradient) -> products(t) (two barriers per step)
+__global__ __launch_bounds__(NT) void cell_wide_spkbwd_persist(CellK P, unsigned lds_floats) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WideWS W = make_wide_ws(P);
+  const int G = gridDim.x, w = blockIdx.x;
+  set_logical_wg((unsigned)w, P.fault);
+  int* lds_ok = (int*)(smem + lds_floats);
+  unsigned* cnt = P.sync + SYNC_SPK_BWD;
+  unsigned nbar = 0;
+  const int gm = P.H / 32;
+  const int Vm = gm * 4 * P.ndir * P.nmb;
+  for (int t = P.T - 1; t >= 0; --t) {
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int vb = w; vb < Vm; vb += G) {
+        const int x = vb % gm, y = (vb / gm) & 3, z = vb / (gm * 4);
+        const int dir = z / P.nmb, mb = z % P.nmb;
+        drop_init(P, P.d[dir]);
+        if (pass == 0) spk_bwd_body<2, 0, false, 1>(P, P.d[dir], W.b[dir], t, y, x * 32, mb, (y & 1) * gm + x, nullptr, nullptr, nullptr, nullptr);
+        else spk_bwd_body<2, 0, false, 2>(P, P.d[dir], W.b[dir], t, y, x * 32, mb, 0, nullptr, smem, smem + RED_FLOATS, nullptr);
+        __syncthreads();
+      }
+      if (t == 0 && pass == 1) break;
+      if (!dir_barrier(cnt, P.sync + SYNC_ABORT, (unsigned)G * ++nbar, lds_ok)) return;
+    }
+  }
+}
+
 // ================================================================================================ small helpers
 // mnext[t][r] = qm[t][r][party[t+1][r]]: the blend weight with which row r's h_q feeds the state that dialogue r reads at t+1
 __global__ void mnext_kernel(const float* qm, const int* party, float* mnext, int T, int B) {
@@ -3251,6 +3438,9 @@ static int g_opt_fwd_sentinel = 1;    // MSER_OPT_FWD_SENTINEL
 static int g_opt_rowsplit = 1;        // MSER_OPT_H256_SPLIT: H = 256 persistent chains share a row phase between two workgroups, BPTT products K-split
 static int g_opt_spk_ks = 1;          // MSER_OPT_SPK_BWD_KSPLIT
 static int g_opt_poll_delay = 0;      // MSER_OPT_BWD_POLL_DELAY
+static int g_opt_wide_persist = 0;    // MSER_OPT_WIDE_PERSISTENT (off: the four launches take 75 ms against 81 ms of per-step kernel time at the configs[4]
+                                      // shard, but they hold every CU, so the weight-gradient GEMMs and attention branches that the per-step
+                                      // launches overlap are serialised behind them: 102-135 ms per step against 90.6)
 static int g_opt_bwd_sentinel = 2;    // MSER_OPT_BWD_SENTINEL (2: both seams of the LSTHM BPTT self-validating; round 2 measured no gain -- the speaker roles
                                       // paced the launch then; with them out of the way: 1321 -> 1225 (seam 2) -> 1166 us (both) per launch)
 static int g_num_cus = 0;
@@ -3269,6 +3459,8 @@ static bool persist_ok(int H, long total_wgs) {
   return g_opt_persistent && (H == 128 || H == 256) && total_wgs <= num_cus();
 }
 static size_t persist_lds(size_t need) { return need > PERSIST_MIN_LDS ? need : PERSIST_MIN_LDS; }
+// H > 512: the per-step bodies inside one launch per pass (cell_wide_*_persist): one workgroup per CU, no external speaker state
+static bool wide_persist_ok(int H, bool ext) { return g_opt_persistent && g_opt_wide_persist && H > 512 && !ext && num_cus() >= 64; }
 
 // phases: MSER_PHASE_SPEAKER_FWD builds the tables, zeroes the initial states and runs the speaker chain (needs only qmask / rev:
 // it can overlap the encoders on another stream); MSER_PHASE_LSTHM_FWD runs the pre-activation GEMMs and the LSTHM chain.
@@ -3365,7 +3557,15 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
     }
     MSER_TRY(check_launch("spk_fwd_persist"));
   }
-  if ((phases & MSER_PHASE_SPEAKER_FWD) && !persist && !ext) {
+  const bool wide = wide_persist_ok(H, ext);
+  if ((phases & MSER_PHASE_SPEAKER_FWD) && wide) {      // H > 512: the whole speaker chain as one launch (one barrier per step)
+    const size_t wl = persist_lds(wide_lds_bytes(H));
+    MSER_TRY(allow_lds((const void*)cell_wide_spkfwd_persist, wl));
+    ProfScope ps(MSER_PROF_SPK_FWD, s);
+    hipLaunchKernelGGL(cell_wide_spkfwd_persist, dim3(num_cus()), dim3(NT), wl, s, K, (unsigned)((wl - 64) / sizeof(float)));
+    MSER_TRY(check_launch("cell_wide_spkfwd_persist"));
+  }
+  if ((phases & MSER_PHASE_SPEAKER_FWD) && !persist && !ext && !wide) {
     // ---- speaker chain as per-step launches (the persistent mode runs it inside the fused launch of the LSTHM phase)
     MSER_TRY(allow_lds((const void*)spk_fwd_step, mm_lds));
     for (int t = 0; t < T; ++t) {
@@ -3447,6 +3647,15 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       MSER_TRY(allow_lds((const void*)cell_fwd_fused<4, 6>, p_lds));
       hipLaunchKernelGGL((cell_fwd_fused<4, 6>), dim3(2 * fwd_wgs), dim3(NT), p_lds, s, K);
     }
+  } else if (wide) {
+    // H > 512: gates and row phase of every time step inside ONE launch (phase boundaries = counter barriers)
+    // (one workgroup per CU; the memory-level parallelism the per-step launches get from 6-8 waves per SIMD comes from four k-passes
+    // of operand loads in flight per wave here: wg_mm32's UN.  Two workgroups per CU were tried: 450 ms per step, the 512 workgroups
+    // were not all resident and the barriers ran into their bounds.)
+    const size_t wl = persist_lds(wide_lds_bytes(H));
+    MSER_TRY(allow_lds((const void*)cell_wide_fwd_persist, wl));
+    ProfScope ps(MSER_PROF_LSTHM_FWD_GATES, s);
+    hipLaunchKernelGGL(cell_wide_fwd_persist, dim3(num_cus()), dim3(NT), wl, s, K, (unsigned)((wl - 64) / sizeof(float)));
   } else {
     MSER_TRY(allow_lds((const void*)lsthm_fwd_gates, mm_lds));
     if (H > 512) MSER_TRY(allow_lds((const void*)lsthm_fwd_z_wide, z_wide_lds_bytes(H)));
@@ -3532,6 +3741,7 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
     }
   }
   K.bwd_sentinel = persist ? g_opt_bwd_sentinel : 0;
+  const bool wide = !persist && wide_persist_ok(H, ext);
   K.spk_ks = (persist && !ext && g_opt_spk_ks) ? 1 : 0;
   K.poll_delay = g_opt_poll_delay;
   if (phases & MSER_PHASE_BWD_PREP) {
@@ -3590,6 +3800,11 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       MSER_TRY(allow_lds((const void*)cell_bwd_fused<8, 8>, f_lds));
       hipLaunchKernelGGL((cell_bwd_fused<8, 8>), dim3(grid), dim3(NT), f_lds, s, K, (unsigned)bwd_nwg);
     }
+  } else if (wide) {
+    const size_t wl = persist_lds(wide_lds_bytes(H));
+    MSER_TRY(allow_lds((const void*)cell_wide_bwd_persist, wl));
+    ProfScope ps(MSER_PROF_LSTHM_BWD_ROW, s);
+    hipLaunchKernelGGL(cell_wide_bwd_persist, dim3(num_cus()), dim3(NT), wl, s, K, (unsigned)((wl - 64) / sizeof(float)));
   } else {
     MSER_TRY(allow_lds((const void*)lsthm_bwd_mat, mm_lds));
     if (H > 512) MSER_TRY(allow_lds((const void*)lsthm_bwd_row_wide, bwd_row_wide_lds_bytes(H)));
@@ -3710,6 +3925,11 @@ int marn_cell_bwd(const mser_cell_desc& d, hipStream_t s, int phases) {
       ProfScope ps(MSER_PROF_SPK_BWD, s);
       hipLaunchKernelGGL(spk_bwd_step, dim3(H / 32, 4, d.ndir * K.nmb), dim3(NT), spk_lds, s, K, t);
     }
+  } else if (!persist && wide) {                // H > 512: prologue and products of every step inside one launch
+    const size_t wl = persist_lds(wide_lds_bytes(H));
+    MSER_TRY(allow_lds((const void*)cell_wide_spkbwd_persist, wl));
+    ProfScope ps(MSER_PROF_SPK_BWD, s);
+    hipLaunchKernelGGL(cell_wide_spkbwd_persist, dim3(num_cus()), dim3(NT), wl, s, K, (unsigned)((wl - 64) / sizeof(float)));
   } else if (!persist) {                        // H >= 512: the gate-gradient tile goes through global memory (two launches per step)
     MSER_TRY(allow_lds((const void*)spk_bwd_mat_wide, mm_lds));
     for (int t = T - 1; t >= 0; --t) {
@@ -3905,6 +4125,7 @@ int mser_set_option(int32_t key, int32_t value) {
     case MSER_OPT_BWD_SENTINEL: g_opt_bwd_sentinel = value == 2 ? 2 : (value ? 1 : 0); return 0;
     case MSER_OPT_H256_SPLIT: g_opt_rowsplit = value ? 1 : 0; return 0;
     case MSER_OPT_SPK_BWD_KSPLIT: g_opt_spk_ks = value ? 1 : 0; return 0;
+    case MSER_OPT_WIDE_PERSISTENT: g_opt_wide_persist = value ? 1 : 0; return 0;
     case MSER_OPT_BWD_POLL_DELAY: g_opt_poll_delay = value < 0 ? 0 : (value > 256 ? 256 : value); return 0;
     default: set_error("mser_set_option: unknown key %d", key); return -1;
   }

@@ -773,6 +773,7 @@ MSER_OPT_BWD_SENTINEL = 7
 MSER_OPT_H256_SPLIT = 8
 MSER_OPT_SPK_BWD_KSPLIT = 9
 MSER_OPT_BWD_POLL_DELAY = 10
+MSER_OPT_WIDE_PERSISTENT = 11
 
 
 def set_option(key: int, value: int) -> None:

@@ -25,4 +25,6 @@ for _ in range(n):
     tr.train_step(*batch)
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t) / n * 1e3
+from mser import fault
+fault.check(dev, "sps_steps")
 print(f"MARN1_sps hidden={H} B={nb} L={bench.L} heads={heads}: {ms:.3f} ms/step (eager), {nb * bench.L / ms * 1e3:.0f} utterances/s, peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")

@@ -372,3 +372,37 @@ def test_cross_attention_module_gradients_are_bit_reproducible(O):
         assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])       # input gradients: bit for bit
         for x, y in zip(runs[0][2:], runs[1][2:]):                    # Wq / Wk / Wv: behind a split-K GEMM whose partials meet in float
             assert maxabs(x, y) <= 1e-6 * max(1.0, float(x.abs().max()))      # atomics (csrc/gemm.hip): equal to rounding
+
+
+# ------------------------------------------------------------------------------------------------ wide cells: one launch per pass
+@pytest.mark.parametrize("H,B,L", [(1024, 3, 6), (1024, 34, 3)])
+def test_wide_persistent_launches_vs_per_step_launches(O, H, B, L):
+    """hid = 1024 (BASELINE configs[4]'s width): the three persistent launches of round 3 (cell_wide_fwd / bwd / spkbwd_persist: the
+    per-step bodies inside one launch per pass, counter barriers between the phases, write-through hand-offs) against one launch per phase
+    and step (MSER_OPT_WIDE_PERSISTENT = 0): the same arithmetic up to summation order -- log-probs 2e-6, gradients to the rounding of
+    the split-K weight-gradient GEMMs; fault word clean.  (Both forms are checked against the oracle by test_model_wide_hidden_vs_oracle.)"""
+    from loss import MaskedLoss
+    from models.lsthm_sps import MARN1_sps
+    from mser import fault, ops
+    d_r = 64
+    P = O.seeded_params(seed=61, d_r=d_r, H=H)
+    x, qmask, umask, label = (t.cuda() for t in O.seeded_batch(B, L, d_r=d_r, seed=62, ragged=True))
+    res = []
+    try:
+        for mode in (1, 0):
+            ops.set_option(ops.MSER_OPT_WIDE_PERSISTENT, mode)
+            net = MARN1_sps(6, d_r=d_r, hidden=H, xattn_heads=8).cuda().eval()
+            load_params(net, P)
+            fault.clear("cuda:0")
+            for _ in range(2):                                  # twice: reused workspace, warm caches
+                net.zero_grad()
+                lp, _, _ = net(x, qmask, umask)
+                MaskedLoss(torch.nn.NLLLoss)(lp, label.view(-1), umask).backward()
+            fault.check("cuda:0", f"wide persistent={mode}")
+            res.append((lp.detach().clone(), net.flat_store.grad.clone()))
+    finally:
+        ops.set_option(ops.MSER_OPT_WIDE_PERSISTENT, 0)
+    # (not bit for bit: the persistent form adds S h_q[t] inside the step's K = 3H product, the per-step form as a hoisted GEMM)
+    assert maxabs(res[0][0], res[1][0]) < 2e-6
+    d = maxabs(res[0][1], res[1][1])
+    assert d < 1e-5 * max(1.0, float(res[1][1].abs().max())), d
