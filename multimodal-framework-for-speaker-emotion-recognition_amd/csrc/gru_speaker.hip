@@ -132,7 +132,10 @@ __global__ __launch_bounds__(GNT) void gru_speaker_fwd_kernel(GruArgs2 aa) {
         float hv = (1.f - zg) * ng + zg * hprev;
         const long rowt = (long)t * B + b;
         if (a.rng) hv *= drop_scale(dk, (uint32_t)(rowt * H + u));         // :177 dropout(gru_s(U, qs_0)): the dropped value is the state
-        a.hs[rowt * H + u] = hv;
+        // linked producer: the row goes straight to the consumer's workspace as a write-through (agent-scope) store -- it is visible
+        // to the consumer's L1-bypassing loads once this wave's stores have drained; no cache write-back fence per thread and step
+        if (a.pub_cnt) __hip_atomic_store(a.hs + rowt * H + u, hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else a.hs[rowt * H + u] = hv;
         if (a.out) {
           const int tau = a.rev ? a.rev[rowt] : t;
           if (tau >= 0) a.out[((long)tau * B + b) * a.ldo + u] = hv;
@@ -152,7 +155,10 @@ __global__ __launch_bounds__(GNT) void gru_speaker_fwd_kernel(GruArgs2 aa) {
         }
       }
     }
-    if (a.pub_cnt) __threadfence();          // release: this thread's hs rows of step t are visible device-wide before the counter moves
+    // release: every wave drains its write-through stores of step t, then the workgroup meets, then the counter moves.  (Round 2 issued
+    // __threadfence() here -- an L2 write-back per thread and step -- and release / sequentially-consistent atomics below, each with
+    // a fence of its own: the linked producer ran at 11.1 us per step against 5.7 alone and paced the LSTHM chain it feeds.)
+    if (a.pub_cnt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (a.pub_cnt && tid < a.pub_rep) {
       // "Publish my progress, then read the others'" is the store-buffering pattern: with release/acquire alone two blocks that
@@ -163,12 +169,15 @@ __global__ __launch_bounds__(GNT) void gru_speaker_fwd_kernel(GruArgs2 aa) {
       // that argument the host raises every replica to T * pub_inc with a stream-ordered fill right behind this kernel
       // (gru_launch), when every block has published everything.
       unsigned mine = 0;
-      if (tid == 0) mine = __hip_atomic_exchange(a.pub_progress + blockIdx.x, (unsigned)(t + 1), __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_AGENT);
+      // (relaxed agent-scope atomics are performed at the memory side; the loads below are issued behind the exchange's RETURN -- the data
+      //  dependency through `mine` -- which is all the argument above needs)
+      if (tid == 0) mine = __hip_atomic_exchange(a.pub_progress + blockIdx.x, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       mine = __shfl(mine, 0, 64);            // every publishing lane orders its loads behind the exchange's return
+      asm volatile("" : "+v"(mine) :: "memory");      // (compiler: nothing below moves above this point; hardware: the value has arrived)
       unsigned mn = (unsigned)(t + 1) + (mine & 0u);
       for (unsigned bi = 0; bi < gridDim.x; ++bi)
-        if (bi != blockIdx.x) mn = min(mn, __hip_atomic_load(a.pub_progress + bi, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_AGENT));
-      __hip_atomic_fetch_max(a.pub_cnt + tid * a.pub_stride, a.pub_inc * mn, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (bi != blockIdx.x) mn = min(mn, __hip_atomic_load(a.pub_progress + bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      __hip_atomic_fetch_max(a.pub_cnt + tid * a.pub_stride, a.pub_inc * mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -218,7 +227,8 @@ __global__ __launch_bounds__(GNT) void gru_speaker_bwd_kernel(GruArgs2 aa) {
         __builtin_amdgcn_s_sleep(8);
         if (++spins > (1u << 22)) { if (a.status) atomicOr(a.status, (unsigned)MSER_FAULT_LINK_TIMEOUT); break; }
       }
-      __threadfence();                 // acquire: the rows read below were published before the counter value seen here
+      // (no acquire fence: the rows are read with device-coherent loads below, which cannot hit a stale line; the poll's value orders
+      //  them behind the producer's drained write-through stores)
     }
     __syncthreads();
     // (partially unrolled: with the 64 W_hh values live a 12-wave workgroup has ~100 registers left per lane; fully unrolled, this
