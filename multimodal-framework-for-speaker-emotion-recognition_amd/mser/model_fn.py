@@ -252,6 +252,9 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
             # scratch/diag_stamps.py trash: 775 us per forward launch right behind the preparation, 917 us with 1 GB of traffic between;
             # in the step: 836 against 870 us per forward launch, the step time itself unchanged within the noise)
             # -- on the side stream, beside the hoisted input products of the LSTHM streams (50 us on this stream)
+            # (round 3, tried: the text stream's products issued right behind its own encoder branch, without waiting for the audio
+            #  stream's -- 53 us idle in the kernel trace --: the hipGraph executor then put the whole audio branch on the text branch's
+            #  queue, BEHIND it: 2.94 against 2.84 ms per step.  Which branch gets which queue follows the fork / join shape; reverted.)
             s_spk.wait_event(ev_x)
             with torch.cuda.stream(s_spk):
                 ops.marn_cell_run(desc, ops.PHASE_FWD_PREP | (ops.PHASE_PREP_BOTH if c.zbuf is not None else 0) | ops.PHASE_SPEAKER_FWD | sep)
@@ -260,15 +263,16 @@ def marn1_forward(P: Getter, x: Tensor, qmask: Tensor, umask: Tensor, dims: Mode
             ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD | ops.PHASE_PRE_DONE | sep)
         else:
             ops.marn_cell_run(desc, ops.PHASE_LSTHM_FWD | sep)
+        # ONE branch for all four modules: with two branches (attn1 path / attn2 path) a hipGraph replay ran the first-level modules of
+        # both on one queue and put the second-level ones on the MAIN queue, behind the chain launch (kernel trace, round 3:
+        # 70 us of attention on the critical path between the chain and the head); a single chain of nodes stays on its side queue and
+        # is done 150 us into the 760 us chain
         s_xa.wait_event(ev_x)
-        s_xb.wait_event(ev_x)
         with torch.cuda.stream(s_xa):
             xattn_a()
-        with torch.cuda.stream(s_xb):
             xattn_b()
         cur.wait_stream(s_spk)
         cur.wait_stream(s_xa)
-        cur.wait_stream(s_xb)
     else:
         ops.marn_cell_run(desc, ops.PHASE_FWD_PREP | ops.PHASE_SPEAKER_FWD)
         text_branch()
@@ -442,17 +446,21 @@ def _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams):
         cur.wait_stream(s_xa)
         cur.wait_stream(s_xb)
         ops.marn_cell_run(desc, ops.PHASE_LSTHM_BWD_DX)            # dx_l += dg W_l + attention branches, likewise dx_a
+        ev_dx = torch.cuda.Event()
+        ev_dx.record(cur)
         s_audio.wait_stream(cur)
-        s_xa.wait_stream(cur)
+        # the encoders' backward is the critical path from here: issued FIRST (a hipGraph replay dispatches nodes in issue order, ~6 us
+        # each: the four bias column sums of the cell, issued in front, delayed the first post_bwd by 17 us; kernel trace, round 3)
+        with torch.cuda.stream(s_audio):
+            audio_branch()
+        text_branch(flush_stream=s_xb, audio_stream=s_audio)
+        s_xa.wait_event(ev_dx)
         if not c.pipelined:
-            s_spk.wait_stream(cur)
+            s_spk.wait_event(ev_dx)
             with torch.cuda.stream(s_spk):
                 ops.marn_cell_run(desc, ops.PHASE_SPEAKER_BWD)     # speaker BPTT: touches only speaker-cell gradients
         with torch.cuda.stream(s_xa):
             ops.marn_cell_run(desc, ops.PHASE_LSTHM_WGRAD)         # LSTHM parameter gradients: nothing downstream reads them
-        with torch.cuda.stream(s_audio):
-            audio_branch()
-        text_branch(flush_stream=s_xb, audio_stream=s_audio)
         # what is left in the batch (the first text layer's and linear_in's weight gradients) has all its operands on this stream: it goes
         # out now, beside the other flush, instead of behind the joins
         ops.wgrad_scope.flush()
