@@ -380,7 +380,12 @@ enum { MSER_OPT_PERSISTENT = 1, MSER_OPT_WGRAD_INKERNEL = 2, MSER_OPT_BPTT_KSPLI
         * workgroup per CU, the per-step phases separated by counter barriers, hand-offs stored write-through and loaded through the
         * caches) instead of 3 + 4 launches per time step; 0 (default; the persistent launches hold every CU and serialise the GEMMs the
         * per-step launches overlap: measured slower end to end): one launch per phase and step */
-       MSER_OPT_WIDE_PERSISTENT = 11 };
+       MSER_OPT_WIDE_PERSISTENT = 11,
+       /* 1 (default): mser_drnn_fwd / mser_drnn_bwd run the whole time loop of both directions inside ONE launch per pass (one workgroup
+        * per CU; the phases of a step are lists of 32-row tiles dealt to the workgroups and separated by grid barriers; the weights
+        * stream from L2 / the infinity cache; hand-offs are stored write-through and loaded L2-bypassing); 0: the 9 + 13 launches per time
+        * step of the first version (kept as the cross-check and as the fallback after a MSER_FAULT_CHAIN_TIMEOUT) */
+       MSER_OPT_DRNN_PERSISTENT = 12 };
 int mser_set_option(int32_t key, int32_t value);
 /* Synchronises `stream` and reports whether a persistent kernel of the last fwd/bwd call on this workspace gave up at a
  * barrier (bounded spins; returns -2 and a message in that case).  Diagnostic; not needed on the hot path. */
@@ -517,6 +522,9 @@ typedef struct mser_drnn_desc {
    * 2: ql (:153), 3: e (:161)} with element indices (t*B + b)*Dg + u, ((t*B + b)*2 + party)*Dp + u (qs and ql), (t*B + b)*De + u,
    * t = the direction's own time index */
   const uint32_t* rng; uint32_t drop_site[2]; float p_drop;
+  /* Sticky fault word in device memory (may be NULL): a persistent launch (MSER_OPT_DRNN_PERSISTENT) that gives up at a bounded
+   * grid barrier ORs MSER_FAULT_CHAIN_TIMEOUT into it; its outputs and gradients are then invalid. */
+  uint32_t* fault;
 } mser_drnn_desc;
 
 size_t mser_drnn_workspace_bytes(int32_t T, int32_t B, int32_t Dm, int32_t Dg, int32_t Dp, int32_t De);

@@ -17,6 +17,8 @@
 
 namespace mser {
 
+int g_opt_drnn_persist = 1;                         // MSER_OPT_DRNN_PERSISTENT (set through mser_set_option, recurrent.hip)
+
 int gemm(const mser_gemm_desc& d, hipStream_t s);   // gemm.hip
 int gemm_group(const mser_gemm_desc* d, int n, hipStream_t s);
 
@@ -52,6 +54,9 @@ __device__ __forceinline__ GateGrad gru_gate_bwd(float dh, float r, float z, flo
 }
 
 struct Dims { int T, B, Dm, Dg, Dp, De; };
+// fragment-ordered ("packed") operands of the persistent launches: K padded to a multiple of 16, rows to a multiple of 32
+__host__ __device__ __forceinline__ int k8p(int K) { return ((K + 15) / 16) * 2; }
+__host__ __device__ __forceinline__ long pack_rows(int rows, int K) { return (long)((rows + 31) / 32) * k8p(K) * 256; }
 
 // Workspace, direction outermost ([2][...]): dir stride = the array's size / 2, so a step's slice of both directions is a
 // batch-2 GEMM operand and the (t, b) rows of one direction have ONE stride (the weight-gradient reductions after the loop).
@@ -64,6 +69,17 @@ struct WS {
   float *gi_g, *gh_g, *gi_p, *gh_p, *gi_l, *gh_l, *gi_e, *gh_e;      // per-step scratch [2][rows][3H]
   // backward
   float *dgi_g, *dgh_g, *dgi_p, *dgh_p, *dgi_l, *dgh_l, *dgi_e, *dgh_e, *dXatt;   // [2][T][rows][3H] (dgi_p / dgi_l summed over parties)
+  unsigned* sync;                                // the persistent launches' barrier counter and abort word (one line each)
+  // persistent forward: packed weights [2 dirs][8 products: g_in g_h p_in p_h l_in l_h e_in e_h] and packed states (offsets in floats
+  // into apk): q0p [dir] | Ghp [parity][dir] | cvp [dir] | Qp [parity][dir][party] | ssp [dir] | qselp [parity][dir] | Ehp [parity][dir]
+  float *wpk, *apk; long wpk_off[8], wpk_dir; long o_q0p, o_Ghp, o_cvp, o_Qp, o_ssp, o_qselp, o_Ehp; size_t apk_floats;
+  // persistent backward: transposed weight packs (they reuse wpk: [2 dirs][8 products: e_ih e_hh l_ih l_hh p_ih p_hh g_ih g_hh], each
+  // [column tile of 32][k / 8][32][8]) and ONE zero-initialised region bk per call, per direction (stride bk_dir):
+  //   row-major [rows][N] exchange buffers: dEdir PEh | Pqsel | QdirL QdirP PQl PQp | Pq0 Pss dqs | Pc Ddir_g PGh
+  //   packed gate gradients (the products' A operands): gi_l gh_l gi_e gh_e gi_p gh_p gi_g gh_g
+  float* bk; long wtk_off[8], wtk_dir, bk_dir; size_t bk_floats;
+  long b_dEdir, b_PEh, b_Pqsel, b_QdirL, b_QdirP, b_PQl, b_PQp, b_Pq0, b_Pss, b_dqs, b_Pc, b_Ddirg, b_PGh;
+  long b_gil, b_ghl, b_gie, b_ghe, b_gip, b_ghp, b_gig, b_ghg;
   float *dGh, *dQ, *dEc, *dqsel, *dss, *dq0sel, *dc, *dqs;   // dGh [2][T+1][B][Dg]; dQ [2 ping-pong][2][B][2][Dp]; dEc [2][B][De]; ...
   size_t bytes;
 };
@@ -102,6 +118,47 @@ WS carve(char* base, const Dims& d) {
   w.dGh = cv.take<float>(2 * (T + 1) * B * d.Dg); w.dQ = cv.take<float>(2 * 2 * B * 2 * d.Dp); w.dEc = cv.take<float>(2 * B * d.De);
   w.dqsel = cv.take<float>(2 * B * d.Dp); w.dss = cv.take<float>(2 * B * d.Dp); w.dq0sel = cv.take<float>(2 * 2 * B * d.Dp);
   w.dc = cv.take<float>(2 * B * d.Dg); w.dqs = cv.take<float>(2 * B * 2 * d.Dp);
+  w.sync = cv.take<unsigned>(128);
+  {
+    const int UWh = 10;                            // = UW (unit slab of the persistent cell tiles)
+    const int Hs[4] = {d.Dg, d.Dp, d.Dp, d.De}, Kin[4] = {d.Dp, d.Dg, d.Dp, d.Dp};
+    long o = 0;
+    for (int c = 0; c < 4; ++c) {
+      const long ns = (Hs[c] + UWh - 1) / UWh;
+      w.wpk_off[2 * c] = o; o += ns * k8p(Kin[c]) * 256;
+      w.wpk_off[2 * c + 1] = o; o += ns * k8p(Hs[c]) * 256;
+    }
+    w.wpk_dir = o;
+    // transposed packs of the backward (same storage): product i = [K3 = 3 H rows][N columns]
+    const int K3[8] = {3 * d.De, 3 * d.De, 3 * d.Dp, 3 * d.Dp, 3 * d.Dp, 3 * d.Dp, 3 * d.Dg, 3 * d.Dg};
+    const int Nn[8] = {d.Dp, d.De, d.Dp, d.Dp, d.Dg, d.Dp, d.Dp, d.Dg};
+    long ot = 0;
+    for (int i = 0; i < 8; ++i) { w.wtk_off[i] = ot; ot += (long)((Nn[i] + 31) / 32) * k8p(K3[i]) * 256; }
+    w.wtk_dir = ot;
+    w.wpk = cv.take<float>((size_t)2 * (o > ot ? o : ot));
+    {
+      const long Bq = d.B;
+      long a = 0;
+      w.b_dEdir = a; a += Bq * d.De; w.b_PEh = a; a += Bq * d.De; w.b_Pqsel = a; a += Bq * d.Dp;
+      w.b_QdirL = a; a += Bq * 2 * d.Dp; w.b_QdirP = a; a += Bq * 2 * d.Dp; w.b_PQl = a; a += Bq * 2 * d.Dp; w.b_PQp = a; a += Bq * 2 * d.Dp;
+      w.b_Pq0 = a; a += Bq * d.Dp; w.b_Pss = a; a += Bq * d.Dp; w.b_dqs = a; a += Bq * 2 * d.Dp;
+      w.b_Pc = a; a += Bq * d.Dg; w.b_Ddirg = a; a += Bq * d.Dg; w.b_PGh = a; a += Bq * d.Dg;
+      a = (a + 63) & ~63L;
+      w.b_gil = a; a += pack_rows(d.B, 3 * d.Dp); w.b_ghl = a; a += pack_rows(2 * d.B, 3 * d.Dp);
+      w.b_gie = a; a += pack_rows(d.B, 3 * d.De); w.b_ghe = a; a += pack_rows(d.B, 3 * d.De);
+      w.b_gip = a; a += pack_rows(d.B, 3 * d.Dp); w.b_ghp = a; a += pack_rows(2 * d.B, 3 * d.Dp);
+      w.b_gig = a; a += pack_rows(d.B, 3 * d.Dg); w.b_ghg = a; a += pack_rows(d.B, 3 * d.Dg);
+      w.bk_dir = a;
+      w.bk_floats = (size_t)2 * a;
+      w.bk = cv.take<float>(w.bk_floats);
+    }
+    const long prg = pack_rows(d.B, d.Dg), prp = pack_rows(d.B, d.Dp), pre = pack_rows(d.B, d.De);
+    long a = 0;
+    w.o_q0p = a; a += 2 * prp; w.o_Ghp = a; a += 4 * prg; w.o_cvp = a; a += 2 * prg; w.o_Qp = a; a += 8 * prp;
+    w.o_ssp = a; a += 2 * prp; w.o_qselp = a; a += 4 * prp; w.o_Ehp = a; a += 4 * pre;
+    w.apk_floats = (size_t)a;
+    w.apk = cv.take<float>((size_t)a);
+  }
   w.bytes = (cv.off + 255) & ~size_t(255);
   return w;
 }
@@ -549,6 +606,1054 @@ __global__ __launch_bounds__(64 * G2_WPB) void general2_bwd_kernel(const float* 
   }
 }
 
+// =====================================================================================================================================
+// Persistent form (MSER_OPT_DRNN_PERSISTENT): ONE launch per pass runs the whole time loop of both directions.  One workgroup per CU;
+// a step is a short list of PHASES, a phase is a list of independent tasks dealt round-robin to the workgroups, phases are separated by
+// a grid barrier (one counter, monotonic).  A GRU-cell task owns 32 dialogue rows x UW hidden units x 3 gates: it streams its slab of
+// W_ih / W_hh (L2 / infinity cache; the two row blocks of a slab run on the same XCD), multiplies on the fp32 MFMA with the 8 waves
+// splitting K, and applies the gate math itself -- no split-K atomics, no gate-product scratch, no epilogue launch.  Everything one
+// workgroup hands to another inside the launch is stored write-through and loaded L2-bypassing (`sc1` buffer accesses through one
+// descriptor per array), the counter add sits behind s_waitcnt vmcnt(0) + a workgroup barrier (MI355X_MICROARCH.md "valid forms").
+// Every wait is bounded: a workgroup that gives up sets the abort word and MSER_FAULT_CHAIN_TIMEOUT, and the whole grid drains.
+constexpr int PNT = 512, PNW = 8, UW = 10;       // 8 waves, one workgroup per CU; UW units x 3 gates = 30 of a product tile's 32 columns
+constexpr int P_NIT = (32 * 2 * UW + PNT - 1) / PNT;      // epilogue items per thread (32 rows x 2 parties x UW units)
+constexpr int P_SC1 = 16;
+constexpr int P_TS = 36, P_T1 = 32 * P_TS;                  // a product tile in LDS: [column][row], row stride padded to 36 (16-byte vector accesses)
+constexpr int P_RED1 = PNW * P_T1, P_TILES = 3 * P_T1;      // LDS: 3 x P_RED1 (the waves' partial tiles of up to 3 products) | P_TILES | per-kernel rest
+constexpr unsigned P_SPIN_LIMIT = 1u << 21;
+typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) unsigned int pgu32;
+
+struct XB { __amdgpu_buffer_rsrc_t r; const void* p; unsigned bytes; };
+__device__ __forceinline__ XB xb_make(const void* p, size_t elems) {
+  XB b;
+  b.p = p; b.bytes = (unsigned)(elems * sizeof(float));
+  b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, b.bytes, 0x00020000);
+  return b;
+}
+// inside a non-inlined task function the descriptor arrives in vector registers (the compiler would wrap every access in a
+// readfirstlane loop): rebuild it from values declared wave-uniform
+__device__ __forceinline__ XB xb_uni(const XB& x) {
+  const unsigned long long a = (unsigned long long)x.p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  const unsigned nb = __builtin_amdgcn_readfirstlane(x.bytes);
+  XB b;
+  b.p = (const void*)(((unsigned long long)hi << 32) | lo); b.bytes = nb;
+  b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(b.p), 0, nb, 0x00020000);
+  return b;
+}
+__device__ __forceinline__ float xb_ld(const XB& b, long e) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b.r, (int)(e * 4), 0, P_SC1));
+}
+__device__ __forceinline__ void xb_st(const XB& b, long e, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), b.r, (int)(e * 4), 0, P_SC1);
+}
+__device__ __forceinline__ void pzero8(float* a) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = 0.f;
+}
+// the waves' partial tiles meet in LDS, summed in a fixed order; tiles[i] = row-major [32][32].  All threads synced on return.
+template <int NA>
+__device__ __forceinline__ void pmm_reduce(const f32x16* acc, float* red, float* tiles) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[wave * 1024 + ((q & 3) + 8 * (q >> 2) + 4 * half) * 32 + r] = acc[i][q];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 1024 / PNT; ++e) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < PNW; ++w) s += red[w * 1024 + tid + e * PNT];
+      tiles[i * 1024 + tid + e * PNT] = s;
+    }
+    __syncthreads();
+  }
+}
+
+#ifdef MSER_STAMPS
+__shared__ unsigned long long pst_acc[16];
+__shared__ unsigned long long pst_last;
+#define PST_INIT() do { if (threadIdx.x == 0) { for (int _i = 0; _i < 16; ++_i) pst_acc[_i] = 0; pst_last = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define PST(k) do { if (threadIdx.x == 0) { const unsigned long long _n = __builtin_amdgcn_s_memrealtime(); pst_acc[k] += _n - pst_last; pst_last = _n; } } while (0)
+#define PSTC(k) PST(k)
+#define PST_DUMP(name, T) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 200 || blockIdx.x == 255 || blockIdx.x == 256)) \
+  printf("[drnn stamps %s wg %3d hwid %08x | 10 ns ticks per step]  %llu %llu %llu %llu %llu %llu %llu %llu | %llu %llu %llu %llu %llu %llu %llu %llu\n", name, (int)blockIdx.x, (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)), pst_acc[0] / (T), pst_acc[1] / (T), \
+         pst_acc[2] / (T), pst_acc[3] / (T), pst_acc[4] / (T), pst_acc[5] / (T), pst_acc[6] / (T), pst_acc[7] / (T), pst_acc[8] / (T), pst_acc[9] / (T), pst_acc[10] / (T), pst_acc[11] / (T), \
+         pst_acc[12] / (T), pst_acc[13] / (T), pst_acc[14] / (T), pst_acc[15] / (T)); } while (0)
+#else
+#define PST_INIT()
+#define PST(k)
+#define PSTC(k)
+#define PST_DUMP(name, T)
+#endif
+
+// Grid barrier in two halves, one counter per direction chain (monotonic; `target` counts the arrivals expected so far).  arrive():
+// the workgroup's stores are complete (s_waitcnt vmcnt(0) by every thread, then a workgroup barrier), one relaxed agent-scope add.
+// wait(): bounded poll.  Between the two a workgroup works for the OTHER direction, so a barrier's latency is not idle time.
+// wait() returns false when some workgroup gave up (the caller returns; every workgroup does, so the grid drains).
+struct GridBar { unsigned* cnt; unsigned* abortw; uint32_t* fault; unsigned target, G; };
+__device__ __forceinline__ void bar_arrive(GridBar& gb) {
+  gb.target += gb.G;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add((pgu32*)gb.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool bar_wait(const GridBar& gb, int* ok_lds) {
+  if (threadIdx.x == 0) {
+    unsigned spins = 0;
+    int ok = 1;
+    while (__hip_atomic_load((const pgu32*)gb.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gb.target) {
+      __builtin_amdgcn_s_sleep(1);
+      ++spins;
+      if ((spins & 1023u) == 0u && __hip_atomic_load((const pgu32*)gb.abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+      if (spins > P_SPIN_LIMIT) {
+        __hip_atomic_store((pgu32*)gb.abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gb.fault) atomicOr(gb.fault, (uint32_t)MSER_FAULT_CHAIN_TIMEOUT);
+        ok = 0;
+        break;
+      }
+    }
+    *ok_lds = ok;
+  }
+  __syncthreads();
+  return *ok_lds != 0;
+}
+
+struct PK {
+  Dims d;
+  mser_drnn_params p[2];       // parameters
+  WS w;
+  const uint32_t* rng; uint32_t site[2]; float pdrop;
+  float* out; const float* dout; long ldo; const int* rev;
+  unsigned* sync; uint32_t* fault;
+};
+
+// ---- packed operands -------------------------------------------------------------------------------------------------------------------
+// An MFMA fragment is 8 consecutive k of one row; lane r of a wave holds row r.  Read straight from a row-major matrix a wave's load
+// touches 32 rows x 32 bytes (32 cache lines for 1 KB of payload: measured 20 us per p-cell tile).  Both operands of the per-step products
+// are therefore kept in FRAGMENT ORDER  [row block of 32][k / 8][row % 32][8]:  a wave's load is 1 KB contiguous, K is zero-padded to a
+// multiple of 16 (no tail masks).  Weights are packed once per call (drnn_pack_w_kernel: [unit slab][k / 8][gate x UW + unit][8], columns
+// 30, 31 zero); the states are written in this order by the epilogue that produces them (and row-major as well, for everything that
+// reads them after the launch).
+__device__ __forceinline__ long pk_off(int b, int k, int K) { return (((long)(b >> 5) * k8p(K) + (k >> 3)) * 32 + (b & 31)) * 8 + (k & 7); }
+
+__global__ void drnn_pack_w_kernel(const float* W, long ldw, int H, int K, float* out, long n_out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  const int j = (int)(i & 7), n = (int)((i >> 3) & 31);
+  const long q = i >> 8;
+  const int k8n = k8p(K);
+  const int k = (int)(q % k8n) * 8 + j, slab = (int)(q / k8n);
+  const int gate = n / UW, u = slab * UW + n - gate * UW;
+  out[i] = (n < 3 * UW && u < H && k < K) ? W[(long)(gate * H + u) * ldw + k] : 0.f;
+}
+
+template <int NA, int UN, class AL, class BL>
+__device__ __forceinline__ void pmm(int Kp, AL aload, BL bload, f32x16* acc) {        // Kp: padded K (multiple of 16)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int KC = ((Kp + PNW * 16 - 1) / (PNW * 16)) * 16;
+  const int kbeg = wave * KC, kend = min(Kp, kbeg + KC);
+  for (int kb = kbeg; kb < kend; kb += 16 * UN) {
+    float a[NA][UN][8], b[UN][8];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int k8 = ((kb + 16 * u) >> 3) + half;
+      if (kb + 16 * u < kend) {
+        bload(r, k8, b[u]);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) aload(i, r, k8, a[i][u]);
+      } else {
+        pzero8(b[u]);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) pzero8(a[i][u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][u][j], b[u][j], acc[i], 0, 0, 0);
+  }
+}
+// fragment loads through a descriptor: e = element offset of the fragment (multiple of 8: the packs are 256-byte aligned), or < 0 for a
+// pass this wave does not have -- the offset then lies beyond the descriptor's range and the load returns zeros (no branch).  SC1 = true:
+// hand-off data (L2-bypassing); false: weights (cached).
+template <bool SC1>
+__device__ __forceinline__ void xb_frag(const XB& b, long e, float* a) {
+  const int off = e >= 0 ? (int)(e * 4) : (int)0xFFFFFF00;
+  const pu32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(b.r, off, 0, SC1 ? P_SC1 : 0);
+  const pu32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(b.r, off, 16, SC1 ? P_SC1 : 0);
+  a[0] = __uint_as_float(v0.x); a[1] = __uint_as_float(v0.y); a[2] = __uint_as_float(v0.z); a[3] = __uint_as_float(v0.w);
+  a[4] = __uint_as_float(v1.x); a[5] = __uint_as_float(v1.y); a[6] = __uint_as_float(v1.z); a[7] = __uint_as_float(v1.w);
+}
+
+// a phase's tile list of one direction: (row block, unit slab); the row blocks of one slab are 8 apart in the list, so that with a grid
+// that is a multiple of 8 they run on the same XCD and share the weight slab in its L2
+__device__ __forceinline__ bool tile_decode(int j, int NRB, int NS, int& rb, int& slab) {
+  const int q = j / (8 * NRB), rem = j - q * 8 * NRB;
+  rb = rem >> 3;
+  slab = q * 8 + (rem & 7);
+  return slab < NS;
+}
+__host__ __device__ __forceinline__ int tile_count(int rows, int H, int uw) {
+  const int NRB = (rows + 31) / 32, NS = (H + uw - 1) / uw;
+  return ((NS + 7) / 8) * 8 * NRB;
+}
+
+struct FB { XB Gh, Q, Eh, qs, apk, wpk; };     // the forward's hand-off arrays (row-major states + the packed operand region)
+
+// ---- a GRU-cell tile: 32 dialogue rows x UW units x 3 gates of one direction -------------------------------------------------------------
+// CELL 0 = g (rows b), 1 = p, 2 = l (rows b, both parties), 3 = e (rows b).  A task is split in two halves around the grid barrier that
+// precedes its phase: `pre` issues the loads that do not depend on the phase just before it (the weight fragments of both products and the
+// epilogue's operands: 78 registers) so that their latency passes while the workgroup waits at the barrier; `post` loads the state
+// fragments, runs the MFMA chains, reduces the waves' partial tiles and applies the gate math.  Widths up to 512: a wave's K share of a
+// product is at most 4 passes of 16, all held in registers (8 waves per workgroup: 256 registers per lane).
+struct Task { int kind, t, dir, rb, slab, b; };      // kind 0..3 = CELL, 4 = attention (b, dir), -1 = none
+struct TRegs {
+  float bi[4][8], bh[4][8];          // weight fragments: input product, hidden product
+};
+struct ERegs {
+  float hp[P_NIT], gi[P_NIT][3], bb[P_NIT][3], qs[P_NIT];   // epilogue operands of this thread's items (qs: the l cell's blend partner)
+  float qm[P_NIT]; int sp[P_NIT], sn[P_NIT];                // (p, l cells) the item's party mask value and the speaker indices of steps t, t + 1
+};
+struct CellGeom {
+  int H, Kin, NPT;
+  const float *bhh, *bih, *GI;
+  long Wi, Wh;                        // element offsets into the packed weights
+  const XB* bh;
+  long h0, ain, ah, ah_pt;
+  float* save;
+  uint32_t site, idx0;
+};
+template <int CELL>
+__device__ __forceinline__ CellGeom cell_geom(const PK& P, const FB& F, const Task& k) {
+  const int B = P.d.B, T = P.d.T, Dg = P.d.Dg, Dp = P.d.Dp, De = P.d.De;
+  const long TB = (long)T * B;
+  const int t = k.t, dir = k.dir;
+  const mser_drnn_params& W = P.p[dir];
+  const WS& w = P.w;
+  const long prg = pack_rows(B, Dg), prp = pack_rows(B, Dp), pre = pack_rows(B, De);
+  const int par = t & 1;
+  CellGeom g;
+  g.NPT = (CELL == 1 || CELL == 2) ? 2 : 1;
+  g.H = CELL == 0 ? Dg : (CELL == 3 ? De : Dp);
+  g.Kin = CELL == 1 ? Dg : Dp;
+  g.bih = nullptr; g.GI = nullptr; g.ah_pt = 0; g.site = P.site[dir] + CELL;
+  const int H = g.H;
+  if constexpr (CELL == 0) {
+    g.bhh = W.g_bhh; g.GI = w.GIg + ((long)dir * TB + (long)t * B) * 3 * H;
+    g.bh = &F.Gh; g.h0 = ((long)dir * (T + 1) + t) * B * H;
+    g.ain = w.o_q0p + dir * prp; g.ah = w.o_Ghp + (par * 2 + dir) * prg;
+    g.save = w.sv_g + ((long)dir * TB + (long)t * B) * 4 * H; g.idx0 = (uint32_t)((long)t * B * H);
+  } else if constexpr (CELL == 1) {
+    g.bhh = W.p_bhh; g.GI = w.GIp + ((long)dir * TB + (long)t * B) * 3 * H;
+    g.bh = &F.Q; g.h0 = ((long)dir * (T + 1) + t) * B * 2 * H;
+    g.ain = w.o_cvp + dir * prg; g.ah = w.o_Qp + (long)(par * 2 + dir) * 2 * prp; g.ah_pt = prp;
+    g.save = w.sv_p + ((long)dir * TB + (long)t * B) * 2 * 4 * H; g.idx0 = (uint32_t)((long)t * B * 2 * H);
+  } else if constexpr (CELL == 2) {
+    g.bhh = W.l_bhh; g.GI = w.GIl + ((long)dir * TB + (long)t * B) * 3 * H;
+    g.bh = &F.Q; g.h0 = ((long)dir * (T + 1) + t) * B * 2 * H;
+    g.ain = w.o_ssp + dir * prp; g.ah = w.o_Qp + (long)(par * 2 + dir) * 2 * prp; g.ah_pt = prp;
+    g.save = w.sv_l + ((long)dir * TB + (long)t * B) * 2 * 4 * H; g.idx0 = (uint32_t)((long)t * B * 2 * H);
+  } else {
+    g.bhh = W.e_bhh; g.bih = W.e_bih;
+    g.bh = &F.Eh; g.h0 = ((long)dir * (T + 1) + t) * B * H;
+    g.ain = w.o_qselp + (par * 2 + dir) * prp; g.ah = w.o_Ehp + (par * 2 + dir) * pre;
+    g.save = w.sv_e + ((long)dir * TB + (long)t * B) * 4 * H; g.idx0 = (uint32_t)((long)t * B * H);
+  }
+  const int k8i = k8p(g.Kin), k8h = k8p(H);
+  g.Wi = (long)dir * w.wpk_dir + w.wpk_off[2 * CELL] + (long)k.slab * k8i * 256;
+  g.Wh = (long)dir * w.wpk_dir + w.wpk_off[2 * CELL + 1] + (long)k.slab * k8h * 256;
+  g.ain += (long)k.rb * k8i * 256;
+  g.ah += (long)k.rb * k8h * 256;
+  return g;
+}
+// this wave's passes (up to 8 = two chunks of 4) of a product with padded reduction length Kp (<= 512): fragment index k8 of pass p, or -1
+__device__ __forceinline__ int pass_k8(int Kp, int p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int KC = ((Kp + PNW * 16 - 1) / (PNW * 16)) * 16;
+  const int kb = wave * KC + 16 * p;
+  return (p * 16 < KC && kb < Kp) ? (kb >> 3) + (lane >> 5) : -1;
+}
+template <bool SC1>
+__device__ __forceinline__ void load_chunk(const XB& x, long base, int Kp, int c, float (*f)[8]) {
+  const int r = threadIdx.x & 31;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int k8 = pass_k8(Kp, 4 * c + p);
+    xb_frag<SC1>(x, k8 >= 0 ? base + ((long)k8 * 32 + r) * 8 : -1, f[p]);
+  }
+}
+__device__ __forceinline__ void mma_chunk(const float (*a)[8], const float (*b)[8], f32x16& acc) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][j], b[p][j], acc, 0, 0, 0);
+}
+template <int CELL>
+__device__ __forceinline__ void cell_pre(const PK& P, const FB& F, const Task& k, TRegs& R) {
+  const CellGeom g = cell_geom<CELL>(P, F, k);
+  constexpr int NPT = (CELL == 1 || CELL == 2) ? 2 : 1;
+  const int Kpi = k8p(g.Kin) * 8, Kph = k8p(g.H) * 8;
+  load_chunk<false>(F.wpk, g.Wi, Kpi, 0, R.bi);
+  load_chunk<false>(F.wpk, g.Wh, Kph, 0, R.bh);
+}
+template <int CELL>
+__device__ __forceinline__ void cell_post(const PK& P, const FB& F, const Task& k, TRegs& R, float* red, float* tiles) {
+  const CellGeom g = cell_geom<CELL>(P, F, k);
+  constexpr int NPT = (CELL == 1 || CELL == 2) ? 2 : 1;
+  const int B = P.d.B, T = P.d.T, H = g.H, t = k.t, dir = k.dir;
+  const long TB = (long)T * B;
+  const WS& w = P.w;
+  const int r = threadIdx.x & 31;
+  const int Kpi = k8p(g.Kin) * 8, Kph = k8p(H) * 8;
+  ERegs E;
+  auto load_epi = [&]() {                       // requested between the two chunks: in flight under the second chunk's MFMA chains
+#pragma unroll
+    for (int j = 0; j < P_NIT; ++j) {
+      const int it = threadIdx.x + j * PNT;
+      const int uu = it % UW, pt = (it / UW) % NPT, rr = it / (UW * NPT);
+      const int b = k.rb * 32 + rr, u = k.slab * UW + uu;
+      E.qs[j] = 0.f;
+      if (it < 32 * NPT * UW && b < B && u < H) {
+        if constexpr (CELL == 3) { E.gi[j][0] = g.bih[u]; E.gi[j][1] = g.bih[H + u]; E.gi[j][2] = g.bih[2 * H + u]; }
+        else { const float* q = g.GI + (long)b * 3 * H; E.gi[j][0] = q[u]; E.gi[j][1] = q[H + u]; E.gi[j][2] = q[2 * H + u]; }
+        E.bb[j][0] = g.bhh[u]; E.bb[j][1] = g.bhh[H + u]; E.bb[j][2] = g.bhh[2 * H + u];
+        E.hp[j] = xb_ld(*g.bh, g.h0 + ((long)b * NPT + pt) * H + u);
+        if constexpr (CELL == 1 || CELL == 2) {
+          const int* ix = w.idx + (long)dir * (TB + B) + (long)t * B + b;
+          E.sp[j] = ix[0]; E.sn[j] = ix[B];
+          E.qm[j] = w.qm[((long)dir * TB + (long)t * B + b) * 2 + pt];
+        }
+        if constexpr (CELL == 2) E.qs[j] = xb_ld(F.qs, ((long)dir * B + b) * 2 * H + (long)pt * H + u);
+      }
+    }
+  };
+  f32x16 acc[1 + NPT];
+#pragma unroll
+  for (int i = 0; i < 1 + NPT; ++i) acc[i] = f32x16{0};
+  // a wave's K share is two chunks of four passes.  Register budget (256 per lane with two workgroups per CU): one chunk's operands at a
+  // time, the second party's state fragments are requested when the input product's operands are dead and arrive under the first
+  // party's MFMA chain; the latencies that stay exposed are covered by the CU's other workgroup (the other direction's chain)
+  constexpr bool two = PNW < 8;                 // (8 waves: a wave's share of K <= 512 is one chunk)
+  {
+    float ai[4][8], ah[NPT][4][8];
+    load_chunk<true>(F.apk, g.ain, Kpi, 0, ai);
+    load_chunk<true>(F.apk, g.ah, Kph, 0, ah[0]);
+    if (!two) load_epi();
+    if (CELL == 1 || CELL == 2) PSTC(8);
+    mma_chunk(ai, R.bi, acc[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NPT == 2) load_chunk<true>(F.apk, g.ah + g.ah_pt, Kph, 0, ah[1]);
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) mma_chunk(ah[i], R.bh, acc[1 + i]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (two) {
+    float ai[4][8], ah[NPT][4][8];
+    load_chunk<false>(F.wpk, g.Wi, Kpi, 1, R.bi);
+    load_chunk<true>(F.apk, g.ain, Kpi, 1, ai);
+    load_chunk<false>(F.wpk, g.Wh, Kph, 1, R.bh);
+    load_chunk<true>(F.apk, g.ah, Kph, 1, ah[0]);
+    load_epi();
+    mma_chunk(ai, R.bi, acc[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NPT == 2) load_chunk<true>(F.apk, g.ah + g.ah_pt, Kph, 1, ah[1]);
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) mma_chunk(ah[i], R.bh, acc[1 + i]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (CELL == 1 || CELL == 2) PSTC(9);
+  {   // the waves' partial tiles meet in LDS (one exchange for all products), summed in a fixed order; kept [column][row] so that an
+      // accumulator's four consecutive rows are one 16-byte access
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 1 + NPT; ++i)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+        *reinterpret_cast<float4*>(red + i * P_RED1 + wave * P_T1 + r * P_TS + 8 * g4 + 4 * half) =
+            make_float4(acc[i][4 * g4], acc[i][4 * g4 + 1], acc[i][4 * g4 + 2], acc[i][4 * g4 + 3]);
+    __syncthreads();
+    for (int e = tid; e < (1 + NPT) * 256; e += PNT) {      // (product, column, group of four rows)
+      const int i = e >> 8, c = (e >> 3) & 31, rg = e & 7;
+      const float* src = red + i * P_RED1 + c * P_TS + rg * 4;
+      float4 sum = *reinterpret_cast<const float4*>(src);
+#pragma unroll
+      for (int wv = 1; wv < PNW; ++wv) {
+        const float4 v = *reinterpret_cast<const float4*>(src + wv * P_T1);
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+      }
+      *reinterpret_cast<float4*>(tiles + i * P_T1 + c * P_TS + rg * 4) = sum;
+    }
+    __syncthreads();
+  }
+  if (CELL == 1 || CELL == 2) PSTC(10);
+  DropKey dk{};
+  const bool drop = P.rng != nullptr;
+  if (drop) dk = drop_key(P.rng, g.site, P.pdrop);
+  const long prg = pack_rows(B, P.d.Dg), prp = pack_rows(B, P.d.Dp), pre = pack_rows(B, P.d.De);
+  const int par = t & 1, b0 = k.rb * 32, u0 = k.slab * UW;
+#pragma unroll
+  for (int j = 0; j < P_NIT; ++j) {
+    const int it = threadIdx.x + j * PNT;
+    const int uu = it % UW, pt = (it / UW) % NPT, rr = it / (UW * NPT);
+    const int b = b0 + rr, u = u0 + uu;
+    if (!(it < 32 * NPT * UW && b < B && u < H)) continue;
+    const float* ti = tiles + rr;                            // element (row rr, column n) at [n * P_TS]
+    const float* th = tiles + P_T1 * (1 + pt) + rr;
+    const float hp = E.hp[j];
+    const float rg = sigmoidf_(E.gi[j][0] + ti[uu * P_TS] + th[uu * P_TS] + E.bb[j][0]);
+    const float z = sigmoidf_(E.gi[j][1] + ti[(UW + uu) * P_TS] + th[(UW + uu) * P_TS] + E.bb[j][1]);
+    const float ghn = th[(2 * UW + uu) * P_TS] + E.bb[j][2];
+    const float n = tanhf(E.gi[j][2] + ti[(2 * UW + uu) * P_TS] + rg * ghn);
+    float h = (1.f - z) * n + z * hp;
+    const long e = ((long)b * NPT + pt) * H + u;            // element index inside the step (rows (b, party))
+    if (drop) h *= drop_scale(dk, g.idx0 + (uint32_t)e);
+    float* sv = g.save + ((long)b * NPT + pt) * 4 * H + u;
+    sv[0] = rg; sv[H] = z; sv[2 * H] = n; sv[3 * H] = ghn;
+    if constexpr (CELL == 0) {
+      xb_st(F.Gh, g.h0 + (long)B * H + (long)b * H + u, h);                  // Gh[t + 1]: the attention's history and the next step's h'
+      xb_st(F.apk, w.o_Ghp + ((par ^ 1) * 2 + dir) * prg + pk_off(b, u, H), h);
+    } else if constexpr (CELL == 1) {
+      xb_st(F.qs, ((long)dir * B + b) * 2 * H + (long)pt * H + u, h);
+      if (pt == E.sp[j]) {
+        w.ss[((long)dir * TB + (long)t * B + b) * H + u] = h;
+        xb_st(F.apk, w.o_ssp + dir * prp + pk_off(b, u, H), h);
+      }
+    } else if constexpr (CELL == 2) {
+      const int sp = E.sp[j], sn = E.sn[j];
+      const float m = E.qm[j];
+      const float qn = h * (1.f - m) + E.qs[j] * m;
+      xb_st(F.Q, g.h0 + (long)B * 2 * H + e, qn);                             // Q[t + 1]
+      xb_st(F.apk, w.o_Qp + ((long)((par ^ 1) * 2 + dir) * 2 + pt) * prp + pk_off(b, u, H), qn);
+      if (pt == sp) {
+        w.qsel[((long)dir * TB + (long)t * B + b) * H + u] = qn;
+        xb_st(F.apk, w.o_qselp + (par * 2 + dir) * prp + pk_off(b, u, H), qn);
+      }
+      if (pt == sn && t + 1 < T) {
+        w.q0sel[((long)dir * TB + (long)(t + 1) * B + b) * H + u] = qn;
+        xb_st(F.apk, w.o_q0p + dir * prp + pk_off(b, u, H), qn);
+      }
+    } else {
+      xb_st(F.Eh, g.h0 + (long)B * H + (long)b * H + u, h);                  // Eh[t + 1]
+      xb_st(F.apk, w.o_Ehp + ((par ^ 1) * 2 + dir) * pre + pk_off(b, u, H), h);
+      const int tau = dir ? P.rev[(long)t * B + b] : t;
+      if (tau >= 0) P.out[((long)tau * B + b) * P.ldo + (long)dir * H + u] = h;
+    }
+  }
+  __syncthreads();            // tiles / red are free for the next task
+  if (CELL == 1 || CELL == 2) PSTC(11);
+}
+
+// attention over the history g_0 .. g_{t-1} of (b, dir) (DialogueRNN.py:56-59,:75) in ONE pass over the history: wave w takes rows
+// s = w, w + 8, ...; a row stays in registers between its score and its share of the pooled vector (running maximum / running sum per
+// wave, merged at the end).  Lane l holds u = 4 l + 256 i .. + 3, i < ATT_V.  LDS: sc[T] raw scores | 16 merge words; wacc = [8][ATT_V * 256]
+constexpr int ATT_V = 2;                         // D_g <= 512
+struct Row4 { float v[ATT_V][4]; };
+__device__ __forceinline__ void att_row_load(const XB& G, long off, int Dg, bool v4, int lane, bool valid, Row4& o) {
+#pragma unroll
+  for (int i = 0; i < ATT_V; ++i) {
+    const int u = 4 * lane + 256 * i;
+    if (valid && v4 && u < Dg) {
+      const pu32x4 q = __builtin_amdgcn_raw_buffer_load_b128(G.r, (int)((off + u) * 4), 0, P_SC1);
+      o.v[i][0] = __uint_as_float(q.x); o.v[i][1] = __uint_as_float(q.y); o.v[i][2] = __uint_as_float(q.z); o.v[i][3] = __uint_as_float(q.w);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o.v[i][c] = (valid && !v4 && u + c < Dg) ? xb_ld(G, off + u + c) : 0.f;
+    }
+  }
+}
+__device__ __forceinline__ void att_fwd_task(const PK& P, const FB& F, int t, int b, int dir, float* sc, float* wacc) {
+  const int B = P.d.B, T = P.d.T, Dg = P.d.Dg;
+  const long TB = (long)T * B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool v4 = (Dg & 3) == 0;
+  float* mrg = sc + T;                                        // [0..8) wave maxima, [8..16) wave sums
+  const float* xs = P.w.Xatt + ((long)dir * TB + (long)t * B + b) * Dg;
+  Row4 x;
+#pragma unroll
+  for (int i = 0; i < ATT_V; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { const int u = 4 * lane + 256 * i + c; x.v[i][c] = u < Dg ? xs[u] : 0.f; }
+  const long g0 = ((long)dir * (T + 1) * B + b) * Dg;        // g_s = Gh[s + 1] at g0 + (s + 1) gs
+  const long gs = (long)B * Dg;
+  float m = -INFINITY, z = 0.f;
+  Row4 acc;
+#pragma unroll
+  for (int i = 0; i < ATT_V; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc.v[i][c] = 0.f;
+  for (int s0 = wave; s0 < t; s0 += PNW * 4) {
+    Row4 rw[4];
+    float scv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) att_row_load(F.Gh, g0 + (long)(s0 + PNW * j + 1) * gs, Dg, v4, lane, s0 + PNW * j < t, rw[j]);
+    float mn = m;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < ATT_V; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d = fmaf(x.v[i][c], rw[j].v[i][c], d);
+      d = wave_sum(d);
+      const bool ok = s0 + PNW * j < t;
+      scv[j] = ok ? d : -INFINITY;
+      if (ok && lane == 0) sc[s0 + PNW * j] = d;
+      mn = fmaxf(mn, scv[j]);
+    }
+    const float scale = expf(m - mn);                          // (m = -inf at the first group: 0)
+    z *= scale;
+#pragma unroll
+    for (int i = 0; i < ATT_V; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc.v[i][c] *= scale;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float e = expf(scv[j] - mn);                       // 0 for the rows beyond the history
+      z += e;
+#pragma unroll
+      for (int i = 0; i < ATT_V; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc.v[i][c] = fmaf(e, rw[j].v[i][c], acc.v[i][c]);
+    }
+    m = mn;
+  }
+  if (lane == 0) { mrg[wave] = m; mrg[8 + wave] = z; }
+#pragma unroll
+  for (int i = 0; i < ATT_V; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wacc[wave * (ATT_V * 256) + 4 * lane + 256 * i + c] = acc.v[i][c];
+  __syncthreads();
+  float M = mrg[0];
+#pragma unroll
+  for (int k = 1; k < PNW; ++k) M = fmaxf(M, mrg[k]);
+  float Z = 0.f, f[PNW];
+#pragma unroll
+  for (int k = 0; k < PNW; ++k) { f[k] = expf(mrg[k] - M); Z = fmaf(mrg[8 + k], f[k], Z); }
+  const float rz = 1.f / Z;
+  float* al = P.w.alpha + ((long)dir * TB + (long)t * B + b) * T;
+  for (int s = tid; s < t; s += PNT) al[s] = expf(sc[s] - M) * rz;
+  const long prg = pack_rows(B, Dg);
+  for (int u = tid; u < Dg; u += PNT) {
+    float c = 0.f;
+#pragma unroll
+    for (int k = 0; k < PNW; ++k) c = fmaf(wacc[k * (ATT_V * 256) + u], f[k], c);
+    c *= rz;
+    P.w.cvec[((long)dir * TB + (long)t * B + b) * Dg + u] = c;
+    xb_st(F.apk, P.w.o_cvp + dir * prg + pk_off(b, u, Dg), c);
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void task_pre(const PK& P, const FB& F, const Task& k, TRegs& R) {
+  switch (k.kind) {
+    case 0: cell_pre<0>(P, F, k, R); break;
+    case 1: cell_pre<1>(P, F, k, R); break;
+    case 2: cell_pre<2>(P, F, k, R); break;
+    case 3: cell_pre<3>(P, F, k, R); break;
+    default: break;
+  }
+}
+__device__ __forceinline__ void task_post(const PK& P, const FB& F, const Task& k, TRegs& R, float* red, float* tiles, float* attx) {
+  switch (k.kind) {
+    case 0: cell_post<0>(P, F, k, R, red, tiles); break;
+    case 1: cell_post<1>(P, F, k, R, red, tiles); break;
+    case 2: cell_post<2>(P, F, k, R, red, tiles); break;
+    case 3: cell_post<3>(P, F, k, R, red, tiles); break;
+    case 4: att_fwd_task(P, F, k.t, k.b, k.dir, attx, red); break;
+    default: break;
+  }
+}
+
+// Per step and direction two phases, two grid barriers (the recurrence l(t-1) -> p(t) -> l(t) needs both exchanges; the rest rides along):
+//   phase B(t): p cell of step t | g cell of step t                                       (read what phase C(t-1) left)
+//   phase C(t): l cell of step t (+ blend) | history attention of step t+1 | e cell of step t-1
+// The two directions are independent chains with a barrier counter each; every workgroup alternates between them
+// (B0 B1 C0 C1 B0 ...): while direction 0's barrier completes it works for direction 1.  A phase of one direction is at most one task
+// per workgroup at the reference's widths (208 / 232 tasks on 256 CUs).
+__global__ __launch_bounds__(PNT) void drnn_fwd_persist(const PK P) {
+  extern __shared__ float psm[];
+  float* red = psm;
+  float* tiles = psm + 3 * P_RED1;
+  float* attx = tiles + P_TILES;
+  __shared__ int bar_ok;
+  const int B = P.d.B, T = P.d.T, Dg = P.d.Dg, Dp = P.d.Dp, De = P.d.De;
+  FB F;
+  F.Gh = xb_make(P.w.Gh, (size_t)2 * (T + 1) * B * Dg); F.Q = xb_make(P.w.Q, (size_t)2 * (T + 1) * B * 2 * Dp);
+  F.Eh = xb_make(P.w.Eh, (size_t)2 * (T + 1) * B * De);
+  F.qs = xb_make(P.w.dqs, (size_t)2 * B * 2 * Dp);
+  F.apk = xb_make(P.w.apk, P.w.apk_floats);
+  F.wpk = xb_make(P.w.wpk, (size_t)2 * P.w.wpk_dir);
+  GridBar gb[2] = {{P.sync, P.sync + 64, P.fault, 0u, gridDim.x}, {P.sync + 32, P.sync + 64, P.fault, 0u, gridDim.x}};
+  const int NRB = (B + 31) / 32;
+  const int ntg = tile_count(B, Dg, UW), ntp = tile_count(B, Dp, UW), nte = tile_count(B, De, UW);
+  const int nsg = (Dg + UW - 1) / UW, nsp = (Dp + UW - 1) / UW, nse = (De + UW - 1) / UW;
+  const int G = gridDim.x;
+  // task v of phase ph (0 = B, 1 = C) of step t, direction dir
+  auto n_tasks = [&](int ph, int t) { return ph == 0 ? (t < T ? ntp + ntg : 0) : (t < T ? ntp : 0) + (t + 1 < T ? B : 0) + (t > 0 ? nte : 0); };
+  auto task_of = [&](int ph, int t, int dir, int v) {
+    Task k{-1, t, dir, 0, 0, 0};
+    if (ph == 0) {
+      if (v < ntp) { if (tile_decode(v, NRB, nsp, k.rb, k.slab)) k.kind = 1; }
+      else if (tile_decode(v - ntp, NRB, nsg, k.rb, k.slab)) k.kind = 0;
+    } else {
+      const int nl = t < T ? ntp : 0, na = t + 1 < T ? B : 0;
+      if (v < nl) { if (tile_decode(v, NRB, nsp, k.rb, k.slab)) k.kind = 2; }
+      else if (v < nl + na) { k.kind = 4; k.t = t + 1; k.b = v - nl; }
+      else if (tile_decode(v - nl - na, NRB, nse, k.rb, k.slab)) { k.kind = 3; k.t = t - 1; }
+    }
+    return k;
+  };
+  TRegs R;
+  PST_INIT();
+  bool first[2] = {true, true};
+  for (int t = 0; t <= T; ++t) {
+#pragma unroll 1
+    for (int ph = 0; ph < 2; ++ph) {
+      const int n = n_tasks(ph, t);
+      if (n == 0) continue;
+#pragma unroll 1
+      for (int dir = 0; dir < 2; ++dir) {
+        int v = blockIdx.x;
+        Task k = task_of(ph, t, dir, v);
+        if (v < n) task_pre(P, F, k, R);
+        PST(4 * ph + 2 * dir);
+        if (!first[dir]) { if (!bar_wait(gb[dir], &bar_ok)) return; }
+        first[dir] = false;
+        PST(4 * ph + 2 * dir + 1);
+        for (; v < n;) {
+          task_post(P, F, k, R, red, tiles, attx);
+          v += G;
+          if (v < n) { k = task_of(ph, t, dir, v); task_pre(P, F, k, R); }
+        }
+        PSTC(12);
+        bar_arrive(gb[dir]);
+        PSTC(13);
+      }
+    }
+  }
+  PST_DUMP("fwd: (work wait) x B0 B1 C0 C1 | loads mfma reduce epilogue | - arrive", (unsigned long long)T);
+}
+
+// ======================================================================================================================================
+// Persistent backward: the BPTT of both directions in ONE launch, same machinery (packed operands, per-direction barrier counters, every
+// workgroup alternating between the two direction chains).  Per step (descending) and direction four phases:
+//   C(t): l cell backward of step t | e cell backward of step t-1 | history-attention backward of step t+1      (element-wise / per row)
+//   D(t): data-gradient products of the gate gradients C(t) left:  dss, dQ (l) ; dqsel, dE (e, step t-1)
+//   E(t): p cell backward | g cell backward of step t
+//   F(t): products: dc, dQ (p) ; dq0sel, dG (g)
+// (The e chain depends on nothing else of its step, so it runs one step ahead of the rest: one phase pair less per step.)  Nothing is
+// accumulated atomically: every product has its own output buffer and the element-wise consumer adds the parts (direct path + products).
+// A product tile = 32 rows x 32 output columns, K = 3 H gate columns split over the 8 waves (chunks of 4 passes, double-buffered); its B
+// operand is the weight matrix in transposed fragment order (drnn_pack_wt_kernel).
+__global__ void drnn_pack_wt_kernel(const float* W, long ldw, int K3, int N, float* out, long n_out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // (n fastest: coalesced reads of W's rows)
+  if (i >= n_out) return;
+  const int n = (int)(i & 31), j = (int)((i >> 5) & 7);
+  const long q = i >> 8;
+  const int k8n = k8p(K3);
+  const int k = (int)(q % k8n) * 8 + j, col = (int)(q / k8n) * 32 + n;
+  out[(q * 32 + n) * 8 + j] = (k < K3 && col < N) ? W[(long)k * ldw + col] : 0.f;
+}
+
+struct BB { XB bk, wt, dGh; };
+__device__ __forceinline__ BB bb_uni(const BB& x) { BB b; b.bk = xb_uni(x.bk); b.wt = xb_uni(x.wt); b.dGh = xb_uni(x.dGh); return b; }
+__device__ __forceinline__ void pk_store3(const XB& bk, long pack, int row, int H, int u, float a, float b, float c) {
+  xb_st(bk, pack + pk_off(row, u, 3 * H), a);
+  xb_st(bk, pack + pk_off(row, H + u, 3 * H), b);
+  xb_st(bk, pack + pk_off(row, 2 * H + u, 3 * H), c);
+}
+__device__ __forceinline__ void row_store3(float* o, int H, float a, float b, float c) { o[0] = a; o[H] = b; o[2 * H] = c; }
+
+// e cell backward of step t: elements (b, u) of chunk `ch`
+__device__ __noinline__ void e_bwd_task(const PK& P, const BB& Xv, int t, int dir, int ch) {
+  const BB X = bb_uni(Xv);
+  const int B = P.d.B, T = P.d.T, H = P.d.De;
+  const long TB = (long)T * B, base = (long)dir * P.w.bk_dir;
+  const int it = ch * PNT + threadIdx.x;
+  if (it >= B * H) return;
+  const int b = it / H, u = it - b * H;
+  const int tau = dir ? P.rev[(long)t * B + b] : t;
+  float dh = xb_ld(X.bk, base + P.w.b_dEdir + it) + xb_ld(X.bk, base + P.w.b_PEh + it);
+  if (tau >= 0) dh += P.dout[((long)tau * B + b) * P.ldo + (long)dir * H + u];
+  if (P.rng) dh *= drop_scale(drop_key(P.rng, P.site[dir] + 3, P.pdrop), (uint32_t)((long)t * B * H) + (uint32_t)it);
+  const float* sv = P.w.sv_e + ((long)dir * TB + (long)t * B + b) * 4 * H + u;
+  const GateGrad g = gru_gate_bwd(dh, sv[0], sv[H], sv[2 * H], sv[3 * H], P.w.Eh[((long)dir * (T + 1) + t) * B * H + it]);
+  const long row = ((long)dir * TB + (long)t * B + b) * 3 * H + u;
+  row_store3(P.w.dgi_e + row, H, g.dar, g.daz, g.dan);
+  row_store3(P.w.dgh_e + row, H, g.dar, g.daz, g.danr);
+  pk_store3(X.bk, base + P.w.b_gie, b, H, u, g.dar, g.daz, g.dan);
+  pk_store3(X.bk, base + P.w.b_ghe, b, H, u, g.dar, g.daz, g.danr);
+  xb_st(X.bk, base + P.w.b_dEdir + it, g.dhp);
+}
+// g cell backward of step t
+__device__ __noinline__ void g_bwd_task(const PK& P, const BB& Xv, int t, int dir, int ch) {
+  const BB X = bb_uni(Xv);
+  const int B = P.d.B, T = P.d.T, H = P.d.Dg;
+  const long TB = (long)T * B, base = (long)dir * P.w.bk_dir;
+  const int it = ch * PNT + threadIdx.x;
+  if (it >= B * H) return;
+  const int b = it / H, u = it - b * H;
+  float dh = xb_ld(X.dGh, ((long)dir * (T + 1) + t + 1) * B * H + it) + xb_ld(X.bk, base + P.w.b_Ddirg + it) + xb_ld(X.bk, base + P.w.b_PGh + it);
+  if (P.rng) dh *= drop_scale(drop_key(P.rng, P.site[dir], P.pdrop), (uint32_t)((long)t * B * H) + (uint32_t)it);
+  const float* sv = P.w.sv_g + ((long)dir * TB + (long)t * B + b) * 4 * H + u;
+  const GateGrad g = gru_gate_bwd(dh, sv[0], sv[H], sv[2 * H], sv[3 * H], P.w.Gh[((long)dir * (T + 1) + t) * B * H + it]);
+  const long row = ((long)dir * TB + (long)t * B + b) * 3 * H + u;
+  row_store3(P.w.dgi_g + row, H, g.dar, g.daz, g.dan);
+  row_store3(P.w.dgh_g + row, H, g.dar, g.daz, g.danr);
+  pk_store3(X.bk, base + P.w.b_gig, b, H, u, g.dar, g.daz, g.dan);
+  pk_store3(X.bk, base + P.w.b_ghg, b, H, u, g.dar, g.daz, g.danr);
+  xb_st(X.bk, base + P.w.b_Ddirg + it, g.dhp);
+}
+// l cell backward + blend (LCELL) or p cell backward of step t, both parties of element (b, u)
+template <bool LCELL>
+__device__ __noinline__ void lp_bwd_task(const PK& P, const BB& Xv, int t, int dir, int ch) {
+  const BB X = bb_uni(Xv);
+  const int B = P.d.B, T = P.d.T, H = P.d.Dp;
+  const long TB = (long)T * B, base = (long)dir * P.w.bk_dir;
+  const WS& w = P.w;
+  const int it = ch * PNT + threadIdx.x;
+  if (it >= B * H) return;
+  const int b = it / H, u = it - b * H;
+  const int* ix = w.idx + (long)dir * (TB + B) + (long)t * B + b;
+  const int sp = ix[0], sn = ix[B];
+  const bool has_next = t + 1 < T;
+  DropKey dk{};
+  if (P.rng) dk = drop_key(P.rng, P.site[dir] + (LCELL ? 2 : 1), P.pdrop);
+  const float* save = (LCELL ? w.sv_l : w.sv_p) + ((long)dir * TB + (long)t * B) * 2 * 4 * H;
+  float* dgh = (LCELL ? w.dgh_l : w.dgh_p) + ((long)dir * TB + (long)t * B) * 2 * 3 * H;
+  float* dgi = (LCELL ? w.dgi_l : w.dgi_p) + ((long)dir * TB + (long)t * B + b) * 3 * H + u;
+  const long pk_gh = base + (LCELL ? w.b_ghl : w.b_ghp), pk_gi = base + (LCELL ? w.b_gil : w.b_gip);
+  // every load of the element first (one round trip), then the arithmetic and the stores
+  float dp[2][4], svv[2][4], hq[2], mm[2];
+  const float sel = xb_ld(X.bk, base + (LCELL ? w.b_Pqsel : w.b_Pss) + it);
+  const float q0n = (LCELL && has_next) ? xb_ld(X.bk, base + w.b_Pq0 + it) : 0.f;
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) {
+    const long qe = ((long)b * 2 + pt) * H + u;
+    if constexpr (LCELL) {
+      dp[pt][0] = xb_ld(X.bk, base + w.b_QdirL + qe); dp[pt][1] = xb_ld(X.bk, base + w.b_QdirP + qe);
+      dp[pt][2] = xb_ld(X.bk, base + w.b_PQl + qe); dp[pt][3] = xb_ld(X.bk, base + w.b_PQp + qe);      // gradient at Q[t+1] (zeros at the last step)
+      mm[pt] = w.qm[((long)dir * TB + (long)t * B + b) * 2 + pt];
+    } else {
+      dp[pt][0] = xb_ld(X.bk, base + w.b_dqs + qe);
+    }
+    const float* sv = save + ((long)b * 2 + pt) * 4 * H + u;
+    svv[pt][0] = sv[0]; svv[pt][1] = sv[H]; svv[pt][2] = sv[2 * H]; svv[pt][3] = sv[3 * H];
+    hq[pt] = w.Q[((long)dir * (T + 1) + t) * B * 2 * H + qe];
+  }
+  float sr = 0.f, sz = 0.f, sna = 0.f;
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) {
+    const long qe = ((long)b * 2 + pt) * H + u;
+    float dh;
+    if constexpr (LCELL) {
+      float d = dp[pt][0] + dp[pt][1] + dp[pt][2] + dp[pt][3];
+      if (pt == sp) d += sel;
+      if (has_next && pt == sn) d += q0n;
+      xb_st(X.bk, base + w.b_dqs + qe, d * mm[pt]);
+      dh = d * (1.f - mm[pt]);
+    } else {
+      dh = dp[pt][0];
+      if (pt == sp) dh += sel;
+    }
+    if (P.rng) dh *= drop_scale(dk, (uint32_t)((long)t * B * 2 * H) + (uint32_t)qe);
+    const GateGrad g = gru_gate_bwd(dh, svv[pt][0], svv[pt][1], svv[pt][2], svv[pt][3], hq[pt]);
+    row_store3(dgh + ((long)b * 2 + pt) * 3 * H + u, H, g.dar, g.daz, g.danr);
+    pk_store3(X.bk, pk_gh, b * 2 + pt, H, u, g.dar, g.daz, g.danr);
+    sr += g.dar; sz += g.daz; sna += g.dan;
+    xb_st(X.bk, base + (LCELL ? w.b_QdirL : w.b_QdirP) + qe, g.dhp);
+  }
+  row_store3(dgi, H, sr, sz, sna);                     // both parties share the input row
+  pk_store3(X.bk, pk_gi, b, H, u, sr, sz, sna);
+}
+// history-attention backward of step t, row (b, dir), in two halves that run in consecutive phases on the SAME workgroup (its LDS carries
+// x, dc, alpha and ds from one to the other):
+//   att_bwd_a (phase C): ONE pass over the history g_0 .. g_{t-1}: dalpha_s = <dc, g_s> and, with the row still in registers,
+//     acc += alpha_s dalpha_s g_s.  Then dot = sum alpha dalpha, ds_s = alpha_s (dalpha_s - dot) and
+//     dx = sum_s ds_s g_s = acc - dot c_t   (c_t = sum alpha_s g_s is the forward's pooled vector)                       -> dXatt[t]
+//   att_bwd_b (phase D, beside the products): dGh[s+1] += alpha_s dc + ds_s x for s < t -- independent read-modify-writes, NB rows'
+//     loads in flight per thread.  (dGh[t] is complete after this: the g cell backward of step t-1 reads it in phase E.)
+// LDS state per direction: x[Dg] | dc[Dg] | ds[T] | alpha[T]
+__device__ __noinline__ void att_bwd_a(const PK& P, const BB& Xv, int t, int b, int dir, float* st, float* wacc, float* redw) {
+  const BB X = bb_uni(Xv);
+  const int B = P.d.B, T = P.d.T, Dg = P.d.Dg;
+  const long TB = (long)T * B, base = (long)dir * P.w.bk_dir;
+  float* x = st; float* dcv = st + Dg; float* ds = st + 2 * Dg; float* al = ds + T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xs = P.w.Xatt + ((long)dir * TB + (long)t * B + b) * Dg;
+  const float* as = P.w.alpha + ((long)dir * TB + (long)t * B + b) * T;
+  for (int u = tid; u < Dg; u += PNT) { x[u] = xs[u]; dcv[u] = xb_ld(X.bk, base + P.w.b_Pc + (long)b * Dg + u); }
+  for (int s = tid; s < t; s += PNT) al[s] = as[s];
+  __syncthreads();
+  const float* G = P.w.Gh + ((long)dir * (T + 1) * B + b) * Dg;          // g_s at G + (s + 1) gs (written by the forward launch)
+  const long gs = (long)B * Dg;
+  Row4 dc4, acc;
+#pragma unroll
+  for (int i = 0; i < ATT_V; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { const int u = 4 * lane + 256 * i + c; dc4.v[i][c] = u < Dg ? dcv[u] : 0.f; acc.v[i][c] = 0.f; }
+  const bool v4 = (Dg & 3) == 0;
+  float dotp = 0.f;
+  for (int s0 = wave; s0 < t; s0 += PNW * 4) {
+    Row4 rw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int s = s0 + PNW * j;
+      const float* row = G + (long)(s + 1) * gs;
+#pragma unroll
+      for (int i = 0; i < ATT_V; ++i) {
+        const int u = 4 * lane + 256 * i;
+        if (s < t && v4 && u < Dg) {
+          const float4 q = *reinterpret_cast<const float4*>(row + u);
+          rw[j].v[i][0] = q.x; rw[j].v[i][1] = q.y; rw[j].v[i][2] = q.z; rw[j].v[i][3] = q.w;
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) rw[j].v[i][c] = (s < t && !v4 && u + c < Dg) ? row[u + c] : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int s = s0 + PNW * j;
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < ATT_V; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d = fmaf(dc4.v[i][c], rw[j].v[i][c], d);
+      d = wave_sum(d);
+      if (s < t) {
+        const float a = al[s];
+        if (lane == 0) ds[s] = d;                      // dalpha_s for now
+        dotp = fmaf(a, d, dotp);
+        const float f = a * d;
+#pragma unroll
+        for (int i = 0; i < ATT_V; ++i)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc.v[i][c] = fmaf(f, rw[j].v[i][c], acc.v[i][c]);
+      }
+    }
+  }
+  if (lane == 0) redw[wave] = dotp;                    // (every lane of the wave holds the wave's partial sum)
+#pragma unroll
+  for (int i = 0; i < ATT_V; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wacc[wave * (ATT_V * 256) + 4 * lane + 256 * i + c] = acc.v[i][c];
+  __syncthreads();
+  float dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < PNW; ++k) dot += redw[k];
+  const float* ct = P.w.cvec + ((long)dir * TB + (long)t * B + b) * Dg;
+  float* dX = P.w.dXatt + ((long)dir * TB + (long)t * B + b) * Dg;
+  for (int u = tid; u < Dg; u += PNT) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < PNW; ++k) a += wacc[k * (ATT_V * 256) + u];
+    dX[u] = a - dot * ct[u];
+  }
+  __syncthreads();                                     // (every thread has read redw / ds before they change)
+  for (int s = tid; s < t; s += PNT) ds[s] = al[s] * (ds[s] - dot);
+  __syncthreads();
+}
+__device__ __noinline__ void att_bwd_b(const PK& P, const BB& Xv, int t, int b, int dir, const float* st) {
+  const BB X = bb_uni(Xv);
+  const int B = P.d.B, T = P.d.T, Dg = P.d.Dg;
+  const float* x = st; const float* dcv = st + Dg; const float* ds = st + 2 * Dg; const float* al = ds + T;
+  const int tid = threadIdx.x;
+  const long g0 = ((long)dir * (T + 1) * B + b) * Dg, gs = (long)B * Dg;
+  if ((Dg & 3) == 0) {
+    // PNT / 128 row groups x 128 column quads: thread (grp, q) updates u = 4 q .. 4 q + 3 of the rows s = grp, grp + NG, ...
+    constexpr int NB = 32, NG = PNT / 128;
+    const int q = tid & 127, grp = tid >> 7;
+    for (int u = 4 * q; u < Dg; u += 512) {
+      const float4 dc4 = *reinterpret_cast<const float4*>(dcv + u), x4 = *reinterpret_cast<const float4*>(x + u);
+      for (int sb = grp; sb < t; sb += NG * NB) {
+        pu32x4 ov[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const int sj = sb + NG * j;
+          if (sj < t) ov[j] = __builtin_amdgcn_raw_buffer_load_b128(X.dGh.r, (int)((g0 + (long)(sj + 1) * gs + u) * 4), 0, P_SC1);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const int sj = sb + NG * j;
+          if (sj < t) {
+            const float a = al[sj], dsv = ds[sj];
+            pu32x4 nv;
+            nv.x = __float_as_uint(__uint_as_float(ov[j].x) + a * dc4.x + dsv * x4.x);
+            nv.y = __float_as_uint(__uint_as_float(ov[j].y) + a * dc4.y + dsv * x4.y);
+            nv.z = __float_as_uint(__uint_as_float(ov[j].z) + a * dc4.z + dsv * x4.z);
+            nv.w = __float_as_uint(__uint_as_float(ov[j].w) + a * dc4.w + dsv * x4.w);
+            __builtin_amdgcn_raw_buffer_store_b128(nv, X.dGh.r, (int)((g0 + (long)(sj + 1) * gs + u) * 4), 0, P_SC1);
+          }
+        }
+      }
+    }
+  } else {
+    constexpr int NB = 8;
+    for (int u = tid % 256; u < Dg; u += 256) {
+      const float dcu = dcv[u], xu = x[u];
+      constexpr int NP = PNT / 256;
+      const int part = tid / 256;
+      const int s0 = (int)((long)t * part / NP), s1 = (int)((long)t * (part + 1) / NP);
+      for (int sb = s0; sb < s1; sb += NB) {
+        float ov[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) if (sb + j < s1) ov[j] = xb_ld(X.dGh, g0 + (long)(sb + j + 1) * gs + u);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          if (sb + j < s1) xb_st(X.dGh, g0 + (long)(sb + j + 1) * gs + u, ov[j] + al[sb + j] * dcu + ds[sb + j] * xu);
+      }
+    }
+  }
+  __syncthreads();
+}
+// product i of direction dir, tile (rb, ct): out[rows, N] tile = dgates[rows, K3] W^T-pack
+struct BProd { long a_off, w_off, o_off; int K3, N, rows; };
+template <int I>
+__device__ __forceinline__ BProd bprod(const PK& P, int dir) {
+  const WS& w = P.w;
+  const int B = P.d.B, Dg = P.d.Dg, Dp = P.d.Dp, De = P.d.De;
+  const long a = I == 0 ? w.b_gie : I == 1 ? w.b_ghe : I == 2 ? w.b_gil : I == 3 ? w.b_ghl : I == 4 ? w.b_gip : I == 5 ? w.b_ghp : I == 6 ? w.b_gig : w.b_ghg;
+  const long o = I == 0 ? w.b_Pqsel : I == 1 ? w.b_PEh : I == 2 ? w.b_Pss : I == 3 ? w.b_PQl : I == 4 ? w.b_Pc : I == 5 ? w.b_PQp : I == 6 ? w.b_Pq0 : w.b_PGh;
+  BProd d;
+  d.a_off = (long)dir * w.bk_dir + a; d.o_off = (long)dir * w.bk_dir + o; d.w_off = (long)dir * w.wtk_dir + w.wtk_off[I];
+  d.K3 = 3 * (I < 2 ? De : I < 6 ? Dp : Dg);
+  d.N = (I == 1) ? De : (I == 4 || I == 7) ? Dg : Dp;
+  d.rows = (I == 3 || I == 5) ? 2 * B : B;
+  return d;
+}
+__device__ __noinline__ void bwd_prod_task(const BB& Xv, const BProd d, int rb, int ct, float* red, float* tiles) {
+  const BB X = bb_uni(Xv);
+  const int k8n = k8p(d.K3), Kp = k8n * 8;
+  const long ab = d.a_off + (long)rb * k8n * 256, wb = d.w_off + (long)ct * k8n * 256;
+  const int KC = ((Kp + PNW * 16 - 1) / (PNW * 16)) * 16;
+  const int nch = (KC / 16 + 3) / 4;
+  f32x16 acc = {0};
+  // the gate gradients (written this phase pair by other workgroups: L2-bypassing loads, the long latency) are requested for the wave's
+  // whole K share at once -- at most 3 chunks of 4 passes (K3 <= 1536), 96 registers; the weight fragments (cached) are double-buffered
+  float a[3][4][8], b0[4][8], b1[4][8];
+  PSTC(10);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) load_chunk<true>(X.bk, ab, Kp, c, a[c]);          // (passes beyond the wave's share read zeros)
+  load_chunk<false>(X.wt, wb, Kp, 0, b0);
+  if (nch > 1) load_chunk<false>(X.wt, wb, Kp, 1, b1);
+  mma_chunk(a[0], b0, acc);
+  if (nch > 1) {
+    if (nch > 2) load_chunk<false>(X.wt, wb, Kp, 2, b0);
+    mma_chunk(a[1], b1, acc);
+    if (nch > 2) mma_chunk(a[2], b0, acc);
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4)
+    *reinterpret_cast<float4*>(red + wave * P_T1 + r * P_TS + 8 * g4 + 4 * half) = make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
+  __syncthreads();
+  PSTC(13);
+  for (int e = tid; e < 1024; e += PNT) {              // (output column fastest: coalesced stores)
+    const int n = e & 31, rr = e >> 5;
+    float s = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < PNW; ++wv) s += red[wv * P_T1 + n * P_TS + rr];
+    const int row = rb * 32 + rr, col = ct * 32 + n;
+    if (row < d.rows && col < d.N) xb_st(X.bk, d.o_off + (long)row * d.N + col, s);
+  }
+  __syncthreads();
+  PSTC(14);
+}
+
+__global__ __launch_bounds__(PNT) void drnn_bwd_persist(const PK P) {
+  extern __shared__ float psm[];
+  float* red = psm;
+  float* tiles = psm + 3 * P_RED1;
+  float* attx = tiles + P_TILES;
+  __shared__ int bar_ok;
+  const int B = P.d.B, T = P.d.T, Dg = P.d.Dg, Dp = P.d.Dp, De = P.d.De;
+  BB X;
+  X.bk = xb_make(P.w.bk, P.w.bk_floats);
+  X.wt = xb_make(P.w.wpk, (size_t)2 * P.w.wtk_dir);
+  X.dGh = xb_make(P.w.dGh, (size_t)2 * (T + 1) * B * Dg);
+  GridBar gb[2] = {{P.sync, P.sync + 64, P.fault, 0u, gridDim.x}, {P.sync + 32, P.sync + 64, P.fault, 0u, gridDim.x}};
+  const int G = gridDim.x;
+  const int nrb1 = (B + 31) / 32, nrb2 = (2 * B + 31) / 32;
+  const int ctg = (Dg + 31) / 32, ctp = (Dp + 31) / 32, cte = (De + 31) / 32;
+  const int nel = (B * Dp + PNT - 1) / PNT, neg = (B * Dg + PNT - 1) / PNT, nee = (B * De + PNT - 1) / PNT;
+  // tiles of the eight products (rows x column tiles of 32, padded for the XCD pairing)
+  const int nt_e_ih = tile_count(B, Dp, 32), nt_e_hh = tile_count(B, De, 32), nt_l_ih = tile_count(B, Dp, 32), nt_l_hh = tile_count(2 * B, Dp, 32);
+  const int nt_p_ih = tile_count(B, Dg, 32), nt_p_hh = tile_count(2 * B, Dp, 32), nt_g_ih = tile_count(B, Dp, 32), nt_g_hh = tile_count(B, Dg, 32);
+  (void)ctg; (void)ctp; (void)cte;
+  // phase ph (0 = C, 1 = D, 2 = E, 3 = F) of step t: number of tasks, and task v
+  auto n_tasks = [&](int ph, int t) {
+    switch (ph) {
+      case 0: return (t + 1 < T ? B : 0) + (t < T ? nel : 0) + (t >= 1 ? nee : 0);
+      case 1: return (t + 1 < T ? B : 0) + (t < T ? nt_l_ih + (t > 0 ? nt_l_hh : 0) : 0) + (t >= 1 ? nt_e_ih + nt_e_hh : 0);
+      case 2: return t < T ? nel + neg : 0;
+      default: return (t < T && t > 0) ? nt_p_ih + nt_p_hh + nt_g_ih + nt_g_hh : 0;
+    }
+  };
+  const int att_st = 2 * Dg + 2 * T;                   // LDS state of an attention row between its two halves, per direction
+  auto run_task = [&](int ph, int t, int dir, int v) {
+    if (ph == 0) {
+      const int na = t + 1 < T ? B : 0, nl = t < T ? nel : 0;
+      PSTC(15);
+      if (v < na) { att_bwd_a(P, X, t + 1, v, dir, attx + dir * att_st, red, tiles); PSTC(8); }
+      else if (v < na + nl) { lp_bwd_task<true>(P, X, t, dir, v - na); PSTC(11); }
+      else { e_bwd_task(P, X, t - 1, dir, v - na - nl); PSTC(11); }
+    } else if (ph == 1) {
+      const int na = t + 1 < T ? B : 0;
+      const int n2 = t < T ? nt_l_ih : 0, n3 = (t < T && t > 0) ? nt_l_hh : 0, n0 = t >= 1 ? nt_e_ih : 0;
+      PSTC(15);
+      if (v < na) { att_bwd_b(P, X, t + 1, v, dir, attx + dir * att_st); PSTC(9); return; }      // (the same workgroup as the row's first half)
+      v -= na;
+      int rb, ct;
+      if (v < n3) { if (tile_decode(v, nrb2, ctp, rb, ct)) bwd_prod_task(X, bprod<3>(P, dir), rb, ct, red, tiles); }
+      else if (v < n3 + n2) { if (tile_decode(v - n3, nrb1, ctp, rb, ct)) bwd_prod_task(X, bprod<2>(P, dir), rb, ct, red, tiles); }
+      else if (v < n3 + n2 + n0) { if (tile_decode(v - n3 - n2, nrb1, ctp, rb, ct)) bwd_prod_task(X, bprod<0>(P, dir), rb, ct, red, tiles); }
+      else if (tile_decode(v - n3 - n2 - n0, nrb1, cte, rb, ct)) bwd_prod_task(X, bprod<1>(P, dir), rb, ct, red, tiles);
+    } else if (ph == 2) {
+      if (v < nel) lp_bwd_task<false>(P, X, t, dir, v);
+      else g_bwd_task(P, X, t, dir, v - nel);
+    } else {
+      const int n5 = nt_p_hh, n4 = nt_p_ih, n6 = nt_g_ih;
+      int rb, ct;
+      if (v < n5) { if (tile_decode(v, nrb2, ctp, rb, ct)) bwd_prod_task(X, bprod<5>(P, dir), rb, ct, red, tiles); }
+      else if (v < n5 + n4) { if (tile_decode(v - n5, nrb1, ctg, rb, ct)) bwd_prod_task(X, bprod<4>(P, dir), rb, ct, red, tiles); }
+      else if (v < n5 + n4 + n6) { if (tile_decode(v - n5 - n4, nrb1, ctp, rb, ct)) bwd_prod_task(X, bprod<6>(P, dir), rb, ct, red, tiles); }
+      else if (tile_decode(v - n5 - n4 - n6, nrb1, ctg, rb, ct)) bwd_prod_task(X, bprod<7>(P, dir), rb, ct, red, tiles);
+    }
+  };
+  PST_INIT();
+  bool first[2] = {true, true};
+  for (int t = T; t >= 0; --t) {
+#pragma unroll 1
+    for (int ph = 0; ph < 4; ++ph) {
+      const int n = n_tasks(ph, t);
+      if (n == 0) continue;
+#pragma unroll 1
+      for (int dir = 0; dir < 2; ++dir) {
+        // (direction 1's task list is dealt from the middle of the grid: a phase has fewer tasks than workgroups, so the two
+        // directions' tasks of a phase mostly land on different workgroups)
+        int v = (int)((blockIdx.x + (unsigned)dir * (G / 2)) % (unsigned)G);
+        PST(2 * ph);
+        if (!first[dir]) { if (!bar_wait(gb[dir], &bar_ok)) return; }
+        first[dir] = false;
+        PST(2 * ph + 1);
+        for (; v < n; v += G) run_task(ph, t, dir, v);
+        PSTC(10);
+        bar_arrive(gb[dir]);
+        PSTC(12);
+      }
+    }
+  }
+  PST_DUMP("bwd: (work wait) x C D E F", (unsigned long long)T);
+}
+
 // ---- host helpers -----------------------------------------------------------------------------------------------------------------------
 mser_gemm_desc gd() {
   mser_gemm_desc g;
@@ -636,6 +1741,37 @@ int validate(const mser_drnn_desc& d, bool bwd) {
 
 #define DS(field) ((long)(d.p[1].field - d.p[0].field))
 
+int persist_grid() {
+  static int g = 0;
+  if (g == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) g = n;
+    if (g <= 0) g = 1;
+    if (g >= 8) g &= ~7;            // a multiple of the 8 XCDs (tile_decode)
+  }
+  return g;
+}
+size_t persist_lds(const Dims& d, bool bwd) {
+  return (size_t)(3 * P_RED1 + P_TILES + (bwd ? 2 * (2 * d.Dg + 2 * d.T) : d.T + 32) + 16) * sizeof(float);
+}
+// every hand-off array is addressed through a 32-bit byte offset (buffer descriptor); one workgroup per CU must fit
+bool persist_ok(const Dims& d, bool bwd) {
+  if (!g_opt_drnn_persist || persist_grid() < 8 || d.Dg > 512 || d.Dp > 512 || d.De > 512) return false;
+  if (bwd && d.B > persist_grid() / 2) return false;        // (an attention row's two halves meet in its workgroup's LDS: one row per workgroup and direction)      // (a wave's K share in registers; ATT_V)
+  const size_t big = (size_t)2 * ((size_t)d.T + 1) * d.B * 2 * (size_t)(d.Dp > d.Dg ? d.Dp : d.Dg) * 3 * sizeof(float);   // >= the largest of them
+  return big < ((size_t)1 << 31) && persist_lds(d, bwd) <= 160 * 1024;
+}
+PK make_pk(const mser_drnn_desc& d, const WS& w) {
+  PK K;
+  K.d = Dims{d.T, d.B, d.Dm, d.Dg, d.Dp, d.De};
+  K.p[0] = d.p[0]; K.p[1] = d.p[1];
+  K.w = w;
+  K.rng = (d.rng && d.p_drop > 0.f) ? d.rng : nullptr; K.site[0] = d.drop_site[0]; K.site[1] = d.drop_site[1]; K.pdrop = d.p_drop;
+  K.out = d.out; K.dout = d.dout; K.ldo = d.ldo; K.rev = d.rev;
+  K.sync = w.sync; K.fault = d.fault;
+  return K;
+}
+
 }  // namespace
 }  // namespace mser
 
@@ -686,6 +1822,26 @@ int mser_drnn_fwd(const mser_drnn_desc* dp, mser_stream_t stream) {
       g.sAm = Dm; g.sAk = 1; g.sBk = 1; g.sBn = h.ld; g.ldc = h.N; g.bias = h.b;
       MSER_TRY(gemm(g, s));
     }
+  }
+  if (persist_ok(dm, false)) {
+    const PK K = make_pk(d, w);
+    const size_t lds = persist_lds(dm, false);
+    MSER_CHECK_HIP(hipMemsetAsync(w.sync, 0, 128 * sizeof(unsigned), s));
+    MSER_CHECK_HIP(hipMemsetAsync(w.apk, 0, w.apk_floats * sizeof(float), s));
+    for (int dir = 0; dir < 2; ++dir) {
+      const mser_drnn_params& P = d.p[dir];
+      struct { const float* W; long ld; int H, K; } pk[8] = {
+        {P.g_wih + Dm, (long)Dm + Dp, Dg, Dp}, {P.g_whh, (long)Dg, Dg, Dg}, {P.p_wih + Dm, (long)Dm + Dg, Dp, Dg}, {P.p_whh, (long)Dp, Dp, Dp},
+        {P.l_wih + Dm, (long)Dm + Dp, Dp, Dp}, {P.l_whh, (long)Dp, Dp, Dp}, {P.e_wih, (long)Dp, De, Dp}, {P.e_whh, (long)De, De, De}};
+      for (int i = 0; i < 8; ++i) {
+        const long n_out = (long)((pk[i].H + UW - 1) / UW) * k8p(pk[i].K) * 256;
+        hipLaunchKernelGGL(drnn_pack_w_kernel, dim3(cdiv(n_out, 256)), dim3(256), 0, s, pk[i].W, pk[i].ld, pk[i].H, pk[i].K,
+                           w.wpk + (long)dir * w.wpk_dir + w.wpk_off[i], n_out);
+      }
+    }
+    MSER_CHECK_HIP(hipFuncSetAttribute((const void*)drnn_fwd_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(drnn_fwd_persist, dim3(persist_grid()), dim3(PNT), lds, s, K);
+    return check_launch("drnn_fwd_persist");
   }
   // the per-step hidden products (and gi_e) are accumulation targets cleared by their readers: zero them once (carved back to back)
   MSER_CHECK_HIP(hipMemsetAsync(w.gi_g, 0, (size_t)((char*)(w.gh_e + (size_t)2 * B * 3 * De) - (char*)w.gi_g), s));
@@ -755,6 +1911,28 @@ int mser_drnn_bwd(const mser_drnn_desc* dp, mser_stream_t stream) {
   const long g_ds = (long)(T + 1) * B * Dg, q_ds = (long)(T + 1) * B * 2 * Dp, e_ds = (long)(T + 1) * B * De;
   const long idx_ds = TB + B;
   MSER_CHECK_HIP(hipMemsetAsync(w.dGh, 0, (size_t)2 * (T + 1) * B * Dg * sizeof(float), s));
+  if (persist_ok(dm, true)) {
+    // ---- persistent BPTT: one launch (drnn_bwd_persist)
+    MSER_CHECK_HIP(hipMemsetAsync(w.bk, 0, w.bk_floats * sizeof(float), s));
+    MSER_CHECK_HIP(hipMemsetAsync(w.sync, 0, 128 * sizeof(unsigned), s));
+    for (int dir = 0; dir < 2; ++dir) {
+      MSER_CHECK_HIP(hipMemsetAsync(w.dXatt + (long)dir * TB * Dg, 0, (size_t)B * Dg * sizeof(float), s));       // step 0 has no attention
+      const mser_drnn_params& P = d.p[dir];
+      struct { const float* W; long ld; int K3, N; } pk[8] = {
+        {P.e_wih, (long)Dp, 3 * De, Dp}, {P.e_whh, (long)De, 3 * De, De}, {P.l_wih + Dm, (long)Dm + Dp, 3 * Dp, Dp}, {P.l_whh, (long)Dp, 3 * Dp, Dp},
+        {P.p_wih + Dm, (long)Dm + Dg, 3 * Dp, Dg}, {P.p_whh, (long)Dp, 3 * Dp, Dp}, {P.g_wih + Dm, (long)Dm + Dp, 3 * Dg, Dp}, {P.g_whh, (long)Dg, 3 * Dg, Dg}};
+      for (int i = 0; i < 8; ++i) {
+        const long n_out = (long)((pk[i].N + 31) / 32) * k8p(pk[i].K3) * 256;
+        hipLaunchKernelGGL(drnn_pack_wt_kernel, dim3(cdiv(n_out, 256)), dim3(256), 0, s, pk[i].W, pk[i].ld, pk[i].K3, pk[i].N,
+                           w.wpk + (long)dir * w.wtk_dir + w.wtk_off[i], n_out);
+      }
+    }
+    const PK K = make_pk(d, w);
+    const size_t lds = persist_lds(dm, true);
+    MSER_CHECK_HIP(hipFuncSetAttribute((const void*)drnn_bwd_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(drnn_bwd_persist, dim3(persist_grid()), dim3(PNT), lds, s, K);
+    MSER_TRY(check_launch("drnn_bwd_persist"));
+  } else {
   MSER_CHECK_HIP(hipMemsetAsync(w.dQ, 0, (size_t)2 * 2 * B * 2 * Dp * sizeof(float), s));
   MSER_CHECK_HIP(hipMemsetAsync(w.dEc, 0, (size_t)2 * B * De * sizeof(float), s));
   MSER_CHECK_HIP(hipMemsetAsync(w.dq0sel, 0, (size_t)2 * 2 * B * Dp * sizeof(float), s));
@@ -812,6 +1990,7 @@ int mser_drnn_bwd(const mser_drnn_desc* dp, mser_stream_t stream) {
     }
     MSER_TRY(check_launch("drnn_bwd step"));
     pp ^= 1;
+  }
   }
   // ---- parameter gradients: reductions over all (t, b) rows of one direction, a few large GEMMs each
   for (int dir = 0; dir < 2; ++dir) {

@@ -3438,6 +3438,7 @@ static int g_opt_fwd_sentinel = 1;    // MSER_OPT_FWD_SENTINEL
 static int g_opt_rowsplit = 1;        // MSER_OPT_H256_SPLIT: H = 256 persistent chains share a row phase between two workgroups, BPTT products K-split
 static int g_opt_spk_ks = 1;          // MSER_OPT_SPK_BWD_KSPLIT
 static int g_opt_poll_delay = 0;      // MSER_OPT_BWD_POLL_DELAY
+extern int g_opt_drnn_persist;         // dialogue.hip
 static int g_opt_wide_persist = 0;    // MSER_OPT_WIDE_PERSISTENT (off: the four launches take 75 ms against 81 ms of per-step kernel time at the configs[4]
                                       // shard, but they hold every CU, so the weight-gradient GEMMs and attention branches that the per-step
                                       // launches overlap are serialised behind them: 102-135 ms per step against 90.6)
@@ -4126,6 +4127,7 @@ int mser_set_option(int32_t key, int32_t value) {
     case MSER_OPT_H256_SPLIT: g_opt_rowsplit = value ? 1 : 0; return 0;
     case MSER_OPT_SPK_BWD_KSPLIT: g_opt_spk_ks = value ? 1 : 0; return 0;
     case MSER_OPT_WIDE_PERSISTENT: g_opt_wide_persist = value ? 1 : 0; return 0;
+    case MSER_OPT_DRNN_PERSISTENT: mser::g_opt_drnn_persist = value ? 1 : 0; return 0;
     case MSER_OPT_BWD_POLL_DELAY: g_opt_poll_delay = value < 0 ? 0 : (value > 256 ? 256 : value); return 0;
     default: set_error("mser_set_option: unknown key %d", key); return -1;
   }

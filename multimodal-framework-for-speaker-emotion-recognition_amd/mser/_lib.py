@@ -104,7 +104,7 @@ class DrnnDesc(C.Structure):
                 ("U", C.c_void_p), ("ldu", C.c_int64), ("qmask", C.c_void_p), ("rev", C.c_void_p),
                 ("p", DrnnParams * 2), ("g", DrnnParams * 2), ("out", C.c_void_p), ("ldo", C.c_int64), ("dout", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("rng", C.c_void_p), ("drop_site", C.c_uint32 * 2), ("p_drop", C.c_float)]
+                ("rng", C.c_void_p), ("drop_site", C.c_uint32 * 2), ("p_drop", C.c_float), ("fault", C.c_void_p)]
 
 
 class XAttnDesc(C.Structure):

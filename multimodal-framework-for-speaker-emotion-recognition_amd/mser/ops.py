@@ -499,6 +499,7 @@ def make_drnn_desc(T: int, B: int, dims, U: Tensor, qmask: Tensor, rev: Tensor, 
         rng, sites, p = drop
         d.rng, d.p_drop = _p(rng), float(p)
         d.drop_site[0], d.drop_site[1] = int(sites[0]), int(sites[1])
+    d.fault = _p(fault.word(workspace.device))
     d._keep = (U, qmask, rev, out, workspace, dout)
     return d
 
@@ -774,6 +775,7 @@ MSER_OPT_H256_SPLIT = 8
 MSER_OPT_SPK_BWD_KSPLIT = 9
 MSER_OPT_BWD_POLL_DELAY = 10
 MSER_OPT_WIDE_PERSISTENT = 11
+MSER_OPT_DRNN_PERSISTENT = 12
 
 
 def set_option(key: int, value: int) -> None:

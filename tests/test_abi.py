@@ -46,7 +46,7 @@ def test_struct_layouts_match_the_header_sizes():
     import subprocess
     import tempfile
     from mser import _lib
-    src = '#include <stdio.h>\n#include "mser.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mser_gemm_desc), sizeof(mser_cell_params), sizeof(mser_cell_dir), sizeof(mser_cell_desc), sizeof(mser_encoder_desc), sizeof(mser_head_tail_desc), sizeof(mser_xattn_desc));return 0;}\n'
+    src = '#include <stdio.h>\n#include "mser.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mser_gemm_desc), sizeof(mser_cell_params), sizeof(mser_cell_dir), sizeof(mser_cell_desc), sizeof(mser_encoder_desc), sizeof(mser_head_tail_desc), sizeof(mser_xattn_desc), sizeof(mser_drnn_desc));return 0;}\n'
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, "s.c")
         open(c, "w").write(src)
@@ -54,4 +54,4 @@ def test_struct_layouts_match_the_header_sizes():
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
     assert sizes == [ctypes.sizeof(_lib.GemmDesc), ctypes.sizeof(_lib.CellParams), ctypes.sizeof(_lib.CellDir), ctypes.sizeof(_lib.CellDesc),
-                     ctypes.sizeof(_lib.EncoderDesc), ctypes.sizeof(_lib.HeadTailDesc), ctypes.sizeof(_lib.XAttnDesc)]
+                     ctypes.sizeof(_lib.EncoderDesc), ctypes.sizeof(_lib.HeadTailDesc), ctypes.sizeof(_lib.XAttnDesc), ctypes.sizeof(_lib.DrnnDesc)]
