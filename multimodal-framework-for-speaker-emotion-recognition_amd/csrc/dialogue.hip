@@ -4,13 +4,15 @@
 //   c  = sum_{s<t} softmax_s(<W_att U_t, g_s>) g_s   (zeros at t = 0)                                            (:137-141, :56-59,:75)
 //   qs = dropout(GRU_p([U_t | c], q[b,p])), p = 0,1 ;  ql = dropout(GRU_l([U_t | qs[b,s_b]], q[b,p]))            (:144-153)
 //   q  = ql (1 - qmask) + qs qmask ;  e = dropout(GRU_e(q[b,s_b], e_{t-1}))                                      (:156-161)
-// Structure of this first version: the U-dependent halves of the four input products and W_att U are ONE GEMM each over all
-// steps (hoisted); inside the loop a step is 8 direction-batched GEMMs on the fp32 MFMA (exact fmaf chains: the gate is 1e-4 on
-// log-probs after 200 dependent steps) + 4 gate epilogues + 1 history-attention launch, issued from this host loop (no Python
-// between launches; capturable).  The BPTT mirrors it (8 GEMMs + 5 launches per step); every weight gradient is a reduction over
-// all (t, b) rows and runs as a few large GEMMs after the loop.  Widths at the reference's configuration (D_g = D_p = 500, 21 MB
-// of fp32 weights per direction) do not fit a register-resident persistent chain the way the LSTHM cell does; the step is
-// MFMA-rate bound (0.9 GFLOP per step and direction at B = 64).
+// Structure: the U-dependent halves of the four input products and W_att U are ONE GEMM each over all steps (hoisted); every weight
+// gradient is a reduction over all (t, b) rows and runs as a few large GEMMs after the time loop.  The time loop itself has two forms:
+//   * persistent (MSER_OPT_DRNN_PERSISTENT = 1, default; widths up to 512): ONE launch per pass runs all steps of both directions --
+//     see "Persistent form" below (drnn_fwd_persist / drnn_bwd_persist).  Widths at the reference's configuration (D_g = D_p = 500,
+//     21 MB of fp32 weights per direction) do not fit a register-resident chain the way the LSTHM cell does: the weights stream from
+//     L2 / the infinity cache in MFMA fragment order, the fp32 MFMA (exact fmaf chains: the gate is 1e-4 on log-probs after 200
+//     dependent steps) does 2.1 GFLOP per step and pass (12 us per step at the chip's rate).
+//   * per step (option = 0; the cross-check and the fallback): a step is 8 direction-batched GEMMs + 4 gate epilogues + 1 history-
+//     attention launch issued from the host loop (no Python between launches; capturable); the BPTT mirrors it (8 GEMMs + 5 launches).
 #include "common.h"
 #include "../../include/mser.h"
 #include <cstring>
@@ -70,6 +72,7 @@ struct WS {
   // backward
   float *dgi_g, *dgh_g, *dgi_p, *dgh_p, *dgi_l, *dgh_l, *dgi_e, *dgh_e, *dXatt;   // [2][T][rows][3H] (dgi_p / dgi_l summed over parties)
   unsigned* sync;                                // the persistent launches' barrier counter and abort word (one line each)
+  void* pk_dev;                                  // the persistent launches' parameter block (struct PK) in device memory
   // persistent forward: packed weights [2 dirs][8 products: g_in g_h p_in p_h l_in l_h e_in e_h] and packed states (offsets in floats
   // into apk): q0p [dir] | Ghp [parity][dir] | cvp [dir] | Qp [parity][dir][party] | ssp [dir] | qselp [parity][dir] | Ehp [parity][dir]
   float *wpk, *apk; long wpk_off[8], wpk_dir; long o_q0p, o_Ghp, o_cvp, o_Qp, o_ssp, o_qselp, o_Ehp; size_t apk_floats;
@@ -119,6 +122,7 @@ WS carve(char* base, const Dims& d) {
   w.dqsel = cv.take<float>(2 * B * d.Dp); w.dss = cv.take<float>(2 * B * d.Dp); w.dq0sel = cv.take<float>(2 * 2 * B * d.Dp);
   w.dc = cv.take<float>(2 * B * d.Dg); w.dqs = cv.take<float>(2 * B * 2 * d.Dp);
   w.sync = cv.take<unsigned>(128);
+  w.pk_dev = cv.take<char>(4096);
   {
     const int UWh = 10;                            // = UW (unit slab of the persistent cell tiles)
     const int Hs[4] = {d.Dg, d.Dp, d.Dp, d.De}, Kin[4] = {d.Dp, d.Dg, d.Dp, d.Dp};
@@ -608,18 +612,25 @@ __global__ __launch_bounds__(64 * G2_WPB) void general2_bwd_kernel(const float* 
 
 // =====================================================================================================================================
 // Persistent form (MSER_OPT_DRNN_PERSISTENT): ONE launch per pass runs the whole time loop of both directions.  One workgroup per CU;
-// a step is a short list of PHASES, a phase is a list of independent tasks dealt round-robin to the workgroups, phases are separated by
-// a grid barrier (one counter, monotonic).  A GRU-cell task owns 32 dialogue rows x UW hidden units x 3 gates: it streams its slab of
-// W_ih / W_hh (L2 / infinity cache; the two row blocks of a slab run on the same XCD), multiplies on the fp32 MFMA with the 8 waves
-// splitting K, and applies the gate math itself -- no split-K atomics, no gate-product scratch, no epilogue launch.  Everything one
-// workgroup hands to another inside the launch is stored write-through and loaded L2-bypassing (`sc1` buffer accesses through one
-// descriptor per array), the counter add sits behind s_waitcnt vmcnt(0) + a workgroup barrier (MI355X_MICROARCH.md "valid forms").
-// Every wait is bounded: a workgroup that gives up sets the abort word and MSER_FAULT_CHAIN_TIMEOUT, and the whole grid drains.
+// a step of a direction is a short list of PHASES, a phase is a list of independent tasks dealt to the workgroups, consecutive phases of
+// a direction are separated by a grid barrier (one monotonic counter per direction, split into arrive / wait: every workgroup alternates
+// between the two directions, so one direction's barrier completes while the workgroup works for the other).  A GRU-cell task owns
+// 32 dialogue rows x UW hidden units x 3 gates: it streams its slab of W_ih / W_hh (L2 / infinity cache; the two row blocks of a slab
+// run on the same XCD), multiplies on the fp32 MFMA with the 8 waves splitting K, and applies the gate math itself -- no split-K
+// atomics, no gate-product scratch, no epilogue launch.  Everything one workgroup hands to another inside the launch is stored
+// write-through and loaded L2-bypassing (`sc1` buffer accesses through one descriptor per array), the counter add sits behind
+// s_waitcnt vmcnt(0) + a workgroup barrier (MI355X_MICROARCH.md "valid forms").  Every wait is bounded: a workgroup that gives up sets
+// the abort word and MSER_FAULT_CHAIN_TIMEOUT, and the whole grid drains.
+// Measured (configs[3], B = 64, T = 200, rocprofv3): forward 18.3 ms, backward 17.7 ms per launch (88-91 us per step, of which the MFMA
+// chains are 12 us per CU: a task is a latency chain -- L2-bypassing operand loads 3 us, MFMA 5 us, cross-wave reduction 2-3 us, gate
+// math 1.5 us, store drain + arrive 1.5 us -- with one task in flight per CU); the per-step launches took 20 + 40 ms.
 constexpr int PNT = 512, PNW = 8, UW = 10;       // 8 waves, one workgroup per CU; UW units x 3 gates = 30 of a product tile's 32 columns
 constexpr int P_NIT = (32 * 2 * UW + PNT - 1) / PNT;      // epilogue items per thread (32 rows x 2 parties x UW units)
 constexpr int P_SC1 = 16;
 constexpr int P_TS = 36, P_T1 = 32 * P_TS;                  // a product tile in LDS: [column][row], row stride padded to 36 (16-byte vector accesses)
-constexpr int P_RED1 = PNW * P_T1, P_TILES = 3 * P_T1;      // LDS: 3 x P_RED1 (the waves' partial tiles of up to 3 products) | P_TILES | per-kernel rest
+constexpr int P_RED1 = PNW * P_T1, P_TILES = 3 * P_T1;
+// dynamic LDS (float offsets): 3 x P_RED1 (the waves' partial tiles of up to 3 products) | P_TILES | per-kernel rest (attention)
+constexpr int P_OFF_TILES = 3 * P_RED1, P_OFF_ATT = 3 * P_RED1 + P_TILES;
 constexpr unsigned P_SPIN_LIMIT = 1u << 21;
 typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) unsigned int pgu32;
@@ -652,33 +663,16 @@ __device__ __forceinline__ void pzero8(float* a) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) a[j] = 0.f;
 }
-// the waves' partial tiles meet in LDS, summed in a fixed order; tiles[i] = row-major [32][32].  All threads synced on return.
-template <int NA>
-__device__ __forceinline__ void pmm_reduce(const f32x16* acc, float* red, float* tiles) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, half = lane >> 5;
-#pragma unroll
-  for (int i = 0; i < NA; ++i) {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) red[wave * 1024 + ((q & 3) + 8 * (q >> 2) + 4 * half) * 32 + r] = acc[i][q];
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 1024 / PNT; ++e) {
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < PNW; ++w) s += red[w * 1024 + tid + e * PNT];
-      tiles[i * 1024 + tid + e * PNT] = s;
-    }
-    __syncthreads();
-  }
-}
-
 #ifdef MSER_STAMPS
 __shared__ unsigned long long pst_acc[16];
 __shared__ unsigned long long pst_last;
 #define PST_INIT() do { if (threadIdx.x == 0) { for (int _i = 0; _i < 16; ++_i) pst_acc[_i] = 0; pst_last = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #define PST(k) do { if (threadIdx.x == 0) { const unsigned long long _n = __builtin_amdgcn_s_memrealtime(); pst_acc[k] += _n - pst_last; pst_last = _n; } } while (0)
+#ifdef MSER_STAMPS_FINE
 #define PSTC(k) PST(k)
+#else
+#define PSTC(k)
+#endif
 #define PST_DUMP(name, T) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 200 || blockIdx.x == 255 || blockIdx.x == 256)) \
   printf("[drnn stamps %s wg %3d hwid %08x | 10 ns ticks per step]  %llu %llu %llu %llu %llu %llu %llu %llu | %llu %llu %llu %llu %llu %llu %llu %llu\n", name, (int)blockIdx.x, (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)), pst_acc[0] / (T), pst_acc[1] / (T), \
          pst_acc[2] / (T), pst_acc[3] / (T), pst_acc[4] / (T), pst_acc[5] / (T), pst_acc[6] / (T), pst_acc[7] / (T), pst_acc[8] / (T), pst_acc[9] / (T), pst_acc[10] / (T), pst_acc[11] / (T), \
@@ -730,6 +724,16 @@ struct PK {
   float* out; const float* dout; long ldo; const int* rev;
   unsigned* sync; uint32_t* fault;
 };
+// The launch parameters live in device memory (drnn_store_pk_kernel writes the by-value argument there -- capturable, no host copy) and are
+// read through the constant address space: scalar loads wherever a field is needed, instead of ~100 preloaded SGPRs spilled all over the
+// kernel, and a plain pointer to hand to the non-inlined task functions.
+typedef const __attribute__((address_space(4))) PK CPK;
+__global__ void drnn_store_pk_kernel(const PK k, PK* dst) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = k; }
+__device__ __forceinline__ const CPK& pk_uni(const CPK* p) {        // (inside a non-inlined function the pointer arrives in vector registers)
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return *(const CPK*)(((unsigned long long)hi << 32) | lo);
+}
 
 // ---- packed operands -------------------------------------------------------------------------------------------------------------------
 // An MFMA fragment is 8 consecutive k of one row; lane r of a wave holds row r.  Read straight from a row-major matrix a wave's load
@@ -831,12 +835,12 @@ struct CellGeom {
   uint32_t site, idx0;
 };
 template <int CELL>
-__device__ __forceinline__ CellGeom cell_geom(const PK& P, const FB& F, const Task& k) {
+__device__ __forceinline__ CellGeom cell_geom(const CPK& P, const FB& F, const Task& k) {
   const int B = P.d.B, T = P.d.T, Dg = P.d.Dg, Dp = P.d.Dp, De = P.d.De;
   const long TB = (long)T * B;
   const int t = k.t, dir = k.dir;
-  const mser_drnn_params& W = P.p[dir];
-  const WS& w = P.w;
+  const auto& W = P.p[dir];
+  const auto& w = P.w;
   const long prg = pack_rows(B, Dg), prp = pack_rows(B, Dp), pre = pack_rows(B, De);
   const int par = t & 1;
   CellGeom g;
@@ -896,20 +900,19 @@ __device__ __forceinline__ void mma_chunk(const float (*a)[8], const float (*b)[
     for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][j], b[p][j], acc, 0, 0, 0);
 }
 template <int CELL>
-__device__ __forceinline__ void cell_pre(const PK& P, const FB& F, const Task& k, TRegs& R) {
+__device__ __forceinline__ void cell_pre(const CPK& P, const FB& F, const Task& k, TRegs& R) {
   const CellGeom g = cell_geom<CELL>(P, F, k);
-  constexpr int NPT = (CELL == 1 || CELL == 2) ? 2 : 1;
   const int Kpi = k8p(g.Kin) * 8, Kph = k8p(g.H) * 8;
   load_chunk<false>(F.wpk, g.Wi, Kpi, 0, R.bi);
   load_chunk<false>(F.wpk, g.Wh, Kph, 0, R.bh);
 }
 template <int CELL>
-__device__ __forceinline__ void cell_post(const PK& P, const FB& F, const Task& k, TRegs& R, float* red, float* tiles) {
+__device__ __forceinline__ void cell_post(const CPK& P, const FB& F, const Task& k, TRegs& R, float* red, float* tiles) {
   const CellGeom g = cell_geom<CELL>(P, F, k);
   constexpr int NPT = (CELL == 1 || CELL == 2) ? 2 : 1;
   const int B = P.d.B, T = P.d.T, H = g.H, t = k.t, dir = k.dir;
   const long TB = (long)T * B;
-  const WS& w = P.w;
+  const auto& w = P.w;
   const int r = threadIdx.x & 31;
   const int Kpi = k8p(g.Kin) * 8, Kph = k8p(H) * 8;
   ERegs E;
@@ -950,6 +953,7 @@ __device__ __forceinline__ void cell_post(const PK& P, const FB& F, const Task& 
     mma_chunk(ai, R.bi, acc[0]);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (NPT == 2) load_chunk<true>(F.apk, g.ah + g.ah_pt, Kph, 0, ah[1]);
+    __builtin_amdgcn_sched_barrier(0);          // (all of them requested before the first party's chain starts, not one per MFMA group)
 #pragma unroll
     for (int i = 0; i < NPT; ++i) mma_chunk(ah[i], R.bh, acc[1 + i]);
     __builtin_amdgcn_sched_barrier(0);
@@ -978,7 +982,9 @@ __device__ __forceinline__ void cell_post(const PK& P, const FB& F, const Task& 
       for (int g4 = 0; g4 < 4; ++g4)
         *reinterpret_cast<float4*>(red + i * P_RED1 + wave * P_T1 + r * P_TS + 8 * g4 + 4 * half) =
             make_float4(acc[i][4 * g4], acc[i][4 * g4 + 1], acc[i][4 * g4 + 2], acc[i][4 * g4 + 3]);
+    if (CELL == 1 || CELL == 2) PSTC(14);
     __syncthreads();
+    if (CELL == 1 || CELL == 2) PSTC(15);
     for (int e = tid; e < (1 + NPT) * 256; e += PNT) {      // (product, column, group of four rows)
       const int i = e >> 8, c = (e >> 3) & 31, rg = e & 7;
       const float* src = red + i * P_RED1 + c * P_TS + rg * 4;
@@ -1068,7 +1074,7 @@ __device__ __forceinline__ void att_row_load(const XB& G, long off, int Dg, bool
     }
   }
 }
-__device__ __forceinline__ void att_fwd_task(const PK& P, const FB& F, int t, int b, int dir, float* sc, float* wacc) {
+__device__ __forceinline__ void att_fwd_task(const CPK& P, const FB& F, int t, int b, int dir, float* sc, float* wacc) {
   const int B = P.d.B, T = P.d.T, Dg = P.d.Dg;
   const long TB = (long)T * B;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1151,37 +1157,52 @@ __device__ __forceinline__ void att_fwd_task(const PK& P, const FB& F, int t, in
   __syncthreads();
 }
 
-__device__ __forceinline__ void task_pre(const PK& P, const FB& F, const Task& k, TRegs& R) {
+__device__ __forceinline__ FB fb_uni(const FB& x) {
+  FB f;
+  f.Gh = xb_uni(x.Gh); f.Q = xb_uni(x.Q); f.Eh = xb_uni(x.Eh); f.qs = xb_uni(x.qs); f.apk = xb_uni(x.apk); f.wpk = xb_uni(x.wpk);
+  return f;
+}
+// a whole task as ONE non-inlined function per kind (its own register allocation; the kernel body stays small): weights and state
+// fragments are requested together
+// (a non-inlined function sees pointer arguments as generic addresses -- LDS through flat instructions: the tasks take nothing but the
+// kernel's fixed LDS layout and address it through the dynamic-LDS symbol themselves)
+template <int CELL>
+__device__ __noinline__ void cell_task(const CPK* Pp, const FB& Fv, const Task k) {
+  const CPK& P = pk_uni(Pp);
+  extern __shared__ float psm[];
+  float* red = psm;
+  float* tiles = psm + P_OFF_TILES;
+  const FB F = fb_uni(Fv);
+  TRegs R;
+  cell_pre<CELL>(P, F, k, R);
+  cell_post<CELL>(P, F, k, R, red, tiles);
+}
+__device__ __noinline__ void att_task(const CPK* Pp, const FB& Fv, const Task k) {
+  const CPK& P = pk_uni(Pp);
+  extern __shared__ float psm[];
+  float* red = psm;
+  float* attx = psm + P_OFF_ATT;
+  const FB F = fb_uni(Fv);
+  att_fwd_task(P, F, k.t, k.b, k.dir, attx, red);
+}
+__device__ __forceinline__ void task_run(const CPK& P, const FB& F, const Task& k) {
   switch (k.kind) {
-    case 0: cell_pre<0>(P, F, k, R); break;
-    case 1: cell_pre<1>(P, F, k, R); break;
-    case 2: cell_pre<2>(P, F, k, R); break;
-    case 3: cell_pre<3>(P, F, k, R); break;
+    case 0: cell_task<0>(&P, F, k); break;
+    case 1: cell_task<1>(&P, F, k); break;
+    case 2: cell_task<2>(&P, F, k); break;
+    case 3: cell_task<3>(&P, F, k); break;
+    case 4: att_task(&P, F, k); break;
     default: break;
   }
 }
-__device__ __forceinline__ void task_post(const PK& P, const FB& F, const Task& k, TRegs& R, float* red, float* tiles, float* attx) {
-  switch (k.kind) {
-    case 0: cell_post<0>(P, F, k, R, red, tiles); break;
-    case 1: cell_post<1>(P, F, k, R, red, tiles); break;
-    case 2: cell_post<2>(P, F, k, R, red, tiles); break;
-    case 3: cell_post<3>(P, F, k, R, red, tiles); break;
-    case 4: att_fwd_task(P, F, k.t, k.b, k.dir, attx, red); break;
-    default: break;
-  }
-}
-
 // Per step and direction two phases, two grid barriers (the recurrence l(t-1) -> p(t) -> l(t) needs both exchanges; the rest rides along):
 //   phase B(t): p cell of step t | g cell of step t                                       (read what phase C(t-1) left)
 //   phase C(t): l cell of step t (+ blend) | history attention of step t+1 | e cell of step t-1
 // The two directions are independent chains with a barrier counter each; every workgroup alternates between them
 // (B0 B1 C0 C1 B0 ...): while direction 0's barrier completes it works for direction 1.  A phase of one direction is at most one task
 // per workgroup at the reference's widths (208 / 232 tasks on 256 CUs).
-__global__ __launch_bounds__(PNT) void drnn_fwd_persist(const PK P) {
-  extern __shared__ float psm[];
-  float* red = psm;
-  float* tiles = psm + 3 * P_RED1;
-  float* attx = tiles + P_TILES;
+__global__ __launch_bounds__(PNT) void drnn_fwd_persist(const PK* __restrict__ pkp) {
+  const CPK& P = *(const CPK*)pkp;
   __shared__ int bar_ok;
   const int B = P.d.B, T = P.d.T, Dg = P.d.Dg, Dp = P.d.Dp, De = P.d.De;
   FB F;
@@ -1210,7 +1231,6 @@ __global__ __launch_bounds__(PNT) void drnn_fwd_persist(const PK P) {
     }
     return k;
   };
-  TRegs R;
   PST_INIT();
   bool first[2] = {true, true};
   for (int t = 0; t <= T; ++t) {
@@ -1220,18 +1240,11 @@ __global__ __launch_bounds__(PNT) void drnn_fwd_persist(const PK P) {
       if (n == 0) continue;
 #pragma unroll 1
       for (int dir = 0; dir < 2; ++dir) {
-        int v = blockIdx.x;
-        Task k = task_of(ph, t, dir, v);
-        if (v < n) task_pre(P, F, k, R);
         PST(4 * ph + 2 * dir);
         if (!first[dir]) { if (!bar_wait(gb[dir], &bar_ok)) return; }
         first[dir] = false;
         PST(4 * ph + 2 * dir + 1);
-        for (; v < n;) {
-          task_post(P, F, k, R, red, tiles, attx);
-          v += G;
-          if (v < n) { k = task_of(ph, t, dir, v); task_pre(P, F, k, R); }
-        }
+        for (int v = blockIdx.x; v < n; v += G) task_run(P, F, task_of(ph, t, dir, v));
         PSTC(12);
         bar_arrive(gb[dir]);
         PSTC(13);
@@ -1272,7 +1285,8 @@ __device__ __forceinline__ void pk_store3(const XB& bk, long pack, int row, int 
 __device__ __forceinline__ void row_store3(float* o, int H, float a, float b, float c) { o[0] = a; o[H] = b; o[2 * H] = c; }
 
 // e cell backward of step t: elements (b, u) of chunk `ch`
-__device__ __noinline__ void e_bwd_task(const PK& P, const BB& Xv, int t, int dir, int ch) {
+__device__ __noinline__ void e_bwd_task(const CPK* Pp, const BB& Xv, int t, int dir, int ch) {
+  const CPK& P = pk_uni(Pp);
   const BB X = bb_uni(Xv);
   const int B = P.d.B, T = P.d.T, H = P.d.De;
   const long TB = (long)T * B, base = (long)dir * P.w.bk_dir;
@@ -1293,7 +1307,8 @@ __device__ __noinline__ void e_bwd_task(const PK& P, const BB& Xv, int t, int di
   xb_st(X.bk, base + P.w.b_dEdir + it, g.dhp);
 }
 // g cell backward of step t
-__device__ __noinline__ void g_bwd_task(const PK& P, const BB& Xv, int t, int dir, int ch) {
+__device__ __noinline__ void g_bwd_task(const CPK* Pp, const BB& Xv, int t, int dir, int ch) {
+  const CPK& P = pk_uni(Pp);
   const BB X = bb_uni(Xv);
   const int B = P.d.B, T = P.d.T, H = P.d.Dg;
   const long TB = (long)T * B, base = (long)dir * P.w.bk_dir;
@@ -1313,11 +1328,12 @@ __device__ __noinline__ void g_bwd_task(const PK& P, const BB& Xv, int t, int di
 }
 // l cell backward + blend (LCELL) or p cell backward of step t, both parties of element (b, u)
 template <bool LCELL>
-__device__ __noinline__ void lp_bwd_task(const PK& P, const BB& Xv, int t, int dir, int ch) {
+__device__ __noinline__ void lp_bwd_task(const CPK* Pp, const BB& Xv, int t, int dir, int ch) {
+  const CPK& P = pk_uni(Pp);
   const BB X = bb_uni(Xv);
   const int B = P.d.B, T = P.d.T, H = P.d.Dp;
   const long TB = (long)T * B, base = (long)dir * P.w.bk_dir;
-  const WS& w = P.w;
+  const auto& w = P.w;
   const int it = ch * PNT + threadIdx.x;
   if (it >= B * H) return;
   const int b = it / H, u = it - b * H;
@@ -1381,7 +1397,12 @@ __device__ __noinline__ void lp_bwd_task(const PK& P, const BB& Xv, int t, int d
 //   att_bwd_b (phase D, beside the products): dGh[s+1] += alpha_s dc + ds_s x for s < t -- independent read-modify-writes, NB rows'
 //     loads in flight per thread.  (dGh[t] is complete after this: the g cell backward of step t-1 reads it in phase E.)
 // LDS state per direction: x[Dg] | dc[Dg] | ds[T] | alpha[T]
-__device__ __noinline__ void att_bwd_a(const PK& P, const BB& Xv, int t, int b, int dir, float* st, float* wacc, float* redw) {
+__device__ __noinline__ void att_bwd_a(const CPK* Pp, const BB& Xv, int t, int b, int dir, int st_off) {
+  const CPK& P = pk_uni(Pp);
+  extern __shared__ float psm[];
+  float* st = psm + P_OFF_ATT + st_off;
+  float* wacc = psm;
+  float* redw = psm + P_OFF_TILES;
   const BB X = bb_uni(Xv);
   const int B = P.d.B, T = P.d.T, Dg = P.d.Dg;
   const long TB = (long)T * B, base = (long)dir * P.w.bk_dir;
@@ -1461,7 +1482,10 @@ __device__ __noinline__ void att_bwd_a(const PK& P, const BB& Xv, int t, int b, 
   for (int s = tid; s < t; s += PNT) ds[s] = al[s] * (ds[s] - dot);
   __syncthreads();
 }
-__device__ __noinline__ void att_bwd_b(const PK& P, const BB& Xv, int t, int b, int dir, const float* st) {
+__device__ __noinline__ void att_bwd_b(const CPK* Pp, const BB& Xv, int t, int b, int dir, int st_off) {
+  const CPK& P = pk_uni(Pp);
+  extern __shared__ float psm[];
+  const float* st = psm + P_OFF_ATT + st_off;
   const BB X = bb_uni(Xv);
   const int B = P.d.B, T = P.d.T, Dg = P.d.Dg;
   const float* x = st; const float* dcv = st + Dg; const float* ds = st + 2 * Dg; const float* al = ds + T;
@@ -1517,8 +1541,8 @@ __device__ __noinline__ void att_bwd_b(const PK& P, const BB& Xv, int t, int b, 
 // product i of direction dir, tile (rb, ct): out[rows, N] tile = dgates[rows, K3] W^T-pack
 struct BProd { long a_off, w_off, o_off; int K3, N, rows; };
 template <int I>
-__device__ __forceinline__ BProd bprod(const PK& P, int dir) {
-  const WS& w = P.w;
+__device__ __forceinline__ BProd bprod(const CPK& P, int dir) {
+  const auto& w = P.w;
   const int B = P.d.B, Dg = P.d.Dg, Dp = P.d.Dp, De = P.d.De;
   const long a = I == 0 ? w.b_gie : I == 1 ? w.b_ghe : I == 2 ? w.b_gil : I == 3 ? w.b_ghl : I == 4 ? w.b_gip : I == 5 ? w.b_ghp : I == 6 ? w.b_gig : w.b_ghg;
   const long o = I == 0 ? w.b_Pqsel : I == 1 ? w.b_PEh : I == 2 ? w.b_Pss : I == 3 ? w.b_PQl : I == 4 ? w.b_Pc : I == 5 ? w.b_PQp : I == 6 ? w.b_Pq0 : w.b_PGh;
@@ -1529,7 +1553,9 @@ __device__ __forceinline__ BProd bprod(const PK& P, int dir) {
   d.rows = (I == 3 || I == 5) ? 2 * B : B;
   return d;
 }
-__device__ __noinline__ void bwd_prod_task(const BB& Xv, const BProd d, int rb, int ct, float* red, float* tiles) {
+__device__ __noinline__ void bwd_prod_task(const BB& Xv, const BProd d, int rb, int ct) {
+  extern __shared__ float psm[];
+  float* red = psm;
   const BB X = bb_uni(Xv);
   const int k8n = k8p(d.K3), Kp = k8n * 8;
   const long ab = d.a_off + (long)rb * k8n * 256, wb = d.w_off + (long)ct * k8n * 256;
@@ -1568,11 +1594,8 @@ __device__ __noinline__ void bwd_prod_task(const BB& Xv, const BProd d, int rb, 
   PSTC(14);
 }
 
-__global__ __launch_bounds__(PNT) void drnn_bwd_persist(const PK P) {
-  extern __shared__ float psm[];
-  float* red = psm;
-  float* tiles = psm + 3 * P_RED1;
-  float* attx = tiles + P_TILES;
+__global__ __launch_bounds__(PNT) void drnn_bwd_persist(const PK* __restrict__ pkp) {
+  const CPK& P = *(const CPK*)pkp;
   __shared__ int bar_ok;
   const int B = P.d.B, T = P.d.T, Dg = P.d.Dg, Dp = P.d.Dp, De = P.d.De;
   BB X;
@@ -1602,30 +1625,30 @@ __global__ __launch_bounds__(PNT) void drnn_bwd_persist(const PK P) {
     if (ph == 0) {
       const int na = t + 1 < T ? B : 0, nl = t < T ? nel : 0;
       PSTC(15);
-      if (v < na) { att_bwd_a(P, X, t + 1, v, dir, attx + dir * att_st, red, tiles); PSTC(8); }
-      else if (v < na + nl) { lp_bwd_task<true>(P, X, t, dir, v - na); PSTC(11); }
-      else { e_bwd_task(P, X, t - 1, dir, v - na - nl); PSTC(11); }
+      if (v < na) { att_bwd_a(&P, X, t + 1, v, dir, dir * att_st); PSTC(8); }
+      else if (v < na + nl) { lp_bwd_task<true>(&P, X, t, dir, v - na); PSTC(11); }
+      else { e_bwd_task(&P, X, t - 1, dir, v - na - nl); PSTC(11); }
     } else if (ph == 1) {
       const int na = t + 1 < T ? B : 0;
       const int n2 = t < T ? nt_l_ih : 0, n3 = (t < T && t > 0) ? nt_l_hh : 0, n0 = t >= 1 ? nt_e_ih : 0;
       PSTC(15);
-      if (v < na) { att_bwd_b(P, X, t + 1, v, dir, attx + dir * att_st); PSTC(9); return; }      // (the same workgroup as the row's first half)
+      if (v < na) { att_bwd_b(&P, X, t + 1, v, dir, dir * att_st); PSTC(9); return; }      // (the same workgroup as the row's first half)
       v -= na;
       int rb, ct;
-      if (v < n3) { if (tile_decode(v, nrb2, ctp, rb, ct)) bwd_prod_task(X, bprod<3>(P, dir), rb, ct, red, tiles); }
-      else if (v < n3 + n2) { if (tile_decode(v - n3, nrb1, ctp, rb, ct)) bwd_prod_task(X, bprod<2>(P, dir), rb, ct, red, tiles); }
-      else if (v < n3 + n2 + n0) { if (tile_decode(v - n3 - n2, nrb1, ctp, rb, ct)) bwd_prod_task(X, bprod<0>(P, dir), rb, ct, red, tiles); }
-      else if (tile_decode(v - n3 - n2 - n0, nrb1, cte, rb, ct)) bwd_prod_task(X, bprod<1>(P, dir), rb, ct, red, tiles);
+      if (v < n3) { if (tile_decode(v, nrb2, ctp, rb, ct)) bwd_prod_task(X, bprod<3>(P, dir), rb, ct); }
+      else if (v < n3 + n2) { if (tile_decode(v - n3, nrb1, ctp, rb, ct)) bwd_prod_task(X, bprod<2>(P, dir), rb, ct); }
+      else if (v < n3 + n2 + n0) { if (tile_decode(v - n3 - n2, nrb1, ctp, rb, ct)) bwd_prod_task(X, bprod<0>(P, dir), rb, ct); }
+      else if (tile_decode(v - n3 - n2 - n0, nrb1, cte, rb, ct)) bwd_prod_task(X, bprod<1>(P, dir), rb, ct);
     } else if (ph == 2) {
-      if (v < nel) lp_bwd_task<false>(P, X, t, dir, v);
-      else g_bwd_task(P, X, t, dir, v - nel);
+      if (v < nel) lp_bwd_task<false>(&P, X, t, dir, v);
+      else g_bwd_task(&P, X, t, dir, v - nel);
     } else {
       const int n5 = nt_p_hh, n4 = nt_p_ih, n6 = nt_g_ih;
       int rb, ct;
-      if (v < n5) { if (tile_decode(v, nrb2, ctp, rb, ct)) bwd_prod_task(X, bprod<5>(P, dir), rb, ct, red, tiles); }
-      else if (v < n5 + n4) { if (tile_decode(v - n5, nrb1, ctg, rb, ct)) bwd_prod_task(X, bprod<4>(P, dir), rb, ct, red, tiles); }
-      else if (v < n5 + n4 + n6) { if (tile_decode(v - n5 - n4, nrb1, ctp, rb, ct)) bwd_prod_task(X, bprod<6>(P, dir), rb, ct, red, tiles); }
-      else if (tile_decode(v - n5 - n4 - n6, nrb1, ctg, rb, ct)) bwd_prod_task(X, bprod<7>(P, dir), rb, ct, red, tiles);
+      if (v < n5) { if (tile_decode(v, nrb2, ctp, rb, ct)) bwd_prod_task(X, bprod<5>(P, dir), rb, ct); }
+      else if (v < n5 + n4) { if (tile_decode(v - n5, nrb1, ctg, rb, ct)) bwd_prod_task(X, bprod<4>(P, dir), rb, ct); }
+      else if (v < n5 + n4 + n6) { if (tile_decode(v - n5 - n4, nrb1, ctp, rb, ct)) bwd_prod_task(X, bprod<6>(P, dir), rb, ct); }
+      else if (tile_decode(v - n5 - n4 - n6, nrb1, ctg, rb, ct)) bwd_prod_task(X, bprod<7>(P, dir), rb, ct);
     }
   };
   PST_INIT();
@@ -1840,7 +1863,8 @@ int mser_drnn_fwd(const mser_drnn_desc* dp, mser_stream_t stream) {
       }
     }
     MSER_CHECK_HIP(hipFuncSetAttribute((const void*)drnn_fwd_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(drnn_fwd_persist, dim3(persist_grid()), dim3(PNT), lds, s, K);
+    hipLaunchKernelGGL(drnn_store_pk_kernel, dim3(1), dim3(64), 0, s, K, (PK*)w.pk_dev);
+    hipLaunchKernelGGL(drnn_fwd_persist, dim3(persist_grid()), dim3(PNT), lds, s, (const PK*)w.pk_dev);
     return check_launch("drnn_fwd_persist");
   }
   // the per-step hidden products (and gi_e) are accumulation targets cleared by their readers: zero them once (carved back to back)
@@ -1930,7 +1954,8 @@ int mser_drnn_bwd(const mser_drnn_desc* dp, mser_stream_t stream) {
     const PK K = make_pk(d, w);
     const size_t lds = persist_lds(dm, true);
     MSER_CHECK_HIP(hipFuncSetAttribute((const void*)drnn_bwd_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(drnn_bwd_persist, dim3(persist_grid()), dim3(PNT), lds, s, K);
+    hipLaunchKernelGGL(drnn_store_pk_kernel, dim3(1), dim3(64), 0, s, K, (PK*)w.pk_dev);
+    hipLaunchKernelGGL(drnn_bwd_persist, dim3(persist_grid()), dim3(PNT), lds, s, (const PK*)w.pk_dev);
     MSER_TRY(check_launch("drnn_bwd_persist"));
   } else {
   MSER_CHECK_HIP(hipMemsetAsync(w.dQ, 0, (size_t)2 * 2 * B * 2 * Dp * sizeof(float), s));
