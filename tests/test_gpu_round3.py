@@ -406,3 +406,63 @@ def test_wide_persistent_launches_vs_per_step_launches(O, H, B, L):
     assert maxabs(res[0][0], res[1][0]) < 2e-6
     d = maxabs(res[0][1], res[1][1])
     assert d < 1e-5 * max(1.0, float(res[1][1].abs().max())), d
+
+
+# ---- DialogueRNN: the persistent launches (MSER_OPT_DRNN_PERSISTENT) against the per-step launches and the oracle ----------------------
+def _bimodel_run(net, U, qmask, umask, label):
+    from loss import MaskedLoss
+    for p in net.parameters():
+        p.grad = None
+    lp, alpha, alpha_f, alpha_b = net(U.cuda(), qmask.cuda(), umask.cuda(), att2=True)
+    loss = MaskedLoss(torch.nn.NLLLoss)(lp.transpose(0, 1).contiguous().view(-1, lp.size(2)), label.cuda().view(-1), umask.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    return (lp.detach().clone(), [a.detach().clone() for a in alpha_f], [a.detach().clone() for a in alpha_b],
+            {n: p.grad.detach().clone() for n, p in net.named_parameters()})
+
+
+@pytest.mark.parametrize("dims,B,L,train", [
+    (dict(D_m=44, D_g=28, D_p=20, D_e=16, D_h=12), 5, 12, False),
+    (dict(D_m=37, D_g=22, D_p=18, D_e=10, D_h=9), 3, 9, True),        # widths that are no multiple of 4 / 8 / UW: every tail path
+    (dict(D_m=40, D_g=36, D_p=52, D_e=24, D_h=16), 40, 6, True),      # two row blocks of 32 dialogues (B = 40), three unit slabs
+])
+def test_drnn_persistent_matches_per_step(O, dims, B, L, train):
+    """One launch per pass (option 12 = 1: packed operands, in-launch grid barriers, no atomics) and the per-step launches (option 12 = 0:
+    GEMMs with split-K atomics) are the same arithmetic up to summation order: log-probs, both directions' attention maps and every
+    parameter gradient agree to rounding; dropout masks are counter-based, so train mode compares mask for mask."""
+    from mser import ops
+    from tests.test_gpu_model import _bimodel
+    net = _bimodel(dims, 151, O, train)
+    U, qmask, umask, label = O.bimodel_seeded_batch(B, L, D_m=dims["D_m"], seed=152 + B, ragged=True)
+    res = {}
+    try:
+        for mode in (0, 1):
+            ops.set_option(ops.MSER_OPT_DRNN_PERSISTENT, mode)
+            net._rng = None                 # (train mode: the same dropout step -- the same masks -- for both runs)
+            res[mode] = _bimodel_run(net, U, qmask, umask, label)
+    finally:
+        ops.set_option(ops.MSER_OPT_DRNN_PERSISTENT, 1)
+    lp0, af0, ab0, g0 = res[0]
+    lp1, af1, ab1, g1 = res[1]
+    assert maxabs(lp1, lp0) < 2e-5
+    for a0, a1 in zip(af0 + ab0, af1 + ab1):
+        assert maxabs(a1, a0) < 2e-6
+    for n in g0:
+        assert maxabs(g1[n], g0[n]) < 2e-5 * max(1.0, float(g0[n].abs().max())), n
+
+
+def test_drnn_persistent_falls_back_beyond_its_widths(O):
+    """Widths above 512 do not fit a wave's register share of K: mser_drnn_fwd / bwd take the per-step path by themselves (same results
+    as with the option switched off)."""
+    from mser import ops
+    from tests.test_gpu_model import _bimodel
+    dims = dict(D_m=24, D_g=520, D_p=16, D_e=8, D_h=8)
+    net = _bimodel(dims, 161, O, False)
+    U, qmask, umask, label = O.bimodel_seeded_batch(2, 4, D_m=dims["D_m"], seed=162, ragged=True)
+    a = _bimodel_run(net, U, qmask, umask, label)
+    try:
+        ops.set_option(ops.MSER_OPT_DRNN_PERSISTENT, 0)
+        b = _bimodel_run(net, U, qmask, umask, label)
+    finally:
+        ops.set_option(ops.MSER_OPT_DRNN_PERSISTENT, 1)
+    assert maxabs(a[0], b[0]) < 1e-6
