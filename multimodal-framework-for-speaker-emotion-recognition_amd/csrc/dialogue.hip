@@ -624,14 +624,25 @@ __global__ __launch_bounds__(64 * G2_WPB) void general2_bwd_kernel(const float* 
 // Measured (configs[3], B = 64, T = 200, rocprofv3): forward 18.3 ms, backward 17.7 ms per launch (88-91 us per step, of which the MFMA
 // chains are 12 us per CU: a task is a latency chain -- L2-bypassing operand loads 3 us, MFMA 5 us, cross-wave reduction 2-3 us, gate
 // math 1.5 us, store drain + arrive 1.5 us -- with one task in flight per CU); the per-step launches took 20 + 40 ms.
-constexpr int PNT = 512, PNW = 8, UW = 10;       // 8 waves, one workgroup per CU; UW units x 3 gates = 30 of a product tile's 32 columns
+#ifndef MSER_DRNN_WAVES
+#define MSER_DRNN_WAVES 8
+#endif
+// 8 waves: one workgroup per CU.  (4 waves = TWO workgroups per CU, one per direction chain, so that one chain's MFMA work could fill the
+// other's load / reduction / barrier time: measured SLOWER, forward 26 ms and backward 31 ms against 18 ms each -- a wave's K share
+// and with it every task's latency chain doubles, and the step is a chain of task latencies, not a throughput problem.)
+// UW units x 3 gates = 30 of a product tile's 32 columns
+constexpr int PNW = MSER_DRNN_WAVES, PNT = 64 * PNW, UW = 10, P_WGS_PER_CU = 8 / PNW;
 constexpr int P_NIT = (32 * 2 * UW + PNT - 1) / PNT;      // epilogue items per thread (32 rows x 2 parties x UW units)
 constexpr int P_SC1 = 16;
 constexpr int P_TS = 36, P_T1 = 32 * P_TS;                  // a product tile in LDS: [column][row], row stride padded to 36 (16-byte vector accesses)
 constexpr int P_RED1 = PNW * P_T1, P_TILES = 3 * P_T1;
 // dynamic LDS (float offsets): 3 x P_RED1 (the waves' partial tiles of up to 3 products) | P_TILES | per-kernel rest (attention)
 constexpr int P_OFF_TILES = 3 * P_RED1, P_OFF_ATT = 3 * P_RED1 + P_TILES;
+constexpr int B_RED = (P_RED1 > PNW * 512 ? P_RED1 : PNW * 512), B_OFF_REDW = B_RED, B_OFF_ATT = B_RED + 64;     // the backward's: red (>= the attention's [PNW][512] sums) | 64 | attention state
 constexpr unsigned P_SPIN_LIMIT = 1u << 21;
+// true: each half of the grid runs ONE direction's chain (the two chains advance concurrently, a phase's tasks take up to two rounds on
+// 128 workgroups); false: every workgroup alternates between the directions (a phase is one round, the chains' phases are serialised)
+constexpr bool P_SPLIT_DIRS = false;           // (measured equal at configs[3]: 47.0 ms per step either way)
 typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) unsigned int pgu32;
 
@@ -1162,21 +1173,8 @@ __device__ __forceinline__ FB fb_uni(const FB& x) {
   f.Gh = xb_uni(x.Gh); f.Q = xb_uni(x.Q); f.Eh = xb_uni(x.Eh); f.qs = xb_uni(x.qs); f.apk = xb_uni(x.apk); f.wpk = xb_uni(x.wpk);
   return f;
 }
-// a whole task as ONE non-inlined function per kind (its own register allocation; the kernel body stays small): weights and state
-// fragments are requested together
-// (a non-inlined function sees pointer arguments as generic addresses -- LDS through flat instructions: the tasks take nothing but the
+// (a non-inlined function sees pointer arguments as generic addresses -- LDS through flat instructions: such tasks take nothing but the
 // kernel's fixed LDS layout and address it through the dynamic-LDS symbol themselves)
-template <int CELL>
-__device__ __noinline__ void cell_task(const CPK* Pp, const FB& Fv, const Task k) {
-  const CPK& P = pk_uni(Pp);
-  extern __shared__ float psm[];
-  float* red = psm;
-  float* tiles = psm + P_OFF_TILES;
-  const FB F = fb_uni(Fv);
-  TRegs R;
-  cell_pre<CELL>(P, F, k, R);
-  cell_post<CELL>(P, F, k, R, red, tiles);
-}
 __device__ __noinline__ void att_task(const CPK* Pp, const FB& Fv, const Task k) {
   const CPK& P = pk_uni(Pp);
   extern __shared__ float psm[];
@@ -1185,23 +1183,35 @@ __device__ __noinline__ void att_task(const CPK* Pp, const FB& Fv, const Task k)
   const FB F = fb_uni(Fv);
   att_fwd_task(P, F, k.t, k.b, k.dir, attx, red);
 }
-__device__ __forceinline__ void task_run(const CPK& P, const FB& F, const Task& k) {
+// the two halves of a task around its phase's barrier wait: `pre` requests the weight fragments (they do not depend on the phase before)
+__device__ __forceinline__ void task_pre(const CPK& P, const FB& F, const Task& k, TRegs& R) {
   switch (k.kind) {
-    case 0: cell_task<0>(&P, F, k); break;
-    case 1: cell_task<1>(&P, F, k); break;
-    case 2: cell_task<2>(&P, F, k); break;
-    case 3: cell_task<3>(&P, F, k); break;
+    case 0: cell_pre<0>(P, F, k, R); break;
+    case 1: cell_pre<1>(P, F, k, R); break;
+    case 2: cell_pre<2>(P, F, k, R); break;
+    case 3: cell_pre<3>(P, F, k, R); break;
+    default: break;
+  }
+}
+__device__ __forceinline__ void task_post(const CPK& P, const FB& F, const Task& k, TRegs& R) {
+  extern __shared__ float psm[];
+  switch (k.kind) {
+    case 0: cell_post<0>(P, F, k, R, psm, psm + P_OFF_TILES); break;
+    case 1: cell_post<1>(P, F, k, R, psm, psm + P_OFF_TILES); break;
+    case 2: cell_post<2>(P, F, k, R, psm, psm + P_OFF_TILES); break;
+    case 3: cell_post<3>(P, F, k, R, psm, psm + P_OFF_TILES); break;
     case 4: att_task(&P, F, k); break;
     default: break;
   }
 }
+
 // Per step and direction two phases, two grid barriers (the recurrence l(t-1) -> p(t) -> l(t) needs both exchanges; the rest rides along):
 //   phase B(t): p cell of step t | g cell of step t                                       (read what phase C(t-1) left)
 //   phase C(t): l cell of step t (+ blend) | history attention of step t+1 | e cell of step t-1
 // The two directions are independent chains with a barrier counter each; every workgroup alternates between them
 // (B0 B1 C0 C1 B0 ...): while direction 0's barrier completes it works for direction 1.  A phase of one direction is at most one task
 // per workgroup at the reference's widths (208 / 232 tasks on 256 CUs).
-__global__ __launch_bounds__(PNT) void drnn_fwd_persist(const PK* __restrict__ pkp) {
+__global__ __launch_bounds__(PNT, 2) void drnn_fwd_persist(const PK* __restrict__ pkp) {
   const CPK& P = *(const CPK*)pkp;
   __shared__ int bar_ok;
   const int B = P.d.B, T = P.d.T, Dg = P.d.Dg, Dp = P.d.Dp, De = P.d.De;
@@ -1211,11 +1221,13 @@ __global__ __launch_bounds__(PNT) void drnn_fwd_persist(const PK* __restrict__ p
   F.qs = xb_make(P.w.dqs, (size_t)2 * B * 2 * Dp);
   F.apk = xb_make(P.w.apk, P.w.apk_floats);
   F.wpk = xb_make(P.w.wpk, (size_t)2 * P.w.wpk_dir);
-  GridBar gb[2] = {{P.sync, P.sync + 64, P.fault, 0u, gridDim.x}, {P.sync + 32, P.sync + 64, P.fault, 0u, gridDim.x}};
+  const int G = P_SPLIT_DIRS ? (int)(gridDim.x >> 1) : (int)gridDim.x;       // workgroups per direction chain
+  const int wg = P_SPLIT_DIRS ? (int)(blockIdx.x % (unsigned)G) : (int)blockIdx.x;
+  const int dir_lo = P_SPLIT_DIRS ? (int)(blockIdx.x / (unsigned)G) : 0, dir_hi = P_SPLIT_DIRS ? dir_lo + 1 : 2;
+  GridBar gb[2] = {{P.sync, P.sync + 64, P.fault, 0u, (unsigned)G}, {P.sync + 32, P.sync + 64, P.fault, 0u, (unsigned)G}};
   const int NRB = (B + 31) / 32;
   const int ntg = tile_count(B, Dg, UW), ntp = tile_count(B, Dp, UW), nte = tile_count(B, De, UW);
   const int nsg = (Dg + UW - 1) / UW, nsp = (Dp + UW - 1) / UW, nse = (De + UW - 1) / UW;
-  const int G = gridDim.x;
   // task v of phase ph (0 = B, 1 = C) of step t, direction dir
   auto n_tasks = [&](int ph, int t) { return ph == 0 ? (t < T ? ntp + ntg : 0) : (t < T ? ntp : 0) + (t + 1 < T ? B : 0) + (t > 0 ? nte : 0); };
   auto task_of = [&](int ph, int t, int dir, int v) {
@@ -1231,6 +1243,7 @@ __global__ __launch_bounds__(PNT) void drnn_fwd_persist(const PK* __restrict__ p
     }
     return k;
   };
+  TRegs R;
   PST_INIT();
   bool first[2] = {true, true};
   for (int t = 0; t <= T; ++t) {
@@ -1239,12 +1252,19 @@ __global__ __launch_bounds__(PNT) void drnn_fwd_persist(const PK* __restrict__ p
       const int n = n_tasks(ph, t);
       if (n == 0) continue;
 #pragma unroll 1
-      for (int dir = 0; dir < 2; ++dir) {
+      for (int dir = dir_lo; dir < dir_hi; ++dir) {
+        int v = wg;
+        Task k = task_of(ph, t, dir, v);
+        if (v < n) task_pre(P, F, k, R);
         PST(4 * ph + 2 * dir);
         if (!first[dir]) { if (!bar_wait(gb[dir], &bar_ok)) return; }
         first[dir] = false;
         PST(4 * ph + 2 * dir + 1);
-        for (int v = blockIdx.x; v < n; v += G) task_run(P, F, task_of(ph, t, dir, v));
+        for (; v < n;) {
+          task_post(P, F, k, R);
+          v += G;
+          if (v < n) { k = task_of(ph, t, dir, v); task_pre(P, F, k, R); }
+        }
         PSTC(12);
         bar_arrive(gb[dir]);
         PSTC(13);
@@ -1400,9 +1420,9 @@ __device__ __noinline__ void lp_bwd_task(const CPK* Pp, const BB& Xv, int t, int
 __device__ __noinline__ void att_bwd_a(const CPK* Pp, const BB& Xv, int t, int b, int dir, int st_off) {
   const CPK& P = pk_uni(Pp);
   extern __shared__ float psm[];
-  float* st = psm + P_OFF_ATT + st_off;
+  float* st = psm + B_OFF_ATT + st_off;
   float* wacc = psm;
-  float* redw = psm + P_OFF_TILES;
+  float* redw = psm + B_OFF_REDW;
   const BB X = bb_uni(Xv);
   const int B = P.d.B, T = P.d.T, Dg = P.d.Dg;
   const long TB = (long)T * B, base = (long)dir * P.w.bk_dir;
@@ -1485,7 +1505,7 @@ __device__ __noinline__ void att_bwd_a(const CPK* Pp, const BB& Xv, int t, int b
 __device__ __noinline__ void att_bwd_b(const CPK* Pp, const BB& Xv, int t, int b, int dir, int st_off) {
   const CPK& P = pk_uni(Pp);
   extern __shared__ float psm[];
-  const float* st = psm + P_OFF_ATT + st_off;
+  const float* st = psm + B_OFF_ATT + st_off;
   const BB X = bb_uni(Xv);
   const int B = P.d.B, T = P.d.T, Dg = P.d.Dg;
   const float* x = st; const float* dcv = st + Dg; const float* ds = st + 2 * Dg; const float* al = ds + T;
@@ -1562,19 +1582,33 @@ __device__ __noinline__ void bwd_prod_task(const BB& Xv, const BProd d, int rb, 
   const int KC = ((Kp + PNW * 16 - 1) / (PNW * 16)) * 16;
   const int nch = (KC / 16 + 3) / 4;
   f32x16 acc = {0};
-  // the gate gradients (written this phase pair by other workgroups: L2-bypassing loads, the long latency) are requested for the wave's
-  // whole K share at once -- at most 3 chunks of 4 passes (K3 <= 1536), 96 registers; the weight fragments (cached) are double-buffered
-  float a[3][4][8], b0[4][8], b1[4][8];
-  PSTC(10);
+  if constexpr (PNW >= 8) {
+    // the gate gradients (written this phase pair by other workgroups: L2-bypassing loads, the long latency) are requested for the wave's
+    // whole K share at once -- at most 3 chunks of 4 passes (K3 <= 1536), 96 registers; the weight fragments (cached) are double-buffered
+    float a[3][4][8], b0[4][8], b1[4][8];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) load_chunk<true>(X.bk, ab, Kp, c, a[c]);          // (passes beyond the wave's share read zeros)
-  load_chunk<false>(X.wt, wb, Kp, 0, b0);
-  if (nch > 1) load_chunk<false>(X.wt, wb, Kp, 1, b1);
-  mma_chunk(a[0], b0, acc);
-  if (nch > 1) {
-    if (nch > 2) load_chunk<false>(X.wt, wb, Kp, 2, b0);
-    mma_chunk(a[1], b1, acc);
-    if (nch > 2) mma_chunk(a[2], b0, acc);
+    for (int c = 0; c < 3; ++c) load_chunk<true>(X.bk, ab, Kp, c, a[c]);          // (passes beyond the wave's share read zeros)
+    load_chunk<false>(X.wt, wb, Kp, 0, b0);
+    if (nch > 1) load_chunk<false>(X.wt, wb, Kp, 1, b1);
+    mma_chunk(a[0], b0, acc);
+    if (nch > 1) {
+      if (nch > 2) load_chunk<false>(X.wt, wb, Kp, 2, b0);
+      mma_chunk(a[1], b1, acc);
+      if (nch > 2) mma_chunk(a[2], b0, acc);
+    }
+  } else {
+    // (fewer waves: a wave's K share is up to 6 chunks -- both operands double-buffered, two chunks in flight)
+    float a0[4][8], b0[4][8], a1[4][8], b1[4][8];
+    load_chunk<true>(X.bk, ab, Kp, 0, a0);
+    load_chunk<false>(X.wt, wb, Kp, 0, b0);
+    for (int c = 0; c < nch; c += 2) {
+      if (c + 1 < nch) { load_chunk<true>(X.bk, ab, Kp, c + 1, a1); load_chunk<false>(X.wt, wb, Kp, c + 1, b1); }
+      mma_chunk(a0, b0, acc);
+      if (c + 1 < nch) {
+        if (c + 2 < nch) { load_chunk<true>(X.bk, ab, Kp, c + 2, a0); load_chunk<false>(X.wt, wb, Kp, c + 2, b0); }
+        mma_chunk(a1, b1, acc);
+      }
+    }
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
 #pragma unroll
@@ -1594,7 +1628,7 @@ __device__ __noinline__ void bwd_prod_task(const BB& Xv, const BProd d, int rb, 
   PSTC(14);
 }
 
-__global__ __launch_bounds__(PNT) void drnn_bwd_persist(const PK* __restrict__ pkp) {
+__global__ __launch_bounds__(PNT, 2) void drnn_bwd_persist(const PK* __restrict__ pkp) {
   const CPK& P = *(const CPK*)pkp;
   __shared__ int bar_ok;
   const int B = P.d.B, T = P.d.T, Dg = P.d.Dg, Dp = P.d.Dp, De = P.d.De;
@@ -1602,8 +1636,10 @@ __global__ __launch_bounds__(PNT) void drnn_bwd_persist(const PK* __restrict__ p
   X.bk = xb_make(P.w.bk, P.w.bk_floats);
   X.wt = xb_make(P.w.wpk, (size_t)2 * P.w.wtk_dir);
   X.dGh = xb_make(P.w.dGh, (size_t)2 * (T + 1) * B * Dg);
-  GridBar gb[2] = {{P.sync, P.sync + 64, P.fault, 0u, gridDim.x}, {P.sync + 32, P.sync + 64, P.fault, 0u, gridDim.x}};
-  const int G = gridDim.x;
+  const int G = P_SPLIT_DIRS ? (int)(gridDim.x >> 1) : (int)gridDim.x;       // workgroups per direction chain
+  const int wg = P_SPLIT_DIRS ? (int)(blockIdx.x % (unsigned)G) : (int)blockIdx.x;
+  const int dir_lo = P_SPLIT_DIRS ? (int)(blockIdx.x / (unsigned)G) : 0, dir_hi = P_SPLIT_DIRS ? dir_lo + 1 : 2;
+  GridBar gb[2] = {{P.sync, P.sync + 64, P.fault, 0u, (unsigned)G}, {P.sync + 32, P.sync + 64, P.fault, 0u, (unsigned)G}};
   const int nrb1 = (B + 31) / 32, nrb2 = (2 * B + 31) / 32;
   const int ctg = (Dg + 31) / 32, ctp = (Dp + 31) / 32, cte = (De + 31) / 32;
   const int nel = (B * Dp + PNT - 1) / PNT, neg = (B * Dg + PNT - 1) / PNT, nee = (B * De + PNT - 1) / PNT;
@@ -1659,10 +1695,10 @@ __global__ __launch_bounds__(PNT) void drnn_bwd_persist(const PK* __restrict__ p
       const int n = n_tasks(ph, t);
       if (n == 0) continue;
 #pragma unroll 1
-      for (int dir = 0; dir < 2; ++dir) {
-        // (direction 1's task list is dealt from the middle of the grid: a phase has fewer tasks than workgroups, so the two
-        // directions' tasks of a phase mostly land on different workgroups)
-        int v = (int)((blockIdx.x + (unsigned)dir * (G / 2)) % (unsigned)G);
+      for (int dir = dir_lo; dir < dir_hi; ++dir) {
+        // (interleaved form: direction 1's task list is dealt from the middle of the grid -- a phase has fewer tasks than workgroups, so
+        // the two directions' tasks of a phase mostly land on different workgroups)
+        int v = P_SPLIT_DIRS ? wg : (int)((blockIdx.x + (unsigned)dir * (G / 2)) % (unsigned)G);
         PST(2 * ph);
         if (!first[dir]) { if (!bar_wait(gb[dir], &bar_ok)) return; }
         first[dir] = false;
@@ -1775,14 +1811,14 @@ int persist_grid() {
   return g;
 }
 size_t persist_lds(const Dims& d, bool bwd) {
-  return (size_t)(3 * P_RED1 + P_TILES + (bwd ? 2 * (2 * d.Dg + 2 * d.T) : d.T + 32) + 16) * sizeof(float);
+  return (size_t)(bwd ? B_OFF_ATT + 2 * (2 * d.Dg + 2 * d.T) + 16 : P_OFF_ATT + d.T + 32 + 16) * sizeof(float);
 }
 // every hand-off array is addressed through a 32-bit byte offset (buffer descriptor); one workgroup per CU must fit
 bool persist_ok(const Dims& d, bool bwd) {
   if (!g_opt_drnn_persist || persist_grid() < 8 || d.Dg > 512 || d.Dp > 512 || d.De > 512) return false;
   if (bwd && d.B > persist_grid() / 2) return false;        // (an attention row's two halves meet in its workgroup's LDS: one row per workgroup and direction)      // (a wave's K share in registers; ATT_V)
   const size_t big = (size_t)2 * ((size_t)d.T + 1) * d.B * 2 * (size_t)(d.Dp > d.Dg ? d.Dp : d.Dg) * 3 * sizeof(float);   // >= the largest of them
-  return big < ((size_t)1 << 31) && persist_lds(d, bwd) <= 160 * 1024;
+  return big < ((size_t)1 << 31) && persist_lds(d, bwd) <= (size_t)160 * 1024 / P_WGS_PER_CU;
 }
 PK make_pk(const mser_drnn_desc& d, const WS& w) {
   PK K;
@@ -1864,7 +1900,7 @@ int mser_drnn_fwd(const mser_drnn_desc* dp, mser_stream_t stream) {
     }
     MSER_CHECK_HIP(hipFuncSetAttribute((const void*)drnn_fwd_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(drnn_store_pk_kernel, dim3(1), dim3(64), 0, s, K, (PK*)w.pk_dev);
-    hipLaunchKernelGGL(drnn_fwd_persist, dim3(persist_grid()), dim3(PNT), lds, s, (const PK*)w.pk_dev);
+    hipLaunchKernelGGL(drnn_fwd_persist, dim3(P_WGS_PER_CU * persist_grid()), dim3(PNT), lds, s, (const PK*)w.pk_dev);
     return check_launch("drnn_fwd_persist");
   }
   // the per-step hidden products (and gi_e) are accumulation targets cleared by their readers: zero them once (carved back to back)
@@ -1955,7 +1991,7 @@ int mser_drnn_bwd(const mser_drnn_desc* dp, mser_stream_t stream) {
     const size_t lds = persist_lds(dm, true);
     MSER_CHECK_HIP(hipFuncSetAttribute((const void*)drnn_bwd_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(drnn_store_pk_kernel, dim3(1), dim3(64), 0, s, K, (PK*)w.pk_dev);
-    hipLaunchKernelGGL(drnn_bwd_persist, dim3(persist_grid()), dim3(PNT), lds, s, (const PK*)w.pk_dev);
+    hipLaunchKernelGGL(drnn_bwd_persist, dim3(P_WGS_PER_CU * persist_grid()), dim3(PNT), lds, s, (const PK*)w.pk_dev);
     MSER_TRY(check_launch("drnn_bwd_persist"));
   } else {
   MSER_CHECK_HIP(hipMemsetAsync(w.dQ, 0, (size_t)2 * 2 * B * 2 * Dp * sizeof(float), s));
