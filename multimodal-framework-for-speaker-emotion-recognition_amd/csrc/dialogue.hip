@@ -1326,15 +1326,12 @@ __device__ __noinline__ void e_bwd_task(const CPK* Pp, const BB& Xv, int t, int 
   pk_store3(X.bk, base + P.w.b_ghe, b, H, u, g.dar, g.daz, g.danr);
   xb_st(X.bk, base + P.w.b_dEdir + it, g.dhp);
 }
-// g cell backward of step t
-__device__ __noinline__ void g_bwd_task(const CPK* Pp, const BB& Xv, int t, int dir, int ch) {
-  const CPK& P = pk_uni(Pp);
-  const BB X = bb_uni(Xv);
+// g cell backward of step t, element (b, u): dh' = dGh[t+1] (the attention's accumulations) + the direct path and the hidden product of
+// step t+1
+__device__ __forceinline__ void g_elem_bwd(const CPK& P, const BB& X, int t, int dir, int b, int u) {
   const int B = P.d.B, T = P.d.T, H = P.d.Dg;
   const long TB = (long)T * B, base = (long)dir * P.w.bk_dir;
-  const int it = ch * PNT + threadIdx.x;
-  if (it >= B * H) return;
-  const int b = it / H, u = it - b * H;
+  const long it = (long)b * H + u;
   float dh = xb_ld(X.dGh, ((long)dir * (T + 1) + t + 1) * B * H + it) + xb_ld(X.bk, base + P.w.b_Ddirg + it) + xb_ld(X.bk, base + P.w.b_PGh + it);
   if (P.rng) dh *= drop_scale(drop_key(P.rng, P.site[dir], P.pdrop), (uint32_t)((long)t * B * H) + (uint32_t)it);
   const float* sv = P.w.sv_g + ((long)dir * TB + (long)t * B + b) * 4 * H + u;
@@ -1345,6 +1342,14 @@ __device__ __noinline__ void g_bwd_task(const CPK* Pp, const BB& Xv, int t, int 
   pk_store3(X.bk, base + P.w.b_gig, b, H, u, g.dar, g.daz, g.dan);
   pk_store3(X.bk, base + P.w.b_ghg, b, H, u, g.dar, g.daz, g.danr);
   xb_st(X.bk, base + P.w.b_Ddirg + it, g.dhp);
+}
+// (stand-alone: only the last time step, whose successor has no attention task to ride on)
+__device__ __noinline__ void g_bwd_task(const CPK* Pp, const BB& Xv, int t, int dir, int ch) {
+  const CPK& P = pk_uni(Pp);
+  const BB X = bb_uni(Xv);
+  const int it = ch * PNT + threadIdx.x;
+  if (it >= P.d.B * P.d.Dg) return;
+  g_elem_bwd(P, X, t, dir, it / P.d.Dg, it % P.d.Dg);
 }
 // l cell backward + blend (LCELL) or p cell backward of step t, both parties of element (b, u)
 template <bool LCELL>
@@ -1556,6 +1561,11 @@ __device__ __noinline__ void att_bwd_b(const CPK* Pp, const BB& Xv, int t, int b
       }
     }
   }
+  // dGh[t] of this row is complete now (steps > t have added theirs before): the g cell backward of step t-1 follows at once, by the
+  // workgroup that holds the row -- no element-wise phase (and grid barrier) of its own
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int u = tid; u < Dg; u += PNT) g_elem_bwd(P, X, t - 1, dir, b, u);
   __syncthreads();
 }
 // product i of direction dir, tile (rb, ct): out[rows, N] tile = dgates[rows, K3] W^T-pack
@@ -1573,10 +1583,68 @@ __device__ __forceinline__ BProd bprod(const CPK& P, int dir) {
   d.rows = (I == 3 || I == 5) ? 2 * B : B;
   return d;
 }
-__device__ __noinline__ void bwd_prod_task(const BB& Xv, const BProd d, int rb, int ct) {
+// operands of the p cell backward of element (b, u), both parties (everything but the dss value that arrives through the product)
+struct PElem { float dqs[2], sv[2][4], hq[2]; int sp; bool ok; };
+__device__ __forceinline__ PElem p_elem_load(const CPK& P, const BB& X, int t, int dir, int b, int u) {
+  const int B = P.d.B, T = P.d.T, H = P.d.Dp;
+  const long TB = (long)T * B, base = (long)dir * P.w.bk_dir;
+  PElem e;
+  e.ok = b < B && u < H;
+  if (e.ok) {
+    e.sp = P.w.idx[(long)dir * (TB + B) + (long)t * B + b];
+    const float* save = P.w.sv_p + ((long)dir * TB + (long)t * B) * 2 * 4 * H;
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      const long qe = ((long)b * 2 + pt) * H + u;
+      e.dqs[pt] = xb_ld(X.bk, base + P.w.b_dqs + qe);
+      const float* sv = save + ((long)b * 2 + pt) * 4 * H + u;
+      e.sv[pt][0] = sv[0]; e.sv[pt][1] = sv[H]; e.sv[pt][2] = sv[2 * H]; e.sv[pt][3] = sv[3 * H];
+      e.hq[pt] = P.w.Q[((long)dir * (T + 1) + t) * B * 2 * H + qe];
+    }
+  }
+  return e;
+}
+// p cell backward of element (b, u) given dss = the l cell's input-product gradient (DialogueRNN.py:144-153 backwards): gate gradients
+// of both parties (row-major for the weight-gradient GEMMs, fragment order for this step's products), the direct path into dQ
+__device__ __forceinline__ void p_elem_bwd(const CPK& P, const BB& X, int t, int dir, int b, int u, const PElem& e, float dss) {
+  const int B = P.d.B, T = P.d.T, H = P.d.Dp;
+  const long TB = (long)T * B, base = (long)dir * P.w.bk_dir;
+  DropKey dk{};
+  if (P.rng) dk = drop_key(P.rng, P.site[dir] + 1, P.pdrop);
+  float* dgh = P.w.dgh_p + ((long)dir * TB + (long)t * B) * 2 * 3 * H;
+  float sr = 0.f, sz = 0.f, sna = 0.f;
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) {
+    const long qe = ((long)b * 2 + pt) * H + u;
+    float dh = e.dqs[pt];
+    if (pt == e.sp) dh += dss;
+    if (P.rng) dh *= drop_scale(dk, (uint32_t)((long)t * B * 2 * H) + (uint32_t)qe);
+    const GateGrad g = gru_gate_bwd(dh, e.sv[pt][0], e.sv[pt][1], e.sv[pt][2], e.sv[pt][3], e.hq[pt]);
+    row_store3(dgh + ((long)b * 2 + pt) * 3 * H + u, H, g.dar, g.daz, g.danr);
+    pk_store3(X.bk, base + P.w.b_ghp, b * 2 + pt, H, u, g.dar, g.daz, g.danr);
+    sr += g.dar; sz += g.daz; sna += g.dan;
+    xb_st(X.bk, base + P.w.b_QdirP + qe, g.dhp);
+  }
+  row_store3(P.w.dgi_p + ((long)dir * TB + (long)t * B + b) * 3 * H + u, H, sr, sz, sna);
+  pk_store3(X.bk, base + P.w.b_gip, b, H, u, sr, sz, sna);
+}
+// FUSE_P: the tile is dss (the l cell's input-product gradient) and its only reader is the p cell backward of the same elements: the
+// tile's owner applies it to them right away (their other operands were requested before the MFMA chain) instead of storing dss for an
+// element-wise phase of its own -- one grid barrier less per step
+template <bool FUSE_P>
+__device__ __noinline__ void bwd_prod_task(const CPK* Pp, const BB& Xv, const BProd d, int rb, int ct, int t, int dir) {
   extern __shared__ float psm[];
   float* red = psm;
   const BB X = bb_uni(Xv);
+  PElem pe[1024 / PNT];
+  if constexpr (FUSE_P) {
+    const CPK& P = pk_uni(Pp);
+#pragma unroll
+    for (int j = 0; j < 1024 / PNT; ++j) {
+      const int e = threadIdx.x + j * PNT;
+      pe[j] = p_elem_load(P, X, t, dir, rb * 32 + (e >> 5), ct * 32 + (e & 31));
+    }
+  }
   const int k8n = k8p(d.K3), Kp = k8n * 8;
   const long ab = d.a_off + (long)rb * k8n * 256, wb = d.w_off + (long)ct * k8n * 256;
   const int KC = ((Kp + PNW * 16 - 1) / (PNW * 16)) * 16;
@@ -1616,13 +1684,19 @@ __device__ __noinline__ void bwd_prod_task(const BB& Xv, const BProd d, int rb, 
     *reinterpret_cast<float4*>(red + wave * P_T1 + r * P_TS + 8 * g4 + 4 * half) = make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
   __syncthreads();
   PSTC(13);
-  for (int e = tid; e < 1024; e += PNT) {              // (output column fastest: coalesced stores)
+#pragma unroll
+  for (int j = 0; j < 1024 / PNT; ++j) {               // (output column fastest: coalesced stores)
+    const int e = tid + j * PNT;
     const int n = e & 31, rr = e >> 5;
     float s = 0.f;
 #pragma unroll
     for (int wv = 0; wv < PNW; ++wv) s += red[wv * P_T1 + n * P_TS + rr];
     const int row = rb * 32 + rr, col = ct * 32 + n;
-    if (row < d.rows && col < d.N) xb_st(X.bk, d.o_off + (long)row * d.N + col, s);
+    if constexpr (FUSE_P) {
+      if (pe[j].ok) p_elem_bwd(pk_uni(Pp), X, t, dir, row, col, pe[j], s);
+    } else {
+      if (row < d.rows && col < d.N) xb_st(X.bk, d.o_off + (long)row * d.N + col, s);
+    }
   }
   __syncthreads();
   PSTC(14);
@@ -1652,7 +1726,7 @@ __global__ __launch_bounds__(PNT, 2) void drnn_bwd_persist(const PK* __restrict_
     switch (ph) {
       case 0: return (t + 1 < T ? B : 0) + (t < T ? nel : 0) + (t >= 1 ? nee : 0);
       case 1: return (t + 1 < T ? B : 0) + (t < T ? nt_l_ih + (t > 0 ? nt_l_hh : 0) : 0) + (t >= 1 ? nt_e_ih + nt_e_hh : 0);
-      case 2: return t < T ? nel + neg : 0;
+      case 2: return t == T - 1 ? neg : 0;                 // (only the last step's g cell: the others ride on the attention rows, the p cell on dss)
       default: return (t < T && t > 0) ? nt_p_ih + nt_p_hh + nt_g_ih + nt_g_hh : 0;
     }
   };
@@ -1671,20 +1745,19 @@ __global__ __launch_bounds__(PNT, 2) void drnn_bwd_persist(const PK* __restrict_
       if (v < na) { att_bwd_b(&P, X, t + 1, v, dir, dir * att_st); PSTC(9); return; }      // (the same workgroup as the row's first half)
       v -= na;
       int rb, ct;
-      if (v < n3) { if (tile_decode(v, nrb2, ctp, rb, ct)) bwd_prod_task(X, bprod<3>(P, dir), rb, ct); }
-      else if (v < n3 + n2) { if (tile_decode(v - n3, nrb1, ctp, rb, ct)) bwd_prod_task(X, bprod<2>(P, dir), rb, ct); }
-      else if (v < n3 + n2 + n0) { if (tile_decode(v - n3 - n2, nrb1, ctp, rb, ct)) bwd_prod_task(X, bprod<0>(P, dir), rb, ct); }
-      else if (tile_decode(v - n3 - n2 - n0, nrb1, cte, rb, ct)) bwd_prod_task(X, bprod<1>(P, dir), rb, ct);
+      if (v < n3) { if (tile_decode(v, nrb2, ctp, rb, ct)) bwd_prod_task<false>(&P, X, bprod<3>(P, dir), rb, ct, t, dir); }
+      else if (v < n3 + n2) { if (tile_decode(v - n3, nrb1, ctp, rb, ct)) bwd_prod_task<true>(&P, X, bprod<2>(P, dir), rb, ct, t, dir); }
+      else if (v < n3 + n2 + n0) { if (tile_decode(v - n3 - n2, nrb1, ctp, rb, ct)) bwd_prod_task<false>(&P, X, bprod<0>(P, dir), rb, ct, t, dir); }
+      else if (tile_decode(v - n3 - n2 - n0, nrb1, cte, rb, ct)) bwd_prod_task<false>(&P, X, bprod<1>(P, dir), rb, ct, t, dir);
     } else if (ph == 2) {
-      if (v < nel) lp_bwd_task<false>(&P, X, t, dir, v);
-      else g_bwd_task(&P, X, t, dir, v - nel);
+      g_bwd_task(&P, X, t, dir, v);
     } else {
       const int n5 = nt_p_hh, n4 = nt_p_ih, n6 = nt_g_ih;
       int rb, ct;
-      if (v < n5) { if (tile_decode(v, nrb2, ctp, rb, ct)) bwd_prod_task(X, bprod<5>(P, dir), rb, ct); }
-      else if (v < n5 + n4) { if (tile_decode(v - n5, nrb1, ctg, rb, ct)) bwd_prod_task(X, bprod<4>(P, dir), rb, ct); }
-      else if (v < n5 + n4 + n6) { if (tile_decode(v - n5 - n4, nrb1, ctp, rb, ct)) bwd_prod_task(X, bprod<6>(P, dir), rb, ct); }
-      else if (tile_decode(v - n5 - n4 - n6, nrb1, ctg, rb, ct)) bwd_prod_task(X, bprod<7>(P, dir), rb, ct);
+      if (v < n5) { if (tile_decode(v, nrb2, ctp, rb, ct)) bwd_prod_task<false>(&P, X, bprod<5>(P, dir), rb, ct, t, dir); }
+      else if (v < n5 + n4) { if (tile_decode(v - n5, nrb1, ctg, rb, ct)) bwd_prod_task<false>(&P, X, bprod<4>(P, dir), rb, ct, t, dir); }
+      else if (v < n5 + n4 + n6) { if (tile_decode(v - n5 - n4, nrb1, ctp, rb, ct)) bwd_prod_task<false>(&P, X, bprod<6>(P, dir), rb, ct, t, dir); }
+      else if (tile_decode(v - n5 - n4 - n6, nrb1, ctg, rb, ct)) bwd_prod_task<false>(&P, X, bprod<7>(P, dir), rb, ct, t, dir);
     }
   };
   PST_INIT();
