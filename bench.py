@@ -640,13 +640,22 @@ def main():
                 ud = torch.ones(Bd, Ld, device=device)
                 ld_ = torch.tensor(rs.randint(0, NCLS, (Bd, Ld)).astype(np.int64)).to(device)
                 ms_dr = with_trainer(trd, lambda: time_steps((Ud, qd, ud, ld_), n=4, tag="dialoguernn_bimodel_B64_L200"))
+                # the same step with the time loop issued launch by launch (MSER_OPT_DRNN_PERSISTENT = 0: 9 + 13 launches per step)
+                from mser import ops
+                ops.set_option(ops.MSER_OPT_DRNN_PERSISTENT, 0)
+                try:
+                    ms_dr0 = with_trainer(trd, lambda: time_steps((Ud, qd, ud, ld_), n=3, tag="dialoguernn_bimodel_B64_L200_per_step_launches"))
+                finally:
+                    ops.set_option(ops.MSER_OPT_DRNN_PERSISTENT, 1)
                 del trd
                 gflop = 3 * 2 * Ld * 2 * (Bd * (500 * 1500 * 2 + 500 * 1500 + 2 * 500 * 1500 + 500 * 1500 + 2 * 500 * 1500 + 500 * 900 + 300 * 900)
                                           + Bd * 712 * (3 * 1500 + 500)) / 1e9
                 variants["dialoguernn_bimodel_B64_L200"] = {
                     "ms_per_step": round(ms_dr, 3), "utterances_per_s": round(Bd * Ld / (ms_dr * 1e-3), 1),
                     "fp32_mfma_frac": round(gflop / (ms_dr * 1e-3) / 1e3 / 157.0, 4),
-                    "note": f"configs[3]; ~{gflop:.0f} GFLOP of exact-fp32 GEMM work per training step against the 157 TFLOP/s fp32 matrix peak"}
+                    "ms_per_step_per_step_launches": round(ms_dr0, 3),
+                    "note": f"configs[3]; ~{gflop:.0f} GFLOP of exact-fp32 GEMM work per training step against the 157 TFLOP/s fp32 matrix peak; "
+                            "the time loop of each pass is ONE persistent launch (ms_per_step_per_step_launches: the same step launch by launch)"}
             guarded("dialoguernn_bimodel_B64_L200", v_drnn)
 
             # BASELINE.json configs[4], one GPU's shard of it: hid = 1024 with the 8-head sequence attention, global batch 256 over 8 GPUs =
