@@ -185,6 +185,7 @@ class ModelTrainer(nn.Module):
         if bits == _lib_bits("CHAIN_TIMEOUT") and not getattr(self, "_fell_back", False):
             fault.clear(self.device)
             ops.set_option(ops.MSER_OPT_PERSISTENT, 0)
+            ops.set_option(ops.MSER_OPT_DRNN_PERSISTENT, 0)          # (DialogueRNN's one-launch-per-pass time loops)
             self._fell_back = True
             print(time.strftime("%m-%d %H:%M:%S") + f" libmser: a persistent recurrent launch timed out in {where}; falling back to one "
                   f"launch per time step and replaying {len(window)} step(s)")

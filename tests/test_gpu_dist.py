@@ -114,6 +114,7 @@ def test_fault_word_skips_adam_and_trainer_raises(O):
             tr.train_network(1, [batch])
     finally:
         ops.set_option(ops.MSER_OPT_PERSISTENT, 1)
+        ops.set_option(ops.MSER_OPT_DRNN_PERSISTENT, 1)
     before = tr.model.flat_store.data.clone()
     tr.train_network(1, [batch])
     assert not torch.equal(tr.model.flat_store.data, before)
