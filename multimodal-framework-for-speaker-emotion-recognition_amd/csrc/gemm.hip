@@ -276,11 +276,14 @@ static int plan(const mser_gemm_desc& d, long group_tiles, Plan& P) {
   const int TM = 64, TN = c1 ? 32 : 64, BKT = c1 ? 64 : 32;
   const long tiles = (long)cdiv(d.M, TM) * cdiv(d.N, TN) * b1 * b2;
   // ---- split-K: `splitk > 1` means "C is initialised, accumulate atomically"; the split itself is chosen here so that the grid
-  // (of the whole group) is about two workgroups per CU while every workgroup still runs at least two k-tiles
+  // (of the whole group) is about two workgroups per CU (four for a product on its own) while every workgroup still runs at least two k-tiles
   int splitk = 1;
   if (d.splitk > 1 && d.K > 0) {
     const long all = group_tiles > 0 ? group_tiles * (c1 ? 2 : 1) : tiles;
-    long want = (2 * FILL + all - 1) / all;
+    // a product on its own: four workgroups per CU (two left 288-tile weight gradients at 2.25 workgroups per CU -- three rounds for
+    // 2.25 rounds of work: DialogueRNN's weight-gradient tail 7.5 -> 6.5 ms; MSER_GEMM_WGS_PER_CU overrides for measurements)
+    static const long per_cu = getenv("MSER_GEMM_WGS_PER_CU") ? atol(getenv("MSER_GEMM_WGS_PER_CU")) : 4;
+    long want = ((group_tiles > 0 ? 2 : per_cu) * FILL + all - 1) / all;
     if (group_tiles > 0 && tiles < 64) {
       // inside a group no SMALL member may become the straggler: at most 16 k-tiles per workgroup (a tiny member that the group-wide
       // count left unsplit ran its whole K = B*L reduction in ONE workgroup: 90 us at the end of the step), and many short
