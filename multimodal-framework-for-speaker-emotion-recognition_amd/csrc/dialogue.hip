@@ -71,7 +71,7 @@ struct WS {
   float *gi_g, *gh_g, *gi_p, *gh_p, *gi_l, *gh_l, *gi_e, *gh_e;      // per-step scratch [2][rows][3H]
   // backward
   float *dgi_g, *dgh_g, *dgi_p, *dgh_p, *dgi_l, *dgh_l, *dgi_e, *dgh_e, *dXatt;   // [2][T][rows][3H] (dgi_p / dgi_l summed over parties)
-  unsigned* sync;                                // the persistent launches' barrier counter and abort word (one line each)
+  unsigned* sync;                                // the persistent launches' barrier counters (2 directions x 8 replicas, one line each) and abort word
   void* pk_dev;                                  // the persistent launches' parameter block (struct PK) in device memory
   // persistent forward: packed weights [2 dirs][8 products: g_in g_h p_in p_h l_in l_h e_in e_h] and packed states (offsets in floats
   // into apk): q0p [dir] | Ghp [parity][dir] | cvp [dir] | Qp [parity][dir][party] | ssp [dir] | qselp [parity][dir] | Ehp [parity][dir]
@@ -121,7 +121,7 @@ WS carve(char* base, const Dims& d) {
   w.dGh = cv.take<float>(2 * (T + 1) * B * d.Dg); w.dQ = cv.take<float>(2 * 2 * B * 2 * d.Dp); w.dEc = cv.take<float>(2 * B * d.De);
   w.dqsel = cv.take<float>(2 * B * d.Dp); w.dss = cv.take<float>(2 * B * d.Dp); w.dq0sel = cv.take<float>(2 * 2 * B * d.Dp);
   w.dc = cv.take<float>(2 * B * d.Dg); w.dqs = cv.take<float>(2 * B * 2 * d.Dp);
-  w.sync = cv.take<unsigned>(128);
+  w.sync = cv.take<unsigned>(4096);
   w.pk_dev = cv.take<char>(4096);
   {
     const int UWh = 10;                            // = UW (unit slab of the persistent cell tiles)
@@ -674,6 +674,23 @@ __device__ __forceinline__ void pzero8(float* a) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) a[j] = 0.f;
 }
+#if defined(MSER_DRNN_EXP) && !defined(MSER_STAMPS)
+#if MSER_DRNN_EXP == 1
+#define PEXP() do { if (threadIdx.x == 0) { unsigned long long _x = __builtin_amdgcn_s_memrealtime(); asm volatile("" :: "s"(_x)); } } while (0)
+#elif MSER_DRNN_EXP == 2
+#define PEXP() do { if ((threadIdx.x >> 6) == 0) __builtin_amdgcn_s_sleep(8); } while (0)
+#elif MSER_DRNN_EXP == 4
+__shared__ unsigned long long pexp_acc[2];
+#define PEXP() do { if (threadIdx.x == 0) { pexp_acc[0] += pexp_acc[1]; pexp_acc[1] += 3; } } while (0)
+#elif MSER_DRNN_EXP == 5
+__shared__ unsigned long long pexp_acc[2];
+#define PEXP() do { if (threadIdx.x == 0) { const unsigned long long _n = __builtin_amdgcn_s_memrealtime(); pexp_acc[0] += _n - pexp_acc[1]; pexp_acc[1] = _n; } } while (0)
+#else
+#define PEXP() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
+#endif
+#else
+#define PEXP()
+#endif
 #ifdef MSER_STAMPS
 __shared__ unsigned long long pst_acc[16];
 __shared__ unsigned long long pst_last;
@@ -684,10 +701,14 @@ __shared__ unsigned long long pst_last;
 #else
 #define PSTC(k)
 #endif
+#ifdef MSER_STAMPS_NODUMP
+#define PST_DUMP(name, T)
+#else
 #define PST_DUMP(name, T) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 200 || blockIdx.x == 255 || blockIdx.x == 256)) \
   printf("[drnn stamps %s wg %3d hwid %08x | 10 ns ticks per step]  %llu %llu %llu %llu %llu %llu %llu %llu | %llu %llu %llu %llu %llu %llu %llu %llu\n", name, (int)blockIdx.x, (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)), pst_acc[0] / (T), pst_acc[1] / (T), \
          pst_acc[2] / (T), pst_acc[3] / (T), pst_acc[4] / (T), pst_acc[5] / (T), pst_acc[6] / (T), pst_acc[7] / (T), pst_acc[8] / (T), pst_acc[9] / (T), pst_acc[10] / (T), pst_acc[11] / (T), \
          pst_acc[12] / (T), pst_acc[13] / (T), pst_acc[14] / (T), pst_acc[15] / (T)); } while (0)
+#endif
 #else
 #define PST_INIT()
 #define PST(k)
@@ -699,19 +720,30 @@ __shared__ unsigned long long pst_last;
 // the workgroup's stores are complete (s_waitcnt vmcnt(0) by every thread, then a workgroup barrier), one relaxed agent-scope add.
 // wait(): bounded poll.  Between the two a workgroup works for the OTHER direction, so a barrier's latency is not idle time.
 // wait() returns false when some workgroup gave up (the caller returns; every workgroup does, so the grid drains).
+#ifndef MSER_DRNN_BAR_REP
+#define MSER_DRNN_BAR_REP 8
+#endif
+#ifndef MSER_DRNN_BAR_SLEEP
+#define MSER_DRNN_BAR_SLEEP 1
+#endif
+constexpr int P_BAR_REP = MSER_DRNN_BAR_REP;
 struct GridBar { unsigned* cnt; unsigned* abortw; uint32_t* fault; unsigned target, G; };
 __device__ __forceinline__ void bar_arrive(GridBar& gb) {
   gb.target += gb.G;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add((pgu32*)gb.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // P_BAR_REP replicas of the counter, one cache line each: an arrival adds to all of them with ONE wave instruction (P_BAR_REP active
+  // lanes), a waiting workgroup polls only replica (workgroup % P_BAR_REP) -- 256 pollers on one line queue the arrivals behind their
+  // loads (measured: forward 16.3 -> ms per launch)
+  if (threadIdx.x < P_BAR_REP) __hip_atomic_fetch_add((pgu32*)(gb.cnt + threadIdx.x * 32), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ bool bar_wait(const GridBar& gb, int* ok_lds) {
   if (threadIdx.x == 0) {
     unsigned spins = 0;
     int ok = 1;
-    while (__hip_atomic_load((const pgu32*)gb.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gb.target) {
-      __builtin_amdgcn_s_sleep(1);
+    const pgu32* mine = (const pgu32*)(gb.cnt + (blockIdx.x % P_BAR_REP) * 32);
+    while (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gb.target) {
+      __builtin_amdgcn_s_sleep(MSER_DRNN_BAR_SLEEP);
       ++spins;
       if ((spins & 1023u) == 0u && __hip_atomic_load((const pgu32*)gb.abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
       if (spins > P_SPIN_LIMIT) {
@@ -1177,7 +1209,7 @@ __device__ __forceinline__ FB fb_uni(const FB& x) {
 // kernel's fixed LDS layout and address it through the dynamic-LDS symbol themselves)
 __device__ __noinline__ void att_task(const CPK* Pp, const FB& Fv, const Task k) {
   const CPK& P = pk_uni(Pp);
-  extern __shared__ float psm[];
+  extern __shared__ __attribute__((aligned(16))) float psm[];
   float* red = psm;
   float* attx = psm + P_OFF_ATT;
   const FB F = fb_uni(Fv);
@@ -1194,7 +1226,7 @@ __device__ __forceinline__ void task_pre(const CPK& P, const FB& F, const Task& 
   }
 }
 __device__ __forceinline__ void task_post(const CPK& P, const FB& F, const Task& k, TRegs& R) {
-  extern __shared__ float psm[];
+  extern __shared__ __attribute__((aligned(16))) float psm[];
   switch (k.kind) {
     case 0: cell_post<0>(P, F, k, R, psm, psm + P_OFF_TILES); break;
     case 1: cell_post<1>(P, F, k, R, psm, psm + P_OFF_TILES); break;
@@ -1214,6 +1246,10 @@ __device__ __forceinline__ void task_post(const CPK& P, const FB& F, const Task&
 __global__ __launch_bounds__(PNT, 2) void drnn_fwd_persist(const PK* __restrict__ pkp) {
   const CPK& P = *(const CPK*)pkp;
   __shared__ int bar_ok;
+#ifdef MSER_DRNN_LDS_PAD
+  __shared__ unsigned long long lds_pad[MSER_DRNN_LDS_PAD];
+  if (threadIdx.x == 0) { lds_pad[0] = 0; asm volatile("" :: "v"(lds_pad[0])); }
+#endif
   const int B = P.d.B, T = P.d.T, Dg = P.d.Dg, Dp = P.d.Dp, De = P.d.De;
   FB F;
   F.Gh = xb_make(P.w.Gh, (size_t)2 * (T + 1) * B * Dg); F.Q = xb_make(P.w.Q, (size_t)2 * (T + 1) * B * 2 * Dp);
@@ -1224,7 +1260,7 @@ __global__ __launch_bounds__(PNT, 2) void drnn_fwd_persist(const PK* __restrict_
   const int G = P_SPLIT_DIRS ? (int)(gridDim.x >> 1) : (int)gridDim.x;       // workgroups per direction chain
   const int wg = P_SPLIT_DIRS ? (int)(blockIdx.x % (unsigned)G) : (int)blockIdx.x;
   const int dir_lo = P_SPLIT_DIRS ? (int)(blockIdx.x / (unsigned)G) : 0, dir_hi = P_SPLIT_DIRS ? dir_lo + 1 : 2;
-  GridBar gb[2] = {{P.sync, P.sync + 64, P.fault, 0u, (unsigned)G}, {P.sync + 32, P.sync + 64, P.fault, 0u, (unsigned)G}};
+  GridBar gb[2] = {{P.sync, P.sync + 2 * P_BAR_REP * 32, P.fault, 0u, (unsigned)G}, {P.sync + P_BAR_REP * 32, P.sync + 2 * P_BAR_REP * 32, P.fault, 0u, (unsigned)G}};
   const int NRB = (B + 31) / 32;
   const int ntg = tile_count(B, Dg, UW), ntp = tile_count(B, Dp, UW), nte = tile_count(B, De, UW);
   const int nsg = (Dg + UW - 1) / UW, nsp = (Dp + UW - 1) / UW, nse = (De + UW - 1) / UW;
@@ -1253,13 +1289,21 @@ __global__ __launch_bounds__(PNT, 2) void drnn_fwd_persist(const PK* __restrict_
       if (n == 0) continue;
 #pragma unroll 1
       for (int dir = dir_lo; dir < dir_hi; ++dir) {
-        int v = wg;
+        // (direction 1's task list is dealt from the middle of the grid: a workgroup that has a heavy p / l tile for one direction gets a
+        // g / attention / e task, or none, for the other)
+        int v = P_SPLIT_DIRS ? wg : (int)((blockIdx.x + (unsigned)dir * (G / 2)) % (unsigned)G);
         Task k = task_of(ph, t, dir, v);
         if (v < n) task_pre(P, F, k, R);
+#if !defined(MSER_STAMPS_SITE) || MSER_STAMPS_SITE == 1
         PST(4 * ph + 2 * dir);
+#endif
+        PEXP();
         if (!first[dir]) { if (!bar_wait(gb[dir], &bar_ok)) return; }
         first[dir] = false;
+#if !defined(MSER_STAMPS_SITE) || MSER_STAMPS_SITE == 2
         PST(4 * ph + 2 * dir + 1);
+#endif
+        PEXP();
         for (; v < n;) {
           task_post(P, F, k, R);
           v += G;
@@ -1424,7 +1468,7 @@ __device__ __noinline__ void lp_bwd_task(const CPK* Pp, const BB& Xv, int t, int
 // LDS state per direction: x[Dg] | dc[Dg] | ds[T] | alpha[T]
 __device__ __noinline__ void att_bwd_a(const CPK* Pp, const BB& Xv, int t, int b, int dir, int st_off) {
   const CPK& P = pk_uni(Pp);
-  extern __shared__ float psm[];
+  extern __shared__ __attribute__((aligned(16))) float psm[];
   float* st = psm + B_OFF_ATT + st_off;
   float* wacc = psm;
   float* redw = psm + B_OFF_REDW;
@@ -1509,7 +1553,7 @@ __device__ __noinline__ void att_bwd_a(const CPK* Pp, const BB& Xv, int t, int b
 }
 __device__ __noinline__ void att_bwd_b(const CPK* Pp, const BB& Xv, int t, int b, int dir, int st_off) {
   const CPK& P = pk_uni(Pp);
-  extern __shared__ float psm[];
+  extern __shared__ __attribute__((aligned(16))) float psm[];
   const float* st = psm + B_OFF_ATT + st_off;
   const BB X = bb_uni(Xv);
   const int B = P.d.B, T = P.d.T, Dg = P.d.Dg;
@@ -1633,7 +1677,7 @@ __device__ __forceinline__ void p_elem_bwd(const CPK& P, const BB& X, int t, int
 // element-wise phase of its own -- one grid barrier less per step
 template <bool FUSE_P>
 __device__ __noinline__ void bwd_prod_task(const CPK* Pp, const BB& Xv, const BProd d, int rb, int ct, int t, int dir) {
-  extern __shared__ float psm[];
+  extern __shared__ __attribute__((aligned(16))) float psm[];
   float* red = psm;
   const BB X = bb_uni(Xv);
   PElem pe[1024 / PNT];
@@ -1705,6 +1749,10 @@ __device__ __noinline__ void bwd_prod_task(const CPK* Pp, const BB& Xv, const BP
 __global__ __launch_bounds__(PNT, 2) void drnn_bwd_persist(const PK* __restrict__ pkp) {
   const CPK& P = *(const CPK*)pkp;
   __shared__ int bar_ok;
+#ifdef MSER_DRNN_LDS_PAD
+  __shared__ unsigned long long lds_pad[MSER_DRNN_LDS_PAD];
+  if (threadIdx.x == 0) { lds_pad[0] = 0; asm volatile("" :: "v"(lds_pad[0])); }
+#endif
   const int B = P.d.B, T = P.d.T, Dg = P.d.Dg, Dp = P.d.Dp, De = P.d.De;
   BB X;
   X.bk = xb_make(P.w.bk, P.w.bk_floats);
@@ -1713,7 +1761,7 @@ __global__ __launch_bounds__(PNT, 2) void drnn_bwd_persist(const PK* __restrict_
   const int G = P_SPLIT_DIRS ? (int)(gridDim.x >> 1) : (int)gridDim.x;       // workgroups per direction chain
   const int wg = P_SPLIT_DIRS ? (int)(blockIdx.x % (unsigned)G) : (int)blockIdx.x;
   const int dir_lo = P_SPLIT_DIRS ? (int)(blockIdx.x / (unsigned)G) : 0, dir_hi = P_SPLIT_DIRS ? dir_lo + 1 : 2;
-  GridBar gb[2] = {{P.sync, P.sync + 64, P.fault, 0u, (unsigned)G}, {P.sync + 32, P.sync + 64, P.fault, 0u, (unsigned)G}};
+  GridBar gb[2] = {{P.sync, P.sync + 2 * P_BAR_REP * 32, P.fault, 0u, (unsigned)G}, {P.sync + P_BAR_REP * 32, P.sync + 2 * P_BAR_REP * 32, P.fault, 0u, (unsigned)G}};
   const int nrb1 = (B + 31) / 32, nrb2 = (2 * B + 31) / 32;
   const int ctg = (Dg + 31) / 32, ctp = (Dp + 31) / 32, cte = (De + 31) / 32;
   const int nel = (B * Dp + PNT - 1) / PNT, neg = (B * Dg + PNT - 1) / PNT, nee = (B * De + PNT - 1) / PNT;
@@ -1958,7 +2006,7 @@ int mser_drnn_fwd(const mser_drnn_desc* dp, mser_stream_t stream) {
   if (persist_ok(dm, false)) {
     const PK K = make_pk(d, w);
     const size_t lds = persist_lds(dm, false);
-    MSER_CHECK_HIP(hipMemsetAsync(w.sync, 0, 128 * sizeof(unsigned), s));
+    MSER_CHECK_HIP(hipMemsetAsync(w.sync, 0, 4096 * sizeof(unsigned), s));
     MSER_CHECK_HIP(hipMemsetAsync(w.apk, 0, w.apk_floats * sizeof(float), s));
     for (int dir = 0; dir < 2; ++dir) {
       const mser_drnn_params& P = d.p[dir];
@@ -2047,7 +2095,7 @@ int mser_drnn_bwd(const mser_drnn_desc* dp, mser_stream_t stream) {
   if (persist_ok(dm, true)) {
     // ---- persistent BPTT: one launch (drnn_bwd_persist)
     MSER_CHECK_HIP(hipMemsetAsync(w.bk, 0, w.bk_floats * sizeof(float), s));
-    MSER_CHECK_HIP(hipMemsetAsync(w.sync, 0, 128 * sizeof(unsigned), s));
+    MSER_CHECK_HIP(hipMemsetAsync(w.sync, 0, 4096 * sizeof(unsigned), s));
     for (int dir = 0; dir < 2; ++dir) {
       MSER_CHECK_HIP(hipMemsetAsync(w.dXatt + (long)dir * TB * Dg, 0, (size_t)B * Dg * sizeof(float), s));       // step 0 has no attention
       const mser_drnn_params& P = d.p[dir];
