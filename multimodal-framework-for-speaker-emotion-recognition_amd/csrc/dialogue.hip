@@ -766,6 +766,10 @@ struct PK {
   const uint32_t* rng; uint32_t site[2]; float pdrop;
   float* out; const float* dout; long ldo; const int* rev;
   unsigned* sync; uint32_t* fault;
+  // backward: host-computed task schedule (make_bwd_sched).  sched[ph][w][k]: the (up to two) tasks of phase ph (0 = C, 1 = D, 2 = F) that
+  // the workgroup with direction-relative index w runs, as indices into the phase's full task list; 255 = none.  sched_ok = 0: deal the
+  // lists round-robin instead.
+  unsigned char sched[3][256][2]; int sched_ok;
 };
 // The launch parameters live in device memory (drnn_store_pk_kernel writes the by-value argument there -- capturable, no host copy) and are
 // read through the constant address space: scalar loads wherever a field is needed, instead of ~100 preloaded SGPRs spilled all over the
@@ -1779,52 +1783,63 @@ __global__ __launch_bounds__(PNT, 2) void drnn_bwd_persist(const PK* __restrict_
     }
   };
   const int att_st = 2 * Dg + 2 * T;                   // LDS state of an attention row between its two halves, per direction
+  // task v of phase ph: v indexes the phase's FULL list (the same at every step; a kind that does not exist at step t is skipped)
   auto run_task = [&](int ph, int t, int dir, int v) {
-    if (ph == 0) {
-      const int na = t + 1 < T ? B : 0, nl = t < T ? nel : 0;
-      PSTC(15);
-      if (v < na) { att_bwd_a(&P, X, t + 1, v, dir, dir * att_st); PSTC(8); }
-      else if (v < na + nl) { lp_bwd_task<true>(&P, X, t, dir, v - na); PSTC(11); }
-      else { e_bwd_task(&P, X, t - 1, dir, v - na - nl); PSTC(11); }
-    } else if (ph == 1) {
-      const int na = t + 1 < T ? B : 0;
-      const int n2 = t < T ? nt_l_ih : 0, n3 = (t < T && t > 0) ? nt_l_hh : 0, n0 = t >= 1 ? nt_e_ih : 0;
-      PSTC(15);
-      if (v < na) { att_bwd_b(&P, X, t + 1, v, dir, dir * att_st); PSTC(9); return; }      // (the same workgroup as the row's first half)
-      v -= na;
-      int rb, ct;
-      if (v < n3) { if (tile_decode(v, nrb2, ctp, rb, ct)) bwd_prod_task<false>(&P, X, bprod<3>(P, dir), rb, ct, t, dir); }
-      else if (v < n3 + n2) { if (tile_decode(v - n3, nrb1, ctp, rb, ct)) bwd_prod_task<true>(&P, X, bprod<2>(P, dir), rb, ct, t, dir); }
-      else if (v < n3 + n2 + n0) { if (tile_decode(v - n3 - n2, nrb1, ctp, rb, ct)) bwd_prod_task<false>(&P, X, bprod<0>(P, dir), rb, ct, t, dir); }
-      else if (tile_decode(v - n3 - n2 - n0, nrb1, cte, rb, ct)) bwd_prod_task<false>(&P, X, bprod<1>(P, dir), rb, ct, t, dir);
-    } else if (ph == 2) {
+    int rb, ct;
+    if (ph == 0) {                                       // C: attention first halves | l cell backward | e cell backward of step t-1
+      if (v < B) { if (t + 1 < T) att_bwd_a(&P, X, t + 1, v, dir, dir * att_st); }
+      else if (v < B + nel) { if (t < T) lp_bwd_task<true>(&P, X, t, dir, v - B); }
+      else if (v < B + nel + nee) { if (t >= 1) e_bwd_task(&P, X, t - 1, dir, v - B - nel); }
+    } else if (ph == 1) {                                // D: attention second halves (same workgroup as the first) | products
+      if (v < B) { if (t + 1 < T) att_bwd_b(&P, X, t + 1, v, dir, dir * att_st); return; }
+      v -= B;
+      if (v < nt_l_hh) { if (t < T && t > 0 && tile_decode(v, nrb2, ctp, rb, ct)) bwd_prod_task<false>(&P, X, bprod<3>(P, dir), rb, ct, t, dir); return; }
+      v -= nt_l_hh;
+      if (v < nt_l_ih) { if (t < T && tile_decode(v, nrb1, ctp, rb, ct)) bwd_prod_task<true>(&P, X, bprod<2>(P, dir), rb, ct, t, dir); return; }
+      v -= nt_l_ih;
+      if (v < nt_e_ih) { if (t >= 1 && tile_decode(v, nrb1, ctp, rb, ct)) bwd_prod_task<false>(&P, X, bprod<0>(P, dir), rb, ct, t, dir); return; }
+      v -= nt_e_ih;
+      if (v < nt_e_hh && t >= 1 && tile_decode(v, nrb1, cte, rb, ct)) bwd_prod_task<false>(&P, X, bprod<1>(P, dir), rb, ct, t, dir);
+    } else if (ph == 2) {                                // E: only the last step's g cell backward
       g_bwd_task(&P, X, t, dir, v);
-    } else {
-      const int n5 = nt_p_hh, n4 = nt_p_ih, n6 = nt_g_ih;
-      int rb, ct;
-      if (v < n5) { if (tile_decode(v, nrb2, ctp, rb, ct)) bwd_prod_task<false>(&P, X, bprod<5>(P, dir), rb, ct, t, dir); }
-      else if (v < n5 + n4) { if (tile_decode(v - n5, nrb1, ctg, rb, ct)) bwd_prod_task<false>(&P, X, bprod<4>(P, dir), rb, ct, t, dir); }
-      else if (v < n5 + n4 + n6) { if (tile_decode(v - n5 - n4, nrb1, ctp, rb, ct)) bwd_prod_task<false>(&P, X, bprod<6>(P, dir), rb, ct, t, dir); }
-      else if (tile_decode(v - n5 - n4 - n6, nrb1, ctg, rb, ct)) bwd_prod_task<false>(&P, X, bprod<7>(P, dir), rb, ct, t, dir);
+    } else {                                             // F: products of the p and g cells
+      if (!(t < T && t > 0)) return;
+      if (v < nt_p_hh) { if (tile_decode(v, nrb2, ctp, rb, ct)) bwd_prod_task<false>(&P, X, bprod<5>(P, dir), rb, ct, t, dir); return; }
+      v -= nt_p_hh;
+      if (v < nt_p_ih) { if (tile_decode(v, nrb1, ctg, rb, ct)) bwd_prod_task<false>(&P, X, bprod<4>(P, dir), rb, ct, t, dir); return; }
+      v -= nt_p_ih;
+      if (v < nt_g_ih) { if (tile_decode(v, nrb1, ctp, rb, ct)) bwd_prod_task<false>(&P, X, bprod<6>(P, dir), rb, ct, t, dir); return; }
+      v -= nt_g_ih;
+      if (v < nt_g_hh && tile_decode(v, nrb1, ctg, rb, ct)) bwd_prod_task<false>(&P, X, bprod<7>(P, dir), rb, ct, t, dir);
     }
   };
+  const int n_full[4] = {B + nel + nee, B + nt_l_hh + nt_l_ih + nt_e_ih + nt_e_hh, neg, nt_p_hh + nt_p_ih + nt_g_ih + nt_g_hh};
+  const bool use_sched = P.sched_ok != 0 && !P_SPLIT_DIRS;
   PST_INIT();
   bool first[2] = {true, true};
   for (int t = T; t >= 0; --t) {
 #pragma unroll 1
     for (int ph = 0; ph < 4; ++ph) {
-      const int n = n_tasks(ph, t);
-      if (n == 0) continue;
+      if (n_tasks(ph, t) == 0) continue;
 #pragma unroll 1
       for (int dir = dir_lo; dir < dir_hi; ++dir) {
-        // (interleaved form: direction 1's task list is dealt from the middle of the grid -- a phase has fewer tasks than workgroups, so
-        // the two directions' tasks of a phase mostly land on different workgroups)
-        int v = P_SPLIT_DIRS ? wg : (int)((blockIdx.x + (unsigned)dir * (G / 2)) % (unsigned)G);
+        // a workgroup's index relative to the direction: direction 1's lists are dealt from the middle of the grid, so that the two
+        // directions' heavy tasks (attention rows: workgroups 0 .. B-1 of a direction) land on different workgroups
+        const int wrel = P_SPLIT_DIRS ? wg : (int)((blockIdx.x + (unsigned)dir * (G / 2)) % (unsigned)G);
         PST(2 * ph);
         if (!first[dir]) { if (!bar_wait(gb[dir], &bar_ok)) return; }
         first[dir] = false;
         PST(2 * ph + 1);
-        for (; v < n; v += G) run_task(ph, t, dir, v);
+        if (use_sched && ph != 2) {
+          const int pi = ph == 3 ? 2 : ph;
+#pragma unroll 1
+          for (int k2 = 0; k2 < 2; ++k2) {
+            const int v = P.sched[pi][wrel][k2];
+            if (v != 255) run_task(ph, t, dir, v);
+          }
+        } else {
+          for (int v = wrel; v < n_full[ph]; v += G) run_task(ph, t, dir, v);
+        }
         PSTC(10);
         bar_arrive(gb[dir]);
         PSTC(12);
@@ -1941,6 +1956,41 @@ bool persist_ok(const Dims& d, bool bwd) {
   const size_t big = (size_t)2 * ((size_t)d.T + 1) * d.B * 2 * (size_t)(d.Dp > d.Dg ? d.Dp : d.Dg) * 3 * sizeof(float);   // >= the largest of them
   return big < ((size_t)1 << 31) && persist_lds(d, bwd) <= (size_t)160 * 1024 / P_WGS_PER_CU;
 }
+// Backward task schedule: which workgroup (index relative to its direction) runs which task of the phases C, D, F.  Greedy, heaviest
+// first: the 2 B attention halves are fixed on workgroups 0 .. B-1 (10 us each), then the product tiles (11 us) and the element-wise chunks
+// (3 us) go to the workgroup whose PAIR (w, w + G/2: the two directions' roles of one physical workgroup) carries the least so far, at
+// most one task per workgroup and phase where the counts allow.  Round-robin lists left the attention workgroups with three products
+// per step on top of their rows (56 us of work per step against 39 on average).
+void make_bwd_sched(PK& K, int G) {
+  const Dims& d = K.d;
+  K.sched_ok = 0;
+  memset(K.sched, 255, sizeof(K.sched));
+  const int nel = cdiv((long)d.B * d.Dp, PNT), nee = cdiv((long)d.B * d.De, PNT);
+  const int nD = tile_count(2 * d.B, d.Dp, 32) + tile_count(d.B, d.Dp, 32) + tile_count(d.B, d.Dp, 32) + tile_count(d.B, d.De, 32);
+  const int nF = tile_count(2 * d.B, d.Dp, 32) + tile_count(d.B, d.Dg, 32) + tile_count(d.B, d.Dp, 32) + tile_count(d.B, d.Dg, 32);
+  if (G != 256 || d.B > G / 2 || d.B + nel + nee >= 255 || d.B + nD >= 255 || nF >= 255) return;
+  float load[256];
+  int used[3][256];
+  for (int w = 0; w < G; ++w) { load[w] = w < d.B ? 20.f : 0.f; used[0][w] = used[1][w] = w < d.B ? 1 : 0; used[2][w] = 0; }
+  for (int w = 0; w < d.B; ++w) { K.sched[0][w][0] = (unsigned char)w; K.sched[1][w][0] = (unsigned char)w; }
+  auto place = [&](int pi, int first, int count, float cost) {
+    for (int j = 0; j < count; ++j) {
+      int best = -1; float bl = 0.f; int bu = 0;
+      for (int w = 0; w < G; ++w) {
+        if (used[pi][w] >= 2) continue;
+        const float pl = load[w] + load[(w + G / 2) % G];
+        if (best < 0 || used[pi][w] < bu || (used[pi][w] == bu && pl < bl)) { best = w; bl = pl; bu = used[pi][w]; }
+      }
+      if (best < 0) { K.sched_ok = -1; return; }
+      K.sched[pi][best][used[pi][best]++] = (unsigned char)(first + j);
+      load[best] += cost;
+    }
+  };
+  place(1, d.B, nD, 11.f);
+  place(2, 0, nF, 11.f);
+  place(0, d.B, nel + nee, 3.f);
+  K.sched_ok = K.sched_ok == 0 ? 1 : 0;
+}
 PK make_pk(const mser_drnn_desc& d, const WS& w) {
   PK K;
   K.d = Dims{d.T, d.B, d.Dm, d.Dg, d.Dp, d.De};
@@ -1949,6 +1999,7 @@ PK make_pk(const mser_drnn_desc& d, const WS& w) {
   K.rng = (d.rng && d.p_drop > 0.f) ? d.rng : nullptr; K.site[0] = d.drop_site[0]; K.site[1] = d.drop_site[1]; K.pdrop = d.p_drop;
   K.out = d.out; K.dout = d.dout; K.ldo = d.ldo; K.rev = d.rev;
   K.sync = w.sync; K.fault = d.fault;
+  K.sched_ok = 0;
   return K;
 }
 
@@ -2108,7 +2159,8 @@ int mser_drnn_bwd(const mser_drnn_desc* dp, mser_stream_t stream) {
                            w.wpk + (long)dir * w.wtk_dir + w.wtk_off[i], n_out);
       }
     }
-    const PK K = make_pk(d, w);
+    PK K = make_pk(d, w);
+    make_bwd_sched(K, persist_grid());
     const size_t lds = persist_lds(dm, true);
     MSER_CHECK_HIP(hipFuncSetAttribute((const void*)drnn_bwd_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(drnn_store_pk_kernel, dim3(1), dim3(64), 0, s, K, (PK*)w.pk_dev);
