@@ -770,7 +770,9 @@ struct PK {
   // the workgroup with direction-relative index w runs, as indices into the phase's full task list; 255 = none.  sched_ok = 0: deal the
   // lists round-robin instead.
   unsigned char sched[3][256][2]; int sched_ok;
+  unsigned char sched_f[2][256][2]; int sched_f_ok;      // forward: phases B, C (make_fwd_sched)
 };
+static_assert(sizeof(PK) + 16 <= 4096, "PK travels as a by-value kernel argument of drnn_store_pk_kernel");
 // The launch parameters live in device memory (drnn_store_pk_kernel writes the by-value argument there -- capturable, no host copy) and are
 // read through the constant address space: scalar loads wherever a field is needed, instead of ~100 preloaded SGPRs spilled all over the
 // kernel, and a plain pointer to hand to the non-inlined task functions.
@@ -1270,49 +1272,53 @@ __global__ __launch_bounds__(PNT, 2) void drnn_fwd_persist(const PK* __restrict_
   const int nsg = (Dg + UW - 1) / UW, nsp = (Dp + UW - 1) / UW, nse = (De + UW - 1) / UW;
   // task v of phase ph (0 = B, 1 = C) of step t, direction dir
   auto n_tasks = [&](int ph, int t) { return ph == 0 ? (t < T ? ntp + ntg : 0) : (t < T ? ntp : 0) + (t + 1 < T ? B : 0) + (t > 0 ? nte : 0); };
+  // task v of phase ph: v indexes the phase's FULL list (the same at every step; a kind that does not exist at step t gives kind -1)
   auto task_of = [&](int ph, int t, int dir, int v) {
     Task k{-1, t, dir, 0, 0, 0};
     if (ph == 0) {
+      if (t >= T) return k;
       if (v < ntp) { if (tile_decode(v, NRB, nsp, k.rb, k.slab)) k.kind = 1; }
-      else if (tile_decode(v - ntp, NRB, nsg, k.rb, k.slab)) k.kind = 0;
+      else if (v < ntp + ntg) { if (tile_decode(v - ntp, NRB, nsg, k.rb, k.slab)) k.kind = 0; }
     } else {
-      const int nl = t < T ? ntp : 0, na = t + 1 < T ? B : 0;
-      if (v < nl) { if (tile_decode(v, NRB, nsp, k.rb, k.slab)) k.kind = 2; }
-      else if (v < nl + na) { k.kind = 4; k.t = t + 1; k.b = v - nl; }
-      else if (tile_decode(v - nl - na, NRB, nse, k.rb, k.slab)) { k.kind = 3; k.t = t - 1; }
+      if (v < ntp) { if (t < T && tile_decode(v, NRB, nsp, k.rb, k.slab)) k.kind = 2; }
+      else if (v < ntp + B) { if (t + 1 < T) { k.kind = 4; k.t = t + 1; k.b = v - ntp; } }
+      else if (v < ntp + B + nte) { if (t > 0 && tile_decode(v - ntp - B, NRB, nse, k.rb, k.slab)) { k.kind = 3; k.t = t - 1; } }
     }
     return k;
   };
+  const int n_full[2] = {ntp + ntg, ntp + B + nte};
+  const bool use_sched = P.sched_f_ok != 0 && !P_SPLIT_DIRS;
   TRegs R;
   PST_INIT();
   bool first[2] = {true, true};
   for (int t = 0; t <= T; ++t) {
 #pragma unroll 1
     for (int ph = 0; ph < 2; ++ph) {
-      const int n = n_tasks(ph, t);
-      if (n == 0) continue;
+      if (n_tasks(ph, t) == 0) continue;
 #pragma unroll 1
       for (int dir = dir_lo; dir < dir_hi; ++dir) {
-        // (direction 1's task list is dealt from the middle of the grid: a workgroup that has a heavy p / l tile for one direction gets a
-        // g / attention / e task, or none, for the other)
-        int v = P_SPLIT_DIRS ? wg : (int)((blockIdx.x + (unsigned)dir * (G / 2)) % (unsigned)G);
-        Task k = task_of(ph, t, dir, v);
-        if (v < n) task_pre(P, F, k, R);
-#if !defined(MSER_STAMPS_SITE) || MSER_STAMPS_SITE == 1
+        // a workgroup's index relative to the direction (direction 1's lists are dealt from the middle of the grid) and its tasks of this
+        // phase: from the host's schedule (make_fwd_sched: at most two, placed so that every physical workgroup carries about the same
+        // work per step), or the list dealt round-robin
+        const int wrel = P_SPLIT_DIRS ? wg : (int)((blockIdx.x + (unsigned)dir * (G / 2)) % (unsigned)G);
+        int vs[2] = {-1, -1};
+        if (use_sched) {
+          const int a = P.sched_f[ph][wrel][0], b2 = P.sched_f[ph][wrel][1];
+          vs[0] = a != 255 ? a : -1; vs[1] = b2 != 255 ? b2 : -1;
+        } else {
+          vs[0] = wrel < n_full[ph] ? wrel : -1; vs[1] = wrel + G < n_full[ph] ? wrel + G : -1;       // (more than two rounds: see persist_ok)
+        }
+        Task k = task_of(ph, t, dir, vs[0] >= 0 ? vs[0] : 0);
+        if (vs[0] < 0) k.kind = -1;
+        task_pre(P, F, k, R);
         PST(4 * ph + 2 * dir);
-#endif
         PEXP();
         if (!first[dir]) { if (!bar_wait(gb[dir], &bar_ok)) return; }
         first[dir] = false;
-#if !defined(MSER_STAMPS_SITE) || MSER_STAMPS_SITE == 2
         PST(4 * ph + 2 * dir + 1);
-#endif
         PEXP();
-        for (; v < n;) {
-          task_post(P, F, k, R);
-          v += G;
-          if (v < n) { k = task_of(ph, t, dir, v); task_pre(P, F, k, R); }
-        }
+        task_post(P, F, k, R);
+        if (vs[1] >= 0) { k = task_of(ph, t, dir, vs[1]); task_pre(P, F, k, R); task_post(P, F, k, R); }
         PSTC(12);
         bar_arrive(gb[dir]);
         PSTC(13);
@@ -1952,7 +1958,8 @@ size_t persist_lds(const Dims& d, bool bwd) {
 // every hand-off array is addressed through a 32-bit byte offset (buffer descriptor); one workgroup per CU must fit
 bool persist_ok(const Dims& d, bool bwd) {
   if (!g_opt_drnn_persist || persist_grid() < 8 || d.Dg > 512 || d.Dp > 512 || d.De > 512) return false;
-  if (bwd && d.B > persist_grid() / 2) return false;        // (an attention row's two halves meet in its workgroup's LDS: one row per workgroup and direction)      // (a wave's K share in registers; ATT_V)
+  if (bwd && d.B > persist_grid() / 2) return false;
+  if (tile_count(d.B, d.Dp, UW) + (d.Dg > d.De ? tile_count(d.B, d.Dg, UW) : d.B + tile_count(d.B, d.De, UW)) > 2 * persist_grid()) return false;    // (a forward phase is at most two rounds)        // (an attention row's two halves meet in its workgroup's LDS: one row per workgroup and direction)      // (a wave's K share in registers; ATT_V)
   const size_t big = (size_t)2 * ((size_t)d.T + 1) * d.B * 2 * (size_t)(d.Dp > d.Dg ? d.Dp : d.Dg) * 3 * sizeof(float);   // >= the largest of them
   return big < ((size_t)1 << 31) && persist_lds(d, bwd) <= (size_t)160 * 1024 / P_WGS_PER_CU;
 }
@@ -1973,12 +1980,14 @@ void make_bwd_sched(PK& K, int G) {
   int used[3][256];
   for (int w = 0; w < G; ++w) { load[w] = w < d.B ? 20.f : 0.f; used[0][w] = used[1][w] = w < d.B ? 1 : 0; used[2][w] = 0; }
   for (int w = 0; w < d.B; ++w) { K.sched[0][w][0] = (unsigned char)w; K.sched[1][w][0] = (unsigned char)w; }
-  auto place = [&](int pi, int first, int count, float cost) {
+  // xcd: a tile task prefers a workgroup of XCD (list index % 8) -- the row blocks of one weight slab / column tile have the same index
+  // modulo 8 (tile_decode), so they share the slab in that XCD's L2
+  auto place = [&](int pi, int first, int count, float cost, bool xcd) {
     for (int j = 0; j < count; ++j) {
       int best = -1; float bl = 0.f; int bu = 0;
       for (int w = 0; w < G; ++w) {
         if (used[pi][w] >= 2) continue;
-        const float pl = load[w] + load[(w + G / 2) % G];
+        const float pl = load[w] + load[(w + G / 2) % G] + ((xcd && (w & 7) != ((first + j) & 7)) ? 1000.f : 0.f);
         if (best < 0 || used[pi][w] < bu || (used[pi][w] == bu && pl < bl)) { best = w; bl = pl; bu = used[pi][w]; }
       }
       if (best < 0) { K.sched_ok = -1; return; }
@@ -1986,10 +1995,41 @@ void make_bwd_sched(PK& K, int G) {
       load[best] += cost;
     }
   };
-  place(1, d.B, nD, 11.f);
-  place(2, 0, nF, 11.f);
-  place(0, d.B, nel + nee, 3.f);
+  place(1, d.B, nD, 11.f, (d.B & 7) == 0);
+  place(2, 0, nF, 11.f, true);
+  place(0, d.B, nel + nee, 3.f, false);
   K.sched_ok = K.sched_ok == 0 ? 1 : 0;
+}
+// Forward task schedule (phases B: p | g tiles; C: l tiles | attention rows | e tiles), same greedy as make_bwd_sched without fixed tasks.
+void make_fwd_sched(PK& K, int G) {
+  const Dims& d = K.d;
+  K.sched_f_ok = 0;
+  memset(K.sched_f, 255, sizeof(K.sched_f));
+  const int ntp = tile_count(d.B, d.Dp, UW), ntg = tile_count(d.B, d.Dg, UW), nte = tile_count(d.B, d.De, UW);
+  if (G != 256 || ntp + ntg >= 255 || ntp + d.B + nte >= 255) return;
+  float load[256];
+  int used[2][256];
+  for (int w = 0; w < G; ++w) { load[w] = 0.f; used[0][w] = used[1][w] = 0; }
+  bool ok = true;
+  auto place = [&](int pi, int first, int count, float cost, int xcd_off) {      // xcd_off >= 0: tile list starting at that index
+    for (int j = 0; j < count; ++j) {
+      int best = -1; float bl = 0.f; int bu = 0;
+      for (int w = 0; w < G; ++w) {
+        if (used[pi][w] >= 2) continue;
+        const float pl = load[w] + load[(w + G / 2) % G] + ((xcd_off >= 0 && (w & 7) != (j & 7)) ? 1000.f : 0.f);
+        if (best < 0 || used[pi][w] < bu || (used[pi][w] == bu && pl < bl)) { best = w; bl = pl; bu = used[pi][w]; }
+      }
+      if (best < 0) { ok = false; return; }
+      K.sched_f[pi][best][used[pi][best]++] = (unsigned char)(first + j);
+      load[best] += cost;
+    }
+  };
+  place(0, 0, ntp, 11.f, 0);            // p tiles (three MFMA chains)
+  place(1, 0, ntp, 11.f, 0);            // l tiles
+  place(0, ntp, ntg, 8.f, 0);           // g tiles
+  place(1, ntp, d.B, 8.f, -1);          // attention rows
+  place(1, ntp + d.B, nte, 7.f, 0);     // e tiles
+  K.sched_f_ok = ok ? 1 : 0;
 }
 PK make_pk(const mser_drnn_desc& d, const WS& w) {
   PK K;
@@ -1999,7 +2039,7 @@ PK make_pk(const mser_drnn_desc& d, const WS& w) {
   K.rng = (d.rng && d.p_drop > 0.f) ? d.rng : nullptr; K.site[0] = d.drop_site[0]; K.site[1] = d.drop_site[1]; K.pdrop = d.p_drop;
   K.out = d.out; K.dout = d.dout; K.ldo = d.ldo; K.rev = d.rev;
   K.sync = w.sync; K.fault = d.fault;
-  K.sched_ok = 0;
+  K.sched_ok = 0; K.sched_f_ok = 0;
   return K;
 }
 
@@ -2055,7 +2095,8 @@ int mser_drnn_fwd(const mser_drnn_desc* dp, mser_stream_t stream) {
     }
   }
   if (persist_ok(dm, false)) {
-    const PK K = make_pk(d, w);
+    PK K = make_pk(d, w);
+    make_fwd_sched(K, persist_grid());
     const size_t lds = persist_lds(dm, false);
     MSER_CHECK_HIP(hipMemsetAsync(w.sync, 0, 4096 * sizeof(unsigned), s));
     MSER_CHECK_HIP(hipMemsetAsync(w.apk, 0, w.apk_floats * sizeof(float), s));
