@@ -621,9 +621,10 @@ __global__ __launch_bounds__(64 * G2_WPB) void general2_bwd_kernel(const float* 
 // write-through and loaded L2-bypassing (`sc1` buffer accesses through one descriptor per array), the counter add sits behind
 // s_waitcnt vmcnt(0) + a workgroup barrier (MI355X_MICROARCH.md "valid forms").  Every wait is bounded: a workgroup that gives up sets
 // the abort word and MSER_FAULT_CHAIN_TIMEOUT, and the whole grid drains.
-// Measured (configs[3], B = 64, T = 200, rocprofv3): forward 18.3 ms, backward 17.7 ms per launch (88-91 us per step, of which the MFMA
-// chains are 12 us per CU: a task is a latency chain -- L2-bypassing operand loads 3 us, MFMA 5 us, cross-wave reduction 2-3 us, gate
-// math 1.5 us, store drain + arrive 1.5 us -- with one task in flight per CU); the per-step launches took 20 + 40 ms.
+// Measured (configs[3], B = 64, T = 200, rocprofv3): forward 11.6 ms, backward 13.4 ms per launch (58 / 67 us per step, of which the MFMA
+// chains are 12 us per CU: a task is a latency chain -- L2-bypassing operand loads 3 us, MFMA 5 us, cross-wave reduction 1-2 us, gate
+// math 1.5 us, store drain + arrive 1.5 us -- with one task in flight per CU); the per-step launches took 20 + 40 ms.  DESIGN.md 7 (f2)
+// lists what each step of the way was worth.
 #ifndef MSER_DRNN_WAVES
 #define MSER_DRNN_WAVES 8
 #endif
@@ -734,7 +735,7 @@ __device__ __forceinline__ void bar_arrive(GridBar& gb) {
   __syncthreads();
   // P_BAR_REP replicas of the counter, one cache line each: an arrival adds to all of them with ONE wave instruction (P_BAR_REP active
   // lanes), a waiting workgroup polls only replica (workgroup % P_BAR_REP) -- 256 pollers on one line queue the arrivals behind their
-  // loads (measured: forward 16.3 -> ms per launch)
+  // loads (measured: configs[3] step 43.5 -> 40.7 ms)
   if (threadIdx.x < P_BAR_REP) __hip_atomic_fetch_add((pgu32*)(gb.cnt + threadIdx.x * 32), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ bool bar_wait(const GridBar& gb, int* ok_lds) {
