@@ -41,6 +41,9 @@ struct DirP {
   const float *W[2], *Wb[2], *U[2], *Ub[2], *V[2], *Vb[2], *S[2], *Sb[2];
   const float *Wih[2], *Whh[2], *bih[2], *bhh[2];
   const float *attWq, *attWk;
+  // wide cells (H > 512, weights streamed every step): the forward launches' B operands in MFMA fragment order, packed once per forward
+  // call (cell_pack_w_kernel): [unit slab of 8][k / 8][gate * 8 + unit][8], K = [W_ih | W_hh] resp. [U | V]; nullptr otherwise
+  float *WpkS[2], *WpkL[2];
   // tables (direction time order)
   int *party, *perm, *rowof, *n0;
   const int* rev;
@@ -592,6 +595,10 @@ struct Role { int x, y, z, gx, gy; };
 struct SpkFwdB {
   const DirP& D; int c, u0, H;
   __device__ __forceinline__ void operator()(int n, int k, float* b) const {
+    if (D.WpkS[c]) {        // fragment order: a wave's load is 1 KB contiguous (row-major it touches 32 rows x 32 bytes)
+      load8(D.WpkS[c] + ((((long)(u0 >> 3) * (2 * H / 8)) + (k >> 3)) * 32 + n) * 8, b);
+      return;
+    }
     const long wrow = (long)(n >> 3) * H + u0 + (n & 7);
     if (k < H) load8(D.Wih[c] + wrow * H + k, b);
     else load8(D.Whh[c] + wrow * H + (k - H), b);
@@ -788,6 +795,10 @@ __device__ __forceinline__ void spk_fwd_role(const CellK& P, const Role R, float
 struct LsthmFwdB {
   const DirP& D; int m, u0, H;
   __device__ __forceinline__ void operator()(int n, int k, float* b) const {
+    if (D.WpkL[m] && k < 2 * H) {
+      load8(D.WpkL[m] + ((((long)(u0 >> 3) * (2 * H / 8)) + (k >> 3)) * 32 + n) * 8, b);
+      return;
+    }
     const long wrow = (long)(n >> 3) * H + u0 + (n & 7);
     if (k < H) load8(D.U[m] + wrow * H + k, b);
     else if (k < 2 * H) load8(D.V[m] + wrow * H + (k - H), b);
@@ -3113,6 +3124,19 @@ __global__ __launch_bounds__(NT) void cell_wide_spkbwd_persist(CellK P, unsigned
 
 // ================================================================================================ small helpers
 // mnext[t][r] = qm[t][r][party[t+1][r]]: the blend weight with which row r's h_q feeds the state that dialogue r reads at t+1
+// out[((slab * K8 + k8) * 32 + n) * 8 + j] = [Wa | Wb][(n >> 3) * H + slab * 8 + (n & 7)][k8 * 8 + j]   (K = 2 H; both halves [4H, H] row-major)
+__global__ void cell_pack_w_kernel(const float* Wa, const float* Wb, int H, float* out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)4 * H * 2 * H;
+  if (i >= total) return;
+  const int j = (int)(i & 7), n = (int)((i >> 3) & 31);
+  const long q = i >> 8;
+  const int K8 = 2 * H / 8;
+  const int k = (int)(q % K8) * 8 + j, slab = (int)(q / K8);
+  const long row = (long)(n >> 3) * H + slab * 8 + (n & 7);
+  out[i] = k < H ? Wa[row * H + k] : Wb[row * H + (k - H)];
+}
+
 __global__ void mnext_kernel(const float* qm, const int* party, float* mnext, int T, int B) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)T * B) return;
@@ -3321,6 +3345,11 @@ static void carve_dir(Carver& cv, DirP& d, int T, int B, int D, int H) {
   const size_t nsl = (H == 128 || H == 256) ? (size_t)H / 16 : 0;
   d.Xp = cv.take<float>(2 * nsl * SB);
   d.dhp = cv.take<float>(2 * 2 * nsl * SB);
+  // fragment-ordered forward weights of the wide cells
+  for (int i = 0; i < 2; ++i) {
+    d.WpkS[i] = H > 512 ? cv.take<float>((size_t)4 * H * 2 * H) : nullptr;
+    d.WpkL[i] = H > 512 ? cv.take<float>((size_t)4 * H * 2 * H) : nullptr;
+  }
 }
 
 struct CellHost {
@@ -3489,6 +3518,15 @@ int marn_cell_fwd(const mser_cell_desc& d, hipStream_t s, int phases) {
   K.fwd_sentinel = (persist && g_opt_fwd_sentinel && !ext) ? 1 : 0;
   K.fwd_rowsplit = (persist && g_opt_rowsplit && H == 256 && 2 * B <= (H / 8) * 2 * K.nmb) ? 2 : 1;
   if (phases & MSER_PHASE_FWD_PREP) {
+  if (H > 512) {      // the wide cells stream their weights every step: fragment order for the forward launches (once per call)
+    const long total = (long)4 * H * 2 * H;
+    for (int i = 0; i < d.ndir; ++i)
+      for (int c = 0; c < 2; ++c) {
+        hipLaunchKernelGGL(cell_pack_w_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, K.d[i].Wih[c], K.d[i].Whh[c], H, K.d[i].WpkS[c]);
+        hipLaunchKernelGGL(cell_pack_w_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, K.d[i].U[c], K.d[i].V[c], H, K.d[i].WpkL[c]);
+      }
+    MSER_TRY(check_launch("cell_pack_w"));
+  }
   {
     // counters zeroed; every word the forward chains hand from workgroup to workgroup starts as the sentinel (HQ | cstate | hz, carved
     // back to back; cell_prep_kernel, below, then zeroes the index-0 states; an external speaker state is copied over HQ by
