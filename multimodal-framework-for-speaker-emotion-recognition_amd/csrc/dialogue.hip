@@ -675,23 +675,6 @@ __device__ __forceinline__ void pzero8(float* a) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) a[j] = 0.f;
 }
-#if defined(MSER_DRNN_EXP) && !defined(MSER_STAMPS)
-#if MSER_DRNN_EXP == 1
-#define PEXP() do { if (threadIdx.x == 0) { unsigned long long _x = __builtin_amdgcn_s_memrealtime(); asm volatile("" :: "s"(_x)); } } while (0)
-#elif MSER_DRNN_EXP == 2
-#define PEXP() do { if ((threadIdx.x >> 6) == 0) __builtin_amdgcn_s_sleep(8); } while (0)
-#elif MSER_DRNN_EXP == 4
-__shared__ unsigned long long pexp_acc[2];
-#define PEXP() do { if (threadIdx.x == 0) { pexp_acc[0] += pexp_acc[1]; pexp_acc[1] += 3; } } while (0)
-#elif MSER_DRNN_EXP == 5
-__shared__ unsigned long long pexp_acc[2];
-#define PEXP() do { if (threadIdx.x == 0) { const unsigned long long _n = __builtin_amdgcn_s_memrealtime(); pexp_acc[0] += _n - pexp_acc[1]; pexp_acc[1] = _n; } } while (0)
-#else
-#define PEXP() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
-#endif
-#else
-#define PEXP()
-#endif
 #ifdef MSER_STAMPS
 __shared__ unsigned long long pst_acc[16];
 __shared__ unsigned long long pst_last;
@@ -702,14 +685,10 @@ __shared__ unsigned long long pst_last;
 #else
 #define PSTC(k)
 #endif
-#ifdef MSER_STAMPS_NODUMP
-#define PST_DUMP(name, T)
-#else
 #define PST_DUMP(name, T) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 200 || blockIdx.x == 255 || blockIdx.x == 256)) \
   printf("[drnn stamps %s wg %3d hwid %08x | 10 ns ticks per step]  %llu %llu %llu %llu %llu %llu %llu %llu | %llu %llu %llu %llu %llu %llu %llu %llu\n", name, (int)blockIdx.x, (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)), pst_acc[0] / (T), pst_acc[1] / (T), \
          pst_acc[2] / (T), pst_acc[3] / (T), pst_acc[4] / (T), pst_acc[5] / (T), pst_acc[6] / (T), pst_acc[7] / (T), pst_acc[8] / (T), pst_acc[9] / (T), pst_acc[10] / (T), pst_acc[11] / (T), \
          pst_acc[12] / (T), pst_acc[13] / (T), pst_acc[14] / (T), pst_acc[15] / (T)); } while (0)
-#endif
 #else
 #define PST_INIT()
 #define PST(k)
@@ -1253,10 +1232,6 @@ __device__ __forceinline__ void task_post(const CPK& P, const FB& F, const Task&
 __global__ __launch_bounds__(PNT, 2) void drnn_fwd_persist(const PK* __restrict__ pkp) {
   const CPK& P = *(const CPK*)pkp;
   __shared__ int bar_ok;
-#ifdef MSER_DRNN_LDS_PAD
-  __shared__ unsigned long long lds_pad[MSER_DRNN_LDS_PAD];
-  if (threadIdx.x == 0) { lds_pad[0] = 0; asm volatile("" :: "v"(lds_pad[0])); }
-#endif
   const int B = P.d.B, T = P.d.T, Dg = P.d.Dg, Dp = P.d.Dp, De = P.d.De;
   FB F;
   F.Gh = xb_make(P.w.Gh, (size_t)2 * (T + 1) * B * Dg); F.Q = xb_make(P.w.Q, (size_t)2 * (T + 1) * B * 2 * Dp);
@@ -1313,11 +1288,9 @@ __global__ __launch_bounds__(PNT, 2) void drnn_fwd_persist(const PK* __restrict_
         if (vs[0] < 0) k.kind = -1;
         task_pre(P, F, k, R);
         PST(4 * ph + 2 * dir);
-        PEXP();
         if (!first[dir]) { if (!bar_wait(gb[dir], &bar_ok)) return; }
         first[dir] = false;
         PST(4 * ph + 2 * dir + 1);
-        PEXP();
         task_post(P, F, k, R);
         if (vs[1] >= 0) { k = task_of(ph, t, dir, vs[1]); task_pre(P, F, k, R); task_post(P, F, k, R); }
         PSTC(12);
@@ -1760,10 +1733,6 @@ __device__ __noinline__ void bwd_prod_task(const CPK* Pp, const BB& Xv, const BP
 __global__ __launch_bounds__(PNT, 2) void drnn_bwd_persist(const PK* __restrict__ pkp) {
   const CPK& P = *(const CPK*)pkp;
   __shared__ int bar_ok;
-#ifdef MSER_DRNN_LDS_PAD
-  __shared__ unsigned long long lds_pad[MSER_DRNN_LDS_PAD];
-  if (threadIdx.x == 0) { lds_pad[0] = 0; asm volatile("" :: "v"(lds_pad[0])); }
-#endif
   const int B = P.d.B, T = P.d.T, Dg = P.d.Dg, Dp = P.d.Dp, De = P.d.De;
   BB X;
   X.bk = xb_make(P.w.bk, P.w.bk_floats);
