@@ -757,7 +757,12 @@ static_assert(sizeof(PK) + 16 <= 4096, "PK travels as a by-value kernel argument
 // read through the constant address space: scalar loads wherever a field is needed, instead of ~100 preloaded SGPRs spilled all over the
 // kernel, and a plain pointer to hand to the non-inlined task functions.
 typedef const __attribute__((address_space(4))) PK CPK;
-__global__ void drnn_store_pk_kernel(const PK k, PK* dst) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = k; }
+__global__ void drnn_store_pk_kernel(const PK k, PK* dst) {
+  static_assert(sizeof(PK) % 4 == 0, "copied word by word");
+  const unsigned* src = reinterpret_cast<const unsigned*>(&k);
+  unsigned* d = reinterpret_cast<unsigned*>(dst);
+  for (unsigned i = threadIdx.x; i < sizeof(PK) / 4; i += blockDim.x) d[i] = src[i];
+}
 __device__ __forceinline__ const CPK& pk_uni(const CPK* p) {        // (inside a non-inlined function the pointer arrives in vector registers)
   const unsigned long long a = (unsigned long long)p;
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
@@ -2082,7 +2087,7 @@ int mser_drnn_fwd(const mser_drnn_desc* dp, mser_stream_t stream) {
       }
     }
     MSER_CHECK_HIP(hipFuncSetAttribute((const void*)drnn_fwd_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(drnn_store_pk_kernel, dim3(1), dim3(64), 0, s, K, (PK*)w.pk_dev);
+    hipLaunchKernelGGL(drnn_store_pk_kernel, dim3(1), dim3(256), 0, s, K, (PK*)w.pk_dev);
     hipLaunchKernelGGL(drnn_fwd_persist, dim3(P_WGS_PER_CU * persist_grid()), dim3(PNT), lds, s, (const PK*)w.pk_dev);
     return check_launch("drnn_fwd_persist");
   }
@@ -2174,7 +2179,7 @@ int mser_drnn_bwd(const mser_drnn_desc* dp, mser_stream_t stream) {
     make_bwd_sched(K, persist_grid());
     const size_t lds = persist_lds(dm, true);
     MSER_CHECK_HIP(hipFuncSetAttribute((const void*)drnn_bwd_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(drnn_store_pk_kernel, dim3(1), dim3(64), 0, s, K, (PK*)w.pk_dev);
+    hipLaunchKernelGGL(drnn_store_pk_kernel, dim3(1), dim3(256), 0, s, K, (PK*)w.pk_dev);
     hipLaunchKernelGGL(drnn_bwd_persist, dim3(P_WGS_PER_CU * persist_grid()), dim3(PNT), lds, s, (const PK*)w.pk_dev);
     MSER_TRY(check_launch("drnn_bwd_persist"));
   } else {
