@@ -1883,13 +1883,16 @@ int mm_nn(hipStream_t s, const float* A, long lda, long a_ds, const float* W, lo
   return gemm(g, s);
 }
 // dW[N, K] += dY[rows, N]^T X[rows, K]   (one direction; split-K over the rows, float atomics)
-int wgrad(hipStream_t s, const float* dY, long ldy, const float* X, long ldx, float* dW, long ldw, int rows, int N, int K) {
+mser_gemm_desc wgrad_desc(const float* dY, long ldy, const float* X, long ldx, float* dW, long ldw, int rows, int N, int K) {
   mser_gemm_desc g = gd();
   g.A = dY; g.B = X; g.C = dW; g.M = N; g.N = K; g.K = rows;
   g.sAm = 1; g.sAk = ldy; g.sBk = ldx; g.sBn = 1; g.ldc = ldw;
   g.flags = MSER_GEMM_ACCUM;
   g.splitk = 2;                      // "C is initialised, accumulate atomically"; the split itself is chosen by mser::gemm
-  return gemm(g, s);
+  return g;
+}
+int wgrad(hipStream_t s, const float* dY, long ldy, const float* X, long ldx, float* dW, long ldw, int rows, int N, int K) {
+  return gemm(wgrad_desc(dY, ldy, X, ldx, dW, ldw, rows, N, K), s);
 }
 
 int validate(const mser_drnn_desc& d, bool bwd) {
@@ -2062,12 +2065,15 @@ int mser_drnn_fwd(const mser_drnn_desc* dp, mser_stream_t stream) {
       {P.p_wih, (long)Dm + Dg, P.p_bih, w.GIp + (long)dir * TB * 3 * Dp, 3 * Dp},
       {P.l_wih, (long)Dm + Dp, P.l_bih, w.GIl + (long)dir * TB * 3 * Dp, 3 * Dp},
       {P.att_w, (long)Dm, nullptr, w.Xatt + (long)dir * TB * Dg, Dg}};
-    for (auto& h : hs) {
+    mser_gemm_desc hg[4];                 // one grouped launch per direction
+    for (int i = 0; i < 4; ++i) {
+      const auto& h = hs[i];
       mser_gemm_desc g = gd();
       g.A = Ud; g.B = h.W; g.C = h.C; g.M = (int)TB; g.N = h.N; g.K = Dm;
       g.sAm = Dm; g.sAk = 1; g.sBk = 1; g.sBn = h.ld; g.ldc = h.N; g.bias = h.b;
-      MSER_TRY(gemm(g, s));
+      hg[i] = g;
     }
+    MSER_TRY(gemm_group(hg, 4, s));
   }
   if (persist_ok(dm, false)) {
     PK K = make_pk(d, w);
@@ -2250,31 +2256,30 @@ int mser_drnn_bwd(const mser_drnn_desc* dp, mser_stream_t stream) {
     const float* dgi_p = w.dgi_p + (long)dir * TB * 3 * Dp; const float* dgh_p = w.dgh_p + (long)dir * TB * 2 * 3 * Dp;
     const float* dgi_l = w.dgi_l + (long)dir * TB * 3 * Dp; const float* dgh_l = w.dgh_l + (long)dir * TB * 2 * 3 * Dp;
     const float* dgi_e = w.dgi_e + (long)dir * TB * 3 * De; const float* dgh_e = w.dgh_e + (long)dir * TB * 3 * De;
-    // g cell
-    MSER_TRY(wgrad(s, dgi_g, 3 * Dg, Ud, Dm, G.g_wih, Dm + Dp, (int)TB, 3 * Dg, Dm));
-    MSER_TRY(wgrad(s, dgi_g, 3 * Dg, w.q0sel + (long)dir * TB * Dp, Dp, G.g_wih + Dm, Dm + Dp, (int)TB, 3 * Dg, Dp));
-    MSER_TRY(wgrad(s, dgh_g, 3 * Dg, w.Gh + (long)dir * g_ds, Dg, G.g_whh, Dg, (int)TB, 3 * Dg, Dg));
+    // the twelve weight-gradient products of the direction as ONE grouped launch (no tail / launch gap between them), the bias gradients
+    // (column sums of the gate gradients) after it
+    const mser_gemm_desc grp[12] = {
+      wgrad_desc(dgi_g, 3 * Dg, Ud, Dm, G.g_wih, Dm + Dp, (int)TB, 3 * Dg, Dm),
+      wgrad_desc(dgi_g, 3 * Dg, w.q0sel + (long)dir * TB * Dp, Dp, G.g_wih + Dm, Dm + Dp, (int)TB, 3 * Dg, Dp),
+      wgrad_desc(dgh_g, 3 * Dg, w.Gh + (long)dir * g_ds, Dg, G.g_whh, Dg, (int)TB, 3 * Dg, Dg),
+      wgrad_desc(dgi_p, 3 * Dp, Ud, Dm, G.p_wih, Dm + Dg, (int)TB, 3 * Dp, Dm),
+      wgrad_desc(dgi_p, 3 * Dp, w.cvec + (long)dir * TB * Dg, Dg, G.p_wih + Dm, Dm + Dg, (int)TB, 3 * Dp, Dg),
+      wgrad_desc(dgh_p, 3 * Dp, w.Q + (long)dir * q_ds, Dp, G.p_whh, Dp, (int)(2 * TB), 3 * Dp, Dp),
+      wgrad_desc(dgi_l, 3 * Dp, Ud, Dm, G.l_wih, Dm + Dp, (int)TB, 3 * Dp, Dm),
+      wgrad_desc(dgi_l, 3 * Dp, w.ss + (long)dir * TB * Dp, Dp, G.l_wih + Dm, Dm + Dp, (int)TB, 3 * Dp, Dp),
+      wgrad_desc(dgh_l, 3 * Dp, w.Q + (long)dir * q_ds, Dp, G.l_whh, Dp, (int)(2 * TB), 3 * Dp, Dp),
+      wgrad_desc(dgi_e, 3 * De, w.qsel + (long)dir * TB * Dp, Dp, G.e_wih, Dp, (int)TB, 3 * De, Dp),
+      wgrad_desc(dgh_e, 3 * De, w.Eh + (long)dir * e_ds, De, G.e_whh, De, (int)TB, 3 * De, De),
+      wgrad_desc(w.dXatt + (long)dir * TB * Dg, Dg, Ud, Dm, G.att_w, Dm, (int)TB, Dg, Dm)};
+    MSER_TRY(gemm_group(grp, 12, s));
     MSER_TRY(mser_colsum_acc(dgi_g, TB, 3 * Dg, 3 * Dg, G.g_bih, s));
     MSER_TRY(mser_colsum_acc(dgh_g, TB, 3 * Dg, 3 * Dg, G.g_bhh, s));
-    // p cell
-    MSER_TRY(wgrad(s, dgi_p, 3 * Dp, Ud, Dm, G.p_wih, Dm + Dg, (int)TB, 3 * Dp, Dm));
-    MSER_TRY(wgrad(s, dgi_p, 3 * Dp, w.cvec + (long)dir * TB * Dg, Dg, G.p_wih + Dm, Dm + Dg, (int)TB, 3 * Dp, Dg));
-    MSER_TRY(wgrad(s, dgh_p, 3 * Dp, w.Q + (long)dir * q_ds, Dp, G.p_whh, Dp, (int)(2 * TB), 3 * Dp, Dp));
     MSER_TRY(mser_colsum_acc(dgi_p, TB, 3 * Dp, 3 * Dp, G.p_bih, s));
     MSER_TRY(mser_colsum_acc(dgh_p, 2 * TB, 3 * Dp, 3 * Dp, G.p_bhh, s));
-    // l cell
-    MSER_TRY(wgrad(s, dgi_l, 3 * Dp, Ud, Dm, G.l_wih, Dm + Dp, (int)TB, 3 * Dp, Dm));
-    MSER_TRY(wgrad(s, dgi_l, 3 * Dp, w.ss + (long)dir * TB * Dp, Dp, G.l_wih + Dm, Dm + Dp, (int)TB, 3 * Dp, Dp));
-    MSER_TRY(wgrad(s, dgh_l, 3 * Dp, w.Q + (long)dir * q_ds, Dp, G.l_whh, Dp, (int)(2 * TB), 3 * Dp, Dp));
     MSER_TRY(mser_colsum_acc(dgi_l, TB, 3 * Dp, 3 * Dp, G.l_bih, s));
     MSER_TRY(mser_colsum_acc(dgh_l, 2 * TB, 3 * Dp, 3 * Dp, G.l_bhh, s));
-    // e cell
-    MSER_TRY(wgrad(s, dgi_e, 3 * De, w.qsel + (long)dir * TB * Dp, Dp, G.e_wih, Dp, (int)TB, 3 * De, Dp));
-    MSER_TRY(wgrad(s, dgh_e, 3 * De, w.Eh + (long)dir * e_ds, De, G.e_whh, De, (int)TB, 3 * De, De));
     MSER_TRY(mser_colsum_acc(dgi_e, TB, 3 * De, 3 * De, G.e_bih, s));
     MSER_TRY(mser_colsum_acc(dgh_e, TB, 3 * De, 3 * De, G.e_bhh, s));
-    // attention transform
-    MSER_TRY(wgrad(s, w.dXatt + (long)dir * TB * Dg, Dg, Ud, Dm, G.att_w, Dm, (int)TB, Dg, Dm));
   }
   return 0;
 }
