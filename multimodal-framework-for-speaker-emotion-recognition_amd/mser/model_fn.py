@@ -451,6 +451,9 @@ def _marn1_backward(c, P, G, dlp, dx_l_out, dx_a_out, use_streams):
         s_audio.wait_stream(cur)
         # the encoders' backward is the critical path from here: issued FIRST (a hipGraph replay dispatches nodes in issue order, ~6 us
         # each: the four bias column sums of the cell, issued in front, delayed the first post_bwd by 17 us; kernel trace, round 3)
+        # (Tried in round 3: the two branches issued layer by layer, interleaved, with the second layers' weight gradients flushed as soon
+        # as both second layers are done instead of after the whole audio branch -- on paper 40-50 us less tail; as a hipGraph replay
+        # 2.99 ms against 2.82: the executor's queue assignment follows the issue order and serialised the branches.)
         with torch.cuda.stream(s_audio):
             audio_branch()
         text_branch(flush_stream=s_xb, audio_stream=s_audio)
