@@ -65,6 +65,11 @@ class wgrad_scope:
         return False
 
 
+def wgrad_stream():
+    """The active wgrad_scope's side stream (None outside a scope or in eager mode)."""
+    return _WG.get("stream")
+
+
 class _deferred:
     """Context: run the enclosed launches on the wgrad stream (if a scope is active) after the work issued so far."""
 
